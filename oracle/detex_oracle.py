@@ -1,0 +1,453 @@
+"""CPU oracle for the Detex hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain NumPy (float64) restatement of the reference algorithm
+(d-chambers/Detex v1.0.9, pure Python) for the two data-parallel hot paths:
+
+  * the all-pairs normalised cross-correlation that fills the similarity / lag
+    matrices (detex/construct.py:369-466), and
+  * the sliding-window subspace detection statistic with its post-processing
+    (detex/detect.py:220-296, 390-445, 501-578; detex/fas.py:120-134) and the
+    SVD basis construction that feeds it (detex/subspace.py:886-1054).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module, and only as the checker / the timed CPU
+baseline.  The product (``detex_amd``) never imports it and has no CPU
+fallback: it fails loudly when the HIP library is missing.
+
+Parity pin: the reference's own tests hold no numerical vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, generated in the build container by ``tests/golden/make_golden.py``
+(which imports /root/reference through a stub/shim preamble) and committed as
+``tests/golden/*.npz``.  ``tests/test_oracle_golden.py`` checks every function
+below against those vectors (<= 1e-9 abs in float64; integers exact).
+
+Each function cites the reference file:line it follows.  Two forms are given
+for the two kernels: ``*_fft`` follows the reference's FFT arithmetic step by
+step, ``*_direct`` is the closed form that the HIP
+kernels implement.
+"""
+import numpy as np
+import scipy.fftpack
+import scipy.linalg
+
+# --------------------------------------------------------------------------
+# small helpers standing in for pandas 0.17 rolling_* (third-party arithmetic)
+# --------------------------------------------------------------------------
+
+
+def _windows(x, n):
+    return np.lib.stride_tricks.sliding_window_view(np.asarray(x), int(n))
+
+
+def rolling_mean_valid(x, n):
+    """pd.rolling_mean(x, n)[n-1:] -- mean of every full window."""
+    x = np.asarray(x, dtype=np.float64)
+    if len(x) * int(n) <= 5_000_000:
+        return _windows(x, n).mean(axis=1)
+    cs = np.concatenate([[0.0], np.cumsum(x.astype(np.longdouble))])
+    return np.asarray((cs[n:] - cs[:-n]) / n, dtype=np.float64)
+
+
+def rolling_var_valid(x, n, ddof=1):
+    """pd.rolling_var(x, n)[n-1:] (ddof=1 as in pandas 0.17)."""
+    x = np.asarray(x, dtype=np.float64)
+    if len(x) * int(n) <= 5_000_000:
+        return _windows(x, n).var(axis=1, ddof=ddof)
+    xl = x.astype(np.longdouble)
+    c1 = np.concatenate([[0.0], np.cumsum(xl)])
+    c2 = np.concatenate([[0.0], np.cumsum(xl * xl)])
+    s1 = c1[n:] - c1[:-n]
+    s2 = c2[n:] - c2[:-n]
+    out = (s2 - s1 * s1 / n) / (n - ddof)
+    return np.asarray(out, dtype=np.float64)
+
+
+def rolling_mean_centered(x, n):
+    """pd.rolling_mean(x, n, center=True): NaN where the window is not full.
+
+    pandas centres a window of n on index i as [i-(n-1)//2 ... ] shifted so the
+    trailing-window result at index j is placed at j - (n-1)//2.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    n = int(n)
+    out = np.full(len(x), np.nan)
+    if n > len(x) or n < 1:
+        return out
+    valid = rolling_mean_valid(x, n)          # trailing windows ending at n-1..
+    off = (n - 1) // 2
+    # trailing result at index j (j >= n-1) moves to j - off
+    out[n - 1 - off: n - 1 - off + len(valid)] = valid
+    return out
+
+
+# --------------------------------------------------------------------------
+# multiplexing / spectra                                     construct.py
+# --------------------------------------------------------------------------
+
+def multiplex(chans, trim=True):
+    """construct.py:928-987 -- interleave Nc channel arrays sample-wise
+    (vstack(chans).flatten(order='F'), lines 977-978), trimming every channel
+    to the shortest (970-974).  ``chans`` must already be in st.sort() order."""
+    chans = [np.asarray(c) for c in chans]
+    L = min(len(c) for c in chans)
+    return np.vstack([c[:L] for c in chans]).flatten(order='F')
+
+
+def fft_len_events(n):
+    """construct.py:669-676 -- nfft = 2 ** (2*len(mp)).bit_length()."""
+    return 2 ** int(2 * n).bit_length()
+
+
+def get_freq_domain(mp):
+    """construct.py:669-676."""
+    return scipy.fftpack.fft(mp, n=fft_len_events(len(mp)))
+
+
+# --------------------------------------------------------------------------
+# pairwise normalised cross-correlation                      construct.py
+# --------------------------------------------------------------------------
+
+def subsamp(ceval, ind):
+    """construct.py:397-422 -- cosine-fit sub-sample shift (Cespedes 1995).
+    Returns ``ind`` itself when |tau| > .5 (reference quirk, 418-421)."""
+    if ind == 0 or ind == len(ceval) - 1:
+        return 0.0
+    cb4 = ceval[ind - 1]
+    caf = ceval[ind + 1]
+    cn = ceval[ind]
+    with np.errstate(all='ignore'):
+        alpha = np.arccos((cb4 + caf) / (2 * cn))
+        alsi = np.sin(alpha)
+        tau = -(np.arctan((cb4 - caf) / (2 * cn * alsi)) / alpha)
+    if abs(tau) > .5:
+        return ind
+    return tau
+
+
+def ccx2_reduce(raw, n, Nc, trunc, scrub_tol=0.0):
+    """construct.py:453-466 -- truncate, scrub, max/argmax, sub-sample, lag.
+
+    ``raw`` is the channel-aligned CC vector ([Nc-1::Nc], 2L-1 lags).
+    ``scrub_tol`` = 0 is the reference rule (> 1 or < -1 -> 0, line 461); the
+    HIP path uses 1e-5 so that a correlation of 1 + one fp32 ulp (identical
+    events) is not zeroed -- the reference itself zeroes or keeps such a value
+    depending on float64 rounding luck, see DESIGN.md "knife-edge scrub".
+    Returns (maxcc, sampleLag, subsamp, scrubbed_vector)."""
+    result = np.array(raw[trunc: -trunc], dtype=np.float64)
+    hi = 1.0 + scrub_tol
+    try:
+        with np.errstate(all='ignore'):
+            maxcc = np.nanmax(result)
+            mincc = np.nanmin(result)
+            maxind = np.nanargmax(result)
+            if maxcc > hi or mincc < -hi:
+                result[(result > hi) | (result < -hi)] = 0
+                maxcc = np.nanmax(result)
+                maxind = np.nanargmax(result)
+    except ValueError:
+        return 0.0, 0.0, 0.0, result
+    ss = subsamp(result, maxind)
+    return maxcc, (maxind + 1 + trunc) * Nc - n, ss, result
+
+
+def ccx2_raw_fft(x1, x2, Nc, fd1=None, fd2=None):
+    """construct.py:438-452 step by step (FFT form): the channel-aligned CC
+    vector before truncation / scrubbing."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    n = len(x1)
+    if fd1 is None:
+        fd1 = get_freq_domain(x1)
+    if fd2 is None:
+        fd2 = get_freq_domain(x2)
+    pad = np.pad(x2, (n - 1, n - 1), 'constant')                 # 443-445
+    a = rolling_mean_valid(pad, n)                               # 446
+    with np.errstate(all='ignore'):
+        b = np.sqrt(rolling_var_valid(pad, n, ddof=1))           # 447
+        b = b * np.sqrt((n - 1.0) / n)                           # 448
+        c = np.real(scipy.fftpack.ifft(np.conj(fd1) * fd2))      # 449
+        c1 = np.concatenate([c[-(n - 1):], c[:n]])               # 450
+        return ((c1 - x1.sum() * a) / (n * b * np.std(x1)))[Nc - 1::Nc]  # 452
+
+
+def ccx2_raw_direct(x1, x2, Nc):
+    """Closed form of construct.py:438-452.
+
+    For sample lag s in [-(L-1), L-1], k = s*Nc: w_s[j] = x2[j+k] (0 outside),
+    cc(s) = (x1.w_s - sum(x1) mean(w_s)) / (n std_pop(w_s) std_pop(x1)).
+    This is the arithmetic the HIP kernel performs."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    n = len(x1)
+    L = n // Nc
+    pad = np.pad(x2, (n - 1, n - 1), 'constant')
+    # element i of the reference's (pre-slice) vector is the window starting at
+    # pad[i]; [Nc-1::Nc] keeps i = Nc-1 + Nc*m, i.e. lag (m+1)*Nc - n
+    idx = np.arange(Nc - 1, 2 * n - 1, Nc)
+    sx1 = x1.sum()
+    sd1 = np.std(x1)
+    res = np.empty(len(idx))
+    with np.errstate(all='ignore'):
+        for o, i in enumerate(idx):
+            w = pad[i: i + n]
+            sd = w.std()
+            if sd == 0:
+                # zero-variance (all-zero / constant) window: the reference
+                # divides FFT round-off by ~0 and gets +-inf, which its scrub
+                # (construct.py:458-462) turns into 0.  State that as +inf.
+                # (All-zero x2, or zero-variance x1, gives exact 0/0 = NaN in the
+                # reference too -> all-NaN -> its ValueError path -> (0, 0, 0).)
+                res[o] = np.inf if (x2.any() and sd1 > 0) else np.nan
+            else:
+                res[o] = (np.dot(x1, w) - sx1 * w.mean()) / (n * sd * sd1)
+    assert len(res) == 2 * L - 1
+    return res
+
+
+def ccx2_fft(x1, x2, Nc, fd1=None, fd2=None, scrub_tol=0.0):
+    """construct.py:425-466 (FFT form) -> (maxcc, sampleLag, subsamp, vector)."""
+    n = len(x1)
+    return ccx2_reduce(ccx2_raw_fft(x1, x2, Nc, fd1, fd2), n, Nc,
+                       n // (2 * Nc) - 1, scrub_tol)             # 439
+
+
+def ccx2_direct(x1, x2, Nc, scrub_tol=0.0):
+    """construct.py:425-466 (closed form) -> (maxcc, sampleLag, subsamp, vector)."""
+    n = len(x1)
+    return ccx2_reduce(ccx2_raw_direct(x1, x2, Nc), n, Nc,
+                       n // (2 * Nc) - 1, scrub_tol)
+
+
+def make_cclags(events_td, Nc, form='fft'):
+    """construct.py:369-394 -- all pairs b < c.  Returns three (N-1)x(N-1)
+    float arrays (index 0..N-2, columns 1..N-1 -> array column c-1), NaN below
+    the diagonal, exactly the layout of DFcc / DFlag / DFsubsamp."""
+    N = len(events_td)
+    cc = np.full((N - 1, N - 1), np.nan)
+    lag = np.full((N - 1, N - 1), np.nan)
+    ss = np.full((N - 1, N - 1), np.nan)
+    fds = [get_freq_domain(np.asarray(e, dtype=np.float64)) for e in events_td] \
+        if form == 'fft' else None
+    for b in range(N - 1):
+        for c in range(b + 1, N):
+            if form == 'fft':
+                m, l, s, _ = ccx2_fft(events_td[b], events_td[c], Nc,
+                                      fds[b], fds[c])
+            else:
+                m, l, s, _ = ccx2_direct(events_td[b], events_td[c], Nc)
+            cc[b, c - 1] = m
+            lag[b, c - 1] = l
+            ss[b, c - 1] = s
+    return cc, lag, ss
+
+
+def condensed_dissimilarity(cc):
+    """construct.py:153-157, 604-612 -- 1.0000001 - cc flattened row-major with
+    the NaNs (below-diagonal cells) dropped = SciPy condensed order."""
+    cx = (1.0000001 - np.asarray(cc, dtype=np.float64)).flatten()
+    return cx[~np.isnan(cx)]
+
+
+def fast_normcorr(t, s):
+    """construct.py:469-483."""
+    t = np.asarray(t, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    if len(t) > len(s):
+        t, s = s, t
+    n = len(t)
+    nt = (t - np.mean(t)) / (np.std(t) * n)
+    sum_nt = nt.sum()
+    a = rolling_mean_valid(s, n)
+    b = np.sqrt(rolling_var_valid(s, n, ddof=1)) * np.sqrt((n - 1.0) / n)
+    c = np.convolve(nt[::-1], s, mode='valid')
+    return (c - sum_nt * a) / b
+
+
+# --------------------------------------------------------------------------
+# subspace detection statistic                      detect.py / fas.py
+# --------------------------------------------------------------------------
+
+def ds_fft_len(data_len_samples, n):
+    """detect.py:367-370 / fas.py:165-167 -- reqlen and its power of two."""
+    reqlen = int(data_len_samples + n)
+    return reqlen, 2 ** reqlen.bit_length()
+
+
+def mpxds_fft(x, U, Nc, rbi=None):
+    """detect.py:559-578 == fas.py:120-134 (FFT form, step by step).
+
+    x : multiplexed data block (M,), U : basis (K, n).  Returns DS of length
+    (M - n)//Nc + 1."""
+    x = np.asarray(x, dtype=np.float64)
+    U = np.atleast_2d(np.asarray(U, dtype=np.float64))
+    n = U.shape[1]
+    if rbi is None:
+        rbi = 2 ** int(len(x) + n).bit_length()
+    a = rolling_mean_valid(x, n)                                 # 566
+    b = rolling_var_valid(x, n, ddof=1) * n                      # 567-568
+    sum_ss = U.sum(axis=1)                                       # 569
+    av_norm = a.reshape(1, -1) * sum_ss.reshape(-1, 1)           # 570-572
+    ssFD = np.array([scipy.fftpack.fft(u[::-1], n=rbi) for u in U])
+    xFD = scipy.fftpack.fft(x, n=rbi)
+    m1 = ssFD * xFD                                              # 573
+    if1 = np.real(scipy.fftpack.ifft(m1))[:, n - 1:len(x)] - av_norm  # 575
+    with np.errstate(all='ignore'):
+        result = np.sum(np.square(if1), axis=0) / b              # 576
+    return result[::Nc]                                          # 577
+
+
+def mpxds_direct(x, U, Nc):
+    """Closed form of detect.py:559-578:
+    DS[p] = sum_k (U_k.w - S_k mu)^2 / (n/(n-1) sum_q (w_q - mu)^2),
+    w = x[p*Nc : p*Nc+n].  This is the arithmetic the HIP kernel performs."""
+    x = np.asarray(x, dtype=np.float64)
+    U = np.atleast_2d(np.asarray(U, dtype=np.float64))
+    K, n = U.shape
+    P = (len(x) - n) // Nc + 1
+    S = U.sum(axis=1)
+    out = np.empty(P)
+    with np.errstate(all='ignore'):
+        for p in range(P):
+            w = x[p * Nc: p * Nc + n]
+            mu = w.mean()
+            den = n / (n - 1.0) * np.sum((w - mu) ** 2)
+            out[p] = np.sum((U @ w - S * mu) ** 2) / den
+    return out
+
+
+def scrub_ds(ssd):
+    """detect.py:275-281 -- MaxDS = ssd.max(); if MaxDS > 1.1 zero the infs and
+    recompute.  Returns (ssd, MaxDS); mutates a copy."""
+    ssd = np.array(ssd, dtype=np.float64)
+    maxds = ssd.max()
+    if maxds > 1.1:
+        ssd[np.isinf(ssd)] = 0
+        maxds = ssd.max()
+    return ssd, maxds
+
+
+HIST_BINS = np.linspace(0, 1, num=401)          # detect.py:80
+FAS_BINS = np.linspace(-.01, 1, num=401)        # fas.py:31
+
+
+def ds_histogram(ds, bins=HIST_BINS):
+    """detect.py:178-181 -- np.histogram(DS, bins)."""
+    return np.histogram(np.asarray(ds, dtype=np.float64), bins=bins)[0]
+
+
+def replace_nan_with_mean(arg):
+    """detect.py:516-524 (note arg[first + 1], reference quirk)."""
+    ind = np.where(~np.isnan(arg))[0]
+    first, last = ind[0], ind[-1]
+    arg[:first] = arg[first + 1]
+    arg[last + 1:] = arg[last]
+    return arg
+
+
+def get_stalta(C, LTA, STA):
+    """detect.py:501-514."""
+    C = np.asarray(C, dtype=np.float64)
+    if STA == 0:
+        STA = 1
+        st = np.abs(C)
+    else:
+        st = replace_nan_with_mean(rolling_mean_centered(np.abs(C), STA))
+    lt = replace_nan_with_mean(rolling_mean_centered(np.abs(C), LTA))
+    with np.errstate(all='ignore'):
+        return np.divide(st, lt)
+
+
+def downplay_around_max(C, sr, dpv=0, buff=20):
+    """detect.py:545-557 -- zero +-buff s around the max, in place."""
+    index = C.argmax()
+    if index < buff * sr + 1:
+        C[0:int(index + buff * sr)] = dpv
+    elif index > len(C) - buff * sr:
+        C[int(index - sr * buff):] = dpv
+    else:
+        C[int(index - sr * buff):int(sr * buff + index)] = dpv
+    return C
+
+
+def eval_trig_con(maxds, threshold):
+    """detect.py:526-543, trigCon == 0: strict '>'."""
+    return bool(maxds > threshold)
+
+
+def pick_triggers(ds, threshold, sr, start, offsets=(0.0,), stalta=None,
+                  maxcount=4000):
+    """detect.py:390-445 -- trigger-picking loop (trigCon == 0, magnitudes off).
+
+    Returns a list of dicts with the reference's columns that do not depend on
+    magnitude estimation: index, DS, DS_STALTA, STMP, MSTAMPmin, MSTAMPmax."""
+    ds = np.asarray(ds, dtype=np.float64)
+    ceval = ds.copy()
+    out = []
+    count = 0
+    minof, maxof = np.min(offsets), np.max(offsets)
+    while ceval.max() >= threshold:                              # 410
+        trig = int(ceval.argmax())                               # 411
+        coef = ds[trig]
+        times = float(trig) / sr + start                         # 413
+        sl = 0.0 if stalta is None else stalta[trig]
+        ceval = downplay_around_max(ceval, sr, 0)                # 421
+        if count > maxcount:                                     # 433
+            raise RuntimeError('over 4000 events found in single data block')
+        out.append(dict(index=trig, DS=coef, DS_STALTA=sl, STMP=times,
+                        MSTAMPmin=times - maxof, MSTAMPmax=times - minof))
+        count += 1
+    return out
+
+
+# --------------------------------------------------------------------------
+# SVD basis construction                                     subspace.py
+# --------------------------------------------------------------------------
+
+def trim_groups(aligned, start=None, end=None):
+    """subspace.py:921-943 -- rows = aligned[start:end] - mean."""
+    rows = []
+    for w in aligned:
+        w = np.asarray(w, dtype=np.float64)
+        if start is not None:
+            s = max(int(start), 0)
+            w = w[s:int(end)]
+        rows.append(w - np.mean(w))
+    return np.vstack(rows)
+
+
+def svd_basis(arr, normalize=False):
+    """subspace.py:886-895 -- U, s of svd(arr.T, full_matrices=False)."""
+    arr = np.asarray(arr, dtype=np.float64)
+    if normalize:
+        arr = np.array([x / np.linalg.norm(x) for x in arr])
+    U, s, Vh = scipy.linalg.svd(arr.T, full_matrices=False)
+    return U, s
+
+
+def frac_energy(U, waveforms):
+    """subspace.py:968-997 -- cumulative fractional energy capture per event
+    (waveforms NOT demeaned here, 979-988), plus Average / Minimum."""
+    fr = []
+    for w in waveforms:
+        w = np.asarray(w, dtype=np.float64)
+        nu = np.dot(U.T, w) / scipy.linalg.norm(w)
+        rep = np.insert(np.square(nu), 0, 0)
+        fr.append([np.sum(rep[:x + 1]) for x in range(len(rep))])
+    fr = np.array(fr)
+    return fr, np.average(fr, axis=0), np.min(fr, axis=0)
+
+
+def used_basis_count(average, selectCriteria, selectValue):
+    """subspace.py:999-1013 -- number of basis vectors kept."""
+    if selectCriteria in (1, 2, 3):
+        av = np.array(average, dtype=np.float64)
+        av[-1] = 1.00
+        return int(np.argmax(av >= selectValue))
+    if selectCriteria == 4:
+        return int(selectValue) + 1
+    raise ValueError('selectCriteria of %s is not supported' % selectCriteria)
+
+
+def threshold_criteria3(minimum, numbasis, selectValue):
+    """subspace.py:1049-1054."""
+    return minimum[numbasis] * selectValue

@@ -1,0 +1,313 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, which does not exist
+on the GPU box).  The reference (d-chambers/Detex v1.0.9) is imported through
+the stub/shim preamble in ``_ref_import.py``; its own hot-path functions are
+called unmodified on seeded synthetic inputs and the inputs + outputs are
+stored as small .npz fixtures.  The fixtures are data only.
+
+    python tests/golden/make_golden.py
+
+Reference entry points exercised (file:line in /root/reference):
+  detex/construct.py:425-466  _CCX2          -> ccx2.npz
+  detex/construct.py:397-422  _subSamp       -> ccx2.npz (through _CCX2)
+  detex/construct.py:369-394  _makeDFcclags  -> cclags.npz
+  detex/construct.py:469-483  fast_normcorr  -> normcorr.npz
+  detex/detect.py:559-578     _MPXDS         -> mpxds.npz
+  detex/fas.py:120-134        _MPXSSCorr     -> mpxds.npz (bit-equal twin)
+  detex/detect.py:501-524     _getStaLtaArray-> trig.npz
+  detex/detect.py:390-445     _CreateCoeffArray, 545-557 _downPlay..., 526-543
+                              _evalTrigCon   -> trig.npz
+"""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import scipy.fftpack
+from scipy.cluster.hierarchy import linkage
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_import import import_reference  # noqa: E402
+
+detex = import_reference()
+construct = detex.construct
+SSDetex = detex.detect._SSDetex
+
+
+def _bandlimited(rs, L, width=5):
+    """Smooth random series (moving-average of white noise), zero mean."""
+    w = rs.randn(L + width - 1)
+    k = np.hanning(width + 2)[1:-1]
+    y = np.convolve(w, k / k.sum(), mode='valid')
+    return y - y.mean()
+
+
+def _mp(chans):
+    return np.vstack(chans).flatten(order='F')
+
+
+# ---------------------------------------------------------------- _CCX2
+def gen_ccx2():
+    out = {}
+    captured = {}
+    orig_subsamp = construct._subSamp
+
+    def spy(ceval, ind):
+        captured['result'] = np.array(ceval, dtype=np.float64)
+        captured['ind'] = int(ind)
+        return orig_subsamp(ceval, ind)
+
+    construct._subSamp = spy
+    names = []
+    try:
+        case = 0
+        for (Nc, L) in [(1, 64), (3, 50), (3, 400), (6, 33), (2, 7)]:
+            for seed in range(4):
+                rs = np.random.RandomState(100 * Nc + L + seed)
+                kinds = ['random', 'shifted', 'identical', 'zeroed_chan',
+                         'offset', 'zero_tail']
+                for kind in kinds:
+                    if kind != 'random' and seed > 1:
+                        continue
+                    c1 = [_bandlimited(rs, L) for _ in range(Nc)]
+                    if kind == 'random':
+                        c2 = [_bandlimited(rs, L) for _ in range(Nc)]
+                    elif kind == 'shifted':
+                        sh = int(rs.randint(-L // 4, L // 4 + 1))
+                        c2 = [np.roll(c, sh) + 0.1 * rs.randn(L) for c in c1]
+                    elif kind == 'identical':
+                        c2 = [c.copy() for c in c1]
+                    elif kind == 'zeroed_chan':
+                        c2 = [_bandlimited(rs, L) for _ in range(Nc)]
+                        c2[-1] = np.zeros(L)
+                        c1[-1] = np.zeros(L)
+                    elif kind == 'offset':
+                        c2 = [c + 3.0 for c in c1]
+                    elif kind == 'zero_tail':
+                        # long zeroed stretch -> zero-variance windows -> inf/nan
+                        c2 = [c.copy() for c in c1]
+                        for c in c2:
+                            c[L // 3:] = 0.0
+                    x1, x2 = _mp(c1), _mp(c2)
+                    fd = lambda x: scipy.fftpack.fft(  # noqa: E731
+                        x, n=2 ** int(2 * len(x)).bit_length())
+                    captured.clear()
+                    cc, lag, ss = construct._CCX2(fd(x1), fd(x2), x1, x2,
+                                                  [0] * Nc, [0] * Nc)
+                    key = 'c%03d' % case
+                    names.append('%s:Nc=%d,L=%d,seed=%d,%s' % (key, Nc, L, seed, kind))
+                    out[key + '_x1'] = x1
+                    out[key + '_x2'] = x2
+                    out[key + '_Nc'] = np.int64(Nc)
+                    out[key + '_out'] = np.array([cc, lag, ss], dtype=np.float64)
+                    out[key + '_result'] = captured.get('result', np.zeros(0))
+                    case += 1
+    finally:
+        construct._subSamp = orig_subsamp
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'ccx2.npz'), **out)
+    print('ccx2.npz: %d cases' % case)
+
+
+# ---------------------------------------------------------------- _makeDFcclags
+def _family_events(rs, nfam, nper, Nc, L, maxshift, snr):
+    evs, fam = [], []
+    for f in range(nfam):
+        wav = [_bandlimited(rs, L + 2 * maxshift) *
+               np.exp(-np.arange(L + 2 * maxshift) / (0.3 * L)) for _ in range(Nc)]
+        for e in range(nper):
+            sh = int(rs.randint(0, 2 * maxshift + 1))
+            amp = rs.uniform(0.5, 2.0)
+            chans = [amp * w[sh: sh + L] + rs.randn(L) * np.std(w) / snr
+                     for w in wav]
+            evs.append(_mp(chans))
+            fam.append(f)
+    return evs, fam
+
+
+def gen_cclags():
+    out = {}
+    for tag, (nfam, nper, Nc, L, seed) in {
+            'a': (2, 3, 3, 120, 7), 'b': (3, 3, 1, 96, 8)}.items():
+        rs = np.random.RandomState(seed)
+        evs, fam = _family_events(rs, nfam, nper, Nc, L, 10, 8.0)
+        names = ['ev%02d' % i for i in range(len(evs))]
+        row = pd.Series({
+            'MPtd': {k: v for k, v in zip(names, evs)},
+            'MPfd': {k: scipy.fftpack.fft(v, n=2 ** int(2 * len(v)).bit_length())
+                     for k, v in zip(names, evs)},
+            'Channels': {k: ['C%d' % c for c in range(Nc)] for k in names},
+        })
+        DFcc, DFlag, DFss = construct._makeDFcclags(names, row)
+        cc = DFcc.values.astype(np.float64)
+        lag = DFlag.values.astype(np.float64)
+        ss = DFss.values.astype(np.float64)
+        # dissimilarity + single linkage exactly as construct.py:153-157
+        cx = 1.0000001 - DFcc
+        cxflat = construct._flatNoNan(cx)
+        cxflat = np.asarray(cxflat, dtype=np.float64)
+        link = linkage(cxflat)
+        out[tag + '_events'] = np.array(evs)
+        out[tag + '_Nc'] = np.int64(Nc)
+        out[tag + '_fam'] = np.array(fam)
+        out[tag + '_cc'] = cc
+        out[tag + '_lag'] = lag
+        out[tag + '_subsamp'] = ss
+        out[tag + '_cx'] = cxflat
+        out[tag + '_link'] = link
+    np.savez_compressed(os.path.join(HERE, 'cclags.npz'), **out)
+    print('cclags.npz written')
+
+
+# ---------------------------------------------------------------- fast_normcorr
+def gen_normcorr():
+    out = {}
+    rs = np.random.RandomState(21)
+    for i, (nt, ns) in enumerate([(30, 30), (40, 200), (17, 100)]):
+        t = _bandlimited(rs, nt) + rs.randn() * 0.2
+        s = _bandlimited(rs, ns)
+        s[5:5 + min(nt, ns - 5)] += 2 * t[:min(nt, ns - 5)]
+        out['n%d_t' % i] = t
+        out['n%d_s' % i] = s
+        out['n%d_out' % i] = construct.fast_normcorr(t, s)
+    np.savez_compressed(os.path.join(HERE, 'normcorr.npz'), **out)
+    print('normcorr.npz written')
+
+
+# ---------------------------------------------------------------- _MPXDS
+def _ref_mpxds(x, U, Nc):
+    n = U.shape[1]
+    reqlen = int(len(x) + n)
+    rbi = 2 ** reqlen.bit_length()
+    ssFD = np.array([scipy.fftpack.fft(u[::-1], n=rbi) for u in U])
+    xFD = scipy.fftpack.fft(x, n=rbi)
+    ds = SSDetex._MPXDS(None, x, reqlen, U, ssFD, Nc, xFD)
+    ds2 = detex.fas._MPXSSCorr(x, reqlen, U, ssFD, Nc)
+    assert np.array_equal(ds, ds2, equal_nan=True)
+    return ds
+
+
+def gen_mpxds():
+    out = {}
+    names = []
+    case = 0
+    for (Nc, K, L, T, seed, kind) in [
+            (1, 1, 40, 700, 0, 'subspace'), (1, 4, 64, 900, 1, 'subspace'),
+            (3, 1, 40, 600, 2, 'single'), (3, 4, 100, 1500, 3, 'subspace'),
+            (3, 8, 300, 2000, 4, 'subspace'), (6, 4, 50, 800, 5, 'subspace'),
+            (6, 1, 33, 500, 6, 'single'), (3, 4, 100, 1500, 7, 'f32'),
+            (3, 2, 60, 900, 8, 'zero_gap'), (2, 3, 45, 701, 9, 'ragged')]:
+        rs = np.random.RandomState(1000 + seed)
+        n = Nc * L
+        if kind == 'single':
+            # singles: U = x/||x||, NOT demeaned (detect.py:364)
+            ev = _mp([_bandlimited(rs, L) + 0.3 for _ in range(Nc)])
+            U = (ev / np.linalg.norm(ev))[None, :]
+        else:
+            A = np.array([_mp([_bandlimited(rs, L) for _ in range(Nc)])
+                          for _ in range(max(K, 2) + 2)])
+            A = A - A.mean(axis=1, keepdims=True)
+            Ufull, s, _ = np.linalg.svd(A.T, full_matrices=False)
+            U = Ufull[:, :K].T.copy()
+        x = _mp([_bandlimited(rs, T) for _ in range(Nc)])
+        if kind == 'ragged':
+            x = x[:-1]                       # M not a multiple of Nc
+        # plant a scaled event (a combination of the basis) + leave noise
+        pos = (T // 3) * Nc
+        coef = rs.uniform(1, 2, U.shape[0]) * rs.choice([-1, 1], U.shape[0])
+        comb = (coef @ U) * 8.0 * np.sqrt(L / 40.0)
+        x[pos: pos + n] += comb
+        if kind == 'zero_gap':
+            x[Nc * 200: Nc * 200 + 3 * n] = 0.0     # fillZeros-style gap
+        if kind == 'f32':
+            x = x.astype(np.float32)
+            U = U.astype(np.float32)
+        ds = _ref_mpxds(x, U, Nc)
+        key = 'm%02d' % case
+        names.append('%s:Nc=%d,K=%d,L=%d,T=%d,%s' % (key, Nc, K, L, T, kind))
+        out[key + '_x'] = x
+        out[key + '_U'] = U
+        out[key + '_Nc'] = np.int64(Nc)
+        out[key + '_ds'] = np.asarray(ds)
+        out[key + '_pos'] = np.int64(pos // Nc)
+        case += 1
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'mpxds.npz'), **out)
+    print('mpxds.npz: %d cases' % case)
+
+
+# ---------------------------------------------------------------- triggers
+def _fake_ssdetex(trigCon=0, fillZeros=False, estimateMags=False):
+    obj = object.__new__(SSDetex)
+    obj.trigCon = trigCon
+    obj.fillZeros = fillZeros
+    obj.estimateMags = estimateMags
+    obj.issubspace = True
+    return obj
+
+
+def gen_trig():
+    out = {}
+    names = []
+    sr = 20.0            # 20 Hz -> +-20 s = +-400 samples
+    P = 6000
+    start = 1.4e9 + 0.25
+    offsets = np.array([1.5, 2.25, 4.0])
+    obj = _fake_ssdetex()
+    case = 0
+    for seed, peaks, thr in [
+            (0, [(3000, .8)], .5),
+            (1, [(100, .7), (5950, .9)], .5),                 # near both edges
+            (2, [(2000, .6), (2300, .75), (2650, .55)], .5),  # < 20 s apart
+            (3, [(401, .7), (5599, .65), (5600, .65)], .6),   # edge rule + tie
+            (4, [], .5),                                      # nothing triggers
+            (5, [(1000, .5)], .5),                            # max == thr (>= vs >)
+            (6, [(10, 1.3), (3000, .9)], .5)]:                # DS > 1.05 case
+        rs = np.random.RandomState(50 + seed)
+        ds = np.abs(rs.randn(P)) * 0.02
+        for (idx, amp) in peaks:
+            w = np.exp(-0.5 * ((np.arange(P) - idx) / 6.0) ** 2)
+            ds = np.maximum(ds, amp * w)
+        for (idx, amp) in peaks:
+            ds[idx] = amp
+        sl = obj._getStaLtaArray(ds.copy(), 5 * sr, 0 * sr)
+        sl2 = obj._getStaLtaArray(ds.copy(), 5 * sr, 0.5 * sr)
+        cor = pd.Series({'SSdetect': ds.copy(), 'STALTA': sl.copy(),
+                         'TimeStamp': start, 'SampRate': sr,
+                         'MaxDS': ds.max(), 'Nc': 3})
+        name = 'SS0'
+        trig = obj._evalTrigCon(cor, name, {name: thr})
+        rows = np.zeros((0, 5))
+        if trig:
+            sar = obj._CreateCoeffArray(cor, name, {name: thr}, 'NET.STA',
+                                        {name: offsets}, None, None, None,
+                                        None, None, None, None)
+            rows = sar[['DS', 'DS_STALTA', 'STMP', 'MSTAMPmin',
+                        'MSTAMPmax']].values.astype(np.float64)
+        key = 't%02d' % case
+        names.append('%s:seed=%d,thr=%g,npk=%d' % (key, seed, thr, len(peaks)))
+        out[key + '_ds'] = ds
+        out[key + '_thr'] = np.float64(thr)
+        out[key + '_trig'] = np.bool_(trig)
+        out[key + '_rows'] = rows
+        out[key + '_stalta_sta0'] = sl
+        out[key + '_stalta_sta05'] = sl2
+        out[key + '_hist'] = np.histogram(ds, bins=np.linspace(0, 1, num=401))[0]
+        case += 1
+    out['sr'] = np.float64(sr)
+    out['start'] = np.float64(start)
+    out['offsets'] = offsets
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'trig.npz'), **out)
+    print('trig.npz: %d cases' % case)
+
+
+if __name__ == '__main__':
+    gen_ccx2()
+    gen_cclags()
+    gen_normcorr()
+    gen_mpxds()
+    gen_trig()
