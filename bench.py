@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Headline benchmark: detection windows/sec of the subspace detection scan
+(BASELINE.json configs[1]: 200 basis vectors x 24 h of 3-channel 100 Hz data,
+as 24 chunks of 3720 s, on one MI355X; N GPUs = N station-days, weak scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one station-day: for each of the 24
+chunks the detection statistic of all 25 detectors (8 basis vectors each) at
+every window, plus the histogram / max / threshold-candidate pass.  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--detectors', type=int, default=25)
+    ap.add_argument('--basis-per-detector', type=int, default=8)
+    ap.add_argument('--chunks', type=int, default=24)
+    ap.add_argument('--chunk-seconds', type=float, default=3720.0)   # 3600 + 120 (getdata.py:299)
+    ap.add_argument('--sr', type=float, default=100.0)
+    ap.add_argument('--nc', type=int, default=3)
+    ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-vectors', type=int, default=40,
+                    help='basis vectors the CPU baseline sample covers')
+    return ap.parse_args()
+
+
+def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
+    """The reference's FFT algorithm (oracle restatement, NumPy/SciPy float64,
+    one thread -- the reference has no parallelism, subspace.py:1843-1845) on ONE
+    chunk and the first `nvec` basis vectors; extrapolated linearly in the number
+    of basis vectors (the cost is one length-2^21 IFFT per vector)."""
+    import scipy.fftpack
+    from oracle import detex_oracle as orc
+    x = x_chunk.astype(np.float64)
+    n = U.shape[1]
+    K = U.shape[0]
+    rbi = 2 ** int(len(x) + n).bit_length()
+    t0 = time.perf_counter()
+    xFD = scipy.fftpack.fft(x, n=rbi)                       # detect.py:255-256
+    done = 0
+    d = 0
+    while done < nvec and d < len(det_off) - 1:
+        Ud = U[det_off[d]:det_off[d + 1]].astype(np.float64)
+        orc.mpxds_fft(x, Ud, Nc, rbi=rbi, xFD=xFD)
+        done += Ud.shape[0]
+        d += 1
+    dt = time.perf_counter() - t0
+    P = (len(x) - n) // Nc + 1
+    full = dt * K / done                                    # seconds per chunk, all K vectors
+    return dict(value=P / full, unit='windows/s', cores=1, kind='port',
+                sample='1 chunk (%d samples) x %d of %d basis vectors, float64 FFT path, '
+                       '%.1f s measured, scaled linearly to %d vectors' % (len(x), done, K, dt, K))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    torch.cuda.set_device(local)
+    from detex_amd.hip import HipContext
+    from detex_amd import synth
+
+    Nc = a.nc
+    L = int(round(a.template_seconds * a.sr))
+    n = Nc * L
+    M = int(round(a.chunk_seconds * a.sr)) * Nc
+    D, k = a.detectors, a.basis_per_detector
+    K = D * k
+    ctx = HipContext(local)
+
+    # detector basis: built on rank 0, broadcast over RCCL/xGMI (the only collective)
+    if rank == 0:
+        U, det_off = synth.detector_bank(1, D, k, n)
+        Ut = torch.from_numpy(U).cuda()
+    else:
+        Ut = torch.empty((K, n), dtype=torch.float32, device='cuda')
+        det_off = (np.arange(D + 1) * k).astype(np.int32)
+    if world > 1:
+        dist.broadcast(Ut, src=0)
+    ctx.upload_basis(Ut, det_off, Nc)
+    Uh = Ut.cpu().numpy()
+
+    # one station-day per rank (seed = 1000*station + day, SURVEY.md 8d cfg 4)
+    x, plants = synth.continuous_day(1000 * rank + 1, a.chunks, M, Nc, Uh, det_off, nplant=50)
+    xt = torch.from_numpy(x).cuda()
+    P = ctx.num_windows(M)
+    ds = torch.empty((a.chunks, D, P), dtype=torch.float32, device='cuda')
+    thr = np.full(D, 0.3, dtype=np.float32)
+    hist = torch.zeros((D, 400), dtype=torch.int32, device='cuda')
+
+    def step():
+        ctx.subspace_ds(xt, out=ds)
+        return ctx.ds_post(ds, thr=thr, hist=hist)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kern_ms = []
+    for _ in range(a.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+        kern_ms.append(None)
+    barrier()
+    dt = time.perf_counter() - t0
+    # dominant-kernel time: HIP events recorded around the MFMA kernel on the
+    # context's stream (the last step's launch; steps are identical)
+    kms = ctx.last_kernel_ms()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    windows = a.chunks * P * world * a.steps
+    value = windows / dt
+
+    # sanity: every planted event is a candidate of its own detector
+    cb, cd, cp, cv = res['cand']
+    found = 0
+    for (b, p, d) in plants:
+        sel = (cb == b) & (cd == d) & (np.abs(cp - p) <= 2)
+        found += bool(sel.any())
+
+    flops = 2.0 * K * n * P * a.chunks
+    achieved = flops / (kms * 1e-3) / 1e12
+    out = {
+        'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)',
+        'value': value, 'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: %d basis vectors (%d detectors x %d) x %d chunks of '
+                               '%g s, %d-ch %g Hz, n=%d, one station-day per GPU'
+                               % (K, D, k, a.chunks, a.chunk_seconds, Nc, a.sr, n),
+                   'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
+        'roofline': {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<13,2>', 'achieved': achieved,
+                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'kernel_ms': kms, 'flop_per_launch': flops},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
+    else:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

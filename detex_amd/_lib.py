@@ -1,0 +1,91 @@
+"""ctypes binding of libdetexhip.so (C ABI declared in include/detex_hip.h).
+
+The library is the product's only compute path: there is no NumPy / CPU
+fallback.  If it is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libdetexhip.so'
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+ABI_VERSION = 1
+
+# every symbol include/detex_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    'dtx_version', 'dtx_ctx_create', 'dtx_ctx_destroy', 'dtx_ctx_sync',
+    'dtx_ctx_stream', 'dtx_last_error', 'dtx_basis_upload', 'dtx_num_windows',
+    'dtx_subspace_ds', 'dtx_ds_post', 'dtx_subspace_ds_host',
+    'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_timer_start',
+    'dtx_timer_stop', 'dtx_last_kernel_ms',
+]
+
+
+class DetexHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdetexhip.so (once) and declare its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DetexHipError(
+            '%s not found: build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (or `make -C detex_amd/csrc`).  detex_amd has no CPU '
+            'fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; importing it first makes this
+    # library resolve against the same HIP runtime instance, so device
+    # pointers and streams are shared with torch tensors.
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+    pf = C.POINTER(C.c_float)
+    lib.dtx_version.restype = i32
+    lib.dtx_version.argtypes = []
+    lib.dtx_ctx_create.restype = i32
+    lib.dtx_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    lib.dtx_ctx_destroy.restype = i32
+    lib.dtx_ctx_destroy.argtypes = [vp]
+    lib.dtx_ctx_sync.restype = i32
+    lib.dtx_ctx_sync.argtypes = [vp]
+    lib.dtx_ctx_stream.restype = vp
+    lib.dtx_ctx_stream.argtypes = [vp]
+    lib.dtx_last_error.restype = C.c_char_p
+    lib.dtx_last_error.argtypes = [vp]
+    lib.dtx_basis_upload.restype = i32
+    lib.dtx_basis_upload.argtypes = [vp, vp, vp, i32, i32, i32]
+    lib.dtx_num_windows.restype = i64
+    lib.dtx_num_windows.argtypes = [i64, i32, i32]
+    lib.dtx_subspace_ds.restype = i32
+    lib.dtx_subspace_ds.argtypes = [vp, vp, i64, i64, i32, vp, i64]
+    lib.dtx_ds_post.restype = i32
+    lib.dtx_ds_post.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, u32, vp]
+    lib.dtx_subspace_ds_host.restype = i32
+    lib.dtx_subspace_ds_host.argtypes = [vp, vp, i64, vp]
+    lib.dtx_xcorr_allpairs.restype = i32
+    lib.dtx_xcorr_allpairs.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i64, i64]
+    lib.dtx_xcorr_allpairs_host.restype = i32
+    lib.dtx_xcorr_allpairs_host.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.dtx_timer_start.restype = i32
+    lib.dtx_timer_start.argtypes = [vp]
+    lib.dtx_timer_stop.restype = i32
+    lib.dtx_timer_stop.argtypes = [vp, pf]
+    lib.dtx_last_kernel_ms.restype = i32
+    lib.dtx_last_kernel_ms.argtypes = [vp, pf]
+    if lib.dtx_version() != ABI_VERSION:
+        raise DetexHipError('libdetexhip.so ABI %d != expected %d; rebuild it'
+                            % (lib.dtx_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc, what):
+    if rc != 0:
+        msg = lib.dtx_last_error(ctx)
+        raise DetexHipError('%s failed (%d): %s' % (
+            what, rc, msg.decode('utf-8', 'replace') if msg else ''))

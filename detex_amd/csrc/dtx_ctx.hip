@@ -1,0 +1,139 @@
+// Context, error reporting, workspaces and HIP-event timers of libdetexhip.so.
+#include "dtx_internal.h"
+
+static thread_local std::string g_create_err;
+
+int dtx_fail(dtx_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else g_create_err = buf;
+  return code;
+}
+
+int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes) {
+  if (bytes <= b.bytes) return DTX_OK;
+  if (b.p) {
+    // the old buffer may still be in use by work queued on the stream
+    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DTX_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return dtx_fail(ctx, DTX_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  }
+  b.bytes = want;
+  return DTX_OK;
+}
+
+void dtx_free_tiles_internal(dtx_ctx* c) {
+  for (auto& t : c->tiles) {
+    if (t.ut_dev) (void)hipFree(t.ut_dev);
+    if (t.srow_dev) (void)hipFree(t.srow_dev);
+    if (t.doff_dev) (void)hipFree(t.doff_dev);
+  }
+  c->tiles.clear();
+}
+
+extern "C" {
+
+int dtx_version(void) { return DTX_ABI_VERSION; }
+
+const char* dtx_last_error(dtx_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+int dtx_ctx_create(int device, void* stream, dtx_ctx** out) {
+  if (!out) return dtx_fail(nullptr, DTX_E_ARG, "dtx_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return dtx_fail(nullptr, DTX_E_HIP, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return dtx_fail(nullptr, DTX_E_ARG, "device %d out of range [0,%d)", device, ndev);
+  DtxDeviceGuard g(device);
+  dtx_ctx* c = new dtx_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return dtx_fail(nullptr, DTX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  hipEvent_t* evs[4] = {&c->ev_t0, &c->ev_t1, &c->ev_k0, &c->ev_k1};
+  for (auto ev : evs) {
+    e = hipEventCreate(ev);
+    if (e != hipSuccess) {
+      delete c;
+      return dtx_fail(nullptr, DTX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = c;
+  return DTX_OK;
+}
+
+int dtx_ctx_destroy(dtx_ctx* ctx) {
+  if (!ctx) return DTX_OK;
+  DtxDeviceGuard g(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  dtx_free_tiles_internal(ctx);
+  DtxBuf* bufs[] = {&ctx->ws_xp, &ctx->ws_mean, &ctx->ws_den,
+                    &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3};
+  for (auto b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  hipEvent_t evs[4] = {ctx->ev_t0, ctx->ev_t1, ctx->ev_k0, ctx->ev_k1};
+  for (auto ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DTX_OK;
+}
+
+int dtx_ctx_sync(dtx_ctx* ctx) {
+  if (!ctx) return DTX_E_ARG;
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DTX_OK;
+}
+
+void* dtx_ctx_stream(dtx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int dtx_timer_start(dtx_ctx* ctx) {
+  if (!ctx) return DTX_E_ARG;
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+  return DTX_OK;
+}
+
+int dtx_timer_stop(dtx_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return DTX_E_ARG;
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+  DTX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
+  DTX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_t0, ctx->ev_t1));
+  return DTX_OK;
+}
+
+int dtx_last_kernel_ms(dtx_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return DTX_E_ARG;
+  if (!ctx->kernel_timed) return dtx_fail(ctx, DTX_E_STATE, "no timed kernel has run yet");
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipEventSynchronize(ctx->ev_k1));
+  DTX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_k0, ctx->ev_k1));
+  return DTX_OK;
+}
+
+}  // extern "C"

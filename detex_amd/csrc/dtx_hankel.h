@@ -1,0 +1,245 @@
+// Implicit-Hankel FP32 MFMA main loop shared by the subspace detection statistic
+// (dtx_subspace.hip) and the all-pairs cross-correlation (dtx_xcorr.hip).
+//
+//   Y[k][p] += sum_c sum_{j in [jlo, jhi)} A_c[j][k] * x_c[p + j]
+//
+//   A   "dense" operand, stored transposed and channel-planar in HBM:
+//       A_c[j][k] = at[(c*Lp + j)*ldk + k]    (basis vectors / template events)
+//   x_c channel planes of the "stream" operand, x_c[t] = xw[c*plane_stride + t]
+//       (xw already points at the block's first window), zero padded so that
+//       every read below is in bounds.  The Hankel matrix H[j][p] = x_c[p + j]
+//       is never built: MFMA B fragments are sliding reads of an LDS copy of x_c.
+//
+// One block = 8 waves computes a [KT = 16*RM] x [PT = 128*TN] tile; wave w owns
+// columns [16*TN*w, 16*TN*(w+1)).  Per step of kBQ = 32 contraction indices the
+// block stages A_c[j0:j0+32][0:KT] and x_c[p0+j0 : p0+j0+PT+32] through LDS
+// (register-staged double buffer: global loads for step s+1 are issued before
+// the MFMAs of step s and written to the other buffer after them; one barrier
+// per step).
+//
+// v_mfma_f32_16x16x4_f32 fragments (lane = 16*kq + i, kq = 0..3, i = 0..15):
+//   A[i][kq] = As[(jj+kq)*KTS + 16 r + i]
+//   B[kq][i] = xs[col0 + 16 t + i + jj + kq]
+//   C: row 16 r + 4 kq + reg, column 16 t + i
+// LDS banks (ds_read_b32: two 32-lane groups, 32 banks): B reads touch 17
+// consecutive dwords per group with equal addresses broadcast -> conflict-free.
+// A reads touch two rows (kq, kq+1) of 16 consecutive dwords: conflict-free iff
+// the row stride KTS % 32 == 16, so KTS = KT (+16 when RM is even).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace dtx {
+
+constexpr int kBQ = 32;        // contraction depth staged per step
+constexpr int kThreads = 512;  // 8 waves, 2 per SIMD
+constexpr int kRmMax = 13;     // 13 * 16 = 208 rows per K-tile
+constexpr int kKtMax = 16 * kRmMax;
+
+__host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? 2 : (rm >= 5 ? 4 : 8); }
+__host__ __device__ constexpr int pt_for(int rm) { return 128 * tn_for(rm); }
+__host__ __device__ constexpr int kts_for(int rm) { return 16 * rm + ((rm & 1) ? 0 : 16); }
+// floats of LDS one block needs
+__host__ __device__ constexpr int lds_floats(int rm) {
+  return 2 * (kBQ * kts_for(rm) + pt_for(rm) + kBQ);
+}
+
+template <int RM, int TN>
+__device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const float* __restrict__ at,
+                                                int ldk, int Lp, const float* __restrict__ xw,
+                                                int64_t plane_stride, int Nc, int jlo, int jhi,
+                                                float* lds) {
+  constexpr int KT = 16 * RM;
+  constexpr int KTS = kts_for(RM);
+  constexpr int PT = 128 * TN;
+  constexpr int KV = KT / 4;                         // float4 per staged row
+  constexpr int UV = kBQ * KV;                       // float4 per A tile
+  constexpr int NUV = (UV + kThreads - 1) / kThreads;
+  constexpr int XV = (PT + kBQ) / 4;                 // float4 per x window
+  constexpr int BUF = kBQ * KTS + PT + kBQ;          // floats per LDS buffer
+  static_assert(XV <= kThreads, "x window staged in one pass");
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  const int col0 = wave * 16 * TN;
+  const int spc = (jhi - jlo) / kBQ;                 // steps per channel
+  const int nsteps = Nc * spc;
+  if (nsteps <= 0) return;
+
+  // per-thread staging coordinates (row / float4-column inside the A tile)
+  int srow[NUV], scol[NUV];
+#pragma unroll
+  for (int m = 0; m < NUV; ++m) {
+    const int v = tid + m * kThreads;
+    srow[m] = v / KV;
+    scol[m] = (v - srow[m] * KV) * 4;
+  }
+  float4 ru[NUV];
+  float4 rx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int m = 0; m < NUV; ++m) ru[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define DTX_LOAD_TILE(s_)                                                                  \
+  do {                                                                                     \
+    const int c_ = (s_) / spc;                                                             \
+    const int j0_ = jlo + ((s_) - c_ * spc) * kBQ;                                         \
+    const float* ab_ = at + ((int64_t)c_ * Lp + j0_) * ldk;                                \
+    _Pragma("unroll") for (int m = 0; m < NUV; ++m) {                                      \
+      if ((m + 1) * kThreads <= UV || tid + m * kThreads < UV)                             \
+        ru[m] = *reinterpret_cast<const float4*>(ab_ + (int64_t)srow[m] * ldk + scol[m]);  \
+    }                                                                                      \
+    if (tid < XV)                                                                          \
+      rx = reinterpret_cast<const float4*>(xw + (int64_t)c_ * plane_stride + j0_)[tid];    \
+  } while (0)
+#define DTX_STORE_TILE(buf_)                                                               \
+  do {                                                                                     \
+    float* ud_ = lds + (buf_) * BUF;                                                       \
+    _Pragma("unroll") for (int m = 0; m < NUV; ++m) {                                      \
+      if ((m + 1) * kThreads <= UV || tid + m * kThreads < UV)                             \
+        *reinterpret_cast<float4*>(ud_ + srow[m] * KTS + scol[m]) = ru[m];                 \
+    }                                                                                      \
+    if (tid < XV) reinterpret_cast<float4*>(ud_ + kBQ * KTS)[tid] = rx;                    \
+  } while (0)
+
+  const int aoff = kq * KTS + i;
+  const int boff = kBQ * KTS + col0 + i + kq;
+
+  DTX_LOAD_TILE(0);
+  DTX_STORE_TILE(0);
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    const float* B = lds + (s & 1) * BUF;
+    if (s + 1 < nsteps) DTX_LOAD_TILE(s + 1);
+#pragma unroll
+    for (int jj = 0; jj < kBQ; jj += 4) {
+      float av[RM], bv[TN];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) av[r] = B[jj * KTS + aoff + 16 * r];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bv[t] = B[boff + 16 * t + jj];
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[t], acc[r][t], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) DTX_STORE_TILE((s + 1) & 1);
+    __syncthreads();
+  }
+#undef DTX_LOAD_TILE
+#undef DTX_STORE_TILE
+}
+
+// ---------------------------------------------------------------------------
+// Sliding window statistics over channel planes, in float64:
+//   mean[p] = (1/n) sum_c sum_{j<L} x_c[p+j],  ssd[p] = sum (x - mean)^2 * scale
+// (scale < 0: ssd[p] = 1/sqrt(sum (x - mean)^2), or 0 for a zero-variance window)
+// One directly summed anchor window per block, then sliding updates combined by
+// a block-wide scan (pandas rolling_mean / rolling_var, detect.py:566-568 and
+// construct.py:446-447).  planes: [batch][Nc][plane_stride].
+// ---------------------------------------------------------------------------
+constexpr int kStatsPB = 2048;  // windows per block
+
+// variance below float64 round-off relative to the window power counts as 0
+__device__ inline double clamp_var(double s2, double s1, double dn) {
+  const double v = s2 - s1 * s1 / dn;
+  return (v <= 1e-13 * s2) ? 0.0 : v;
+}
+
+__device__ inline float stats_out(double scale, double v) {
+  if (scale >= 0.0) return (float)(scale * v);
+  return v > 0.0 ? (float)(1.0 / sqrt(v)) : 0.f;
+}
+
+__device__ inline double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
+static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __restrict__ planes,
+                                                        int64_t plane_stride, int Nc, int L,
+                                                        int64_t P, int64_t Ppad, double scale,
+                                                        float* __restrict__ mean,
+                                                        float* __restrict__ ssd) {
+  constexpr int E = kStatsPB / 256;  // windows per thread
+  __shared__ double sh1[4], sh2[4];
+  __shared__ double anchor[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.y;
+  const float* xb = planes + (int64_t)b * Nc * plane_stride;
+  const int64_t p0 = (int64_t)blockIdx.x * kStatsPB;
+  if (p0 >= P) return;
+
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < Nc; ++c) {
+    const float* w0 = xb + (int64_t)c * plane_stride + p0;
+    for (int j = tid; j < L; j += 256) {
+      const double v = (double)w0[j];
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (lane == 0) { sh1[wv] = s1; sh2[wv] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    anchor[0] = sh1[0] + sh1[1] + sh1[2] + sh1[3];
+    anchor[1] = sh2[0] + sh2[1] + sh2[2] + sh2[3];
+  }
+  __syncthreads();
+
+  // local element e turns window (p0 + E*tid + e) into the next one
+  double l1[E], l2[E];
+  double r1 = 0.0, r2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int64_t pw = p0 + (int64_t)E * tid + e;
+    if (pw + 1 < P) {
+      for (int c = 0; c < Nc; ++c) {
+        const float* o = xb + (int64_t)c * plane_stride + pw;
+        const double vo = (double)o[0], vn = (double)o[L];
+        r1 += vn - vo;
+        r2 += vn * vn - vo * vo;
+      }
+    }
+    l1[e] = r1;
+    l2[e] = r2;
+  }
+  const double i1 = wave_incl_scan(r1, lane), i2 = wave_incl_scan(r2, lane);
+  __syncthreads();
+  if (lane == 63) { sh1[wv] = i1; sh2[wv] = i2; }
+  __syncthreads();
+  double off1 = i1 - r1, off2 = i2 - r2;  // exclusive within the wave
+  for (int w = 0; w < wv; ++w) { off1 += sh1[w]; off2 += sh2[w]; }
+  const double a1 = anchor[0], a2 = anchor[1];
+  const double dn = (double)Nc * (double)L;
+  float* mo = mean + (int64_t)b * Ppad;
+  float* so = ssd + (int64_t)b * Ppad;
+  if (tid == 0) {
+    mo[p0] = (float)(a1 / dn);
+    so[p0] = stats_out(scale, clamp_var(a2, a1, dn));
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int64_t pw = p0 + (int64_t)E * tid + e + 1;
+    if (pw < P && pw < p0 + kStatsPB) {
+      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e];
+      mo[pw] = (float)(S1 / dn);
+      so[pw] = stats_out(scale, clamp_var(S2, S1, dn));
+    }
+  }
+}
+
+}  // namespace dtx

@@ -1,0 +1,76 @@
+// Internal definitions shared by the translation units of libdetexhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/detex_hip.h"
+
+#define DTX_ABI_VERSION 1
+
+// One K-tile of the stacked basis: up to KT_MAX rows (whole detectors only),
+// stored transposed and channel-planar for the MFMA kernel (see dtx_subspace.hip).
+struct DtxKTile {
+  int rm = 0;             // row blocks of 16 (KT = 16*rm rows incl. zero padding)
+  int rows = 0;           // real rows
+  int det0 = 0;           // first global detector in this tile
+  int nd = 0;             // detectors in this tile
+  float* ut_dev = nullptr;      // [Nc*Lp][KT] transposed basis (rotated, see kernel)
+  float* srow_dev = nullptr;    // [KT] row sums S_k
+  int32_t* doff_dev = nullptr;  // [nd+1] detector row offsets local to the tile
+};
+
+struct DtxBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct dtx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // basis
+  int D = 0, n = 0, Nc = 0, L = 0, Lp = 0, Ktot = 0;
+  std::vector<DtxKTile> tiles;
+
+  // workspaces (grown on demand, never shrunk)
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3;
+
+  // timing
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // dominant-kernel timer
+  bool kernel_timed = false;
+};
+
+int dtx_fail(dtx_ctx* ctx, int code, const char* fmt, ...);
+int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes);
+void dtx_free_tiles_internal(dtx_ctx* c);
+
+#define DTX_HIP(ctx, call)                                                    \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+      return dtx_fail((ctx), DTX_E_HIP, "%s failed: %s (%s:%d)", #call,       \
+                      hipGetErrorString(e_), __FILE__, __LINE__);             \
+  } while (0)
+
+struct DtxDeviceGuard {
+  int prev = -1;
+  explicit DtxDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DtxDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static inline int64_t dtx_round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

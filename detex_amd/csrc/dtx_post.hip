@@ -1,0 +1,102 @@
+// Post-processing of the detection statistic on the device: histogram
+// (detex/detect.py:178-181), block maximum (detect.py:275) and the list of
+// samples at or above the detector threshold that feeds the reference's
+// trigger-picking loop (detect.py:410).  HBM-bound single pass over DS.
+#include "dtx_internal.h"
+
+namespace {
+
+constexpr int kPostThreads = 256;
+constexpr int kPostItems = 16;   // float4 loads per thread -> 16 KiB of DS per block
+
+// np.histogram(v, np.linspace(0, 1, 401)): bin i holds e_i <= v < e_{i+1}, the
+// last bin also v == 1; edges are e_i = i * (1/400) in float64 and e_400 = 1.
+__device__ inline int hist_bin(float vf) {
+  const double v = (double)vf;
+  if (!(v >= 0.0) || v > 1.0) return -1;          // also drops NaN
+  const double step = 1.0 / 400.0;
+  int i = (int)(v * 400.0);
+  if (i > 399) i = 399;
+  while (i > 0 && v < (double)i * step) --i;
+  while (i < 399 && v >= (double)(i + 1) * step) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
+    const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
+    float* __restrict__ maxds, const float* __restrict__ thr, uint64_t* __restrict__ cand_key,
+    float* __restrict__ cand_val, uint32_t cand_cap, uint32_t* __restrict__ ncand) {
+  __shared__ uint32_t sh_hist[DTX_HIST_BINS];
+  __shared__ int sh_max[kPostThreads / 64];
+  const int tid = threadIdx.x;
+  const int det = blockIdx.y, chunk = blockIdx.z;
+  const float* row = ds + ((int64_t)chunk * D + det) * ldp;
+  if (hist)
+    for (int b = tid; b < DTX_HIST_BINS; b += kPostThreads) sh_hist[b] = 0u;
+  __syncthreads();
+  const float th = thr ? thr[det] : 0.f;
+  const bool do_cand = thr && cand_key && cand_val && ncand;
+  int vmax = 0;   // bit pattern; DS >= 0 so integer order == float order, NaN sorts highest
+  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
+  for (int it = 0; it < kPostItems; ++it) {
+    const int64_t p = base + (int64_t)it * kPostThreads + tid;
+    if (p < P) {
+      const float v = row[p];
+      int bits = __float_as_int(v);
+      if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
+      vmax = max(vmax, bits);
+      if (hist) {
+        const int b = hist_bin(v);
+        if (b >= 0) atomicAdd(&sh_hist[b], 1u);
+      }
+      if (do_cand && v >= th) {
+        const uint32_t slot = atomicAdd(ncand, 1u);
+        if (slot < cand_cap) {
+          cand_key[slot] = ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;  // dtx_cand_pack
+          cand_val[slot] = v;
+        }
+      }
+    }
+  }
+  if (maxds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, __shfl_down(vmax, off, 64));
+    if ((tid & 63) == 0) sh_max[tid >> 6] = vmax;
+  }
+  __syncthreads();
+  if (maxds && tid == 0) {
+    int m = sh_max[0];
+    for (int w = 1; w < kPostThreads / 64; ++w) m = max(m, sh_max[w]);
+    atomicMax(reinterpret_cast<int*>(maxds) + (int64_t)chunk * D + det, m);
+  }
+  if (hist)
+    for (int b = tid; b < DTX_HIST_BINS; b += kPostThreads) {
+      const uint32_t c = sh_hist[b];
+      if (c) atomicAdd(&hist[(int64_t)det * DTX_HIST_BINS + b], c);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
+                uint32_t* hist_dev, float* maxds_dev, const float* thr_dev,
+                uint64_t* cand_key_dev, float* cand_val_dev, uint32_t cand_cap,
+                uint32_t* ncand_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!ds_dev || P <= 0 || ldp < P || nchunk <= 0 || D <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_ds_post: bad argument");
+  if (nchunk > 65535 || D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
+  DtxDeviceGuard g(ctx->device);
+  if (maxds_dev)
+    DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * D * sizeof(float), ctx->stream));
+  const int64_t per_block = (int64_t)kPostThreads * kPostItems;
+  dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
+  hipLaunchKernelGGL(ds_post_kernel, grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+                     hist_dev, maxds_dev, thr_dev, cand_key_dev, cand_val_dev, cand_cap, ncand_dev);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// Subspace detection statistic on CDNA4 (gfx950): replaces the per-detector
+// FFT loop of the reference (detex/detect.py:259-268 -> _MPXDS 559-578, and its
+// twin detex/fas.py:120-134) by one implicit-Hankel FP32 MFMA contraction.
+//
+//   DS[d][p] = sum_{k in d} (U_k . w_p - S_k mu_p)^2 / (n/(n-1) sum_q (w_pq - mu_p)^2)
+//   w_p = x[p*Nc : p*Nc + n]                       
+//
+// With the stream de-multiplexed into channel planes x_c[t] = x[Nc*t + c] and
+// the basis permuted the same way, U_k . w_p = sum_c sum_j U_c[k][j] x_c[p + j]:
+// a GEMM  Y[K x P] = U[K x n] * H[n x P]  whose right operand is a Hankel matrix
+// that is never materialised (dtx_hankel.h).  The normalisation terms (mu_p,
+// denominator) come from a float64 sliding-sum kernel; the per-detector sum of
+// squares is a second, tiny MFMA with a 0/1 detector-membership matrix, done in
+// registers on the accumulator tile (no LDS round trip, no atomics,
+// deterministic).
+#include "dtx_hankel.h"
+#include "dtx_internal.h"
+
+using namespace dtx;
+
+namespace {
+
+// ------------------------------------------------------------------ demux
+// xp[b][c][t] = x_b[Nc*t + c] for the samples the windows touch, 0 beyond.
+__global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x, int64_t M,
+                                                    int64_t chunk_stride, int Nc, int64_t Tvalid,
+                                                    int64_t Tpad, float* __restrict__ xp) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const float* xb = x + (int64_t)b * chunk_stride;
+  float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tpad;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = t * Nc + c;
+    dst[t] = (t < Tvalid && src < M) ? xb[src] : 0.f;
+  }
+}
+
+struct DsArgs {
+  const float* xp;      // [nchunk][Nc][Tpad] channel planes (zero padded)
+  const float* ut;      // [Nc*Lp][KT] transposed, channel-planar basis tile
+  const float* srow;    // [KT] row sums S_k
+  const int32_t* doff;  // [nd+1] detector row offsets (local to this K-tile)
+  const float* mean;    // [nchunk][Ppad]
+  const float* den;     // [nchunk][Ppad]  n/(n-1) * sum (w - mu)^2
+  float* ds;            // [nchunk][D][ldp]
+  int64_t Tpad, Ppad, ldp, P;
+  int Nc, Lp, D, det0, nd, nptiles;
+};
+
+template <int RM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
+  constexpr int KT = 16 * RM;
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  const int chunk = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - chunk * a.nptiles;
+  const int64_t p0 = (int64_t)pt * PT;
+  const int col0 = wave * 16 * TN;
+
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  hankel_mainloop<RM, TN>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
+                          a.Nc, 0, a.Lp, lds);
+
+  // ---------------- epilogue: mean correction, per-detector energy, normalise
+  float* srow_s = lds;
+  int* doff_s = reinterpret_cast<int*>(lds + KT);
+  for (int v = tid; v < KT; v += kThreads) srow_s[v] = a.srow[v];
+  for (int v = tid; v <= a.nd; v += kThreads) doff_s[v] = a.doff[v];
+  __syncthreads();
+
+  float mu[TN], dn[TN];
+  const int64_t pcol = p0 + col0 + i;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int64_t p = pcol + 16 * t;  // < Ppad by construction
+    mu[t] = a.mean[(int64_t)chunk * a.Ppad + p];
+    dn[t] = a.den[(int64_t)chunk * a.Ppad + p];
+  }
+  float sr[RM][4];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sr[r][e] = srow_s[16 * r + 4 * kq + e];
+
+  // DS tile of 16 detectors x 16 windows = G[16 x rows] * V[rows x 16] with
+  // V = (Y - S mu)^2 taken straight from the accumulator registers: for a fixed
+  // register e the four lane groups kq hold rows 16r+4kq+e, which is exactly the
+  // k-slab a 16x16x4 MFMA B operand needs.
+  const int ndb = (a.nd + 15) >> 4;
+  for (int db = 0; db < ndb; ++db) {
+    const int d = 16 * db + i;
+    const int dlo = (d < a.nd) ? doff_s[d] : 0;
+    const int dhi = (d < a.nd) ? doff_s[d + 1] : 0;
+    const int rlo = doff_s[16 * db];
+    const int rhi = doff_s[min(16 * db + 16, a.nd)];
+    f32x4 out[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) out[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (16 * r < rhi && 16 * r + 16 > rlo) {  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = 16 * r + 4 * kq + e;
+          const float g = (row >= dlo && row < dhi) ? 1.f : 0.f;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) {
+            const float y = acc[r][t][e] - sr[r][e] * mu[t];
+            out[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, y * y, out[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int64_t p = pcol + 16 * t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int det = 16 * db + 4 * kq + e;
+        if (det < a.nd && p < a.P) {
+          float v = (dn[t] > 0.f) ? out[t][e] / dn[t] : 0.f;
+          if (__builtin_isinf(v)) v = 0.f;
+          a.ds[((int64_t)chunk * a.D + a.det0 + det) * a.ldp + p] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int RM>
+int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
+  constexpr int TN = tn_for(RM);
+  constexpr int PT = 128 * TN;
+  DsArgs b = a;
+  b.nptiles = (int)((a.P + PT - 1) / PT);
+  dim3 grid((unsigned)(b.nptiles * nchunk));
+  hipLaunchKernelGGL((ds_mfma_kernel<RM, TN>), grid, dim3(kThreads), 0, ctx->stream, b);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+int launch_tile_rm(dtx_ctx* ctx, int rm, const DsArgs& a, int nchunk) {
+  switch (rm) {
+    case 1: return launch_tile<1>(ctx, a, nchunk);
+    case 2: return launch_tile<2>(ctx, a, nchunk);
+    case 3: return launch_tile<3>(ctx, a, nchunk);
+    case 4: return launch_tile<4>(ctx, a, nchunk);
+    case 5: return launch_tile<5>(ctx, a, nchunk);
+    case 6: return launch_tile<6>(ctx, a, nchunk);
+    case 7: return launch_tile<7>(ctx, a, nchunk);
+    case 8: return launch_tile<8>(ctx, a, nchunk);
+    case 9: return launch_tile<9>(ctx, a, nchunk);
+    case 10: return launch_tile<10>(ctx, a, nchunk);
+    case 11: return launch_tile<11>(ctx, a, nchunk);
+    case 12: return launch_tile<12>(ctx, a, nchunk);
+    case 13: return launch_tile<13>(ctx, a, nchunk);
+  }
+  return dtx_fail(ctx, DTX_E_ARG, "bad row-block count %d", rm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dtx_num_windows(int64_t M, int n, int Nc) {
+  if (n <= 0 || Nc <= 0 || M < n) return 0;
+  return (M - n) / Nc + 1;
+}
+
+int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D, int n,
+                     int Nc) {
+  if (!ctx) return DTX_E_ARG;
+  if (!U || !det_off || D <= 0 || n <= 0 || Nc <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_basis_upload: null pointer or non-positive size");
+  if (n % Nc != 0)
+    return dtx_fail(ctx, DTX_E_ARG, "basis length n=%d is not a multiple of Nc=%d", n, Nc);
+  if (n < 2) return dtx_fail(ctx, DTX_E_ARG, "basis length must be >= 2");
+  if (D > 65535) return dtx_fail(ctx, DTX_E_ARG, "at most 65535 detectors per upload (got %d)", D);
+  if (det_off[0] != 0) return dtx_fail(ctx, DTX_E_ARG, "det_off[0] must be 0");
+  for (int d = 0; d < D; ++d) {
+    const int k = det_off[d + 1] - det_off[d];
+    if (k <= 0) return dtx_fail(ctx, DTX_E_ARG, "detector %d has %d basis vectors", d, k);
+    if (k > kKtMax)
+      return dtx_fail(ctx, DTX_E_ARG, "detector %d has %d basis vectors (max %d)", d, k, kKtMax);
+  }
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int Ktot = det_off[D];
+  const int L = n / Nc;
+  const int Lp = (int)dtx_round_up(L, kBQ);
+  std::vector<float> hU((size_t)Ktot * n);
+  DTX_HIP(ctx, hipMemcpy(hU.data(), U, hU.size() * sizeof(float), hipMemcpyDefault));
+
+  dtx_free_tiles_internal(ctx);
+  ctx->D = D; ctx->n = n; ctx->Nc = Nc; ctx->L = L; ctx->Lp = Lp; ctx->Ktot = Ktot;
+
+  // greedy packing of whole detectors into K-tiles of <= 208 rows
+  int d = 0;
+  while (d < D) {
+    DtxKTile t;
+    t.det0 = d;
+    const int row0 = det_off[d];
+    int dend = d;
+    while (dend < D && det_off[dend + 1] - row0 <= kKtMax) ++dend;
+    t.nd = dend - d;
+    t.rows = det_off[dend] - row0;
+    t.rm = (t.rows + 15) / 16;
+    const int KT = 16 * t.rm;
+    const size_t nq = (size_t)Nc * Lp;
+    std::vector<float> ut(nq * KT, 0.f);
+    std::vector<float> srow(KT, 0.f);
+    std::vector<int32_t> doff(t.nd + 1);
+    for (int e = 0; e <= t.nd; ++e) doff[e] = det_off[d + e] - row0;
+    for (int k = 0; k < t.rows; ++k) {
+      const float* u = hU.data() + (size_t)(row0 + k) * n;
+      double s = 0.0;
+      for (int c = 0; c < Nc; ++c)
+        for (int j = 0; j < L; ++j) {
+          const float v = u[(size_t)j * Nc + c];
+          s += (double)v;
+          ut[((size_t)c * Lp + j) * KT + k] = v;
+        }
+      srow[k] = (float)s;
+    }
+    DTX_HIP(ctx, hipMalloc(&t.ut_dev, ut.size() * sizeof(float)));
+    DTX_HIP(ctx, hipMalloc(&t.srow_dev, srow.size() * sizeof(float)));
+    DTX_HIP(ctx, hipMalloc(&t.doff_dev, doff.size() * sizeof(int32_t)));
+    ctx->tiles.push_back(t);  // pushed first so a failed copy still gets freed
+    DTX_HIP(ctx, hipMemcpy(t.ut_dev, ut.data(), ut.size() * sizeof(float), hipMemcpyHostToDevice));
+    DTX_HIP(ctx, hipMemcpy(t.srow_dev, srow.data(), srow.size() * sizeof(float),
+                           hipMemcpyHostToDevice));
+    DTX_HIP(ctx, hipMemcpy(t.doff_dev, doff.data(), doff.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice));
+    d = dend;
+  }
+  return DTX_OK;
+}
+
+int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                    int nchunk, float* ds_dev, int64_t ldp) {
+  if (!ctx) return DTX_E_ARG;
+  if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "dtx_subspace_ds: no basis uploaded");
+  if (!x_dev || !ds_dev || nchunk <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_subspace_ds: null pointer or nchunk <= 0");
+  const int n = ctx->n, Nc = ctx->Nc;
+  const int64_t P = dtx_num_windows(M, n, Nc);
+  // detect.py:262-266: a block not longer than the template is rejected
+  if (M <= n || P <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "data block of %lld samples is not longer than the basis (%d)",
+                    (long long)M, n);
+  if (ldp < P) return dtx_fail(ctx, DTX_E_ARG, "ldp=%lld < P=%lld", (long long)ldp, (long long)P);
+  if (nchunk > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk > 65535");
+  if (P >= (int64_t)1 << 31) return dtx_fail(ctx, DTX_E_ARG, "too many windows per block");
+  DtxDeviceGuard g(ctx->device);
+
+  const int64_t Ppad = dtx_round_up(P, 1024);
+  const int64_t Tpad = Ppad + ctx->Lp + 64;
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_xp, (size_t)nchunk * Nc * Tpad * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_mean, (size_t)nchunk * Ppad * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_den, (size_t)nchunk * Ppad * sizeof(float)))) return rc;
+  float* xp = (float*)ctx->ws_xp.p;
+  float* mean = (float*)ctx->ws_mean.p;
+  float* den = (float*)ctx->ws_den.p;
+
+  {
+    const int64_t Tvalid = P + ctx->L - 1;
+    dim3 grid((unsigned)std::min<int64_t>((Tpad + 255) / 256, 4096), (unsigned)Nc,
+              (unsigned)nchunk);
+    hipLaunchKernelGGL(demux_kernel, grid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
+                       Tvalid, Tpad, xp);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  {
+    // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
+    const double scale = (double)n / ((double)n - 1.0);
+    dim3 grid((unsigned)((P + kStatsPB - 1) / kStatsPB), (unsigned)nchunk);
+    hipLaunchKernelGGL(win_stats_kernel, grid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
+                       Nc, ctx->L, P, Ppad, scale, mean, den);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  for (const DtxKTile& t : ctx->tiles) {
+    DsArgs a;
+    a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
+    a.mean = mean; a.den = den; a.ds = ds_dev;
+    a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
+    a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
+    if ((rc = launch_tile_rm(ctx, t.rm, a, nchunk))) return rc;
+  }
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  ctx->kernel_timed = true;
+  return DTX_OK;
+}
+
+int dtx_subspace_ds_host(dtx_ctx* ctx, const float* x_host, int64_t M, float* ds_host) {
+  if (!ctx) return DTX_E_ARG;
+  if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "no basis uploaded");
+  if (!x_host || !ds_host) return dtx_fail(ctx, DTX_E_ARG, "null pointer");
+  const int64_t P = dtx_num_windows(M, ctx->n, ctx->Nc);
+  if (M <= ctx->n || P <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "data block of %lld samples is not longer than the basis (%d)",
+                    (long long)M, ctx->n);
+  DtxDeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc, (size_t)M * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc2, (size_t)ctx->D * P * sizeof(float)))) return rc;
+  DTX_HIP(ctx, hipMemcpyAsync(ctx->ws_misc.p, x_host, (size_t)M * sizeof(float),
+                              hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dtx_subspace_ds(ctx, (const float*)ctx->ws_misc.p, M, M, 1, (float*)ctx->ws_misc2.p, P)))
+    return rc;
+  DTX_HIP(ctx, hipMemcpyAsync(ds_host, ctx->ws_misc2.p, (size_t)ctx->D * P * sizeof(float),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+// All-pairs normalised cross-correlation on CDNA4 (gfx950): replaces the
+// Python pair loop of the reference (detex/construct.py:369-394 _makeDFcclags
+// calling _CCX2, 425-466, once per pair with one FFT each) by the same
+// implicit-Hankel FP32 MFMA contraction as the detection statistic.
+//
+// For a fixed "later" event c, zero-pad its channel planes by S = L - L//2
+// samples on both sides (z_c) -- the central half of the lag range the
+// reference keeps after result[trunc:-trunc] (construct.py:439, 453).  Then for
+// every earlier event b and every kept lag s = p - S
+//     Y[b][p] = sum_ch sum_t x_b,ch[t] * z_c,ch[p + t]        (= x_b . w_s)
+// is a GEMM [events x n] * Hankel(z_c): the events are the dense operand
+// (stored transposed + channel-planar once), z_c is the stream.  Steps of the
+// contraction whose z window is entirely padding are skipped.  The epilogue
+// normalises (means / stds over the zero-padded
+// windows), scrubs |cc| > 1, and reduces max / first-argmax over the lags with
+// one 64-bit atomicMax per (pair, wave).  A finishing kernel re-evaluates the
+// winning lag and its two neighbours in float64 and applies the cosine
+// sub-sample fit (construct.py:397-422).
+#include <algorithm>
+
+#include "dtx_hankel.h"
+#include "dtx_internal.h"
+
+using namespace dtx;
+
+namespace {
+
+constexpr float kScrubTol = 1e-5f;   // see DESIGN.md "knife-edge scrub"
+
+__host__ __device__ inline int64_t condensed_index(int64_t N, int64_t b, int64_t c) {
+  return N * b - b * (b + 1) / 2 + (c - b - 1);
+}
+
+// XT[kt][ch*Lp + t][208] = td[208*kt + k][Nc*t + ch]   (0 where t >= L or event >= N)
+__global__ __launch_bounds__(256) void xc_transpose_kernel(const float* __restrict__ td, int N,
+                                                           int n, int Nc, int L, int Lp,
+                                                           float* __restrict__ xt) {
+  const int kt = blockIdx.z;
+  const int64_t rows = (int64_t)Nc * Lp;
+  for (int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); q < rows;
+       q += (int64_t)gridDim.x * 4) {
+    const int ch = (int)(q / Lp), t = (int)(q - (int64_t)ch * Lp);
+    for (int k = threadIdx.x & 63; k < kKtMax; k += 64) {
+      const int e = kt * kKtMax + k;
+      float v = 0.f;
+      if (e < N && t < L) v = td[(int64_t)e * n + (int64_t)t * Nc + ch];
+      xt[((int64_t)kt * rows + q) * kKtMax + k] = v;
+    }
+  }
+}
+
+// z[e][ch][tau] = td[e][Nc*(tau - S) + ch] for 0 <= tau - S < L, else 0
+__global__ __launch_bounds__(256) void xc_pad_kernel(const float* __restrict__ td, int n, int Nc,
+                                                     int L, int S, int64_t Tz,
+                                                     float* __restrict__ z) {
+  const int e = blockIdx.z, ch = blockIdx.y;
+  const float* src = td + (int64_t)e * n;
+  float* dst = z + ((int64_t)e * Nc + ch) * Tz;
+  for (int64_t tau = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tau < Tz;
+       tau += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = tau - S;
+    dst[tau] = (t >= 0 && t < L) ? src[t * Nc + ch] : 0.f;
+  }
+}
+
+// per event: sum, sum of squared deviations (float64), 1/sqrt(ssd) (float32)
+__global__ __launch_bounds__(256) void xc_event_stats_kernel(const float* __restrict__ td, int n,
+                                                             double* __restrict__ esum,
+                                                             double* __restrict__ essd,
+                                                             double* __restrict__ esq,
+                                                             float* __restrict__ fsum,
+                                                             float* __restrict__ frs) {
+  __shared__ double sh[8];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const float* x = td + (int64_t)e * n;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = tid; j < n; j += 256) {
+    const double v = (double)x[j];
+    s1 += v;
+    s2 += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if ((tid & 63) == 0) { sh[tid >> 6] = s1; sh[4 + (tid >> 6)] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    s1 = sh[0] + sh[1] + sh[2] + sh[3];
+    s2 = sh[4] + sh[5] + sh[6] + sh[7];
+    const double ssd = clamp_var(s2, s1, (double)n);
+    esum[e] = s1;
+    essd[e] = ssd;
+    esq[e] = s2;
+    fsum[e] = (float)s1;
+    frs[e] = ssd > 0.0 ? (float)(1.0 / sqrt(ssd)) : 0.f;
+  }
+}
+
+struct XcArgs {
+  const float* xt;      // [nkt][Nc*Lp][208]
+  const float* z;       // [N][Nc][Tz]
+  const float* fsum;    // [N]   sum(x_b)
+  const float* frs;     // [N]   1/sqrt(ssd(x_b)), 0 for a dead event
+  const float* mean_w;  // [N][Ppad] mean of the padded window of event c at lag p
+  const float* rsw;     // [N][Ppad] 1/sqrt(ssd) of that window, 0 if zero variance
+  unsigned long long* keys;  // [npairs] (orderable cc << 32) | ~p
+  const int2* items;    // (c, kt) work items of this launch
+  int64_t Tz, Ppad, pair_begin, pair_end;
+  int N, Nc, L, Lp, S, Pz, nptiles;
+};
+
+template <int RM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+  const int item = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - item * a.nptiles;
+  const int2 it = a.items[item];
+  const int c = it.x, kt = it.y;
+  const int p0 = pt * PT;
+  const int col0 = wave * 16 * TN;
+
+  // contraction range with a non-padding z window: S <= p + t < S + L
+  int jlo = a.S - p0 - PT + 1;
+  jlo = jlo > 0 ? (jlo / kBQ) * kBQ : 0;
+  int jhi = a.S + a.L - p0;
+  jhi = min(a.Lp, ((jhi + kBQ - 1) / kBQ) * kBQ);
+
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  hankel_mainloop<RM, TN>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
+                          a.z + (int64_t)c * a.Nc * a.Tz + p0, a.Tz, a.Nc, jlo, jhi, lds);
+
+  // ---------------- epilogue: normalise, scrub, max / first argmax over lags
+  float mu[TN], rw[TN];
+  const int pcol = p0 + col0 + i;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int p = pcol + 16 * t;   // < Ppad
+    mu[t] = a.mean_w[(int64_t)c * a.Ppad + p];
+    rw[t] = a.rsw[(int64_t)c * a.Ppad + p];
+  }
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int b = kt * kKtMax + 16 * r + 4 * kq + e;
+      const bool rowok = b < c;
+      const float s1 = rowok ? a.fsum[b] : 0.f;
+      const float r1 = rowok ? a.frs[b] : 0.f;
+      unsigned long long key = 0ull;
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int p = pcol + 16 * t;
+        float cc = (acc[r][t][e] - s1 * mu[t]) * (r1 * rw[t]);
+        if (cc > 1.f + kScrubTol || cc < -1.f - kScrubTol) cc = 0.f;   // construct.py:458-462
+        if (p < a.Pz && cc == cc) {
+          const unsigned bits = __float_as_uint(cc);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          const unsigned long long k2 =
+              ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
+          key = k2 > key ? k2 : key;
+        }
+      }
+      // the 16 lanes sharing kq hold the other columns of this row
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const unsigned long long o = __shfl_xor(key, m, 64);
+        key = o > key ? o : key;
+      }
+      if (i == 0 && rowok && r1 > 0.f && key != 0ull) {
+        const int64_t idx = condensed_index(a.N, b, c);
+        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+      }
+    }
+  }
+}
+
+// One wave per pair: float64 re-evaluation of the winning lag and its two
+// neighbours, reference scrub, cosine sub-sample fit, outputs.
+__global__ __launch_bounds__(256) void xc_finish_kernel(
+    const float* __restrict__ td, const unsigned long long* __restrict__ keys,
+    const double* __restrict__ esum, const double* __restrict__ essd,
+    const double* __restrict__ esq, int N, int n, int Nc, int S, int Pz, int trunc,
+    int64_t pair_begin, int64_t pair_end, float* __restrict__ cc_out, int32_t* __restrict__ lag_out,
+    float* __restrict__ ss_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t idx = pair_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= pair_end) return;
+  // invert the condensed index
+  const double tn1 = 2.0 * N - 1.0;
+  int64_t b = (int64_t)((tn1 - sqrt(tn1 * tn1 - 8.0 * (double)idx)) * 0.5);
+  if (b < 0) b = 0;
+  while (b > 0 && condensed_index(N, b, b + 1) > idx) --b;
+  while (condensed_index(N, b + 1, b + 2) <= idx && b + 2 < N) ++b;
+  const int64_t c = idx - condensed_index(N, b, b + 1) + b + 1;
+
+  const unsigned long long key = keys[idx];
+  const double ssd1 = essd[b], sum1 = esum[b];
+  if (key == 0ull || !(ssd1 > 0.0) || !(esq[c] > 0.0)) {
+    // construct.py:463-464: all-NaN CC vector -> (0, 0, 0)
+    if (lane == 0) { cc_out[idx] = 0.f; lag_out[idx] = 0; ss_out[idx] = 0.f; }
+    return;
+  }
+  const int p = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  const float* x1 = td + b * n;
+  const float* x2 = td + c * n;
+  double dot[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+  for (int j = lane; j < n; j += 64) {
+    const double a1 = (double)x1[j];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const int jj = j + (p - 1 + l - S) * Nc;
+      if (jj >= 0 && jj < n) {
+        const double v = (double)x2[jj];
+        dot[l] += a1 * v;
+        sw[l] += v;
+        sq[l] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      dot[l] += __shfl_down(dot[l], off, 64);
+      sw[l] += __shfl_down(sw[l], off, 64);
+      sq[l] += __shfl_down(sq[l], off, 64);
+    }
+  if (lane != 0) return;
+  const double dn = (double)n;
+  double cv[3];
+  for (int l = 0; l < 3; ++l) {
+    const double vw = clamp_var(sq[l], sw[l], dn);
+    // zero-variance window: the reference gets +-inf and scrubs it to 0
+    double v = vw > 0.0 ? (dot[l] - sum1 * sw[l] / dn) / sqrt(ssd1 * vw) : 0.0;
+    if (v > 1.0 + (double)kScrubTol || v < -1.0 - (double)kScrubTol) v = 0.0;
+    cv[l] = v;
+  }
+  double tau = 0.0;
+  if (p != 0 && p != Pz - 1) {                       // construct.py:409-410
+    const double cb4 = cv[0], cn = cv[1], caf = cv[2];
+    const double alpha = acos((cb4 + caf) / (2.0 * cn));
+    const double alsi = sin(alpha);
+    tau = -(atan((cb4 - caf) / (2.0 * cn * alsi)) / alpha);
+    if (fabs(tau) > 0.5) tau = (double)p;            // construct.py:418-421 (returns ind)
+  }
+  cc_out[idx] = (float)cv[1];
+  lag_out[idx] = (p + 1 + trunc) * Nc - n;           // construct.py:466
+  ss_out[idx] = (float)tau;
+}
+
+template <int RM>
+int launch_items(dtx_ctx* ctx, XcArgs a, const int2* items_dev, int nitems) {
+  constexpr int TN = tn_for(RM);
+  constexpr int PT = 128 * TN;
+  a.items = items_dev;
+  a.nptiles = (a.Pz + PT - 1) / PT;
+  const int64_t nblk = (int64_t)a.nptiles * nitems;
+  // grid.x limit is 2^31-1 blocks; split anyway to keep launches bounded
+  const int64_t per = ((int64_t)1 << 20) / a.nptiles * a.nptiles;
+  for (int64_t off = 0; off < nblk; off += per) {
+    XcArgs b = a;
+    b.items = items_dev + off / a.nptiles;
+    const int64_t cnt = std::min(per, nblk - off);
+    hipLaunchKernelGGL((xc_mfma_kernel<RM, TN>), dim3((unsigned)cnt), dim3(kThreads), 0,
+                       ctx->stream, b);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  return DTX_OK;
+}
+
+int launch_items_rm(dtx_ctx* ctx, int rm, const XcArgs& a, const int2* items_dev, int nitems) {
+  switch (rm) {
+    case 1: return launch_items<1>(ctx, a, items_dev, nitems);
+    case 2: return launch_items<2>(ctx, a, items_dev, nitems);
+    case 3: return launch_items<3>(ctx, a, items_dev, nitems);
+    case 4: return launch_items<4>(ctx, a, items_dev, nitems);
+    case 5: return launch_items<5>(ctx, a, items_dev, nitems);
+    case 6: return launch_items<6>(ctx, a, items_dev, nitems);
+    case 7: return launch_items<7>(ctx, a, items_dev, nitems);
+    case 8: return launch_items<8>(ctx, a, items_dev, nitems);
+    case 9: return launch_items<9>(ctx, a, items_dev, nitems);
+    case 10: return launch_items<10>(ctx, a, items_dev, nitems);
+    case 11: return launch_items<11>(ctx, a, items_dev, nitems);
+    case 12: return launch_items<12>(ctx, a, items_dev, nitems);
+    case 13: return launch_items<13>(ctx, a, items_dev, nitems);
+  }
+  return dtx_fail(ctx, DTX_E_ARG, "bad row-block count %d", rm);
+}
+
+// first row b of the condensed index idx
+int64_t row_of_index(int64_t N, int64_t idx) {
+  int64_t lo = 0, hi = N - 2;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) / 2;
+    if (condensed_index(N, mid, mid + 1) <= idx) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, float* cc_dev,
+                       int32_t* lag_dev, float* subsamp_dev, int64_t pair_begin,
+                       int64_t pair_end) {
+  if (!ctx) return DTX_E_ARG;
+  if (!td_dev || !cc_dev || !lag_dev || !subsamp_dev)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_xcorr_allpairs: null pointer");
+  if (N < 2 || n <= 0 || Nc <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_xcorr_allpairs: need N >= 2, n > 0, Nc > 0");
+  if (n % Nc != 0)
+    // construct.py:434-436: 'Lengths not equal on multiplexed data, cannot correlate'
+    return dtx_fail(ctx, DTX_E_ARG, "event length n=%d is not a multiple of Nc=%d", n, Nc);
+  const int64_t npairs = (int64_t)N * (N - 1) / 2;
+  if (pair_begin < 0 || pair_end > npairs || pair_begin > pair_end)
+    return dtx_fail(ctx, DTX_E_ARG, "pair range [%lld, %lld) outside [0, %lld]",
+                    (long long)pair_begin, (long long)pair_end, (long long)npairs);
+  if (pair_begin == pair_end) return DTX_OK;
+  DtxDeviceGuard g(ctx->device);
+  const int64_t cnt = pair_end - pair_begin;
+  const int L = n / Nc;
+  const int trunc = n / (2 * Nc) - 1;               // construct.py:439
+  if (trunc <= 0) {
+    // result[trunc:-trunc] is empty -> ValueError path -> (0, 0, 0) (construct.py:463-464)
+    DTX_HIP(ctx, hipMemsetAsync(cc_dev + pair_begin, 0, cnt * sizeof(float), ctx->stream));
+    DTX_HIP(ctx, hipMemsetAsync(lag_dev + pair_begin, 0, cnt * sizeof(int32_t), ctx->stream));
+    DTX_HIP(ctx, hipMemsetAsync(subsamp_dev + pair_begin, 0, cnt * sizeof(float), ctx->stream));
+    return DTX_OK;
+  }
+  const int S = (L - 1) - trunc;
+  const int Pz = 2 * S + 1;
+  const int Lp = (int)dtx_round_up(L, kBQ);
+  const int64_t Ppad = dtx_round_up(Pz, 1024);
+  const int64_t Tz = Ppad + Lp + 64;
+  const int nkt = (N + kKtMax - 1) / kKtMax;
+
+  // ---- workspaces (one arena)
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_xt = carve((size_t)nkt * Nc * Lp * kKtMax * sizeof(float));
+  const size_t o_z = carve((size_t)N * Nc * Tz * sizeof(float));
+  const size_t o_mw = carve((size_t)N * Ppad * sizeof(float));
+  const size_t o_rw = carve((size_t)N * Ppad * sizeof(float));
+  const size_t o_es = carve((size_t)N * sizeof(double));
+  const size_t o_ed = carve((size_t)N * sizeof(double));
+  const size_t o_eq = carve((size_t)N * sizeof(double));
+  const size_t o_fs = carve((size_t)N * sizeof(float));
+  const size_t o_fr = carve((size_t)N * sizeof(float));
+  const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc, off))) return rc;
+  char* base = (char*)ctx->ws_misc.p;
+  float* xt = (float*)(base + o_xt);
+  float* z = (float*)(base + o_z);
+  float* mean_w = (float*)(base + o_mw);
+  float* rsw = (float*)(base + o_rw);
+  double* esum = (double*)(base + o_es);
+  double* essd = (double*)(base + o_ed);
+  double* esq = (double*)(base + o_eq);
+  float* fsum = (float*)(base + o_fs);
+  float* frs = (float*)(base + o_fr);
+  unsigned long long* keys = (unsigned long long*)(base + o_keys);
+
+  // ---- work items: (c, kt) for every column c and row tile kt that holds a pair in range
+  const int64_t b_begin = row_of_index(N, pair_begin);
+  const int64_t b_end = row_of_index(N, pair_end - 1);
+  std::vector<std::vector<int2>> items(kRmMax + 1);
+  for (int kt = 0; kt < nkt; ++kt) {           // kt-major: concurrent blocks share the XT tile
+    const int64_t r0 = (int64_t)kt * kKtMax;
+    for (int c = 1; c < N; ++c) {
+      const int64_t lo = std::max<int64_t>(r0, b_begin);
+      const int64_t hi = std::min<int64_t>({r0 + kKtMax - 1, (int64_t)c - 1, b_end});
+      if (lo > hi) continue;
+      const int rm = (int)((hi - r0) / 16 + 1);
+      items[rm].push_back(make_int2(c, kt));
+    }
+  }
+  size_t nitems = 0;
+  for (auto& v : items) nitems += v.size();
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc2, std::max<size_t>(nitems, 1) * sizeof(int2)))) return rc;
+  {
+    std::vector<int2> flat;
+    flat.reserve(nitems);
+    for (auto& v : items) flat.insert(flat.end(), v.begin(), v.end());
+    // ws_misc2 may be read by a previous launch still in flight on the stream
+    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DTX_HIP(ctx, hipMemcpy(ctx->ws_misc2.p, flat.data(), flat.size() * sizeof(int2),
+                           hipMemcpyHostToDevice));
+  }
+
+  // ---- prep kernels
+  {
+    dim3 grid((unsigned)std::min<int64_t>(((int64_t)Nc * Lp + 3) / 4, 8192), 1, (unsigned)nkt);
+    hipLaunchKernelGGL(xc_transpose_kernel, grid, dim3(256), 0, ctx->stream, td_dev, N, n, Nc, L,
+                       Lp, xt);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  {
+    dim3 grid((unsigned)((Tz + 255) / 256), (unsigned)Nc, (unsigned)N);
+    hipLaunchKernelGGL(xc_pad_kernel, grid, dim3(256), 0, ctx->stream, td_dev, n, Nc, L, S, Tz, z);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(xc_event_stats_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, td_dev, n,
+                     esum, essd, esq, fsum, frs);
+  DTX_HIP(ctx, hipGetLastError());
+  {
+    dim3 grid((unsigned)((Pz + kStatsPB - 1) / kStatsPB), (unsigned)N);
+    hipLaunchKernelGGL(win_stats_kernel, grid, dim3(256), 0, ctx->stream, (const float*)z, Tz, Nc, L,
+                       (int64_t)Pz, Ppad, -1.0 /* 1/sqrt mode */, mean_w, rsw);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  DTX_HIP(ctx, hipMemsetAsync(keys + pair_begin, 0, cnt * sizeof(unsigned long long), ctx->stream));
+
+  // ---- the MFMA launches, one per row-block count
+  XcArgs a;
+  a.xt = xt; a.z = z; a.fsum = fsum; a.frs = frs; a.mean_w = mean_w; a.rsw = rsw; a.keys = keys;
+  a.items = nullptr; a.Tz = Tz; a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
+  a.N = N; a.Nc = Nc; a.L = L; a.Lp = Lp; a.S = S; a.Pz = Pz; a.nptiles = 0;
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  {
+    const int2* p = (const int2*)ctx->ws_misc2.p;
+    for (int rm = kRmMax; rm >= 1; --rm) {
+      size_t skip = 0;
+      for (int q = 0; q < rm; ++q) skip += items[q].size();
+      if (items[rm].empty()) continue;
+      if ((rc = launch_items_rm(ctx, rm, a, p + skip, (int)items[rm].size()))) return rc;
+    }
+  }
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  ctx->kernel_timed = true;
+
+  hipLaunchKernelGGL(xc_finish_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, ctx->stream,
+                     td_dev, (const unsigned long long*)keys, (const double*)esum,
+                     (const double*)essd, (const double*)esq, N, n, Nc, S, Pz, trunc, pair_begin,
+                     pair_end, cc_dev, lag_dev, subsamp_dev);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+int dtx_xcorr_allpairs_host(dtx_ctx* ctx, const float* td_host, int N, int n, int Nc,
+                            float* cc_host, int32_t* lag_host, float* subsamp_host) {
+  if (!ctx) return DTX_E_ARG;
+  if (!td_host || !cc_host || !lag_host || !subsamp_host)
+    return dtx_fail(ctx, DTX_E_ARG, "null pointer");
+  if (N < 2 || n <= 0) return dtx_fail(ctx, DTX_E_ARG, "need N >= 2, n > 0");
+  DtxDeviceGuard g(ctx->device);
+  const int64_t npairs = (int64_t)N * (N - 1) / 2;
+  const size_t tdb = (size_t)N * n * sizeof(float);
+  const size_t o1 = (tdb + 255) / 256 * 256, o2 = o1 + (npairs * 4 + 255) / 256 * 256,
+               o3 = o2 + (npairs * 4 + 255) / 256 * 256, tot = o3 + npairs * 4;
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc3, tot))) return rc;
+  char* base = (char*)ctx->ws_misc3.p;
+  DTX_HIP(ctx, hipMemcpyAsync(base, td_host, tdb, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dtx_xcorr_allpairs(ctx, (const float*)base, N, n, Nc, (float*)(base + o1),
+                               (int32_t*)(base + o2), (float*)(base + o3), 0, npairs)))
+    return rc;
+  DTX_HIP(ctx, hipMemcpyAsync(cc_host, base + o1, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DTX_HIP(ctx, hipMemcpyAsync(lag_host, base + o2, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DTX_HIP(ctx, hipMemcpyAsync(subsamp_host, base + o3, npairs * 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""Thin Python face of the C ABI: one ``HipContext`` per GPU.
+
+torch is used for device memory, streams and (elsewhere) torch.distributed --
+plumbing only; all arithmetic happens in the hand-written HIP kernels of
+libdetexhip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+HIST_BINS = 400
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class HipContext(object):
+    """One HIP device + stream.  All tensors passed in must live on it."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.DetexHipError('no HIP device visible to torch; detex_amd '
+                                     'has no CPU fallback')
+        self.device = torch.device('cuda', int(device))
+        torch.cuda.set_device(self.device)
+        self._stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.dtx_ctx_create(int(device), C.c_void_p(self._stream.cuda_stream),
+                                     C.byref(h))
+        _lib.check(self.lib, None, rc, 'dtx_ctx_create')
+        self.h = h
+        self.D = self.n = self.Nc = 0
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dtx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        _lib.check(self.lib, self.h, rc, what)
+
+    def sync(self):
+        self._ck(self.lib.dtx_ctx_sync(self.h), 'dtx_ctx_sync')
+
+    # ------------------------------------------------------------ subspace
+    def upload_basis(self, U, det_off, Nc):
+        """U: [Ktot, n] float32 (numpy or torch, host or device);
+        det_off: D+1 ints (detector d owns rows det_off[d]:det_off[d+1])."""
+        if isinstance(U, torch.Tensor):
+            Ut = U.to(torch.float32).contiguous()
+        else:
+            Ut = torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32))
+        off = np.ascontiguousarray(det_off, dtype=np.int32)
+        if Ut.dim() != 2 or off.ndim != 1 or off[-1] != Ut.shape[0]:
+            raise ValueError('U must be [Ktot, n] and det_off[-1] == Ktot')
+        D = len(off) - 1
+        rc = self.lib.dtx_basis_upload(self.h, _ptr(Ut), off.ctypes.data_as(C.c_void_p),
+                                       D, int(Ut.shape[1]), int(Nc))
+        self._ck(rc, 'dtx_basis_upload')
+        self.D, self.n, self.Nc = D, int(Ut.shape[1]), int(Nc)
+
+    def num_windows(self, M):
+        return int(self.lib.dtx_num_windows(int(M), self.n, self.Nc))
+
+    def subspace_ds(self, x, M=None, chunk_stride=None, nchunk=None, out=None):
+        """Detection statistic of every uploaded detector.
+
+        x: float32 CUDA tensor.  Either [nchunk, M] (contiguous rows) or a flat
+        buffer together with M / chunk_stride / nchunk (overlapping blocks).
+        Returns ds [nchunk, D, P] (asynchronous on torch's current stream)."""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError('x must be a float32 CUDA tensor')
+        if M is None:
+            if x.dim() == 1:
+                x = x[None, :]
+            if x.stride(-1) != 1:
+                x = x.contiguous()
+            nchunk, M = int(x.shape[0]), int(x.shape[1])
+            chunk_stride = int(x.stride(0)) if nchunk > 1 else M
+        else:
+            need = (nchunk - 1) * chunk_stride + M
+            if x.numel() < need or not x.is_contiguous():
+                raise ValueError('flat buffer too small for the chunk layout')
+        P = self.num_windows(M)
+        if out is None:
+            out = torch.empty((nchunk, self.D, max(P, 0)), dtype=torch.float32,
+                              device=x.device)
+        rc = self.lib.dtx_subspace_ds(self.h, _ptr(x), int(M), int(chunk_stride),
+                                      int(nchunk), _ptr(out), int(out.stride(1)))
+        self._ck(rc, 'dtx_subspace_ds')
+        return out
+
+    def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
+        """Histogram / max / threshold candidates of a DS tensor [nchunk, D, P].
+
+        Returns dict(hist=[D,400] uint32-as-int64 tensor or None, maxds=[nchunk,D],
+        cand=(chunk, det, index, value) numpy arrays sorted by (chunk, det, index),
+        ncand=total found)."""
+        nchunk, D, P = (int(s) for s in ds.shape)
+        dev = ds.device
+        if hist is None:
+            hist = torch.zeros((D, HIST_BINS), dtype=torch.int32, device=dev)
+        maxds = torch.empty((nchunk, D), dtype=torch.float32, device=dev) if want_max else None
+        thr_t = key = val = cnt = None
+        if thr is not None:
+            thr_t = torch.as_tensor(np.broadcast_to(np.asarray(thr, dtype=np.float32), (D,)).copy(),
+                                    device=dev)
+            key = torch.empty((cand_cap,), dtype=torch.int64, device=dev)
+            val = torch.empty((cand_cap,), dtype=torch.float32, device=dev)
+            cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        rc = self.lib.dtx_ds_post(self.h, _ptr(ds), P, int(ds.stride(1)), nchunk, D,
+                                  _ptr(hist), _ptr(maxds), _ptr(thr_t), _ptr(key), _ptr(val),
+                                  int(cand_cap), _ptr(cnt))
+        self._ck(rc, 'dtx_ds_post')
+        res = dict(hist=hist, maxds=maxds, cand=None, ncand=0)
+        if thr is not None:
+            n = int(cnt.item())
+            res['ncand'] = n
+            m = min(n, cand_cap)
+            k = key[:m].cpu().numpy().astype(np.uint64)
+            v = val[:m].cpu().numpy()
+            order = np.argsort(k, kind='stable')
+            k, v = k[order], v[order]
+            res['cand'] = ((k >> np.uint64(48)).astype(np.int64),
+                           ((k >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64),
+                           (k & np.uint64(0xFFFFFFFF)).astype(np.int64), v)
+        return res
+
+    def subspace_ds_host(self, x):
+        """numpy in, numpy out (one block); includes the PCIe transfers."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        P = self.num_windows(len(x))
+        out = np.empty((self.D, max(P, 0)), dtype=np.float32)
+        rc = self.lib.dtx_subspace_ds_host(self.h, x.ctypes.data_as(C.c_void_p), len(x),
+                                           out.ctypes.data_as(C.c_void_p))
+        self._ck(rc, 'dtx_subspace_ds_host')
+        return out
+
+    # ------------------------------------------------------------ xcorr
+    def xcorr_allpairs(self, td, Nc, pair_begin=0, pair_end=None):
+        """td: [N, n] float32 CUDA tensor of multiplexed events.  Returns
+        (cc, lag, subsamp) condensed CUDA tensors of length N(N-1)/2."""
+        if td.dtype != torch.float32 or not td.is_cuda or td.dim() != 2:
+            raise ValueError('td must be a [N, n] float32 CUDA tensor')
+        td = td.contiguous()
+        N, n = int(td.shape[0]), int(td.shape[1])
+        npair = N * (N - 1) // 2
+        if pair_end is None:
+            pair_end = npair
+        cc = torch.zeros((npair,), dtype=torch.float32, device=td.device)
+        lag = torch.zeros((npair,), dtype=torch.int32, device=td.device)
+        ss = torch.zeros((npair,), dtype=torch.float32, device=td.device)
+        rc = self.lib.dtx_xcorr_allpairs(self.h, _ptr(td), N, n, int(Nc), _ptr(cc), _ptr(lag),
+                                         _ptr(ss), int(pair_begin), int(pair_end))
+        self._ck(rc, 'dtx_xcorr_allpairs')
+        return cc, lag, ss
+
+    # ------------------------------------------------------------ timing
+    def timer_start(self):
+        self._ck(self.lib.dtx_timer_start(self.h), 'dtx_timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.dtx_timer_stop(self.h, C.byref(ms)), 'dtx_timer_stop')
+        return float(ms.value)
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._ck(self.lib.dtx_last_kernel_ms(self.h, C.byref(ms)), 'dtx_last_kernel_ms')
+        return float(ms.value)

@@ -1,0 +1,168 @@
+/* detex_hip.h -- C ABI of libdetexhip.so: the MI355X (gfx950) hot path of Detex.
+ *
+ * The reference (d-chambers/Detex v1.0.9) is pure Python and has no FFI; the
+ * seam this library replaces is the set of plain-Python calls between its
+ * orchestration layer and its NumPy/SciPy numerics:
+ *
+ *   detex/construct.py:148   _makeDFcclags(eventList, row)       -> dtx_xcorr_allpairs
+ *   detex/construct.py:389   _CCX2(fd1, fd2, td1, td2, Nc1, Nc2) -> (one pair of the above)
+ *   detex/detect.py:259-268  per-detector loop calling _MPXDS    -> dtx_subspace_ds
+ *   detex/detect.py:559-578  _SSDetex._MPXDS(MPcon, reqlen, ssTD, ssFD, Nc, MPconFD)
+ *   detex/fas.py:120-134     _MPXSSCorr(MPcon, reqlen, ssTD, ssFD, Nc)  (same statistic)
+ *   detex/detect.py:319-388  _loadMPSubSpace (stack basis vectors)      -> dtx_basis_upload
+ *   detex/detect.py:178-181  np.histogram(DS, linspace(0,1,401))  -> dtx_ds_post (hist)
+ *   detex/detect.py:275-281  MaxDS / inf scrub                    -> dtx_ds_post (maxds)
+ *   detex/detect.py:410      candidates for the trigger loop      -> dtx_ds_post (cand)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - every function returns 0 on success, <0 on error (DTX_E_*); the message
+ *     is available from dtx_last_error(ctx) (ctx may be NULL for creation
+ *     errors).  No exceptions cross the ABI, no global mutable state.
+ *   - one context = one HIP device + one stream.  All "_dev" pointers are
+ *     device pointers valid on that device; work is enqueued on the context's
+ *     stream and is asynchronous unless stated; dtx_ctx_sync() waits for it.
+ *   - float data is IEEE float32; the detection statistic and CC coefficients
+ *     match the reference's float64 NumPy path to 1e-5 absolute.
+ *   - "multiplexed" = channels interleaved sample-wise exactly as
+ *     detex/construct.py:928-987 (multiplex): x[Nc*t + c].
+ */
+#ifndef DETEX_HIP_H
+#define DETEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTX_OK 0
+#define DTX_E_ARG (-1)     /* bad argument */
+#define DTX_E_HIP (-2)     /* a HIP runtime call failed */
+#define DTX_E_STATE (-3)   /* call sequence error (e.g. no basis uploaded) */
+#define DTX_E_NOMEM (-4)
+
+#define DTX_HIST_BINS 400  /* detect.py:80: np.linspace(0, 1, num=401) */
+
+typedef struct dtx_ctx dtx_ctx;
+
+/* Library ABI version (bumped on any signature change). */
+int dtx_version(void);
+
+/* Create a context on HIP device `device`.  `stream` is an existing
+ * hipStream_t to enqueue on (e.g. torch's current stream) or NULL to let the
+ * context create and own one. */
+int dtx_ctx_create(int device, void* stream, dtx_ctx** out);
+int dtx_ctx_destroy(dtx_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int dtx_ctx_sync(dtx_ctx* ctx);
+/* The hipStream_t the context enqueues on. */
+void* dtx_ctx_stream(dtx_ctx* ctx);
+const char* dtx_last_error(dtx_ctx* ctx);
+
+/* ------------------------------------------------------------------------
+ * Subspace detection statistic            (detect.py:559-578, fas.py:120-134)
+ * ------------------------------------------------------------------------ */
+
+/* Stack the basis vectors of all detectors acting on one station
+ * (detect.py:319-388 builds ssTD[name] = U per detector; here they are one
+ * [Ktot][n] row-major matrix, detector d owning rows det_off[d]..det_off[d+1]).
+ * U may be a host or a device pointer; det_off is a host array of D+1 ints.
+ * n must be a multiple of Nc (templates are multiplexed streams) and equal for
+ * all detectors of the station.  Synchronous. */
+int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
+                     int D, int n, int Nc);
+
+/* Number of detection windows for a data block of M multiplexed samples:
+ * len(_MPXDS(...)) = (M - n)//Nc + 1 (detect.py:577), or 0 if M < n. */
+int64_t dtx_num_windows(int64_t M, int n, int Nc);
+
+/* Detection statistic of every uploaded detector over `nchunk` data blocks.
+ *   x_dev    multiplexed data, block b starts at x_dev + b*chunk_stride and
+ *            holds M samples (blocks may overlap: chunk_stride < M is fine,
+ *            cf. the 3600 s + 120 s chunks of getdata.py:509-518)
+ *   ds_dev   out, [nchunk][D][ldp] float32, ldp >= P = dtx_num_windows(M,n,Nc):
+ *            ds[b][d][p] = sum_k (U_k.w - S_k mu)^2 / (n/(n-1) sum (w-mu)^2),
+ *            w = x_b[p*Nc : p*Nc+n]            
+ * Deliberate, documented deviations from the reference's round-off artefacts:
+ * a window of exactly zero variance scores 0 (the reference divides round-off
+ * by ~0), and +inf is stored as 0 (the reference zeroes infs whenever one is
+ * present, detect.py:278-281).  Asynchronous. */
+int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M,
+                    int64_t chunk_stride, int nchunk, float* ds_dev,
+                    int64_t ldp);
+
+/* Post-processing of a DS tensor produced by dtx_subspace_ds (any of the
+ * outputs may be NULL to skip it).
+ *   hist_dev   [D][DTX_HIST_BINS] uint32, ACCUMULATED over the nchunk blocks
+ *              with np.histogram(DS, np.linspace(0,1,401)) semantics
+ *              (detect.py:178-181); caller zeroes it before the first call
+ *   maxds_dev  [nchunk][D] float32 = DS.max() (detect.py:275); NaN propagates
+ *   thr_dev    [D] float32 thresholds; entries with ds >= thr (detect.py:410)
+ *              are appended to the candidate list
+ *   cand_key_dev / cand_val_dev  capacity `cand_cap` entries; key packs
+ *              chunk << 48 | det << 32 | window index -- see dtx_cand_unpack
+ *   ncand_dev  uint32 counter (caller zeroes it); may exceed cand_cap, in which
+ *              case only cand_cap entries were stored (order unspecified)
+ * Asynchronous. */
+int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
+                int nchunk, int D, uint32_t* hist_dev, float* maxds_dev,
+                const float* thr_dev, uint64_t* cand_key_dev,
+                float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
+
+static inline uint64_t dtx_cand_pack(uint32_t chunk, uint32_t det, uint32_t p) {
+  return ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;
+}
+static inline void dtx_cand_unpack(uint64_t key, uint32_t* chunk, uint32_t* det,
+                                   uint32_t* p) {
+  *chunk = (uint32_t)(key >> 48);
+  *det = (uint32_t)((key >> 32) & 0xFFFFu);
+  *p = (uint32_t)(key & 0xFFFFFFFFu);
+}
+
+/* Host-pointer convenience: one data block in host memory -> DS in host memory
+ * (what a single reference _MPXDS loop over detectors returns).  Synchronous;
+ * includes the PCIe transfers. */
+int dtx_subspace_ds_host(dtx_ctx* ctx, const float* x_host, int64_t M,
+                         float* ds_host /* [D][P] */);
+
+/* ------------------------------------------------------------------------
+ * All-pairs normalised cross-correlation          (construct.py:369-466)
+ * ------------------------------------------------------------------------ */
+
+/* Events: N multiplexed templates of equal length n = Nc*L, row-major
+ * td_dev[N][n] (device).  For every pair b < c (reference loop order,
+ * construct.py:380-381) computes what _CCX2 returns:
+ *   cc      max over the channel-aligned lags in the central half of the lag
+ *           range of the Pearson CC of x_b against the zero-padded, shifted x_c
+ *   lag     (maxind + 1 + trunc)*Nc - n, in multiplexed samples (int32)
+ *   subsamp cosine-fit sub-sample shift (construct.py:397-422)
+ * written at the SciPy condensed index of (b, c):
+ *   idx = N*b - b*(b+1)/2 + (c - b - 1)
+ * Only pairs with pair_begin <= idx < pair_end are computed (multi-GPU
+ * sharding); outputs are full-size [N*(N-1)/2] arrays, device pointers.
+ * Asynchronous. */
+int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc,
+                       float* cc_dev, int32_t* lag_dev, float* subsamp_dev,
+                       int64_t pair_begin, int64_t pair_end);
+
+/* Host-pointer convenience for small problems.  Synchronous. */
+int dtx_xcorr_allpairs_host(dtx_ctx* ctx, const float* td_host, int N, int n,
+                            int Nc, float* cc_host, int32_t* lag_host,
+                            float* subsamp_host);
+
+/* ------------------------------------------------------------------------
+ * Timing helper: HIP events on the context's stream (bench.py roofline).
+ * ------------------------------------------------------------------------ */
+int dtx_timer_start(dtx_ctx* ctx);
+/* Records the stop event, waits for it, returns elapsed milliseconds. */
+int dtx_timer_stop(dtx_ctx* ctx, float* ms);
+/* Milliseconds spent inside the dominant kernel of the last dtx_subspace_ds /
+ * dtx_xcorr_allpairs call (events recorded around that kernel only; valid
+ * after dtx_ctx_sync). */
+int dtx_last_kernel_ms(dtx_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETEX_HIP_H */

@@ -273,11 +273,12 @@ def ds_fft_len(data_len_samples, n):
     return reqlen, 2 ** reqlen.bit_length()
 
 
-def mpxds_fft(x, U, Nc, rbi=None):
+def mpxds_fft(x, U, Nc, rbi=None, xFD=None, ssFD=None):
     """detect.py:559-578 == fas.py:120-134 (FFT form, step by step).
 
     x : multiplexed data block (M,), U : basis (K, n).  Returns DS of length
-    (M - n)//Nc + 1."""
+    (M - n)//Nc + 1.  ``xFD`` / ``ssFD`` may carry the precomputed spectra the
+    reference passes in (detect.py:255-256, 367-371)."""
     x = np.asarray(x, dtype=np.float64)
     U = np.atleast_2d(np.asarray(U, dtype=np.float64))
     n = U.shape[1]
@@ -287,8 +288,10 @@ def mpxds_fft(x, U, Nc, rbi=None):
     b = rolling_var_valid(x, n, ddof=1) * n                      # 567-568
     sum_ss = U.sum(axis=1)                                       # 569
     av_norm = a.reshape(1, -1) * sum_ss.reshape(-1, 1)           # 570-572
-    ssFD = np.array([scipy.fftpack.fft(u[::-1], n=rbi) for u in U])
-    xFD = scipy.fftpack.fft(x, n=rbi)
+    if ssFD is None:
+        ssFD = np.array([scipy.fftpack.fft(u[::-1], n=rbi) for u in U])
+    if xFD is None:
+        xFD = scipy.fftpack.fft(x, n=rbi)
     m1 = ssFD * xFD                                              # 573
     if1 = np.real(scipy.fftpack.ifft(m1))[:, n - 1:len(x)] - av_norm  # 575
     with np.errstate(all='ignore'):

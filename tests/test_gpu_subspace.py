@@ -1,0 +1,177 @@
+"""GPU parity of the subspace detection statistic (HIP, through the C ABI)
+against the golden vectors produced by the reference and against the CPU oracle.
+Tolerance: 1e-5 absolute on DS (BASELINE.json north_star), trigger indices and
+histogram counts bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import detex_oracle as orc  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from detex_amd.hip import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def _live(x, n, Nc):
+    win = np.lib.stride_tricks.sliding_window_view(np.asarray(x, dtype=np.float64), n)[::Nc]
+    return win.std(axis=1) > 1e-9
+
+
+def _gpu_ds(ctx, x, U, det_off, Nc):
+    ctx.upload_basis(np.asarray(U, dtype=np.float32), det_off, Nc)
+    ds = ctx.subspace_ds(torch.from_numpy(np.asarray(x, dtype=np.float32)).cuda())
+    ctx.sync()
+    return ds[0].cpu().numpy()
+
+
+def test_golden_mpxds(ctx):
+    z = np.load(os.path.join(G, 'mpxds.npz'))
+    for nm in z['names']:
+        key = nm.split(':')[0]
+        x, U, Nc = z[key + '_x'], z[key + '_U'], int(z[key + '_Nc'])
+        ref = z[key + '_ds']
+        got = _gpu_ds(ctx, x, U, [0, U.shape[0]], Nc)[0]
+        assert got.shape == ref.shape, nm
+        live = _live(x, U.shape[1], Nc)
+        tol = 3e-5 if x.dtype == np.float32 else TOL   # reference itself ran in f32 there
+        assert np.max(np.abs(got[live] - ref[live])) <= tol, nm
+        # zero-variance windows score exactly 0 (documented deviation)
+        dead = np.lib.stride_tricks.sliding_window_view(
+            np.asarray(x, dtype=np.float32), U.shape[1])[::Nc].std(axis=1) == 0
+        assert np.all(got[dead] == 0), nm
+        assert np.all(np.isfinite(got)), nm
+
+
+@pytest.mark.parametrize('Nc,L,ks', [
+    (3, 100, [8]), (3, 100, [1] * 5), (1, 128, [16]), (3, 64, [7, 9, 16, 1]),
+    (3, 100, [8] * 25), (6, 50, [64]), (2, 90, [3] * 30), (3, 33, [40, 60, 108]),
+    (3, 100, [100, 100, 30]), (3, 47, [1] * 230), (1, 31, [5, 11]),
+])
+def test_ds_vs_oracle_shapes(ctx, Nc, L, ks):
+    """Every K-tile row-block count (RM 1..13), several tiles, mixed detector
+    sizes, non-zero-mean rows (singles), L not a multiple of 32."""
+    rs = np.random.RandomState(sum(ks) + L)
+    n = Nc * L
+    K = sum(ks)
+    U = rs.standard_normal((K, n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    U[::3] += 0.02                      # some rows with non-zero mean
+    off = np.concatenate([[0], np.cumsum(ks)])
+    T = 1500
+    x = rs.standard_normal(Nc * T) + 0.3
+    x[Nc * 400: Nc * 400 + n] += 5 * U[off[1] - 1] * np.sqrt(n)
+    got = _gpu_ds(ctx, x, U, off, Nc)
+    Uf = U.astype(np.float32).astype(np.float64)
+    xf = x.astype(np.float32).astype(np.float64)
+    assert got.shape == (len(ks), T - L + 1)
+    for d in range(len(ks)):
+        ref = orc.mpxds_fft(xf, Uf[off[d]:off[d + 1]], Nc)
+        assert np.max(np.abs(got[d] - ref)) <= TOL, (d, ks[d])
+
+
+def test_ragged_and_short_blocks(ctx):
+    rs = np.random.RandomState(5)
+    Nc, L = 3, 40
+    n = Nc * L
+    U = rs.standard_normal((4, n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    for M in [n + 1, n + Nc, n + 10 * Nc + 2, 2 * n + 1, 1000, 4099]:
+        x = rs.standard_normal(M)
+        got = _gpu_ds(ctx, x, U, [0, 4], Nc)
+        ref = orc.mpxds_fft(x.astype(np.float32), U.astype(np.float32), Nc)
+        assert got.shape == (1, len(ref)) and len(ref) == (M - n) // Nc + 1
+        assert np.max(np.abs(got[0] - ref)) <= TOL, M
+    # a block not longer than the template is an error (detect.py:262-266)
+    from detex_amd import DetexHipError
+    ctx.upload_basis(U.astype(np.float32), [0, 4], Nc)
+    with pytest.raises(DetexHipError):
+        ctx.subspace_ds(torch.zeros(n, device='cuda'))
+
+
+def test_overlapping_chunks_and_linearity(ctx):
+    """chunk_stride < M (the 3600 s + 120 s chunking) and scale invariance."""
+    rs = np.random.RandomState(11)
+    Nc, L = 3, 60
+    n = Nc * L
+    U = rs.standard_normal((6, n))
+    U -= U.mean(axis=1, keepdims=True)
+    U = np.linalg.qr(U.T)[0].T
+    ctx.upload_basis(U.astype(np.float32), [0, 2, 6], Nc)
+    day = torch.from_numpy(rs.standard_normal(Nc * 5000).astype(np.float32)).cuda()
+    M, stride, nchunk = Nc * 1200, Nc * 1000, 4
+    ds = ctx.subspace_ds(day, M=M, chunk_stride=stride, nchunk=nchunk)
+    ds2 = ctx.subspace_ds(day * 1000.0, M=M, chunk_stride=stride, nchunk=nchunk)
+    ctx.sync()
+    ds, ds2 = ds.cpu().numpy(), ds2.cpu().numpy()
+    dayh = day.cpu().numpy().astype(np.float64)
+    for b in range(nchunk):
+        xb = dayh[b * stride: b * stride + M]
+        for d, (lo, hi) in enumerate([(0, 2), (2, 6)]):
+            ref = orc.mpxds_fft(xb, U.astype(np.float32)[lo:hi], Nc)
+            assert np.max(np.abs(ds[b, d] - ref)) <= TOL
+    # overlapping parts of consecutive chunks agree to rounding
+    ov = 100
+    assert np.max(np.abs(ds[0, :, 1000:1000 + ov] - ds[1, :, :ov])) <= 2e-6
+    assert np.max(np.abs(ds - ds2)) <= 2e-6          # DS is scale invariant
+    assert ds.min() >= 0 and ds.max() <= 1 + 1e-5    # orthonormal zero-mean basis
+
+
+def test_post_hist_max_triggers(ctx):
+    """Histogram counts, MaxDS and trigger picking on GPU-computed DS are
+    bit-exact with the reference algorithms run on the same DS values."""
+    rs = np.random.RandomState(21)
+    Nc, L, sr = 3, 50, 10.0          # +-20 s = +-200 windows
+    n = Nc * L
+    ks = [4, 1, 3]
+    off = np.concatenate([[0], np.cumsum(ks)])
+    U = rs.standard_normal((sum(ks), n))
+    U -= U.mean(axis=1, keepdims=True)
+    U = np.linalg.qr(U.T)[0].T
+    ctx.upload_basis(U.astype(np.float32), off, Nc)
+    nchunk, T = 3, 4000
+    x = rs.standard_normal((nchunk, Nc * T))
+    plants = [(0, 5, 0), (0, 900, 0), (0, 1020, 0), (1, 2000, 2), (2, T - L - 3, 1), (2, 100, 0)]
+    for (b, p, d) in plants:
+        c = rs.standard_normal(ks[d])
+        x[b, Nc * p: Nc * p + n] += (c / np.linalg.norm(c)) @ U[off[d]:off[d + 1]] * 4 * np.sqrt(n)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    ds = ctx.subspace_ds(xt)
+    thr = np.array([0.35, 0.3, 0.4], dtype=np.float32)
+    res = ctx.ds_post(ds, thr=thr)
+    ctx.sync()
+    dsh = ds.cpu().numpy()
+    hist = res['hist'].cpu().numpy()
+    for d in range(3):
+        want = sum(orc.ds_histogram(dsh[b, d]) for b in range(nchunk))
+        assert np.array_equal(hist[d], want)
+    assert np.array_equal(res['maxds'].cpu().numpy(), dsh.max(axis=2))
+    cb, cd, cp, cv = res['cand']
+    assert res['ncand'] == len(cv) == int((dsh >= thr[None, :, None]).sum())
+    from detex_amd.detect import pick_triggers_sparse
+    nfound = 0
+    for b in range(nchunk):
+        for d in range(3):
+            want = [t['index'] for t in orc.pick_triggers(dsh[b, d], thr[d], sr, 0.0)] \
+                if orc.eval_trig_con(dsh[b, d].max(), thr[d]) else []
+            sel = (cb == b) & (cd == d)
+            got = pick_triggers_sparse(cp[sel], cv[sel], dsh.shape[2], float(thr[d]), sr,
+                                       float(res['maxds'][b, d]))
+            assert [g[0] for g in got] == want, (b, d)
+            for g in got:
+                assert g[1] == dsh[b, d, g[0]]
+            nfound += len(got)
+    assert nfound >= len(plants) - 1     # the two plants 12 s apart merge into one
+    for (b, p, d) in plants:
+        assert dsh[b, d, p] > 0.5

@@ -1,0 +1,158 @@
+"""GPU parity of the all-pairs normalised cross-correlation (HIP, through the C
+ABI) against the reference-generated golden vectors and the CPU oracle.
+Tolerances: cc 1e-5, lag exact, subsamp 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import detex_oracle as orc  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SCRUB = 1e-5
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from detex_amd.hip import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def _gpu(ctx, td, Nc, **kw):
+    t = torch.from_numpy(np.ascontiguousarray(td, dtype=np.float32)).cuda()
+    cc, lag, ss = ctx.xcorr_allpairs(t, Nc, **kw)
+    ctx.sync()
+    return cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy()
+
+
+def _knife(raw, trunc):
+    """True if the oracle's raw CC vector has a value within the scrub band of
+    +-1, where float32 vs float64 rounding legitimately flips the decision."""
+    tr = raw[trunc:-trunc]
+    tr = tr[np.isfinite(tr)]
+    return bool(np.any(np.abs(np.abs(tr) - 1.0) < 2 * SCRUB))
+
+
+def _check_pair(x1, x2, Nc, got, what):
+    x1 = np.asarray(x1, dtype=np.float32).astype(np.float64)
+    x2 = np.asarray(x2, dtype=np.float32).astype(np.float64)
+    n = len(x1)
+    trunc = n // (2 * Nc) - 1
+    raw = orc.ccx2_raw_direct(x1, x2, Nc)
+    cc, lag, ss, res = orc.ccx2_reduce(raw, n, Nc, trunc, SCRUB)
+    if _knife(raw, trunc):
+        # e.g. identical events: cc must still be the scrub-tolerant answer
+        assert abs(got[0] - cc) <= 2e-5, what
+        return 'knife'
+    # near-ties between two lags can legitimately resolve differently in f32
+    order = np.sort(res[np.isfinite(res)])
+    if len(order) > 1 and order[-1] - order[-2] < 5e-6:
+        assert abs(got[0] - cc) <= 1e-5, what
+        return 'tie'
+    assert abs(got[0] - cc) <= 1e-5, (what, got, cc, lag, ss)
+    assert got[1] == lag, (what, got, cc, lag, ss)
+    if abs(ss) <= .5:
+        assert abs(got[2] - ss) <= 1e-4, (what, got, ss)
+    else:
+        assert got[2] == np.float32(ss), (what, got, ss)
+    return 'ok'
+
+
+def test_golden_ccx2_pairs(ctx):
+    """Every golden _CCX2 case as a 2-event problem; compared with the reference
+    output where the case is not a knife-edge, and with the oracle always."""
+    z = np.load(os.path.join(G, 'ccx2.npz'))
+    stats = {'ok': 0, 'knife': 0, 'tie': 0}
+    nref = 0
+    for nm in z['names']:
+        key = nm.split(':')[0]
+        x1, x2, Nc = z[key + '_x1'], z[key + '_x2'], int(z[key + '_Nc'])
+        cc, lag, ss = _gpu(ctx, np.stack([x1, x2]), Nc)
+        got = (float(cc[0]), int(lag[0]), float(ss[0]))
+        kind = _check_pair(x1, x2, Nc, got, nm)
+        stats[kind] += 1
+        ref = z[key + '_out']
+        if kind == 'ok' and 'zero' not in nm:
+            assert abs(got[0] - ref[0]) <= 1e-5 and got[1] == ref[1], (nm, got, ref)
+            if abs(ref[2]) <= .5:
+                assert abs(got[2] - ref[2]) <= 1e-4, (nm, got, ref)
+            nref += 1
+    assert stats['ok'] >= 45 and nref >= 35, (stats, nref)
+
+
+def test_golden_cclags_matrix(ctx):
+    z = np.load(os.path.join(G, 'cclags.npz'))
+    for tag in 'ab':
+        ev, Nc = z[tag + '_events'], int(z[tag + '_Nc'])
+        N = len(ev)
+        cc, lag, ss = _gpu(ctx, ev, Nc)
+        iu = np.triu_indices(N, 1)
+        rcc = z[tag + '_cc'][iu[0], iu[1] - 1]
+        rlag = z[tag + '_lag'][iu[0], iu[1] - 1]
+        rss = z[tag + '_subsamp'][iu[0], iu[1] - 1]
+        assert np.max(np.abs(cc - rcc)) <= 1e-5
+        assert np.array_equal(lag, rlag.astype(np.int32))
+        assert np.max(np.abs(ss - rss)) <= 1e-4
+        # the dissimilarity vector feeds scipy linkage in condensed order
+        assert np.max(np.abs((1.0000001 - cc) - z[tag + '_cx'])) <= 1e-5
+
+
+@pytest.mark.parametrize('N,Nc,L', [(5, 3, 64), (17, 1, 100), (40, 3, 37), (9, 6, 50),
+                                    (230, 2, 24), (12, 3, 333)])
+def test_allpairs_vs_oracle(ctx, N, Nc, L):
+    """Row tiles of every size (N > 208 spans two tiles), odd lengths."""
+    from detex_amd import synth
+    td = synth.event_families(N + L, max(1, N // 4), 4, Nc, L, maxshift=L // 8, snr=4.0)[:N]
+    if len(td) < N:
+        td = np.concatenate([td, synth.event_families(7, N - len(td), 1, Nc, L, L // 8)])
+    cc, lag, ss = _gpu(ctx, td, Nc)
+    rs = np.random.RandomState(N)
+    pairs = [(b, c) for b in range(N) for c in range(b + 1, N)]
+    if len(pairs) > 150:
+        pairs = [pairs[i] for i in rs.choice(len(pairs), 150, replace=False)]
+    nok = 0
+    for (b, c) in pairs:
+        idx = N * b - b * (b + 1) // 2 + (c - b - 1)
+        got = (float(cc[idx]), int(lag[idx]), float(ss[idx]))
+        nok += _check_pair(td[b], td[c], Nc, got, (b, c)) == 'ok'
+    assert nok >= 0.9 * len(pairs)
+
+
+def test_pair_range_sharding(ctx):
+    """Disjoint [pair_begin, pair_end) ranges reproduce the full result (the
+    multi-GPU partition) and leave other entries untouched."""
+    from detex_amd import synth
+    N, Nc, L = 30, 3, 48
+    td = synth.event_families(3, 6, 5, Nc, L, maxshift=6)
+    full = _gpu(ctx, td, Nc)
+    npairs = N * (N - 1) // 2
+    cuts = [0, 1, 57, 200, 201, npairs]
+    acc = [np.zeros(npairs, np.float32), np.zeros(npairs, np.int32), np.zeros(npairs, np.float32)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = _gpu(ctx, td, Nc, pair_begin=lo, pair_end=hi)
+        for a, p in zip(acc, part):
+            assert not p[:lo].any() and not p[hi:].any()
+            a[lo:hi] = p[lo:hi]
+    for a, f in zip(acc, full):
+        assert np.array_equal(a, f)
+
+
+def test_dead_and_degenerate_events(ctx):
+    rs = np.random.RandomState(2)
+    Nc, L = 3, 40
+    td = rs.standard_normal((4, Nc * L)).astype(np.float32)
+    td[1] = 0.0                       # all-zero event -> (0, 0, 0) (construct.py:463-464)
+    td[3] = 2.5                       # constant event: zero variance
+    cc, lag, ss = _gpu(ctx, td, Nc)
+    N = 4
+    for (b, c) in [(0, 1), (1, 2), (1, 3)]:
+        idx = N * b - b * (b + 1) // 2 + (c - b - 1)
+        assert cc[idx] == 0 and lag[idx] == 0 and ss[idx] == 0
+    # too short for the central-half truncation (L < 4): all zeros
+    cc, lag, ss = _gpu(ctx, rs.standard_normal((3, 6)).astype(np.float32), 2)
+    assert not cc.any() and not lag.any() and not ss.any()
