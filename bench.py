@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-vectors', type=int, default=40,
+    ap.add_argument('--cpu-vectors', type=int, default=200,
                     help='basis vectors the CPU baseline sample covers')
     return ap.parse_args()
 

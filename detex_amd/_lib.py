@@ -48,7 +48,7 @@ def load():
     lib.dtx_version.restype = i32
     lib.dtx_version.argtypes = []
     lib.dtx_ctx_create.restype = i32
-    lib.dtx_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    lib.dtx_ctx_create.argtypes = [i32, vp, i32, C.POINTER(vp)]
     lib.dtx_ctx_destroy.restype = i32
     lib.dtx_ctx_destroy.argtypes = [vp]
     lib.dtx_ctx_sync.restype = i32

@@ -50,7 +50,7 @@ const char* dtx_last_error(dtx_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_err.c_str();
 }
 
-int dtx_ctx_create(int device, void* stream, dtx_ctx** out) {
+int dtx_ctx_create(int device, void* stream, int own_stream, dtx_ctx** out) {
   if (!out) return dtx_fail(nullptr, DTX_E_ARG, "dtx_ctx_create: out is NULL");
   *out = nullptr;
   int ndev = 0;
@@ -63,8 +63,8 @@ int dtx_ctx_create(int device, void* stream, dtx_ctx** out) {
   DtxDeviceGuard g(device);
   dtx_ctx* c = new dtx_ctx();
   c->device = device;
-  if (stream) {
-    c->stream = (hipStream_t)stream;
+  if (!own_stream) {
+    c->stream = (hipStream_t)stream;   // NULL = the default stream
   } else {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {

@@ -30,7 +30,7 @@ class HipContext(object):
         torch.cuda.set_device(self.device)
         self._stream = torch.cuda.current_stream(self.device)
         h = C.c_void_p()
-        rc = self.lib.dtx_ctx_create(int(device), C.c_void_p(self._stream.cuda_stream),
+        rc = self.lib.dtx_ctx_create(int(device), C.c_void_p(self._stream.cuda_stream), 0,
                                      C.byref(h))
         _lib.check(self.lib, None, rc, 'dtx_ctx_create')
         self.h = h

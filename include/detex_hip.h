@@ -49,10 +49,11 @@ typedef struct dtx_ctx dtx_ctx;
 /* Library ABI version (bumped on any signature change). */
 int dtx_version(void);
 
-/* Create a context on HIP device `device`.  `stream` is an existing
- * hipStream_t to enqueue on (e.g. torch's current stream) or NULL to let the
- * context create and own one. */
-int dtx_ctx_create(int device, void* stream, dtx_ctx** out);
+/* Create a context on HIP device `device`.  With own_stream == 0 the context
+ * enqueues on `stream`, an existing hipStream_t (e.g. torch's current stream);
+ * NULL is HIP's default (null) stream.  With own_stream != 0 `stream` is
+ * ignored and the context creates and owns a non-blocking stream. */
+int dtx_ctx_create(int device, void* stream, int own_stream, dtx_ctx** out);
 int dtx_ctx_destroy(dtx_ctx* ctx);
 /* Block until everything enqueued on the context's stream has finished. */
 int dtx_ctx_sync(dtx_ctx* ctx);

@@ -46,7 +46,7 @@ def test_fails_loudly_without_gpu(lib):
     if torch.cuda.is_available():
         pytest.skip('GPU present')
     h = ctypes.c_void_p()
-    rc = lib.dtx_ctx_create(0, None, ctypes.byref(h))
+    rc = lib.dtx_ctx_create(0, None, 0, ctypes.byref(h))
     assert rc < 0 and b'HIP' in lib.dtx_last_error(None)
     from detex_amd.hip import HipContext
     from detex_amd import DetexHipError
