@@ -29,12 +29,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace dtx {
 
-constexpr int kBQ = 32;        // contraction depth staged per step
+constexpr int kBQ = 64;        // contraction depth staged per step
 constexpr int kThreads = 512;  // 8 waves, 2 per SIMD
 constexpr int kRmMax = 13;     // 13 * 16 = 208 rows per K-tile
 constexpr int kKtMax = 16 * kRmMax;
@@ -45,6 +46,31 @@ __host__ __device__ constexpr int kts_for(int rm) { return 16 * rm + ((rm & 1) ?
 // floats of LDS one block needs
 __host__ __device__ constexpr int lds_floats(int rm) {
   return 2 * (kBQ * kts_for(rm) + pt_for(rm) + kBQ);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ds_read_b32 with a 16-bit immediate byte offset: one base VGPR serves a whole
+// 64-row tile, so the fragment reads need no address arithmetic between MFMAs
+// (hipcc otherwise merges pairs into ds_read2_b32, whose 8-bit offsets force a
+// v_add per pair -- VALU issue next to MFMAs is what costs).
+// The result is asynchronous: the caller waits with lds_wait_all() before use.
+template <int OFF>
+__device__ __forceinline__ float lds_read_imm(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset is 16 bits");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep MFMAs behind the wait (hipcc would hoist them)
 }
 
 template <int RM, int TN>
@@ -111,25 +137,104 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   DTX_STORE_TILE(0);
   __syncthreads();
 
+#ifndef DTX_PIPE
+#define DTX_PIPE 3
+#endif
+// fragments of k-step jj_ into register set set_
+#define DTX_LOAD_FRAGS(set_, jj_)                                                          \
+  do {                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < RM; ++r) av[set_][r] = B[(jj_) * KTS + aoff + 16 * r]; \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t) bv[set_][t] = B[boff + 16 * t + (jj_)]; \
+  } while (0)
+
+#if DTX_PIPE == 3
+  // Hand-scheduled k-loop: the LDS reads of k-step ks+1 (immediate-offset
+  // ds_read_b32 from two base registers) are issued between the MFMAs of k-step
+  // ks, one row block at a time; a single lgkmcnt(0) per k-step, long after the
+  // reads were issued.
+  const unsigned lds_base = (unsigned)(unsigned long long)(
+      (__attribute__((address_space(3))) float*)lds);
+  constexpr int KS = kBQ / 4;
+  for (int s = 0; s < nsteps; ++s) {
+    const unsigned bufb = lds_base + (unsigned)((s & 1) * BUF) * 4u;
+    const unsigned abase = bufb + (unsigned)aoff * 4u;
+    const unsigned bbase = bufb + (unsigned)boff * 4u;
+    float av[2][RM], bv[2][TN];
+    static_for<0, RM>([&](auto rc) { av[0][rc] = lds_read_imm<(16 * rc) * 4>(abase); });
+    static_for<0, TN>([&](auto tc) { bv[0][tc] = lds_read_imm<(16 * tc) * 4>(bbase); });
+    if (s + 1 < nsteps) DTX_LOAD_TILE(s + 1);
+    lds_wait_all();
+    static_for<0, KS>([&](auto ksc) {
+      constexpr int ks = ksc, cur = ks & 1, nxt = cur ^ 1;
+      static_for<0, RM>([&](auto rc) {
+        constexpr int r = rc;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][r], bv[cur][t], acc[r][t], 0, 0, 0);
+        if constexpr (ks + 1 < KS) {
+          av[nxt][r] = lds_read_imm<((ks + 1) * 4 * KTS + 16 * r) * 4>(abase);
+          // the TN stream fragments ride along with the first row blocks
+          constexpr int TPR = (TN + RM - 1) / RM;
+          static_for<0, TPR>([&](auto qc) {
+            constexpr int t = r * TPR + qc;
+            if constexpr (t < TN) bv[nxt][t] = lds_read_imm<(16 * t + (ks + 1) * 4) * 4>(bbase);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (ks + 1 < KS) lds_wait_all();
+    });
+    if (s + 1 < nsteps) DTX_STORE_TILE((s + 1) & 1);
+    __syncthreads();
+  }
+#else
   for (int s = 0; s < nsteps; ++s) {
     const float* B = lds + (s & 1) * BUF;
+#ifndef DTX_DBG_NOSTAGE
     if (s + 1 < nsteps) DTX_LOAD_TILE(s + 1);
+#endif
+    // fragment reads run one k-step ahead of the MFMAs that consume them
+    float av[2][RM], bv[2][TN];
+    DTX_LOAD_FRAGS(0, 0);
 #pragma unroll
-    for (int jj = 0; jj < kBQ; jj += 4) {
-      float av[RM], bv[TN];
-#pragma unroll
-      for (int r = 0; r < RM; ++r) av[r] = B[jj * KTS + aoff + 16 * r];
-#pragma unroll
-      for (int t = 0; t < TN; ++t) bv[t] = B[boff + 16 * t + jj];
+    for (int ks = 0; ks < kBQ / 4; ++ks) {
+      const int cur = ks & 1;
+#ifdef DTX_DBG_NOFRAG
+      if (ks + 1 < kBQ / 4) {
+        _Pragma("unroll") for (int r = 0; r < RM; ++r) av[cur ^ 1][r] = av[cur][r] + 1.f;
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) bv[cur ^ 1][t] = bv[cur][t] + 1.f;
+      }
+#else
+      if (ks + 1 < kBQ / 4) DTX_LOAD_FRAGS(cur ^ 1, (ks + 1) * 4);
+#endif
+#if DTX_PIPE == 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int t = 0; t < TN; ++t)
-          acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[t], acc[r][t], 0, 0, 0);
+          acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][r], bv[cur][t], acc[r][t], 0, 0, 0);
+#if DTX_PIPE == 2
+      // interleave: the next k-step's LDS reads are spread between this k-step's MFMAs
+      if (ks + 1 < kBQ / 4) {
+#pragma unroll
+        for (int g = 0; g < (RM + TN + 1) / 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (RM * TN) / ((RM + TN + 1) / 2), 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                // DS read
+        }
+      }
+#elif DTX_PIPE == 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+#ifndef DTX_DBG_NOSTAGE
     if (s + 1 < nsteps) DTX_STORE_TILE((s + 1) & 1);
     __syncthreads();
+#endif
   }
+#undef DTX_LOAD_FRAGS
+#endif
 #undef DTX_LOAD_TILE
 #undef DTX_STORE_TILE
 }
