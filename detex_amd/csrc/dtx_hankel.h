@@ -73,7 +73,7 @@ __device__ __forceinline__ void lds_wait_all() {
   __builtin_amdgcn_sched_barrier(0);   // keep MFMAs behind the wait (hipcc would hoist them)
 }
 
-template <int RM, int TN>
+template <int RM, int TN, bool GL = false>
 __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const float* __restrict__ at,
                                                 int ldk, int Lp, const float* __restrict__ xw,
                                                 int64_t plane_stride, int Nc, int jlo, int jhi,
@@ -130,11 +130,45 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
     if (tid < XV) reinterpret_cast<float4*>(ud_ + kBQ * KTS)[tid] = rx;                    \
   } while (0)
 
+  // LDS-DMA staging of the A tile (GL): the tile is one linear image when the LDS
+  // row stride equals the global one (KTS == KT == ldk), so each wave copies whole
+  // 1 KiB units with global_load_lds_dwordx4 -- no staging VGPRs, no ds_write, no
+  // address VALU beyond one 64-bit add per unit.
+  static_assert(!GL || KTS == KT, "LDS-DMA needs an unpadded LDS image");
+  constexpr int UNITS = kBQ * KT * 4 / 1024;         // 1 KiB wave-instructions per A tile
+  constexpr int NGU = (UNITS + 7) / 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define DTX_GLDS_TILE(s_, buf_)                                                            \
+  do {                                                                                     \
+    const int c_ = (s_) / spc;                                                             \
+    const int j0_ = jlo + ((s_) - c_ * spc) * kBQ;                                         \
+    const float* ab_ = at + ((int64_t)c_ * Lp + j0_) * KT + lane * 4;                      \
+    float* ld_ = lds + (buf_) * BUF;                                                       \
+    _Pragma("unroll") for (int m = 0; m < NGU; ++m) {                                      \
+      const int u_ = wave_u + 8 * m;                                                       \
+      if ((m + 1) * 8 <= UNITS || u_ < UNITS)                                              \
+        __builtin_amdgcn_global_load_lds(                                                  \
+            (const __attribute__((address_space(1))) void*)(ab_ + u_ * 256),               \
+            (__attribute__((address_space(3))) void*)(ld_ + u_ * 256), 16, 0, 0);          \
+    }                                                                                      \
+    if (tid < XV)                                                                          \
+      rx = reinterpret_cast<const float4*>(xw + (int64_t)c_ * plane_stride + j0_)[tid];    \
+  } while (0)
+#define DTX_STORE_X(buf_)                                                                  \
+  do {                                                                                     \
+    if (tid < XV) reinterpret_cast<float4*>(lds + (buf_) * BUF + kBQ * KTS)[tid] = rx;     \
+  } while (0)
+
   const int aoff = kq * KTS + i;
   const int boff = kBQ * KTS + col0 + i + kq;
 
-  DTX_LOAD_TILE(0);
-  DTX_STORE_TILE(0);
+  if constexpr (GL) {
+    DTX_GLDS_TILE(0, 0);
+    DTX_STORE_X(0);
+  } else {
+    DTX_LOAD_TILE(0);
+    DTX_STORE_TILE(0);
+  }
   __syncthreads();
 
 #ifndef DTX_PIPE
@@ -162,7 +196,10 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
     float av[2][RM], bv[2][TN];
     static_for<0, RM>([&](auto rc) { av[0][rc] = lds_read_imm<(16 * rc) * 4>(abase); });
     static_for<0, TN>([&](auto tc) { bv[0][tc] = lds_read_imm<(16 * tc) * 4>(bbase); });
-    if (s + 1 < nsteps) DTX_LOAD_TILE(s + 1);
+    if (s + 1 < nsteps) {
+      if constexpr (GL) DTX_GLDS_TILE(s + 1, (s + 1) & 1);
+      else DTX_LOAD_TILE(s + 1);
+    }
     lds_wait_all();
     static_for<0, KS>([&](auto ksc) {
       constexpr int ks = ksc, cur = ks & 1, nxt = cur ^ 1;
@@ -184,7 +221,10 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
       });
       if constexpr (ks + 1 < KS) lds_wait_all();
     });
-    if (s + 1 < nsteps) DTX_STORE_TILE((s + 1) & 1);
+    if (s + 1 < nsteps) {
+      if constexpr (GL) DTX_STORE_X((s + 1) & 1);
+      else DTX_STORE_TILE((s + 1) & 1);
+    }
     __syncthreads();
   }
 #else
@@ -236,6 +276,8 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
 #undef DTX_LOAD_FRAGS
 #endif
 #undef DTX_LOAD_TILE
+#undef DTX_GLDS_TILE
+#undef DTX_STORE_X
 #undef DTX_STORE_TILE
 }
 

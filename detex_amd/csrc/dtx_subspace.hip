@@ -18,6 +18,10 @@
 
 using namespace dtx;
 
+#ifndef DTX_USE_GLDS
+#define DTX_USE_GLDS 1
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------ demux
@@ -66,7 +70,8 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  hankel_mainloop<RM, TN>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
+  // odd RM: LDS row stride == KT == global row stride -> LDS-DMA staging
+  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
                           a.Nc, 0, a.Lp, lds);
 
   // ---------------- epilogue: mean correction, per-detector energy, normalise

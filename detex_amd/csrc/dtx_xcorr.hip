@@ -23,6 +23,10 @@
 
 using namespace dtx;
 
+#ifndef DTX_USE_GLDS
+#define DTX_USE_GLDS 1
+#endif
+
 namespace {
 
 constexpr float kScrubTol = 1e-5f;   // see DESIGN.md "knife-edge scrub"
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  hankel_mainloop<RM, TN>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
+  // RM == 13: the 208-wide event tile is copied whole -> LDS-DMA staging
+  hankel_mainloop<RM, TN, RM == kRmMax && DTX_USE_GLDS>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
                           a.z + (int64_t)c * a.Nc * a.Tz + p0, a.Tz, a.Nc, jlo, jhi, lds);
 
   // ---------------- epilogue: normalise, scrub, max / first argmax over lags
