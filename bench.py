@@ -93,14 +93,12 @@ def main():
     ctx = HipContext(local)
 
     # detector basis: built on rank 0, broadcast over RCCL/xGMI (the only collective)
+    from detex_amd import parallel
     if rank == 0:
         U, det_off = synth.detector_bank(1, D, k, n)
-        Ut = torch.from_numpy(U).cuda()
     else:
-        Ut = torch.empty((K, n), dtype=torch.float32, device='cuda')
-        det_off = (np.arange(D + 1) * k).astype(np.int32)
-    if world > 1:
-        dist.broadcast(Ut, src=0)
+        U, det_off = None, None
+    Ut, det_off = parallel.broadcast_basis(U, det_off, n, torch.device('cuda', local))
     ctx.upload_basis(Ut, det_off, Nc)
     Uh = Ut.cpu().numpy()
 
