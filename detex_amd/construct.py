@@ -1,0 +1,304 @@
+"""createCluster / createSubSpace with the reference's names and argument meaning
+(detex/construct.py:25-171, 177-301), on in-memory pre-processed waveforms.
+
+The numerics seam is ``_makeDFcclags`` (detex/construct.py:369-394): the
+reference's Python pair loop is replaced by ONE call into the HIP library
+(dtx_xcorr_allpairs); everything around it (dissimilarity, SciPy single linkage,
+dendrogram cut, alignment by accumulated lags, Harris 2006 App. B) is host logic
+on tiny arrays and follows the reference line by line.
+"""
+import numpy as np
+import pandas as pd
+from scipy.cluster.hierarchy import linkage
+
+from ._lib import DetexHipError
+from .getdata import EventFetcher, multiplex
+
+
+def _error(msg, exc=DetexHipError):
+    """detex.log(level='error') raises (detex/__init__.py:131-138)."""
+    raise exc(msg)
+
+
+# --------------------------------------------------------------------------
+# event loading                                   construct.py:615-706
+# --------------------------------------------------------------------------
+
+def _loadEvents(fetcher, dtype):
+    """construct.py:615-655 on an EventFetcher: one row per station with
+    Events (sorted), MPtd {event: multiplexed float array}, Channels, Stats."""
+    np_dtype = np.float32 if dtype == 'single' else np.float64
+    rows = []
+    for sta in fetcher.stations():
+        mptd, stats, chans = {}, {}, {}
+        for name, rec in fetcher.getTemData(sta):
+            mptd[name] = multiplex(list(np.asarray(rec['data'], dtype=np_dtype)))
+            stats[name] = dict(Nc=len(fetcher.channels), sampling_rate=fetcher.sampling_rate,
+                               starttime=rec['starttime'], origintime=rec['origintime'],
+                               magnitude=rec['magnitude'],
+                               offset=rec['starttime'] - rec['origintime'])
+            chans[name] = list(fetcher.channels)
+        if not mptd:
+            continue
+        # construct.py:679-694 _testStreamLengths: trim to the smallest length that is
+        # within 90 % of the median, drop shorter events
+        lens = np.array([len(v) for v in mptd.values()])
+        le = int(np.min(lens[lens > np.median(lens) * .9]))
+        events = sorted(k for k, v in mptd.items() if len(v) >= le)
+        mptd = {k: mptd[k][:le] for k in events}
+        rows.append(dict(Station=sta, Events=events, MPtd=mptd,
+                         Channels={k: chans[k] for k in events},
+                         Stats={k: stats[k] for k in events},
+                         Link=None, CCs=None, Lags=None, Subsamp=None, numEvents=len(events)))
+    TRDF = pd.DataFrame(rows, dtype=object)
+    if len(TRDF):
+        TRDF = TRDF.sort_values(by='Station').reset_index(drop=True)
+    return TRDF
+
+
+# --------------------------------------------------------------------------
+# the numerics seam                                construct.py:369-394
+# --------------------------------------------------------------------------
+
+def _frames_from_condensed(N, cc, lag, ss):
+    """Condensed (b < c, row-major) vectors -> DFcc, DFlag, DFsubsamp with the
+    reference's layout: index 0..N-2, columns 1..N-1, NaN below the diagonal
+    (construct.py:373-378)."""
+    cols = np.arange(1, N)
+    idx = np.arange(0, N - 1)
+    iu = np.triu_indices(N, 1)
+    out = []
+    for v in (cc, lag, ss):
+        m = np.full((N - 1, N - 1), np.nan, dtype=np.float64)
+        m[iu[0], iu[1] - 1] = np.asarray(v, dtype=np.float64)
+        out.append(pd.DataFrame(m, columns=cols, index=idx))
+    return out[0], out[1], out[2]
+
+
+def _makeDFcclags(eventList, row, ctx):
+    """construct.py:369-394 on the GPU: all pairs b < c of ``eventList`` in one
+    dtx_xcorr_allpairs call.  Returns (DFcc, DFlag, DFsubsamp)."""
+    import torch
+    if len(set(len(row.Channels[e]) for e in eventList)) != 1:
+        _error('Number of Channels not equal, cannot perform correlation')      # 429-431
+    if len(set(len(row.MPtd[e]) for e in eventList)) != 1:
+        _error('Lengths not equal on multiplexed data, cannot correlate')       # 433-436
+    Nc = len(row.Channels[eventList[0]])
+    td = np.ascontiguousarray([row.MPtd[e] for e in eventList], dtype=np.float32)
+    cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc)
+    ctx.sync()
+    return _frames_from_condensed(len(eventList), cc.cpu().numpy(), lag.cpu().numpy(),
+                                  ss.cpu().numpy())
+
+
+def _flatNoNan(df):
+    """construct.py:702-708."""
+    ar = np.asarray(df.values, dtype=np.float64).flatten()
+    return ar[~np.isnan(ar)]
+
+
+# --------------------------------------------------------------------------
+# createCluster                                    construct.py:25-171
+# --------------------------------------------------------------------------
+
+def _checkClusterInputs(filt, dtype, trim, decimate):
+    """construct.py:304-... argument validation."""
+    if filt is not None and len(filt) != 4:
+        _error('filt must be a list of length 4: [freqmin, freqmax, corners, zerophase]',
+               ValueError)
+    if dtype not in ('double', 'single'):
+        _error('dtype must be "double" or "single"', ValueError)
+    if trim is not None and len(trim) != 2:
+        _error('trim must be a list of length 2', ValueError)
+    if decimate is not None and (not isinstance(decimate, int) or decimate < 1):
+        _error('decimate must be None or a positive int', ValueError)
+
+
+def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=None,
+                  templateKey=None, trim=[10, 120], saveclust=False, fileName='clust.pkl',
+                  decimate=None, dtype='double', eventsOnAllStations=False,
+                  enforceOrigin=False, fillZeros=False, phases=None, device=0, ctx=None):
+    """Create a ClusterStream (detex/construct.py:25-171).
+
+    Differences from the reference, all outside the hot path: ``fetch_arg`` is an
+    ``EventFetcher`` holding pre-processed waveforms (ObsPy I/O and filtering are
+    out of scope); ``stationKey`` / ``templateKey`` / ``phases`` are accepted and
+    stored but the station and event lists come from the fetcher; ``filt``,
+    ``trim`` and ``decimate`` are recorded (they describe how the data WERE
+    processed).  ``device`` / ``ctx`` select the GPU context."""
+    from .subspace import ClusterStream
+    from .hip import HipContext
+    _checkClusterInputs(filt, dtype, trim, decimate)
+    if not isinstance(fetch_arg, EventFetcher):
+        _error('fetch_arg must be a detex_amd.getdata.EventFetcher', TypeError)
+    TRDF = _loadEvents(fetch_arg, dtype)
+    if len(TRDF) < 1:
+        _error('No events survived pre-processing, check DataFetcher and event quality')
+    if eventsOnAllStations:
+        eventList = sorted(set.intersection(*[set(x) for x in TRDF.Events]))
+        if len(eventList) < 2:
+            _error('less than 2 events in population have required stations')
+    own = ctx is None
+    if own:
+        ctx = HipContext(device)
+    try:
+        for ind, row in TRDF.iterrows():
+            if not eventsOnAllStations:
+                eventList = list(row.Events)
+            if len(row.Events) < 2:       # construct.py:143-146: skip the station
+                continue
+            DFcc, DFlag, DFsubsamp = _makeDFcclags(eventList, row, ctx)
+            TRDF.at[ind, 'Lags'] = DFlag
+            TRDF.at[ind, 'CCs'] = DFcc
+            TRDF.at[ind, 'Subsamp'] = DFsubsamp
+            cx = _flatNoNan(1.0000001 - DFcc)                  # construct.py:153-156
+            TRDF.at[ind, 'Link'] = linkage(cx)                 # default: single
+    finally:
+        if own:
+            ctx.close()
+    colstk = ['Station', 'Link', 'CCs', 'Lags', 'Subsamp', 'Events', 'Stats']
+    keep = TRDF[[x is not None for x in TRDF.Link]].reset_index(drop=True)
+    if len(keep) < 1:
+        _error('Less than 2 valid events on every station')
+    eventListAll = sorted(set.union(*[set(x) for x in keep.Events]))
+    clust = ClusterStream(keep[colstk], templateKey, stationKey, fetch_arg, eventListAll,
+                          CCreq, filt, decimate, trim, fileName, eventsOnAllStations,
+                          enforceOrigin)
+    clust._mptd = {r.Station: r.MPtd for _, r in TRDF.iterrows()}
+    clust._channels = {r.Station: r.Channels for _, r in TRDF.iterrows()}
+    if saveclust:
+        clust.write()
+    return clust
+
+
+# --------------------------------------------------------------------------
+# alignment (Harris 2006 App. B)                   construct.py:710-812
+# --------------------------------------------------------------------------
+
+def _triangular(n):
+    return n * (n + 1) // 2
+
+
+def _getClustDict(link):
+    """construct.py:800-812: members (leaf indices) of every dendrogram node."""
+    N = len(link)
+    d = {i: [i] for i in range(N + 1)}
+    for a in range(N):
+        d[N + 1 + a] = d[int(link[a, 0])] + d[int(link[a, 1])]
+    return d
+
+
+def _getDelays(link, cx, lags, n_events):
+    """construct.py:710-760 (_getDelays + _traceEventDendro + _updateLags).
+
+    link : SciPy single linkage of the condensed dissimilarities ``cx``;
+    lags : condensed pair lags (multiplexed samples, positive = second event
+    later).  Walk the merges in order; the pair whose dissimilarity equals the
+    merge height supplies the lag between the two merged groups; every event of
+    the second group is shifted by it and all pair lags touching that event are
+    updated.  Returns the accumulated shift per event (array of n_events)."""
+    N = n_events
+    cx = np.asarray(cx, dtype=np.float64)
+    lags = np.array(lags, dtype=np.float64)
+    iu = np.triu_indices(N, 1)
+    pair_of = {}                            # condensed position -> (b, c)
+    for k, (b, c) in enumerate(zip(iu[0], iu[1])):
+        pair_of[k] = (int(b), int(c))
+    pos = {bc: k for k, bc in pair_of.items()}
+    clust = _getClustDict(link)
+    total = np.zeros(N, dtype=np.int64)
+    for a in range(len(link)):
+        i1, i2, height = int(link[a, 0]), int(link[a, 1]), link[a, 2]
+        # construct.py:727-729: first (row, column) whose dissimilarity == merge height
+        k = int(np.nonzero(cx == height)[0][0])
+        ev1, _ev2 = pair_of[k]
+        cl22 = clust[i2] if ev1 in clust[i1] else clust[i1]          # 747-750
+        currentLag = int(np.round(lags[k]))                           # 752
+        for b in cl22:                                                # 754-756
+            total[b] += currentLag
+            for c in range(b + 1, N):     # _getAcr: pairs (b, c): lag += currentLag
+                lags[pos[(b, c)]] += currentLag
+            for r in range(0, b):         # _getDow: pairs (r, b): lag -= currentLag
+                lags[pos[(r, b)]] -= currentLag
+    return total
+
+
+def _alignTD(sample_delays, events, mptd):
+    """construct.py:486-504: slice each multiplexed event by its delay."""
+    TDlengths = len(mptd[events[0]]) - int(np.max(sample_delays))
+    aligned = {}
+    for ev, d in zip(events, sample_delays):
+        orig = mptd[ev][int(d):][:TDlengths]
+        if len(orig) == 0:
+            _error('Alignment of multiplexed stream failing, try raising ccreq or '
+                   'widening trim window')
+        aligned[ev] = orig
+    return aligned
+
+
+def _sub_condensed(df, sel):
+    """construct.py:304-320 _getInfoFromClust: CC / lag sub-matrix of the events
+    ``sel`` (positions in the station's event list, ascending) in condensed order."""
+    vals = np.asarray(df.values, dtype=np.float64)
+    out = []
+    for a in range(len(sel)):
+        for b in range(a + 1, len(sel)):
+            out.append(vals[sel[a], sel[b] - 1])
+    return np.array(out)
+
+
+def createSubSpace(Pf=10 ** -12, clust=None, minEvents=2, dtype='double', conDatFetcher=None):
+    """Create a SubSpace from a ClusterStream (detex/construct.py:177-301): for
+    every cluster with >= minEvents events re-use the stored CC / lag values (no
+    recomputation, construct.py:270), re-link, accumulate the alignment delays
+    through the dendrogram and slice the waveforms; unclustered events become
+    singles (construct.py:525-559)."""
+    from .subspace import ClusterStream, SubSpace
+    if not isinstance(clust, ClusterStream):
+        _error('Invalid clust type, must be a ClusterStream instance.', ValueError)
+    cl = clust
+    np_dtype = np.float32 if dtype == 'single' else np.float64
+    ssDict, singDic = {}, {}
+    for _, trow in cl.trdf.iterrows():
+        sta = trow.Station
+        events_all = list(trow.Events)
+        mptd = {k: np.asarray(v, dtype=np_dtype) for k, v in cl._mptd[sta].items()}
+        stats_all = trow.Stats
+        c = cl[sta]
+        rows = []
+        for num, evelist in enumerate(c.clusts):
+            evelist = sorted(evelist)                               # construct.py:584-585
+            if len(evelist) < minEvents:
+                continue
+            sel = [events_all.index(e) for e in evelist]            # _makeEventListKey
+            cx = 1.0000001 - _sub_condensed(trow.CCs, sel)
+            lags = _sub_condensed(trow.Lags, sel)
+            link = linkage(cx)
+            delays = _getDelays(link, cx, lags, len(evelist))
+            sdel = delays - np.min(delays)                          # construct.py:282-283
+            aligned = _alignTD(sdel, evelist, mptd)
+            stats = {}
+            for ev, d in zip(evelist, sdel):                        # _updateStartTimes 346-366
+                s = dict(stats_all[ev])
+                s['starttime'] = s['starttime'] + d / (s['sampling_rate'] * s['Nc'])
+                s['offset'] = s['starttime'] - s['origintime']
+                stats[ev] = s
+            offs = [stats[e]['offset'] for e in evelist]
+            rows.append(dict(Name='SS%d' % num, Station=sta, Events=evelist, AlignedTD=aligned,
+                             SVD=None, UsedSVDKeys=None, FracEnergy=None, SVDdefined=False,
+                             SampleTrims={}, Threshold=np.nan, FAS=None, NumBasis=0,
+                             Offsets=[np.min(offs), np.median(offs), np.max(offs)],
+                             Stats=stats, Channels={e: cl._channels[sta][e] for e in evelist},
+                             numEvents=len(evelist)))
+        if rows:
+            ssDict[sta] = pd.DataFrame(rows, dtype=object)
+        srows = []
+        for sn, ev in enumerate(c.singles):                         # construct.py:525-559
+            srows.append(dict(Name='SG%d' % sn, Station=sta, Events=[ev],
+                              MPtd={ev: mptd[ev]}, Stats={ev: dict(stats_all[ev])},
+                              Channels={ev: cl._channels[sta][ev]}, SampleTrims={}, FAS=None,
+                              Threshold=np.nan,
+                              Offsets=[stats_all[ev]['offset']] * 3))
+        if srows:
+            singDic[sta] = pd.DataFrame(srows, dtype=object)
+    return SubSpace(singDic, ssDict, cl, dtype, Pf, conDatFetcher)

@@ -76,9 +76,89 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     }
 }
 
+// False-alarm statistics pass (detex/fas.py:72-86): histogram of DS with uniform
+// np.linspace(lo, hi, nbins+1) edges and the sufficient statistics of the beta
+// maximum-likelihood fit scipy.stats.beta.fit(dss, floc=0, fscale=1) performs
+// (n, sum x, sum x^2, sum log x, sum log1p(-x) over 0 < x < 1), all in float64.
+__device__ inline int linspace_bin(double v, double lo, double step, int nbins, double hi) {
+  if (!(v >= lo) || v > hi) return -1;
+  int i = (int)((v - lo) / step);
+  if (i > nbins - 1) i = nbins - 1;
+  if (i < 0) i = 0;
+  // numpy: edge_i = i * step + lo (separate multiply and add), last edge = hi
+  while (i > 0 && v < __dadd_rn(__dmul_rn((double)i, step), lo)) --i;
+  while (i < nbins - 1 && v >= __dadd_rn(__dmul_rn((double)(i + 1), step), lo)) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(kPostThreads) void ds_moments_kernel(
+    const float* __restrict__ ds, int64_t P, int64_t ldp, int D, double lo, double hi, int nbins,
+    uint32_t* __restrict__ hist, double* __restrict__ sums) {
+  extern __shared__ uint32_t sh_h[];
+  __shared__ double sh_s[kPostThreads / 64][5];
+  const int tid = threadIdx.x;
+  const int det = blockIdx.y, chunk = blockIdx.z;
+  const float* row = ds + ((int64_t)chunk * D + det) * ldp;
+  if (hist)
+    for (int b = tid; b < nbins; b += kPostThreads) sh_h[b] = 0u;
+  __syncthreads();
+  const double step = (hi - lo) / (double)nbins;
+  double a[5] = {0, 0, 0, 0, 0};
+  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
+  for (int it = 0; it < kPostItems; ++it) {
+    const int64_t p = base + (int64_t)it * kPostThreads + tid;
+    if (p < P) {
+      const double v = (double)row[p];
+      if (hist) {
+        const int b = linspace_bin(v, lo, step, nbins, hi);
+        if (b >= 0) atomicAdd(&sh_h[b], 1u);
+      }
+      if (v > 0.0 && v < 1.0) {
+        a[0] += 1.0; a[1] += v; a[2] += v * v; a[3] += log(v); a[4] += log1p(-v);
+      }
+    }
+  }
+  if (sums) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off, 64);
+      if ((tid & 63) == 0) sh_s[tid >> 6][k] = a[k];
+    }
+  }
+  __syncthreads();
+  if (sums && tid < 5) {
+    double t = 0.0;
+    for (int w = 0; w < kPostThreads / 64; ++w) t += sh_s[w][tid];
+    atomicAdd(&sums[(int64_t)det * 5 + tid], t);
+  }
+  if (hist)
+    for (int b = tid; b < nbins; b += kPostThreads) {
+      const uint32_t c = sh_h[b];
+      if (c) atomicAdd(&hist[(int64_t)det * nbins + b], c);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
+                   double lo, double hi, int nbins, uint32_t* hist_dev, double* sums_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!ds_dev || P <= 0 || ldp < P || nchunk <= 0 || D <= 0 || nbins <= 0 || nbins > 8192 ||
+      !(hi > lo))
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_ds_moments: bad argument");
+  if (nchunk > 65535 || D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
+  DtxDeviceGuard g(ctx->device);
+  const int64_t per_block = (int64_t)kPostThreads * kPostItems;
+  dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
+  hipLaunchKernelGGL(ds_moments_kernel, grid, dim3(kPostThreads), nbins * sizeof(uint32_t),
+                     ctx->stream, ds_dev, P, ldp, D, lo, hi, nbins, hist_dev, sums_dev);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
 
 int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
                 uint32_t* hist_dev, float* maxds_dev, const float* thr_dev,

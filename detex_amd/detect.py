@@ -43,3 +43,145 @@ def pick_triggers_sparse(idx, val, P, threshold, sr, maxds, buff=20, maxcount=40
             raise RuntimeError('over 4000 events found in single data block')
         count += 1
     return out
+
+
+# --------------------------------------------------------------------------
+# STA/LTA of the detection statistic at a trigger       detect.py:501-524
+# --------------------------------------------------------------------------
+
+def _centered_mean_at(fetch, i, n, P):
+    """Value at index i of ``replace_nan_with_mean(pd.rolling_mean(|C|, n,
+    center=True))`` (detect.py:509-511, 516-524) without forming the whole
+    vector: ``fetch(lo, hi)`` returns |C|[lo:hi]."""
+    n = int(n)
+    if n < 1 or n > P:
+        raise IndexError('window longer than the detection statistic')   # reference: except -> 0.0
+    off = (n - 1) // 2
+    first = n - 1 - off                 # first index with a full window
+    last = first + (P - n)
+    if i < first:                       # arg[:first] = arg[first + 1]   (reference quirk)
+        i = first + 1
+        if i > P - 1:
+            raise IndexError('arg[first + 1] is out of range')
+        if i > last:
+            return float('nan')         # arg[first + 1] is itself a NaN of the rolling mean
+    elif i > last:                      # arg[last + 1:] = arg[last]
+        i = last
+    lo = i - first
+    return float(np.mean(fetch(lo, lo + n)))
+
+
+def stalta_at(fetch, i, P, LTA, STA):
+    """detect.py:501-514 evaluated at one index."""
+    if STA == 0:
+        st = float(fetch(i, i + 1)[0])
+    else:
+        st = _centered_mean_at(fetch, i, STA, P)
+    lt = _centered_mean_at(fetch, i, LTA, P)
+    with np.errstate(all='ignore'):
+        return float(np.divide(st, lt))
+
+
+# --------------------------------------------------------------------------
+# one station: chunks -> GPU detection statistic -> triggers   detect.py:137-218
+# --------------------------------------------------------------------------
+
+def _chunk_batches(bounds):
+    """Group consecutive chunks of equal length and equal spacing so that each
+    group is one dtx_subspace_ds launch with a chunk_stride."""
+    batches = []
+    i = 0
+    while i < len(bounds):
+        j = i + 1
+        stride = bounds[j][0] - bounds[i][0] if j < len(bounds) else bounds[i][1]
+        while (j < len(bounds) and bounds[j][1] == bounds[i][1] and
+               bounds[j][0] - bounds[j - 1][0] == stride):
+            j += 1
+        batches.append((i, j, stride))
+        i = j
+    return batches
+
+
+def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
+                 useSubSpaces, useSingles, fillZeros, device=0, ctx=None):
+    """_SSDetex._corDat (detect.py:137-218) for one station with all its
+    detectors in one GPU basis: per batch of chunks the detection statistic
+    (dtx_subspace_ds), histogram / max / candidates (dtx_ds_post), then the
+    reference's trigger loop on the sparse candidates.  Returns dict(ss=DataFrame,
+    sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None."""
+    import pandas as pd
+    import torch
+    from .getdata import multiplex
+    from .hip import HipContext
+    names, kinds, U, det_off, offsets, thr = ss._detector_bank(sta, useSubSpaces, useSingles)
+    if not names:
+        return None
+    fetcher = ss.cfetcher
+    if sta not in fetcher.data:
+        return None
+    sr = fetcher.sampling_rate
+    Nc = len(fetcher.channels)
+    n = U.shape[1]
+    D = len(names)
+    own = ctx is None
+    if own:
+        ctx = HipContext(device)
+    cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
+            'ProEnMag']
+    rows = {'ss': [], 'sg': []}
+    try:
+        ctx.upload_basis(U, det_off, Nc)
+        data, t0 = fetcher.data[sta]
+        xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
+                                ).to(ctx.device)
+        thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
+        hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
+        bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
+        # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
+        bounds = [b for b in bounds if b[1] * Nc > n and (b[1] * Nc - n) // Nc + 1 >= 10]
+        LTA = triggerLTATime * sr
+        STA = triggerSTATime * sr
+        for (i0, i1, stride) in _chunk_batches(bounds):
+            s0, cnt = bounds[i0][0], bounds[i0][1]
+            M = cnt * Nc
+            ds = ctx.subspace_ds(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc, nchunk=i1 - i0)
+            res = ctx.ds_post(ds, thr=thr_arr, hist=hist if calcHist else None)
+            P = int(ds.shape[2])
+            maxds = res['maxds'].cpu().numpy()
+            cb, cd, cp, cv = res['cand']
+            if res['ncand'] > len(cv):
+                raise RuntimeError('candidate buffer overflow (%d > %d): threshold far too low'
+                                   % (res['ncand'], len(cv)))
+            for b in range(i1 - i0):
+                start = bounds[i0 + b][2]
+                for d, name in enumerate(names):
+                    sel = (cb == b) & (cd == d)
+                    trig = pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
+                                                float(maxds[b, d]))
+                    row_dev = ds[b, d]
+
+                    def fetch(lo, hi, _r=row_dev):
+                        return np.abs(_r[lo:hi].cpu().numpy().astype(np.float64))
+                    for (ti, coef) in trig:
+                        if coef > 1.05:                          # detect.py:199-204
+                            continue
+                        if fillZeros:                            # detect.py:414-415
+                            sl = 0.0
+                        else:
+                            try:
+                                sl = stalta_at(fetch, ti, P, LTA, STA)
+                            except IndexError:                   # detect.py:289-295, 417-420
+                                sl = 0.0
+                        times = float(ti) / sr + start           # detect.py:413
+                        of = offsets[name]
+                        rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
+                                               times - np.min(of), np.nan, np.nan, np.nan])
+        ctx.sync()
+        h = hist.cpu().numpy()
+    finally:
+        if own:
+            ctx.close()
+    out = {k: pd.DataFrame(v, columns=cols) for k, v in rows.items()}
+    out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
+    out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
+    return out

@@ -1,0 +1,132 @@
+"""False-alarm statistics (detex/fas.py:23-117 _initFAS / _getDSVect, driven by
+SubSpace.getFAS, detex/subspace.py:1652-1743): the detection statistic of every
+detector over randomly chosen continuous chunks without high-amplitude signals,
+its histogram, and a beta distribution fitted to it by maximum likelihood; the
+threshold is then beta.isf(Pf) (subspace.py:1033-1047).
+
+The statistic is the same HIP kernel as the scan (fas.py:120-134 is a twin of
+detect.py:559-578).  The beta fit with floc=0, fscale=1 depends on the data only
+through n, sum log x and sum log1p(-x) (and the moment-based start values), which
+the GPU accumulates in float64 (dtx_ds_moments); the two-parameter root solve is
+SciPy's, restated from scipy.stats.beta.fit's fixed-loc/scale branch.
+"""
+import numpy as np
+import scipy.optimize
+import scipy.special as sc
+
+from ._lib import DetexHipError
+
+
+def classic_sta_lta(a, nsta, nlta):
+    """obspy.signal.trigger.classic_sta_lta (third-party, restated from its
+    documented pure-Python form): ratio of trailing means of a**2."""
+    a = np.asarray(a, dtype=np.float64)
+    nsta, nlta = int(nsta), int(nlta)
+    sta = np.cumsum(a ** 2)
+    lta = sta.copy()
+    sta[nsta:] = sta[nsta:] - sta[:-nsta]
+    sta /= nsta
+    lta[nlta:] = lta[nlta:] - lta[:-nlta]
+    lta /= nlta
+    sta[:nlta - 1] = 0
+    dtiny = np.finfo(0.0).tiny
+    lta[lta < dtiny] = dtiny
+    return sta / lta
+
+
+def _checkSTALTA(chunk, channels, sr, STATime, LTATime, limit):
+    """fas.py:175-205: the Z (else first) channel must not exceed ``limit``."""
+    if limit is None:
+        return True
+    zi = [i for i, c in enumerate(channels) if str(c).upper().endswith('Z')]
+    z = chunk[zi[0] if zi else 0]
+    if len(z) <= LTATime * sr:
+        return False
+    return bool(np.max(classic_sta_lta(z, STATime * sr, LTATime * sr)) <= limit)
+
+
+def beta_mle(n, sx, sxx, s1, s2):
+    """scipy.stats.beta.fit(data, floc=0, fscale=1) from sufficient statistics:
+    method-of-moments start, then fsolve of the likelihood equations
+    s1 = n (psi(a) - psi(a+b)), s2 = n (psi(b) - psi(a+b))."""
+    xbar = sx / n
+    var = sxx / n - xbar * xbar
+    fac = xbar * (1 - xbar) / var - 1
+    a0, b0 = xbar * fac, (1 - xbar) * fac
+
+    def eqs(theta):
+        a, b = theta
+        psiab = sc.psi(a + b)
+        return [s1 - n * (-psiab + sc.psi(a)), s2 - n * (-psiab + sc.psi(b))]
+    theta, info, ier, mesg = scipy.optimize.fsolve(eqs, [a0, b0], full_output=True)
+    if ier != 1:
+        raise DetexHipError('beta fit did not converge: %s' % mesg)
+    a, b = float(theta[0]), float(theta[1])
+    nnlf = -((a - 1) * s1 + (b - 1) * s2 - n * sc.betaln(a, b))
+    return (a, b, 0, 1), float(nnlf)
+
+
+def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces=True,
+            useSingles=False, numBins=401, recalc=False, device=0, seed=None):
+    """fas._initFAS for every station of a SubSpace; stores a dict with 'bins',
+    'hist', 'betadist', 'nnlf' in the FAS column of each subspace / single."""
+    import torch
+    from .getdata import multiplex
+    from .hip import HipContext
+    rs = np.random.RandomState(seed)
+    fetcher = ss.cfetcher
+    if fetcher is None:
+        raise DetexHipError('no continuous-data fetcher attached (conDatFetcher)')
+    bins = np.linspace(-.01, 1, num=numBins)                        # fas.py:31
+    ctx = HipContext(device)
+    try:
+        for sta in ss.Stations:
+            names, kinds, U, det_off, _, _ = ss._detector_bank_nothr(sta, useSubSpaces, useSingles)
+            if not names or sta not in fetcher.data:
+                continue
+            Nc = len(fetcher.channels)
+            sr = fetcher.sampling_rate
+            n = U.shape[1]
+            data, _t0 = fetcher.data[sta]
+            bounds = [b for b in fetcher.chunk_bounds(sta) if b[1] * Nc > n]
+            if not bounds:
+                raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
+            # fas.py:92-93: ask for 4x more chunks than needed, in random order
+            order = rs.permutation(len(bounds))[:conDatNum * 4]
+
+            def pick(limit):
+                chosen, count = [], 0
+                for k in order:
+                    s, cnt, _ = bounds[k]
+                    count += 1
+                    if not _checkSTALTA(data[:, s:s + cnt], fetcher.channels, sr, STATime,
+                                        LTATime, limit):
+                        continue
+                    if len(chosen) >= conDatNum:
+                        break
+                    chosen.append(k)
+                return chosen, count
+            chosen, count = pick(staltalimit)
+            if count and float(len(chosen)) / count <= .25:           # fas.py:60-68
+                chosen, count = pick(None)
+            ctx.upload_basis(U, det_off, Nc)
+            D = len(names)
+            xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)),
+                                                         dtype=np.float32)).to(ctx.device)
+            hist = torch.zeros((D, numBins - 1), dtype=torch.int32, device=ctx.device)
+            sums = torch.zeros((D, 5), dtype=torch.float64, device=ctx.device)
+            for k in chosen:
+                s, cnt, _ = bounds[k]
+                ds = ctx.subspace_ds(xdev[s * Nc:], M=cnt * Nc, chunk_stride=cnt * Nc, nchunk=1)
+                ctx.ds_moments(ds, lo=-.01, hi=1.0, nbins=numBins - 1, hist=hist, sums=sums)
+            ctx.sync()
+            h = hist.cpu().numpy()
+            sm = sums.cpu().numpy()
+            for d, name in enumerate(names):
+                params, nnlf = beta_mle(*sm[d])
+                rec = {'bins': bins, 'hist': h[d], 'betadist': params, 'nnlf': nnlf}
+                df = ss.subspaces[sta] if kinds[d] == 'ss' else ss.singles[sta]
+                ind = df.index[df.Name == name][0]
+                df.at[ind, 'FAS'] = rec
+    finally:
+        ctx.close()

@@ -1,0 +1,107 @@
+"""In-memory stand-ins for the reference's DataFetcher (detex/getdata.py) on the
+hot path.  ObsPy I/O, response removal and filtering are out of scope
+(SURVEY.md section 8): the fetchers below hand out arrays that are already
+pre-processed (what ``construct._applyFilter`` returns), with the reference's
+chunk geometry restated.
+
+Channel order inside every [Nc, L] array is the reference's ``st.sort()`` order
+(detex/construct.py:998); ``multiplex`` then interleaves channels sample-wise
+exactly as detex/construct.py:928-987.
+"""
+import numpy as np
+
+
+def multiplex(chans):
+    """detex/construct.py:928-987: trim every channel to the shortest (970-974)
+    and interleave sample-wise, ``vstack(chans).flatten(order='F')`` (977-978)."""
+    chans = [np.asarray(c) for c in chans]
+    L = min(len(c) for c in chans)
+    return np.vstack([c[:L] for c in chans]).flatten(order='F')
+
+
+class EventFetcher(object):
+    """Template-event waveforms of one or more stations, already filtered and
+    trimmed (the ``fetcher.getTemData`` + ``_applyFilter`` output of
+    detex/construct.py:852-869).
+
+    events[station][name] = dict(data=[Nc, L] array, starttime=float epoch
+    seconds of the first sample, origintime=float, magnitude=float)
+    """
+    method = 'memory'
+
+    def __init__(self, sampling_rate, channels):
+        self.sampling_rate = float(sampling_rate)
+        self.channels = list(channels)
+        self.events = {}
+
+    def add(self, station, name, data, starttime=0.0, origintime=None, magnitude=np.nan):
+        data = np.atleast_2d(np.asarray(data))
+        if data.shape[0] != len(self.channels):
+            raise ValueError('event %s on %s has %d channels, fetcher has %d'
+                             % (name, station, data.shape[0], len(self.channels)))
+        self.events.setdefault(station, {})[name] = dict(
+            data=data, starttime=float(starttime),
+            origintime=float(starttime if origintime is None else origintime),
+            magnitude=float(magnitude))
+        return self
+
+    def stations(self):
+        return sorted(self.events.keys())
+
+    def getTemData(self, station):
+        """Yield (name, record) in sorted event-name order."""
+        evs = self.events[station]
+        for name in sorted(evs.keys()):
+            yield name, evs[name]
+
+
+class ContinuousFetcher(object):
+    """Continuous pre-processed data of each station as one [Nc, T] array with a
+    start time.  ``getConData`` cuts it into the reference's chunks: starts on
+    multiples of ``conDatDuration`` (detex/getdata.py:869-886 _divideIntoChunks),
+    each ``conDatDuration + conBuff`` seconds long (getdata.py:518), trimmed to
+    the available data.  Defaults 3600 s + 120 s (getdata.py:299)."""
+    method = 'memory'
+
+    def __init__(self, sampling_rate, channels, conDatDuration=3600, conBuff=120):
+        self.sampling_rate = float(sampling_rate)
+        self.channels = list(channels)
+        self.conDatDuration = conDatDuration
+        self.conBuff = conBuff
+        self.data = {}
+
+    def add(self, station, data, starttime):
+        data = np.atleast_2d(np.asarray(data))
+        if data.shape[0] != len(self.channels):
+            raise ValueError('continuous data on %s has %d channels, fetcher has %d'
+                             % (station, data.shape[0], len(self.channels)))
+        self.data[station] = (data, float(starttime))
+        return self
+
+    def chunk_bounds(self, station, utcStart=None, utcEnd=None):
+        """[(first sample, number of samples, chunk start time)] of every chunk."""
+        data, t0 = self.data[station]
+        sr = self.sampling_rate
+        T = data.shape[1]
+        t_end = t0 + T / sr
+        ts1 = t0 if utcStart is None else float(utcStart)
+        ts2 = t_end if utcEnd is None else float(utcEnd)
+        dur = self.conDatDuration
+        a = ts1 - ts1 % dur                       # getdata.py:877-878
+        b = ts2 - ts2 % dur
+        out = []
+        t = a
+        while t <= b:                             # getdata.py:880-883
+            s = int(round((max(t, t0) - t0) * sr))
+            e_time = min(t + dur + self.conBuff, ts2, t_end)
+            e = int(round((e_time - t0) * sr))
+            if e - s > 0 and s < T:
+                out.append((s, min(e, T) - s, t0 + s / sr))
+            t += dur
+        return out
+
+    def getConData(self, station, utcStart=None, utcEnd=None):
+        """Yield ([Nc, Tc] chunk view, chunk start time)."""
+        data, _ = self.data[station]
+        for s, cnt, ts in self.chunk_bounds(station, utcStart, utcEnd):
+            yield data[:, s:s + cnt], ts

@@ -137,6 +137,20 @@ class HipContext(object):
                            (k & np.uint64(0xFFFFFFFF)).astype(np.int64), v)
         return res
 
+    def ds_moments(self, ds, lo=-.01, hi=1.0, nbins=400, hist=None, sums=None):
+        """FAS pass over a DS tensor [nchunk, D, P]: histogram on
+        np.linspace(lo, hi, nbins+1) and the beta-MLE sufficient statistics
+        [D, 5] (n, sum x, sum x^2, sum log x, sum log1p(-x)); both accumulate."""
+        nchunk, D, P = (int(s) for s in ds.shape)
+        if hist is None:
+            hist = torch.zeros((D, nbins), dtype=torch.int32, device=ds.device)
+        if sums is None:
+            sums = torch.zeros((D, 5), dtype=torch.float64, device=ds.device)
+        rc = self.lib.dtx_ds_moments(self.h, _ptr(ds), P, int(ds.stride(1)), nchunk, D,
+                                     float(lo), float(hi), int(nbins), _ptr(hist), _ptr(sums))
+        self._ck(rc, 'dtx_ds_moments')
+        return hist, sums
+
     def subspace_ds_host(self, x):
         """numpy in, numpy out (one block); includes the PCIe transfers."""
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -1,0 +1,464 @@
+"""ClusterStream / Cluster / SubSpace with the reference's names for the hot path
+(detex/subspace.py:46-707, 715-2037): dendrogram cut, SVD basis construction and
+selection, thresholds, and the detection scan ``SubSpace.detex`` that drives the
+HIP kernels.  Plotting, GUI picking, HypoDD/KML writers are out of scope.
+"""
+import os
+import pickle
+import sqlite3
+
+import numpy as np
+import pandas as pd
+import scipy.linalg
+import scipy.stats
+from scipy.cluster.hierarchy import fcluster  # noqa: F401  (kept for parity checks)
+
+from ._lib import DetexHipError
+
+
+def _error(msg, exc=DetexHipError):
+    raise exc(msg)
+
+
+# --------------------------------------------------------------------------
+# ClusterStream / Cluster                          subspace.py:46-707
+# --------------------------------------------------------------------------
+
+class Cluster(object):
+    """One station's dendrogram (subspace.py:290-412)."""
+
+    def __init__(self, clustStream, station, temkey, eventList, link, ccReq, filt, decimate,
+                 trim, DFcc):
+        self.link = link
+        self.DFcc = DFcc
+        self.station = station
+        self.temkey = temkey
+        self.key = list(eventList)
+        self.updateReqCC(ccReq)
+        self.trim = trim
+        self.decimate = decimate
+
+    def _makeDFLINK(self):
+        """subspace.py:385-412: merges with the member leaves of both sides."""
+        N = len(self.link)
+        members = {i: [i] for i in range(N + 1)}
+        rows = []
+        for a in range(N):
+            i1, i2 = int(self.link[a, 0]), int(self.link[a, 1])
+            members[N + 1 + a] = members[i1] + members[i2]
+            rows.append(dict(i1=i1, i2=i2, disSim=self.link[a, 2], num=self.link[a, 3],
+                             clust=N + 1 + a, II=members[i1] + members[i2]))
+        return rows
+
+    def updateReqCC(self, newccReq):
+        """subspace.py:305-346: cut the dendrogram at 1 - ccReq.  Clusters are
+        numbered by their top merge, highest dissimilarity first."""
+        if newccReq < 0. or newccReq > 1.:
+            _error('Parameter ccReq must be between 0 and 1')
+        self.ccReq = newccReq
+        self.dflink = self._makeDFLINK()
+        dfcl = [r for r in self.dflink if r['disSim'] <= 1 - self.ccReq]
+        dfcl.sort(key=lambda r: -r['disSim'])           # stable, like sort_values
+        clustlinks, clustEvents = {}, {}
+        clnum = 0
+        rest = dfcl
+        while rest:
+            top = rest[0]
+            inside = [r for r in rest if set(r['II']).issubset(top['II'])]
+            clustlinks[clnum] = [r['clust'] for r in inside]
+            clustEvents[clnum] = sorted(set(y for r in inside for y in r['II']))
+            rest = [r for r in rest if r not in inside]
+            clnum += 1
+        self.clustlinks = clustlinks
+        self.clusts = [[self.key[y] for y in clustEvents[x]] for x in sorted(clustEvents)]
+        clustset = set(y for x in self.clusts for y in x)
+        self.singles = [k for k in self.key if k not in clustset]
+        self.clustcount = int(np.sum([len(x) for x in self.clusts])) if self.clusts else 0
+
+    def __getitem__(self, index):
+        return self.clusts[index]
+
+    def __len__(self):
+        return len(self.clusts)
+
+
+class ClusterStream(object):
+    """Container of per-station clusters (subspace.py:46-288).  ``trdf`` has the
+    reference's columns Station, Link, CCs, Lags, Subsamp, Events, Stats
+    (construct.py:159)."""
+
+    def __init__(self, trdf, temkey, stakey, fetcher, eventList, ccReq, filt, decimate, trim,
+                 fileName, eventsOnAllStations, enforceOrigin):
+        self.trdf = trdf
+        self.temkey = temkey
+        self.stakey = stakey
+        self.fetcher = fetcher
+        self.eventList = eventList
+        self.filt = filt
+        self.decimate = decimate
+        self.trim = trim
+        self.filename = fileName
+        self.eventsOnAllStations = eventsOnAllStations
+        self.enforceOrigin = enforceOrigin
+        self.ccReq = None
+        self.stalist = trdf.Station.values.tolist()
+        self.stalist2 = [x.split('.')[1] if '.' in x else x for x in self.stalist]
+        self.clusters = []
+        for _, row in trdf.iterrows():
+            evlist = eventList if eventsOnAllStations else row.Events
+            self.clusters.append(Cluster(self, row.Station, temkey, evlist, row.Link, ccReq, filt,
+                                         decimate, trim, row.CCs))
+
+    def updateReqCC(self, reqCC):
+        """subspace.py:174-201: float for all stations, or {station: ccReq}."""
+        if isinstance(reqCC, dict):
+            for sta, v in reqCC.items():
+                self[sta].updateReqCC(v)
+        else:
+            for c in self.clusters:
+                c.updateReqCC(reqCC)
+
+    def write(self):
+        """subspace.py:261-267 (pickle)."""
+        with open(self.filename, 'wb') as f:
+            pickle.dump(self, f, 2)
+
+    def __getitem__(self, key):
+        if isinstance(key, int):
+            return self.clusters[key]
+        if key in self.stalist:
+            return self.clusters[self.stalist.index(key)]
+        if key in self.stalist2:
+            return self.clusters[self.stalist2.index(key)]
+        _error('%s is not a station in this ClusterStream' % key, KeyError)
+
+    def __len__(self):
+        return len(self.clusters)
+
+
+# --------------------------------------------------------------------------
+# SubSpace                                         subspace.py:715-2037
+# --------------------------------------------------------------------------
+
+class SubSpace(object):
+    """Subspaces (clusters of aligned events) and singles of every station
+    (subspace.py:715-733)."""
+
+    def __init__(self, singlesDict, subSpaceDict, cl, dtype, Pf, cfetcher):
+        self.cfetcher = cfetcher
+        self.clusters = cl
+        self.subspaces = subSpaceDict
+        self.singles = singlesDict
+        self.dtype = dtype
+        self.Pf = Pf
+        self.ssStations = sorted(self.subspaces.keys())
+        self.singStations = sorted(self.singles.keys())
+        self.Stations = sorted(set(self.ssStations) | set(self.singStations))
+        self.histSubSpaces = {}
+        self.histSingles = {}
+
+    # ------------------------------------------------------------ trims
+    def attachPickTimes(self, startSeconds=0.0, defaultDuration=30):
+        """Window of the (aligned) waveforms the detectors use, as
+        SampleTrims = {Starttime, Endtime} in multiplexed samples, both multiples
+        of Nc (subspace.py:1461-1615; default duration 30 s, line 1462).  The
+        reference derives the start from a phase-pick file; here it is given
+        directly as seconds from the start of the aligned waveforms.  Existing
+        trims are not overridden (reference behaviour)."""
+        for dfs in (self.subspaces, self.singles):
+            for sta, df in dfs.items():
+                for ind, row in df.iterrows():
+                    if row.SampleTrims:
+                        continue
+                    ev = row.Events[0]
+                    Nc = row.Stats[ev]['Nc']
+                    sr = row.Stats[ev]['sampling_rate']
+                    wf = row.AlignedTD[ev] if 'AlignedTD' in row.index else row.MPtd[ev]
+                    s = int(round(startSeconds * sr)) * Nc
+                    e = min(s + int(round(defaultDuration * sr)) * Nc, len(wf) - len(wf) % Nc)
+                    df.at[ind, 'SampleTrims'] = {'Starttime': s, 'Endtime': e,
+                                                 'DurationSeconds': (e - s) / (sr * Nc)}
+
+    # ------------------------------------------------------------ SVD
+    def _trimGroups(self, row, keys):
+        """subspace.py:921-943."""
+        ali = row.AlignedTD
+        st = row.SampleTrims
+        if 'Starttime' in st and 'Endtime' in st:
+            stim, etim = max(st['Starttime'], 0), st['Endtime']
+            arr = np.vstack([ali[x][stim:etim] - np.mean(ali[x][stim:etim]) for x in keys])
+        else:
+            arr = np.vstack([ali[x] - np.mean(ali[x]) for x in keys])
+        return np.asarray(arr, dtype=np.float64), arr.shape[1]
+
+    def _getFracEnergy(self, row, U):
+        """subspace.py:968-997: cumulative fractional energy capture."""
+        st = row.SampleTrims
+        frac = {}
+        for key in row.Events:
+            w = np.asarray(row.AlignedTD[key], dtype=np.float64)
+            if 'Starttime' in st and 'Endtime' in st:
+                w = w[st['Starttime']:st['Endtime']]
+            nu = np.dot(U.T, w) / scipy.linalg.norm(w)
+            rep = np.insert(np.square(nu), 0, 0)
+            frac[key] = [np.sum(rep[:x + 1]) for x in range(len(rep))]
+        frac['Average'] = np.average([frac[x] for x in row.Events], axis=0)
+        frac['Minimum'] = np.min([frac[x] for x in row.Events], axis=0)
+        return frac
+
+    @staticmethod
+    def _getUsedBasis(nsv, fracEnergy, selectCriteria, selectValue):
+        """subspace.py:999-1013: number of leading singular vectors kept."""
+        if selectCriteria in (1, 2, 3):
+            fracEnergy['Average'][-1] = 1.00
+            return int(np.argmax(fracEnergy['Average'] >= selectValue))
+        return min(int(selectValue) + 1, nsv)               # criteria 4: keys[:selectValue+1]
+
+    def _checkSelection(self, selectCriteria, selectValue, threshold):
+        """subspace.py:945-966."""
+        if selectCriteria in (1, 2, 3):
+            if selectValue > 1 or selectValue < 0:
+                _error('When selectCriteria==%d selectValue must be a float between 0 and 1'
+                       % selectCriteria, ValueError)
+        elif selectCriteria == 4:
+            if selectValue < 0 or not isinstance(selectValue, int):
+                _error('When selectCriteria==4 selectValue must be an integer >= 0', ValueError)
+        else:
+            _error('selectCriteria of %s is not supported' % selectCriteria)
+        if threshold is not None:
+            if not isinstance(threshold, (int, float)) or threshold < 0:
+                _error('Unsupported type for threshold, must be None or float', ValueError)
+
+    def SVD(self, selectCriteria=2, selectValue=0.9, conDatNum=100, threshold=None,
+            normalize=False, useSingles=True, validateWaveforms=True, backupThreshold=None,
+            **kwargs):
+        """subspace.py:786-912: SVD of the aligned, trimmed, demeaned events of
+        every subspace; basis selection by fractional energy capture; thresholds.
+        The SVD itself is LAPACK on the host exactly as in the reference (tiny:
+        n x nEvents).  Singular vectors are kept as columns of ``SVD['U']`` in
+        descending singular-value order (the reference's dict keyed by singular
+        value sorted descending, lines 892-895 / 1004-1005)."""
+        self._checkSelection(selectCriteria, selectValue, threshold)
+        for sta in self.ssStations:
+            df = self.subspaces[sta]
+            for ind, row in df.iterrows():
+                keys = sorted(row.Events)
+                arr, basisLength = self._trimGroups(row, keys)
+                if basisLength == 0:
+                    df.drop(index=ind, inplace=True)       # subspace.py:880-885
+                    continue
+                if normalize:
+                    arr = np.array([x / np.linalg.norm(x) for x in arr])
+                U, s, _ = scipy.linalg.svd(arr.T, full_matrices=False)
+                frac = self._getFracEnergy(row, U)
+                nb = self._getUsedBasis(len(s), frac, selectCriteria, selectValue)
+                df.at[ind, 'SVD'] = {'U': U, 's': s}
+                df.at[ind, 'FracEnergy'] = frac
+                df.at[ind, 'UsedSVDKeys'] = list(s[:nb])
+                df.at[ind, 'SVDdefined'] = True
+                df.at[ind, 'NumBasis'] = nb
+        if self.ssStations:
+            self._setThresholds(selectCriteria, selectValue, conDatNum, threshold,
+                                backupThreshold, kwargs)
+        if self.singStations and useSingles:
+            self.setSinglesThresholds(conDatNum=conDatNum, threshold=threshold,
+                                      backupThreshold=backupThreshold, **kwargs)
+
+    def _setThresholds(self, selectCriteria, selectValue, conDatNum, threshold,
+                       backupThreshold, kwargs):
+        """subspace.py:1015-1054."""
+        if threshold is not None and threshold > 0:
+            for sta in self.ssStations:
+                for ind in self.subspaces[sta].index:
+                    self.subspaces[sta].at[ind, 'Threshold'] = threshold
+        elif selectCriteria == 1:
+            _error('selectCriteria 1 currently not supported', ValueError)
+        elif selectCriteria in (2, 4):
+            self.getFAS(conDatNum, **kwargs)
+            for sta in self.ssStations:
+                for ind, row in self.subspaces[sta].iterrows():
+                    a, b = row.FAS['betadist'][0:2]
+                    self.subspaces[sta].at[ind, 'Threshold'] = self._beta_threshold(
+                        a, b, sta, row.Name, backupThreshold)
+        elif selectCriteria == 3:
+            for sta in self.ssStations:
+                for ind, row in self.subspaces[sta].iterrows():
+                    th = row.FracEnergy['Minimum'][row.NumBasis] * selectValue
+                    self.subspaces[sta].at[ind, 'Threshold'] = th
+
+    def _beta_threshold(self, a, b, sta, name, backupThreshold):
+        """subspace.py:1033-1047 + _approxThld 1110-1140."""
+        th = scipy.stats.beta.isf(self.Pf, a, b, 0, 1)
+        if th > .9:
+            th = self._approxThld(a, b, sta, name, self.Pf, 1000, 3, backupThreshold)
+        return th
+
+    @staticmethod
+    def _approxThld(beta_a, beta_b, sta, name, target, numint, numloops, backupThreshold):
+        startVal, stopVal = 0, 1
+        loops = 0
+        bestX = None
+        while loops < numloops:
+            Xs = np.linspace(startVal, stopVal, numint)
+            pfs = scipy.stats.beta.sf(Xs, beta_a, beta_b)
+            minind = int(np.abs(pfs - target).argmin())
+            if minind == 0 or minind == numint - 1:
+                if backupThreshold is None:
+                    _error('Grid search for threshold failing for %s on %s, set it manually '
+                           'or use default' % (sta, name), ValueError)
+                return backupThreshold
+            bestX = Xs[minind]
+            startVal, stopVal = Xs[minind - 1], Xs[minind + 1]
+            loops += 1
+        return bestX
+
+    def setSinglesThresholds(self, conDatNum=50, recalc=False, threshold=None,
+                             backupThreshold=None, **kwargs):
+        """subspace.py:1056-1108: singles without trims are dropped."""
+        for sta in self.singStations:
+            sing = self.singles[sta]
+            sing = sing[[len(x) > 0 for x in sing.SampleTrims]].reset_index(drop=True)
+            sing['Name'] = ['SG%d' % x for x in range(len(sing))]
+            self.singles[sta] = sing
+        if threshold is None:
+            self.getFAS(conDatNum, useSingles=True, useSubSpaces=False, **kwargs)
+        for sta in self.singStations:
+            for ind, row in self.singles[sta].iterrows():
+                if threshold:
+                    th = threshold
+                else:
+                    a, b = row.FAS['betadist'][0:2]
+                    th = self._beta_threshold(a, b, sta, row.Name, backupThreshold)
+                self.singles[sta].at[ind, 'Threshold'] = th
+
+    # ------------------------------------------------------------ detectors
+    def _detector_bank(self, sta, useSubSpaces=True, useSingles=True, need_thr=True):
+        """Stack the detectors acting on one station (detect.py:319-388
+        _loadMPSubSpace): subspaces contribute their used left singular vectors,
+        singles their trimmed, normalised, NOT demeaned template
+        (detect.py:357-364).  Returns (names, kinds, U [Ktot, n], det_off,
+        offsets {name: array}, thresholds {name: float})."""
+        names, kinds, blocks, offsets, thr = [], [], [], {}, {}
+        if useSubSpaces and sta in self.subspaces:
+            for _, row in self.subspaces[sta].iterrows():
+                if not row.SVDdefined or row.NumBasis < 1:
+                    continue
+                blocks.append(np.asarray(row.SVD['U'][:, :row.NumBasis].T, dtype=np.float64))
+                names.append(row.Name)
+                kinds.append('ss')
+                offsets[row.Name] = np.asarray(row.Offsets, dtype=np.float64)
+                thr[row.Name] = float(row.Threshold) if need_thr else np.nan
+        if useSingles and sta in self.singles:
+            for _, row in self.singles[sta].iterrows():
+                if not row.SampleTrims:
+                    continue
+                ev = row.Events[0]
+                x = np.asarray(row.MPtd[ev], dtype=np.float64)
+                x = x[row.SampleTrims['Starttime']:row.SampleTrims['Endtime']]
+                blocks.append((x / np.linalg.norm(x))[None, :])
+                names.append(row.Name)
+                kinds.append('sg')
+                offsets[row.Name] = np.asarray(row.Offsets, dtype=np.float64)
+                thr[row.Name] = float(row.Threshold) if need_thr else np.nan
+        if not blocks:
+            return [], [], None, None, {}, {}
+        lens = set(b.shape[1] for b in blocks)
+        if len(lens) != 1:
+            # the reference mis-broadcasts here; refuse instead
+            _error('all detectors of station %s must have the same length (got %s)'
+                   % (sta, sorted(lens)))
+        U = np.concatenate(blocks, axis=0)
+        det_off = np.concatenate([[0], np.cumsum([b.shape[0] for b in blocks])]).astype(np.int32)
+        return names, kinds, U, det_off, offsets, thr
+
+    def _detector_bank_nothr(self, sta, useSubSpaces=True, useSingles=True):
+        names, kinds, U, det_off, offsets, _ = self._detector_bank(sta, useSubSpaces, useSingles,
+                                                                   need_thr=False)
+        return names, kinds, U, det_off, offsets, None
+
+    # ------------------------------------------------------------ FAS
+    def getFAS(self, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces=True,
+               useSingles=False, numBins=401, recalc=False, device=0, seed=None, **kwargs):
+        """subspace.py:1652-1743 -> fas._initFAS: empirical null distribution of
+        the detection statistic over random continuous chunks, beta fit."""
+        from . import fas
+        fas.run_fas(self, conDatNum, LTATime=LTATime, STATime=STATime, staltalimit=staltalimit,
+                    useSubSpaces=useSubSpaces, useSingles=useSingles, numBins=numBins,
+                    recalc=recalc, device=device, seed=seed)
+
+    # ------------------------------------------------------------ detex
+    def detex(self, utcStart=None, utcEnd=None, subspaceDB='SubSpace.db', trigCon=0,
+              triggerLTATime=5, triggerSTATime=0, multiprocess=False, delOldCorrs=True,
+              calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=False,
+              classifyEvents=None, eventCorFile='EventCors', utcSaves=None, fillZeros=False,
+              device=0, ctx=None):
+        """subspace.py:1745-1902: run every detector over the continuous data.
+
+        Returns {'ss_df': DataFrame, 'sg_df': DataFrame} with the reference's
+        columns (detect.py:397-398) and writes them, the histograms and the
+        detector info to the SQLite file ``subspaceDB`` (None: no file).
+        ``estimateMags`` (detect.py:447-499) is not part of this round: Mag, SNR
+        and ProEnMag are NaN as with estimateMags=False in the reference."""
+        from .detect import scan_station
+        if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
+            _error('multiprocessing and trigcon other than 0 not supported')
+        if estimateMags:
+            _error('estimateMags=True is not supported yet; pass estimateMags=False')
+        if classifyEvents is not None or utcSaves is not None:
+            _error('classifyEvents / utcSaves are not supported')
+        if self.cfetcher is None:
+            _error('no continuous-data fetcher attached (conDatFetcher)')
+        if subspaceDB is not None and delOldCorrs and os.path.exists(subspaceDB):
+            os.remove(subspaceDB)                           # subspace.py:1847-1854
+        out = {'ss_df': [], 'sg_df': []}
+        for sta in self.Stations:
+            res = scan_station(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime,
+                               calcHist, useSubSpaces, useSingles, fillZeros, device, ctx)
+            if res is None:
+                continue
+            for kind in ('ss', 'sg'):
+                if len(res[kind]):
+                    out[kind + '_df'].append(res[kind])
+            self.histSubSpaces[sta] = res['hist_ss']
+            self.histSingles[sta] = res['hist_sg']
+        cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
+                'ProEnMag']
+        for k in out:
+            out[k] = pd.concat(out[k], ignore_index=True) if out[k] else pd.DataFrame(columns=cols)
+        if subspaceDB is not None:
+            self._write_db(subspaceDB, out)
+        return out
+
+    def _write_db(self, path, out):
+        """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /
+        sg_hist, filt_params."""
+        con = sqlite3.connect(path)
+        try:
+            for k, df in out.items():
+                if len(df):
+                    df.to_sql(k, con, if_exists='append', index=False)
+            info = []
+            for sta in self.ssStations:
+                for _, r in self.subspaces[sta].iterrows():
+                    info.append(dict(Sta=sta, Name=r.Name, Events='-'.join(r.Events),
+                                     Threshold=r.Threshold, NumBasisUsed=r.NumBasis,
+                                     beta1=(r.FAS or {}).get('betadist', [np.nan])[0],
+                                     beta2=(r.FAS or {}).get('betadist', [np.nan] * 2)[1]))
+            if info:
+                pd.DataFrame(info).to_sql('ss_info', con, if_exists='replace', index=False)
+            for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
+                rows = [dict(Sta=sta, Name=name, Value=' '.join(str(int(v)) for v in h))
+                        for sta, d in hd.items() for name, h in (d or {}).items()]
+                if rows:
+                    pd.DataFrame(rows).to_sql(tab, con, if_exists='replace', index=False)
+            cl = self.clusters
+            fp = pd.DataFrame([[cl.filt[0], cl.filt[1], cl.filt[2], cl.filt[3], cl.decimate]],
+                              columns=['FREQMIN', 'FREQMAX', 'CORNERS', 'ZEROPHASE', 'DECIMATE'])
+            fp.to_sql('filt_params', con, if_exists='replace', index=False)
+        finally:
+            con.close()
+
+    def write(self, filename='subspace.pkl'):
+        """subspace.py:2018-2026."""
+        with open(filename, 'wb') as f:
+            pickle.dump(self, f, 2)

@@ -111,6 +111,19 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
                 const float* thr_dev, uint64_t* cand_key_dev,
                 float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* False-alarm statistics of a DS tensor (detex/fas.py:72-86: np.histogram(dss,
+ * np.linspace(-.01, 1, 401)) and scipy.stats.beta.fit(dss, floc=0, fscale=1)).
+ *   hist_dev  [D][nbins] uint32, accumulated, uniform np.linspace(lo, hi, nbins+1)
+ *             edges with np.histogram semantics (may be NULL)
+ *   sums_dev  [D][5] float64, accumulated: n, sum x, sum x^2, sum log x,
+ *             sum log1p(-x) over the samples with 0 < x < 1 -- the sufficient
+ *             statistics of the beta MLE (may be NULL).  Float64 atomics: the
+ *             last bits depend on arrival order.
+ * Caller zeroes both before the first call.  Asynchronous. */
+int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
+                   int nchunk, int D, double lo, double hi, int nbins,
+                   uint32_t* hist_dev, double* sums_dev);
+
 static inline uint64_t dtx_cand_pack(uint32_t chunk, uint32_t det, uint32_t p) {
   return ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;
 }

@@ -1,0 +1,208 @@
+"""CPU tests of the host-side logic around the kernels (no GPU): event loading,
+dissimilarity + linkage + dendrogram cut, alignment through the dendrogram, SVD
+basis selection, chunk geometry, STA/LTA at a trigger, beta MLE.  The GPU seam
+(_makeDFcclags -> dtx_xcorr_allpairs) is stood in for by the oracle through a
+fake context -- test infrastructure only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.cluster.hierarchy import fcluster
+
+from detex_amd import (ContinuousFetcher, EventFetcher, createCluster, createSubSpace)
+from detex_amd import construct, detect, fas
+from oracle import detex_oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+class OracleCtx(object):
+    """Stands in for HipContext.xcorr_allpairs in CPU tests."""
+    device = torch.device('cpu')
+
+    def xcorr_allpairs(self, td, Nc):
+        td = td.numpy().astype(np.float64)
+        cc, lag, ss = orc.make_cclags(list(td), Nc, form='fft')
+        iu = np.triu_indices(len(td), 1)
+        f = lambda m: torch.from_numpy(m[iu[0], iu[1] - 1])  # noqa: E731
+        return f(cc), f(lag), f(ss)
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _fetcher_from_golden(tag):
+    z = np.load(os.path.join(G, 'cclags.npz'))
+    ev, Nc, fam = z[tag + '_events'], int(z[tag + '_Nc']), z[tag + '_fam']
+    f = EventFetcher(100.0, ['C%d' % c for c in range(Nc)])
+    for i, e in enumerate(ev):
+        f.add('NET.STA', 'ev%02d' % i, e.reshape(-1, Nc).T, starttime=1000.0 + i,
+              origintime=995.0 + i, magnitude=1.0 + 0.1 * i)
+    return f, z, fam
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_createCluster_matches_reference_linkage(tag):
+    f, z, fam = _fetcher_from_golden(tag)
+    cl = createCluster(CCreq=0.5, fetch_arg=f, ctx=OracleCtx())
+    row = cl.trdf.iloc[0]
+    assert list(cl.trdf.columns) == ['Station', 'Link', 'CCs', 'Lags', 'Subsamp', 'Events', 'Stats']
+    assert np.allclose(row.CCs.values.astype(float), z[tag + '_cc'], equal_nan=True, atol=1e-9)
+    assert np.array_equal(np.nan_to_num(row.Lags.values.astype(float), nan=-1),
+                          np.nan_to_num(z[tag + '_lag'], nan=-1))
+    assert np.allclose(row.Link, z[tag + '_link'], atol=1e-9)
+    assert list(row.CCs.index) == list(range(len(fam) - 1))
+    assert list(row.CCs.columns) == list(range(1, len(fam)))
+    # dendrogram cut == scipy fcluster at the same height, families recovered
+    c = cl['NET.STA']
+    T = fcluster(row.Link, 1 - 0.5, criterion='distance')
+    groups = {}
+    for i, t in enumerate(T):
+        groups.setdefault(t, []).append('ev%02d' % i)
+    want = sorted(sorted(g) for g in groups.values() if len(g) > 1)
+    assert sorted(sorted(g) for g in c.clusts) == want
+    assert sorted(c.singles) == sorted(g[0] for g in groups.values() if len(g) == 1)
+    cl.updateReqCC(0.999999)
+    assert c.clusts == [] and len(c.singles) == len(fam)
+    cl.updateReqCC(0.0)
+    assert len(c.clusts) == 1 and c.singles == []
+    with pytest.raises(Exception):
+        cl.updateReqCC(1.5)
+
+
+def _shifted_family(rs, Nc, L, shifts, snr=20.0):
+    pad = max(shifts) + 5
+    wav = [np.convolve(rs.standard_normal(L + pad + 8), np.hanning(9), 'valid') *
+           np.exp(-np.arange(L + pad) / (0.25 * L)) for _ in range(Nc)]
+    evs = []
+    for sh in shifts:
+        evs.append(np.array([w[pad - sh: pad - sh + L] + rs.standard_normal(L) * np.std(w) / snr
+                             for w in wav]))
+    return evs
+
+
+def test_alignment_through_dendrogram():
+    """After createSubSpace the aligned events correlate best at zero lag and the
+    recovered delays equal the planted shifts (Harris 2006 App. B logic of
+    construct.py:710-760)."""
+    rs = np.random.RandomState(4)
+    Nc, L = 3, 300
+    shifts = [0, 7, 3, 12, 5]
+    evs = _shifted_family(rs, Nc, L, shifts)
+    other = _shifted_family(rs, Nc, L, [0, 4])
+    f = EventFetcher(50.0, ['E', 'N', 'Z'])
+    for i, e in enumerate(evs + other):
+        f.add('NET.STA', 'ev%d' % i, e, starttime=100.0 * i, origintime=100.0 * i - 2.0)
+    cl = createCluster(CCreq=0.6, fetch_arg=f, ctx=OracleCtx())
+    assert sorted(map(sorted, cl['STA'].clusts)) == [['ev%d' % i for i in range(5)], ['ev5', 'ev6']]
+    ss = createSubSpace(clust=cl, conDatFetcher=None)
+    df = ss.subspaces['NET.STA']
+    row = df[[len(e) == 5 for e in df.Events]].iloc[0]
+    ali = row.AlignedTD
+    lens = set(len(v) for v in ali.values())
+    assert len(lens) == 1 and lens.pop() == Nc * (L - (max(shifts) - min(shifts)))
+    ref = ali['ev0']
+    for k in ['ev1', 'ev2', 'ev3', 'ev4']:
+        cc, lag, _, _ = orc.ccx2_fft(ref, ali[k], Nc)
+        assert lag == 0 and cc > 0.9, (k, cc, lag)
+    # start times moved by the trimmed delay: event shifted by s samples starts s/sr later
+    st = {k: row.Stats[k]['starttime'] - 100.0 * int(k[2:]) for k in ali}
+    d = np.array([st['ev%d' % i] for i in range(5)]) * 50.0
+    assert np.allclose(d - d[0], -(np.array(shifts) - shifts[0]), atol=1e-9) or \
+        np.allclose(d - d[0], (np.array(shifts) - shifts[0]), atol=1e-9)
+    assert len(row.Offsets) == 3 and row.Offsets[0] <= row.Offsets[1] <= row.Offsets[2]
+    # singles: none here; minEvents filter
+    ss3 = createSubSpace(clust=cl, minEvents=3)
+    assert len(ss3.subspaces['NET.STA']) == 1
+
+
+def test_svd_basis_selection_and_thresholds():
+    rs = np.random.RandomState(8)
+    Nc, L = 3, 300
+    evs = _shifted_family(rs, Nc, L, [0, 2, 4, 1, 3, 5], snr=6.0)
+    f = EventFetcher(50.0, ['E', 'N', 'Z'])
+    for i, e in enumerate(evs):
+        f.add('NET.STA', 'ev%d' % i, e * rs.uniform(.5, 2))
+    cl = createCluster(CCreq=0.4, fetch_arg=f, ctx=OracleCtx())
+    ss = createSubSpace(clust=cl)
+    ss.attachPickTimes(startSeconds=0.2, defaultDuration=3.0)
+    row = ss.subspaces['NET.STA'].iloc[0]
+    assert row.SampleTrims['Starttime'] == 10 * Nc and row.SampleTrims['Endtime'] == 160 * Nc
+    ss.SVD(selectCriteria=3, selectValue=0.8, useSingles=False)
+    row = ss.subspaces['NET.STA'].iloc[0]
+    U, s = row.SVD['U'], row.SVD['s']
+    keys = sorted(row.Events)
+    arr = orc.trim_groups([row.AlignedTD[k] for k in keys], 10 * Nc, 160 * Nc)
+    Uo, so = orc.svd_basis(arr)
+    assert np.allclose(s, so) and np.allclose(np.abs(U.T @ Uo), np.eye(len(s)), atol=1e-8)
+    fr, av, mn = orc.frac_energy(Uo, [row.AlignedTD[k][10 * Nc:160 * Nc] for k in row.Events])
+    nb = orc.used_basis_count(av, 3, 0.8)
+    assert row.NumBasis == nb and len(row.UsedSVDKeys) == nb
+    assert np.isclose(row.Threshold, orc.threshold_criteria3(mn, nb, 0.8))
+    ss.SVD(selectCriteria=4, selectValue=1, threshold=0.25, useSingles=False)
+    row = ss.subspaces['NET.STA'].iloc[0]
+    assert row.NumBasis == 2 and row.Threshold == 0.25
+    names, kinds, Ub, off, offsets, thr = ss._detector_bank('NET.STA')
+    assert names == ['SS0'] and Ub.shape == (2, 150 * Nc) and list(off) == [0, 2]
+    with pytest.raises(ValueError):
+        ss.SVD(selectCriteria=2, selectValue=1.5)
+    with pytest.raises(Exception):
+        ss.detex(multiprocess=True)
+
+
+def test_chunk_geometry():
+    """getdata.py:509-518, 869-886: starts on multiples of conDatDuration, each
+    chunk conDatDuration + conBuff long, the last trimmed to the data."""
+    c = ContinuousFetcher(100.0, ['E', 'N', 'Z'])
+    T = int(2.5 * 3600 * 100)
+    c.add('NET.STA', np.zeros((3, T), np.float32), starttime=7200.0)
+    b = c.chunk_bounds('NET.STA')
+    assert [x[0] for x in b] == [0, 360000, 720000]
+    assert [x[1] for x in b] == [372000, 372000, T - 720000]
+    assert [x[2] for x in b] == [7200.0, 10800.0, 14400.0]
+    assert detect._chunk_batches(b) == [(0, 2, 360000), (2, 3, T - 720000)]
+    chunks = list(c.getConData('NET.STA'))
+    assert chunks[0][0].shape == (3, 372000)
+    b2 = c.chunk_bounds('NET.STA', utcStart=7200.0 + 1800.0, utcEnd=7200.0 + 5400.0)
+    assert [x[2] for x in b2][0] == 7200.0 and b2[-1][0] + b2[-1][1] == 540000
+
+
+def test_stalta_at_matches_oracle():
+    rs = np.random.RandomState(0)
+    C = np.abs(rs.standard_normal(900)) * 0.05
+    fetch = lambda lo, hi: np.abs(C[lo:hi])  # noqa: E731
+    for LTA, STA in [(100, 0), (100, 10), (99, 7), (900, 0)]:
+        want = orc.get_stalta(C, LTA, STA)
+        for i in [0, 1, 48, 49, 50, 51, 450, 849, 850, 851, 899]:
+            got = detect.stalta_at(fetch, i, len(C), LTA, STA)
+            assert np.isclose(got, want[i], rtol=1e-12), (LTA, STA, i)
+    with pytest.raises(IndexError):
+        detect.stalta_at(fetch, 5, len(C), 901, 0)
+
+
+def test_beta_mle_matches_scipy():
+    import scipy.stats
+    rs = np.random.RandomState(1)
+    x = rs.beta(2.5, 60.0, size=20000)
+    p, nnlf = fas.beta_mle(len(x), x.sum(), (x * x).sum(), np.log(x).sum(), np.log1p(-x).sum())
+    ref = scipy.stats.beta.fit(x, floc=0, fscale=1)
+    assert np.allclose(p, ref, rtol=1e-8)
+    assert np.isclose(nnlf, scipy.stats.beta.nnlf(ref, x), rtol=1e-10)
+    thr = scipy.stats.beta.isf(1e-12, p[0], p[1], 0, 1)
+    assert 0 < thr < 1
+
+
+def test_classic_sta_lta_restatement():
+    rs = np.random.RandomState(2)
+    a = rs.standard_normal(2000)
+    a[1200:1230] *= 15
+    cft = fas.classic_sta_lta(a, 10, 100)
+    assert np.all(cft[:99] == 0) and cft.argmax() in range(1200, 1245) and cft.max() > 7.5
+    i = 700
+    assert np.isclose(cft[i], np.mean(a[i - 9:i + 1] ** 2) / np.mean(a[i - 99:i + 1] ** 2))
+    assert fas._checkSTALTA(np.stack([a, a, a]), ['HHE', 'HHN', 'HHZ'], 1.0, 10, 100, 7.5) is False
+    assert fas._checkSTALTA(np.stack([a, a, a]), ['HHE', 'HHN', 'HHZ'], 1.0, 10, 100, None) is True
