@@ -179,7 +179,7 @@ def test_stalta_at_matches_oracle():
         want = orc.get_stalta(C, LTA, STA)
         for i in [0, 1, 48, 49, 50, 51, 450, 849, 850, 851, 899]:
             got = detect.stalta_at(fetch, i, len(C), LTA, STA)
-            assert np.isclose(got, want[i], rtol=1e-12), (LTA, STA, i)
+            assert np.isclose(got, want[i], rtol=1e-12, equal_nan=True), (LTA, STA, i)
     with pytest.raises(IndexError):
         detect.stalta_at(fetch, 5, len(C), 901, 0)
 
