@@ -1,0 +1,160 @@
+"""End-to-end on the GPU with the reference's workflow names (BASELINE.json
+configs[0] in miniature): createCluster -> createSubSpace -> attachPickTimes ->
+SVD -> detex, checked against the same workflow run with the CPU oracle."""
+import os
+import sqlite3
+
+import numpy as np
+import pandas as pd
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace  # noqa: E402
+from detex_amd.getdata import multiplex  # noqa: E402
+from oracle import detex_oracle as orc  # noqa: E402
+
+SR, NC, L = 20.0, 3, 200
+
+
+def _wavelets(rs, nfam):
+    env = np.exp(-np.arange(L + 40) / (0.3 * L))
+    k = np.hanning(7)
+    return [[np.convolve(rs.standard_normal(L + 46), k / k.sum(), 'valid') * env
+             for _ in range(NC)] for _ in range(nfam)]
+
+
+@pytest.fixture(scope='module')
+def workflow():
+    rs = np.random.RandomState(0)
+    fams = _wavelets(rs, 2)
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    shifts = {}
+    n = 0
+    for f, wav in enumerate(fams):
+        for _ in range(5):
+            sh = int(rs.randint(0, 30))
+            amp = rs.uniform(.5, 2)
+            data = np.array([amp * w[sh:sh + L] + rs.standard_normal(L) * np.std(w) / 8 for w in wav])
+            ef.add('TA.M17A', 'ev%02d' % n, data, starttime=5000.0 + 50 * n,
+                   origintime=4990.0 + 50 * n, magnitude=1.5)
+            shifts['ev%02d' % n] = (f, sh)
+            n += 1
+    # one loner that should stay a single
+    ef.add('TA.M17A', 'ev%02d' % n, rs.standard_normal((NC, L)), starttime=9000., origintime=8990.)
+    # continuous data: 2000 s, chunks of 600 s + 60 s
+    T = int(2000 * SR)
+    con = rs.standard_normal((NC, T)) * 0.05
+    plants = [(3000, 0, 1.0), (9000, 1, 0.7), (15000, 0, 0.5), (15200, 1, 0.9), (27000, 0, 1.2),
+              (35000, 1, 0.6)]
+    for (t, f, a) in plants:
+        for c in range(NC):
+            con[c, t:t + L] += a * fams[f][c][10:10 + L]
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], conDatDuration=600, conBuff=60)
+    cf.add('TA.M17A', con.astype(np.float32), starttime=1.2e6)
+    cl = createCluster(CCreq=0.55, fetch_arg=ef, device=0)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=0.0, defaultDuration=6.0)
+    return dict(ef=ef, cf=cf, cl=cl, ss=ss, plants=plants, shifts=shifts, con=con)
+
+
+def test_cluster_stage(workflow):
+    cl, ef = workflow['cl'], workflow['ef']
+    c = cl['TA.M17A']
+    assert sorted(map(sorted, c.clusts)) == [['ev%02d' % i for i in range(5)],
+                                             ['ev%02d' % i for i in range(5, 10)]]
+    assert c.singles == ['ev10']
+    # the stored matrices equal the oracle's to the kernel tolerances
+    row = cl.trdf.iloc[0]
+    td = [multiplex(list(ef.events['TA.M17A'][e]['data'].astype(np.float32))) for e in row.Events]
+    cc, lag, ss_ = orc.make_cclags(td, NC)
+    assert np.nanmax(np.abs(row.CCs.values.astype(float) - cc)) <= 1e-5
+    assert np.array_equal(np.nan_to_num(row.Lags.values.astype(float), nan=-1),
+                          np.nan_to_num(lag, nan=-1))
+    assert np.nanmax(np.abs(row.Subsamp.values.astype(float) - ss_)) <= 1e-4
+
+
+def test_detex_matches_oracle_workflow(workflow, tmp_path):
+    ss, cf = workflow['ss'], workflow['cf']
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    ss.setSinglesThresholds(threshold=0.4)
+    db = str(tmp_path / 'SubSpace.db')
+    res = ss.detex(subspaceDB=db, useSingles=True, triggerLTATime=5, triggerSTATime=0)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A')
+    assert kinds.count('ss') == 2 and kinds.count('sg') == 1
+    # the same scan with the oracle
+    want = []
+    hist = {nm: np.zeros(400, dtype=np.int64) for nm in names}
+    for chunk, t0 in cf.getConData('TA.M17A'):
+        x = multiplex(list(chunk)).astype(np.float64)
+        for d, nm in enumerate(names):
+            ds = orc.mpxds_fft(x, U[off[d]:off[d + 1]].astype(np.float32), NC)
+            ds, maxds = orc.scrub_ds(ds)
+            hist[nm] += orc.ds_histogram(ds)
+            if orc.eval_trig_con(maxds, np.float32(thr[nm])):
+                sl = orc.get_stalta(ds, 5 * SR, 0)
+                for t in orc.pick_triggers(ds, np.float32(thr[nm]), SR, t0, offsets[nm], stalta=sl):
+                    if t['DS'] <= 1.05:
+                        want.append((nm, t['STMP'], t['DS'], t['DS_STALTA'], t['MSTAMPmin'],
+                                     t['MSTAMPmax']))
+    got = pd.concat([res['ss_df'], res['sg_df']], ignore_index=True)
+    assert len(got) == len(want) and len(want) >= 6
+    got = got.sort_values(['Name', 'STMP']).reset_index(drop=True)
+    want.sort(key=lambda r: (r[0], r[1]))
+    for (_, g), w in zip(got.iterrows(), want):
+        assert g.Name == w[0] and g.STMP == w[1]                   # trigger index bit-exact
+        assert abs(g.DS - w[2]) <= 1e-5
+        assert abs(g.DS_STALTA - w[3]) <= 1e-3 * max(1, abs(w[3]))
+        assert abs(g.MSTAMPmin - w[4]) < 1e-6 and abs(g.MSTAMPmax - w[5]) < 1e-6
+        assert g.Sta == 'TA.M17A' and np.isnan(g.Mag)
+    # every planted event is found by its family's subspace (overlap chunks find it twice)
+    t0 = 1.2e6
+    for (t, f, a) in workflow['plants']:
+        hit = got[(np.abs(got.STMP - (t0 + (t + 0) / SR)) < 2.0) & got.Name.str.startswith('SS')]
+        assert len(hit) >= 1, (t, f, a)
+    # histograms agree with the oracle except for bin-edge flips within 1e-6 of an edge
+    for nm in names:
+        h = (ss.histSubSpaces['TA.M17A'] | ss.histSingles['TA.M17A'])[nm] \
+            if hasattr(dict, '__or__') else None
+        assert h.sum() == hist[nm].sum() and np.abs(h - hist[nm]).sum() <= 6
+    # SQLite output with the reference's tables
+    con = sqlite3.connect(db)
+    tabs = set(r[0] for r in con.execute("select name from sqlite_master where type='table'"))
+    assert {'ss_df', 'ss_info', 'ss_hist', 'sg_hist', 'filt_params'} <= tabs
+    n_db = con.execute('select count(*) from ss_df').fetchone()[0]
+    con.close()
+    assert n_db == len(res['ss_df'])
+
+
+def test_fas_matches_scipy(workflow):
+    import scipy.stats
+    from detex_amd.hip import HipContext
+    ss, cf = workflow['ss'], workflow['cf']
+    ss.SVD(selectCriteria=2, selectValue=0.75, conDatNum=3, useSingles=False, staltalimit=None,
+           seed=3)
+    df = ss.subspaces['TA.M17A']
+    names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
+    ctx = HipContext(0)
+    ctx.upload_basis(U, off, NC)
+    rs = np.random.RandomState(3)
+    bounds = cf.chunk_bounds('TA.M17A')
+    order = rs.permutation(len(bounds))[:12][:3]
+    data = cf.data['TA.M17A'][0]
+    allds = [[] for _ in names]
+    for k in order:
+        s, cnt, _ = bounds[k]
+        x = torch.from_numpy(multiplex(list(data[:, s:s + cnt])).astype(np.float32)).cuda()
+        ds = ctx.subspace_ds(x)[0].cpu().numpy()
+        for d in range(len(names)):
+            allds[d].append(ds[d])
+    for d, nm in enumerate(names):
+        fasrec = df[df.Name == nm].iloc[0].FAS
+        dss = np.concatenate(allds[d]).astype(np.float64)
+        assert np.array_equal(fasrec['hist'], np.histogram(dss, bins=np.linspace(-.01, 1, 401))[0])
+        ref = scipy.stats.beta.fit(dss[(dss > 0) & (dss < 1)], floc=0, fscale=1)
+        assert np.allclose(fasrec['betadist'][:2], ref[:2], rtol=1e-6)
+        th = df[df.Name == nm].iloc[0].Threshold
+        want = scipy.stats.beta.isf(ss.Pf, ref[0], ref[1], 0, 1)
+        assert np.isclose(th, want, rtol=1e-5) or want > .9
+    ctx.close()
