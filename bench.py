@@ -147,6 +147,18 @@ def main():
         found += bool(sel.any())
 
     flops = 2.0 * K * n * P * a.chunks
+    # HBM-side bytes per launch of the dominant kernel: PMC counters collected by
+    # scripts/profile.sh (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) for this
+    # exact configuration, committed under profiles/; None for any other configuration
+    traffic = None
+    default_cfg = (D, k, a.chunks, Nc, a.sr, a.chunk_seconds, a.template_seconds) == \
+        (25, 8, 24, 3, 100.0, 3720.0, 30.0)
+    if default_cfg:
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_pmc_ds_mfma_kernel.json')))
+        if pm:
+            with open(pm[-1]) as f:
+                traffic = json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
     achieved = flops / (kms * 1e-3) / 1e12
     out = {
         'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)',
@@ -159,7 +171,7 @@ def main():
                    'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
         'roofline': {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<13,2>', 'achieved': achieved,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                      'kernel_ms': kms, 'flop_per_launch': flops},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

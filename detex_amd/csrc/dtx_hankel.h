@@ -40,7 +40,10 @@ constexpr int kThreads = 512;  // 8 waves, 2 per SIMD
 constexpr int kRmMax = 13;     // 13 * 16 = 208 rows per K-tile
 constexpr int kKtMax = 16 * kRmMax;
 
-__host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? 2 : (rm >= 5 ? 4 : 8); }
+#ifndef DTX_TN_BIG
+#define DTX_TN_BIG 2
+#endif
+__host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? DTX_TN_BIG : (rm >= 5 ? 4 : 8); }
 __host__ __device__ constexpr int pt_for(int rm) { return 128 * tn_for(rm); }
 __host__ __device__ constexpr int kts_for(int rm) { return 16 * rm + ((rm & 1) ? 0 : 16); }
 // floats of LDS one block needs
