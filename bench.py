@@ -77,10 +77,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if world > 1:
+    torch.cuda.set_device(local)
+    use_dist = 'RANK' in os.environ          # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    torch.cuda.set_device(local)
     from detex_amd.hip import HipContext
     from detex_amd import synth
 
@@ -115,7 +116,7 @@ def main():
         return ctx.ds_post(ds, thr=thr, hist=hist)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +133,7 @@ def main():
     # dominant-kernel time: HIP events recorded around the MFMA kernel on the
     # context's stream (the last step's launch; steps are identical)
     kms = ctx.last_kernel_ms()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -180,7 +181,7 @@ def main():
         out['cpu_baseline'] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

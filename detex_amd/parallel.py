@@ -39,7 +39,7 @@ def broadcast_basis(U, det_off, n, device, src=0):
     other ranks can size the buffer), then the basis itself."""
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return torch.as_tensor(U, dtype=torch.float32, device=device), np.asarray(det_off, np.int32)
     if rank == src:
         off = torch.as_tensor(np.asarray(det_off, dtype=np.int64), device=device)
