@@ -103,7 +103,7 @@ def _chunk_batches(bounds):
 
 
 def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
-                 useSubSpaces, useSingles, fillZeros, device=0, ctx=None):
+                 useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=False):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
     detectors in one GPU basis: per batch of chunks the detection statistic
     (dtx_subspace_ds), histogram / max / candidates (dtx_ds_post), then the
@@ -132,8 +132,8 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     try:
         ctx.upload_basis(U, det_off, Nc)
         data, t0 = fetcher.data[sta]
-        xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
-                                ).to(ctx.device)
+        xhost = np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
+        xdev = torch.from_numpy(xhost).to(ctx.device)
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
@@ -174,8 +174,14 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
                                 sl = 0.0
                         times = float(ti) / sr + start           # detect.py:413
                         of = offsets[name]
+                        pem = stm = snr = np.nan
+                        if estimateMags:                         # detect.py:422-429
+                            c0 = (bounds[i0 + b][0]) * Nc
+                            pem, stm, snr = est_mag(ti, Nc, xhost[c0:c0 + M], ss._bank_mags[name],
+                                                    U[det_off[d]:det_off[d + 1]],
+                                                    ss._bank_ewf[name], kinds[d] == 'ss')
                         rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
-                                               times - np.min(of), np.nan, np.nan, np.nan])
+                                               times - np.min(of), stm, snr, pem])
         ctx.sync()
         h = hist.cpu().numpy()
     finally:
@@ -185,3 +191,60 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
     out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
     return out
+
+
+# --------------------------------------------------------------------------
+# magnitude estimates at a trigger                 detect.py:447-499, 637-664
+# --------------------------------------------------------------------------
+
+def _rolling_std_median(pe, n):
+    """median(pd.rolling_std(pe, n)[n-1:]) (ddof=1) by prefix sums in float64."""
+    pe = np.asarray(pe, dtype=np.float64)
+    pe = pe - pe.mean()                      # shift invariance: kills the cancellation
+    c1 = np.concatenate([[0.0], np.cumsum(pe)])
+    c2 = np.concatenate([[0.0], np.cumsum(pe * pe)])
+    s1 = c1[n:] - c1[:-n]
+    s2 = c2[n:] - c2[:-n]
+    var = np.maximum((s2 - s1 * s1 / n) / (n - 1.0), 0.0)
+    return float(np.median(np.sqrt(var)))
+
+
+def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
+    """Projected-energy and standard-deviation magnitude estimates and the SNR
+    of a detection (Chambers et al. 2015; detect.py:447-499).  Same results as
+    the reference without its n x n ``UtU`` (648 MB per detector at n = 9000,
+    detect.py:367): U^T (U w) replaces UtU w, and (WFs U^T) U replaces WFs UtU.
+    Returns (projectedEnergyMag, stdMag, SNR); per trigger, rare, on the host."""
+    MPcon = np.asarray(MPcon)
+    ewf = np.asarray(ewf, dtype=np.float64)
+    mags = np.asarray(mags, dtype=np.float64)
+    WFlen = ewf.shape[1]
+    a = trigIndex * Nc
+    ConDat = np.asarray(MPcon[a: a + WFlen], dtype=np.float64)
+    if a > 5 * WFlen:                                            # detect.py:466-471
+        pe = MPcon[a - 5 * WFlen: a]
+    else:
+        pe = MPcon[a: a + WFlen + 6 * WFlen]
+    SNR = np.std(ConDat) / _rolling_std_median(pe, WFlen)        # detect.py:472-473
+    touse = mags > -15
+    if issubspace:
+        U = np.asarray(U, dtype=np.float64)
+        if not touse.any():                                      # detect.py:478-482
+            return np.nan, np.nan, SNR
+        ssCon = U.T @ (U @ ConDat)                               # = UtU . ConDat
+        WFU = (ewf @ U.T) @ U                                    # = WFs . UtU
+        proEn = np.var(ssCon) / np.var(WFU, axis=1)              # detect.py:463
+        cd = ConDat - ConDat.mean()
+        ec = np.array([np.dot(x - x.mean(), cd) / (len(x) * np.std(x) * np.std(ConDat))
+                       for x in ewf])                            # fast_normcorr(x, ConDat)[0]
+        we = np.square(ec) * touse
+        pem = np.sum((mags + np.log10(np.sqrt(proEn)))[touse] * we[touse]) / we.sum()
+        stm = np.sum((mags + np.log10(np.std(ConDat) / np.std(ewf, axis=1)))[touse] *
+                     we[touse]) / we.sum()
+        return float(pem), float(stm), float(SNR)
+    if np.isnan(mags[0]) or mags[0] < -15:                       # detect.py:490-492
+        return np.nan, np.nan, float(SNR)
+    d1 = np.dot(ConDat, ewf[0])
+    d2 = np.dot(ewf[0], ewf[0])
+    return (float(mags[0] + d1 / d2),
+            float(mags[0] + np.log10(np.std(ConDat) / np.std(ewf[0]))), float(SNR))

@@ -339,6 +339,7 @@ class SubSpace(object):
         (detect.py:357-364).  Returns (names, kinds, U [Ktot, n], det_off,
         offsets {name: array}, thresholds {name: float})."""
         names, kinds, blocks, offsets, thr = [], [], [], {}, {}
+        self._bank_ewf, self._bank_mags = {}, {}
         if useSubSpaces and sta in self.subspaces:
             for _, row in self.subspaces[sta].iterrows():
                 if not row.SVDdefined or row.NumBasis < 1:
@@ -346,6 +347,13 @@ class SubSpace(object):
                 blocks.append(np.asarray(row.SVD['U'][:, :row.NumBasis].T, dtype=np.float64))
                 names.append(row.Name)
                 kinds.append('ss')
+                st = row.SampleTrims                               # detect.py:347-355
+                wfs = [np.asarray(row.AlignedTD[e], dtype=np.float64) for e in row.Events]
+                if 'Starttime' in st:
+                    wfs = [w[st['Starttime']:st['Endtime']] for w in wfs]
+                self._bank_ewf[row.Name] = np.array(wfs)
+                self._bank_mags[row.Name] = np.array([row.Stats[e]['magnitude']
+                                                      for e in row.Events], dtype=np.float64)
                 offsets[row.Name] = np.asarray(row.Offsets, dtype=np.float64)
                 thr[row.Name] = float(row.Threshold) if need_thr else np.nan
         if useSingles and sta in self.singles:
@@ -358,6 +366,8 @@ class SubSpace(object):
                 blocks.append((x / np.linalg.norm(x))[None, :])
                 names.append(row.Name)
                 kinds.append('sg')
+                self._bank_ewf[row.Name] = x[None, :]
+                self._bank_mags[row.Name] = np.array([row.Stats[ev]['magnitude']])
                 offsets[row.Name] = np.asarray(row.Offsets, dtype=np.float64)
                 thr[row.Name] = float(row.Threshold) if need_thr else np.nan
         if not blocks:
@@ -402,8 +412,6 @@ class SubSpace(object):
         from .detect import scan_station
         if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
             _error('multiprocessing and trigcon other than 0 not supported')
-        if estimateMags:
-            _error('estimateMags=True is not supported yet; pass estimateMags=False')
         if classifyEvents is not None or utcSaves is not None:
             _error('classifyEvents / utcSaves are not supported')
         if self.cfetcher is None:
@@ -413,7 +421,8 @@ class SubSpace(object):
         out = {'ss_df': [], 'sg_df': []}
         for sta in self.Stations:
             res = scan_station(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime,
-                               calcHist, useSubSpaces, useSingles, fillZeros, device, ctx)
+                               calcHist, useSubSpaces, useSingles, fillZeros, device, ctx,
+                               estimateMags=estimateMags)
             if res is None:
                 continue
             for kind in ('ss', 'sg'):

@@ -454,3 +454,53 @@ def used_basis_count(average, selectCriteria, selectValue):
 def threshold_criteria3(minimum, numbasis, selectValue):
     """subspace.py:1049-1054."""
     return minimum[numbasis] * selectValue
+
+
+# --------------------------------------------------------------------------
+# magnitude estimates at a trigger                 detect.py:447-499, 637-664
+# --------------------------------------------------------------------------
+
+def rolling_std_valid(x, n):
+    """pd.rolling_std(x, n)[n-1:] (ddof=1)."""
+    return np.sqrt(rolling_var_valid(x, n, ddof=1))
+
+
+def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
+    """detect.py:447-499 literally, including the n x n UtU of detect.py:367 and
+    WFU = WFs.UtU of 381.  Returns (projectedEnergyMag, stdMag, SNR)."""
+    MPcon = np.asarray(MPcon, dtype=np.float64)
+    ewf = np.asarray(ewf, dtype=np.float64)
+    mags = np.asarray(mags, dtype=np.float64)
+    if issubspace:
+        U = np.asarray(U, dtype=np.float64)
+        UtU = np.dot(U.T, U)
+        WFU = np.dot(ewf, UtU)
+    else:
+        WFU = ewf
+    WFlen = np.shape(WFU)[1]
+    ConDat = MPcon[trigIndex * Nc: trigIndex * Nc + WFlen]
+    if issubspace:
+        ssCon = np.dot(UtU, ConDat)
+        proEn = np.var(ssCon) / np.var(WFU, axis=1)
+    if trigIndex * Nc > 5 * WFlen:
+        pe = MPcon[trigIndex * Nc - 5 * WFlen: trigIndex * Nc]
+    else:
+        pe = MPcon[trigIndex * Nc: trigIndex * Nc + WFlen + 6 * WFlen]
+    baseNoise = np.median(rolling_std_valid(pe, WFlen))
+    SNR = np.std(ConDat) / baseNoise
+    touse = mags > -15
+    if issubspace:
+        ecor = np.array([fast_normcorr(x, ConDat)[0] for x in ewf])
+        weDenom = np.sum(np.square(ecor[touse]))
+        pem = stm = 0.0
+        for x in range(len(ewf)):
+            if mags[x] > -15:
+                we = np.square(ecor[x])
+                pem += (mags[x] + np.log10(np.sqrt(proEn[x]))) * we
+                stm += (mags[x] + np.log10(np.std(ConDat) / np.std(ewf[x]))) * we
+        return pem / weDenom, stm / weDenom, SNR
+    if np.isnan(mags[0]) or mags[0] < -15:
+        return np.nan, np.nan, SNR
+    d1 = np.dot(ConDat, WFU[0])
+    d2 = np.dot(WFU[0], WFU[0])
+    return mags[0] + d1 / d2, mags[0] + np.log10(np.std(ConDat) / np.std(WFU[0])), SNR

@@ -19,6 +19,7 @@ Reference entry points exercised (file:line in /root/reference):
   detex/detect.py:501-524     _getStaLtaArray-> trig.npz
   detex/detect.py:390-445     _CreateCoeffArray, 545-557 _downPlay..., 526-543
                               _evalTrigCon   -> trig.npz
+  detex/detect.py:447-499     _estMag (+637-664) -> estmag.npz
 """
 import os
 import sys
@@ -305,9 +306,50 @@ def gen_trig():
     print('trig.npz: %d cases' % case)
 
 
+# ---------------------------------------------------------------- _estMag
+def gen_estmag():
+    """detect.py:447-499 (+ _estPEMag / _estSTDMag 637-664) on a subspace and a
+    singleton detector."""
+    out = {}
+    rs = np.random.RandomState(77)
+    Nc, L, nev = 3, 60, 4
+    n = Nc * L
+    base = _mp([_bandlimited(rs, L) for _ in range(Nc)])
+    ewf = np.array([a * base + 0.15 * _mp([_bandlimited(rs, L) for _ in range(Nc)])
+                    for a in (1.0, 2.0, 0.5, 4.0)])
+    mags = np.array([1.0, 1.3, -20.0, 1.9])          # one undefined magnitude (< -15)
+    A = ewf - ewf.mean(axis=1, keepdims=True)
+    Uf, s, _ = np.linalg.svd(A.T, full_matrices=False)
+    U = Uf[:, :2].T.copy()
+    UtU = np.dot(U.T, U)                              # detect.py:367
+    WFU = np.dot(ewf, UtU)                            # detect.py:381
+    T = 1500
+    MPcon = _mp([_bandlimited(rs, T) * 0.1 for _ in range(Nc)])
+    cases = [('early', 40, 3.0), ('late', 900, 0.7)]  # < and > 5*WFlen of pre-event data
+    for tag, trig, amp in cases:
+        MPcon[trig * Nc: trig * Nc + n] += amp * base
+    for issub in (True, False):
+        obj = _fake_ssdetex()
+        obj.issubspace = issub
+        for tag, trig, amp in cases:
+            cor = pd.Series({'Nc': Nc})
+            if issub:
+                r = obj._estMag(trig, cor, MPcon, mags, ['e%d' % i for i in range(nev)], WFU, UtU,
+                                ewf, 0.5, 0.0, 'SS0', 'STA')
+            else:
+                r = obj._estMag(trig, cor, MPcon, mags[:1], ['e0'], ewf[:1], None, ewf[:1], 0.5,
+                                0.0, 'SG0', 'STA')
+            out['%s_%s' % ('ss' if issub else 'sg', tag)] = np.array(r, dtype=np.float64)
+    out.update(MPcon=MPcon, U=U, ewf=ewf, mags=mags, Nc=np.int64(Nc),
+               trigs=np.array([c[1] for c in cases]))
+    np.savez_compressed(os.path.join(HERE, 'estmag.npz'), **out)
+    print('estmag.npz written', {k: v for k, v in out.items() if k[:2] in ('ss', 'sg')})
+
+
 if __name__ == '__main__':
     gen_ccx2()
     gen_cclags()
     gen_normcorr()
     gen_mpxds()
     gen_trig()
+    gen_estmag()

@@ -80,7 +80,8 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
     ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
     ss.setSinglesThresholds(threshold=0.4)
     db = str(tmp_path / 'SubSpace.db')
-    res = ss.detex(subspaceDB=db, useSingles=True, triggerLTATime=5, triggerSTATime=0)
+    res = ss.detex(subspaceDB=db, useSingles=True, triggerLTATime=5, triggerSTATime=0,
+                   estimateMags=True)
     names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A')
     assert kinds.count('ss') == 2 and kinds.count('sg') == 1
     # the same scan with the oracle
@@ -96,8 +97,10 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
                 sl = orc.get_stalta(ds, 5 * SR, 0)
                 for t in orc.pick_triggers(ds, np.float32(thr[nm]), SR, t0, offsets[nm], stalta=sl):
                     if t['DS'] <= 1.05:
+                        mg = orc.est_mag(t['index'], NC, x, ss._bank_mags[nm],
+                                         U[off[d]:off[d + 1]], ss._bank_ewf[nm], kinds[d] == 'ss')
                         want.append((nm, t['STMP'], t['DS'], t['DS_STALTA'], t['MSTAMPmin'],
-                                     t['MSTAMPmax']))
+                                     t['MSTAMPmax'], mg))
     got = pd.concat([res['ss_df'], res['sg_df']], ignore_index=True)
     assert len(got) == len(want) and len(want) >= 6
     got = got.sort_values(['Name', 'STMP']).reset_index(drop=True)
@@ -107,7 +110,10 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
         assert abs(g.DS - w[2]) <= 1e-5
         assert abs(g.DS_STALTA - w[3]) <= 1e-3 * max(1, abs(w[3]))
         assert abs(g.MSTAMPmin - w[4]) < 1e-6 and abs(g.MSTAMPmax - w[5]) < 1e-6
-        assert g.Sta == 'TA.M17A' and np.isnan(g.Mag)
+        assert g.Sta == 'TA.M17A'
+        pem, stm, snr = w[6]
+        assert np.allclose([g.ProEnMag, g.Mag, g.SNR], [pem, stm, snr], rtol=1e-5, equal_nan=True)
+        assert np.isfinite(g.SNR)
     # every planted event is found by its family's subspace (overlap chunks find it twice)
     t0 = 1.2e6
     for (t, f, a) in workflow['plants']:

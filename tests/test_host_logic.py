@@ -206,3 +206,20 @@ def test_classic_sta_lta_restatement():
     assert np.isclose(cft[i], np.mean(a[i - 9:i + 1] ** 2) / np.mean(a[i - 99:i + 1] ** 2))
     assert fas._checkSTALTA(np.stack([a, a, a]), ['HHE', 'HHN', 'HHZ'], 1.0, 10, 100, 7.5) is False
     assert fas._checkSTALTA(np.stack([a, a, a]), ['HHE', 'HHN', 'HHZ'], 1.0, 10, 100, None) is True
+
+
+def test_est_mag_matches_reference():
+    """Oracle (literal, with UtU) and product (UtU-free) against the reference."""
+    z = np.load(os.path.join(G, 'estmag.npz'))
+    MPcon, U, ewf, mags, Nc = z['MPcon'], z['U'], z['ewf'], z['mags'], int(z['Nc'])
+    for tag, trig in zip(['early', 'late'], z['trigs']):
+        for kind, issub in (('ss', True), ('sg', False)):
+            ref = z['%s_%s' % (kind, tag)]
+            m = mags if issub else mags[:1]
+            e = ewf if issub else ewf[:1]
+            o = orc.est_mag(int(trig), Nc, MPcon, m, U, e, issubspace=issub)
+            g = detect.est_mag(int(trig), Nc, MPcon, m, U, e, issubspace=issub)
+            assert np.allclose(o, ref, rtol=1e-10), (kind, tag)
+            assert np.allclose(g, ref, rtol=1e-9), (kind, tag)
+    g = detect.est_mag(40, Nc, MPcon, np.array([-99., -99, -99, -99]), U, ewf)
+    assert np.isnan(g[0]) and np.isnan(g[1]) and g[2] > 0
