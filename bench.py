@@ -148,6 +148,8 @@ def main():
         found += bool(sel.any())
 
     flops = 2.0 * K * n * P * a.chunks
+    rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
+    kname = 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8))
     # HBM-side bytes per launch of the dominant kernel: PMC counters collected by
     # scripts/profile.sh (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) for this
     # exact configuration, committed under profiles/; None for any other configuration
@@ -166,11 +168,12 @@ def main():
         'value': value, 'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: %d basis vectors (%d detectors x %d) x %d chunks of '
+        'config': {'workload': '%s%d basis vectors (%d detectors x %d) x %d chunks of '
                                '%g s, %d-ch %g Hz, n=%d, one station-day per GPU'
-                               % (K, D, k, a.chunks, a.chunk_seconds, Nc, a.sr, n),
+                               % ('configs[1]: ' if default_cfg else 'custom: ', K, D, k, a.chunks,
+                                  a.chunk_seconds, Nc, a.sr, n),
                    'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
-        'roofline': {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<13,2>', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                      'kernel_ms': kms, 'flop_per_launch': flops},

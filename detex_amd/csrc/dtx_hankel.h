@@ -11,11 +11,12 @@
 //       is never built: MFMA B fragments are sliding reads of an LDS copy of x_c.
 //
 // One block = 8 waves computes a [KT = 16*RM] x [PT = 128*TN] tile; wave w owns
-// columns [16*TN*w, 16*TN*(w+1)).  Per step of kBQ = 32 contraction indices the
-// block stages A_c[j0:j0+32][0:KT] and x_c[p0+j0 : p0+j0+PT+32] through LDS
-// (register-staged double buffer: global loads for step s+1 are issued before
-// the MFMAs of step s and written to the other buffer after them; one barrier
-// per step).
+// columns [16*TN*w, 16*TN*(w+1)).  Per step of kBQ = 64 contraction indices the
+// block stages A_c[j0:j0+64][0:KT] and x_c[p0+j0 : p0+j0+PT+64] into an LDS
+// double buffer: the A tile by LDS-DMA (global_load_lds_dwordx4) when its LDS
+// image is linear (template flag GL), else through registers; the loads for
+// step s+1 are issued at the top of step s; one barrier per step.  The k-loop
+// is hand-scheduled: fragment reads run one k-step ahead of the MFMAs.
 //
 // v_mfma_f32_16x16x4_f32 fragments (lane = 16*kq + i, kq = 0..3, i = 0..15):
 //   A[i][kq] = As[(jj+kq)*KTS + 16 r + i]
