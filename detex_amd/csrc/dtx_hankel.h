@@ -48,8 +48,13 @@ __host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? DTX_TN_BIG :
 __host__ __device__ constexpr int pt_for(int rm) { return 128 * tn_for(rm); }
 __host__ __device__ constexpr int kts_for(int rm) { return 16 * rm + ((rm & 1) ? 0 : 16); }
 // floats of LDS one block needs
+// first float of the wave-private patches the TAIL hand-over uses (behind the
+// 2*KT + 1 floats the epilogues keep at the start of the buffer)
+__host__ __device__ constexpr int patch_base(int rm) { return 2 * 16 * rm + 64; }
 __host__ __device__ constexpr int lds_floats(int rm) {
-  return 2 * (kBQ * kts_for(rm) + pt_for(rm) + kBQ);
+  const int loop = 2 * (kBQ * kts_for(rm) + pt_for(rm) + kBQ);
+  const int tail = patch_base(rm) + 8 * 8 * 16 * tn_for(rm);
+  return loop > tail ? loop : tail;
 }
 
 template <int I, int N, class F>
@@ -77,7 +82,7 @@ __device__ __forceinline__ void lds_wait_all() {
   __builtin_amdgcn_sched_barrier(0);   // keep MFMAs behind the wait (hipcc would hoist them)
 }
 
-template <int RM, int TN, bool GL = false>
+template <int RM, int TN, bool GL = false, bool TAIL = false>
 __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const float* __restrict__ at,
                                                 int ldk, int Lp, const float* __restrict__ xw,
                                                 int64_t plane_stride, int Nc, int jlo, int jhi,
@@ -175,31 +180,48 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   }
   __syncthreads();
 
-#ifndef DTX_PIPE
-#define DTX_PIPE 3
-#endif
-// fragments of k-step jj_ into register set set_
-#define DTX_LOAD_FRAGS(set_, jj_)                                                          \
-  do {                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < RM; ++r) av[set_][r] = B[(jj_) * KTS + aoff + 16 * r]; \
-    _Pragma("unroll") for (int t = 0; t < TN; ++t) bv[set_][t] = B[boff + 16 * t + (jj_)]; \
-  } while (0)
-
-#if DTX_PIPE == 3
   // Hand-scheduled k-loop: the LDS reads of k-step ks+1 (immediate-offset
-  // ds_read_b32 from two base registers) are issued between the MFMAs of k-step
-  // ks, one row block at a time; a single lgkmcnt(0) per k-step, long after the
-  // reads were issued.
+  // ds_read_b32 from per-lane base registers) are issued between the MFMAs of
+  // k-step ks, one row block at a time; a single lgkmcnt(0) per k-step, long
+  // after the reads were issued; sched_barrier pins the order.
+  //
+  // TAIL: the last row block holds at most 8 real rows.  Instead of a 16x16x4
+  // MFMA on a half-empty block it is computed by v_mfma_f32_4x4x1_16B_f32 with
+  // CBSZ = 3 (the A rows of block ABID are broadcast to the 8 blocks of each
+  // half-wave): one instruction = 8 rows x 32 columns x 1 contraction index in 8
+  // cycles, i.e. half the matrix-pipe time of the padded block.  Lane l = 32 g +
+  // 4 a + j: A register holds row 4 g + j at contraction index a (a < 4), B
+  // registers hold column (l & 31) at index a = 0..3; result registers are rows
+  // 4 g + e of column (l & 31).
   const unsigned lds_base = (unsigned)(unsigned long long)(
       (__attribute__((address_space(3))) float*)lds);
   constexpr int KS = kBQ / 4;
+  constexpr int RF = TAIL ? RM - 1 : RM;          // full 16-row blocks
+  constexpr int TH = TN / 2;                      // 32-column groups of the tail
+  static_assert(!TAIL || (RM >= 2 && TN % 2 == 0), "tail path needs a full block and even TN");
+  const int tg = lane >> 5, ta = (lane >> 2) & 3, tj = lane & 3;
+  const int taoff = ta * KTS + 16 * RF + 4 * tg + tj;
+  const int tboff = kBQ * KTS + col0 + (lane & 31);
+  f32x4 tacc[TH > 0 ? TH : 1];
+#pragma unroll
+  for (int h = 0; h < (TH > 0 ? TH : 1); ++h) tacc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
   for (int s = 0; s < nsteps; ++s) {
     const unsigned bufb = lds_base + (unsigned)((s & 1) * BUF) * 4u;
     const unsigned abase = bufb + (unsigned)aoff * 4u;
     const unsigned bbase = bufb + (unsigned)boff * 4u;
-    float av[2][RM], bv[2][TN];
-    static_for<0, RM>([&](auto rc) { av[0][rc] = lds_read_imm<(16 * rc) * 4>(abase); });
+    const unsigned tabase = bufb + (unsigned)taoff * 4u;
+    const unsigned tbbase = bufb + (unsigned)tboff * 4u;
+    float av[2][RF], bv[2][TN];
+    float tav[2], tbv[2][TH > 0 ? TH : 1][4];
+    static_for<0, RF>([&](auto rc) { av[0][rc] = lds_read_imm<(16 * rc) * 4>(abase); });
     static_for<0, TN>([&](auto tc) { bv[0][tc] = lds_read_imm<(16 * tc) * 4>(bbase); });
+    if constexpr (TAIL) {
+      tav[0] = lds_read_imm<0>(tabase);
+      static_for<0, TH>([&](auto hc) {
+        static_for<0, 4>([&](auto ac) { tbv[0][hc][ac] = lds_read_imm<(32 * hc + ac) * 4>(tbbase); });
+      });
+    }
     if (s + 1 < nsteps) {
       if constexpr (GL) DTX_GLDS_TILE(s + 1, (s + 1) & 1);
       else DTX_LOAD_TILE(s + 1);
@@ -207,19 +229,45 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
     lds_wait_all();
     static_for<0, KS>([&](auto ksc) {
       constexpr int ks = ksc, cur = ks & 1, nxt = cur ^ 1;
-      static_for<0, RM>([&](auto rc) {
+      static_for<0, RF>([&](auto rc) {
         constexpr int r = rc;
 #pragma unroll
         for (int t = 0; t < TN; ++t)
           acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][r], bv[cur][t], acc[r][t], 0, 0, 0);
+        if constexpr (TAIL) {
+          // the four dependent tail MFMAs of each column group are spread over the k-step
+          static_for<0, 4>([&](auto ac) {
+            constexpr int a = ac;
+            if constexpr (r == ((a + 1) * RF + 3) / 4 - 1) {
+              static_for<0, TH>([&](auto hc) {
+                tacc[hc] = __builtin_amdgcn_mfma_f32_4x4x1f32(tav[cur], tbv[cur][hc][a], tacc[hc],
+                                                              3, a, 0);
+              });
+            }
+          });
+        }
         if constexpr (ks + 1 < KS) {
           av[nxt][r] = lds_read_imm<((ks + 1) * 4 * KTS + 16 * r) * 4>(abase);
           // the TN stream fragments ride along with the first row blocks
-          constexpr int TPR = (TN + RM - 1) / RM;
+          constexpr int TPR = (TN + RF - 1) / RF;
           static_for<0, TPR>([&](auto qc) {
             constexpr int t = r * TPR + qc;
             if constexpr (t < TN) bv[nxt][t] = lds_read_imm<(16 * t + (ks + 1) * 4) * 4>(bbase);
           });
+          if constexpr (TAIL) {
+            // 1 + 4*TH tail fragments, spread over the row blocks from the back
+            constexpr int NTF = 1 + 4 * TH;
+            constexpr int FPR = (NTF + RF - 1) / RF;
+            static_for<0, FPR>([&](auto qc) {
+              constexpr int f = (RF - 1 - r) * FPR + qc;
+              if constexpr (f == 0) {
+                tav[nxt] = lds_read_imm<((ks + 1) * 4 * KTS) * 4>(tabase);
+              } else if constexpr (f < NTF) {
+                constexpr int h = (f - 1) / 4, a = (f - 1) % 4;
+                tbv[nxt][h][a] = lds_read_imm<(32 * h + (ks + 1) * 4 + a) * 4>(tbbase);
+              }
+            });
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -231,54 +279,21 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
     }
     __syncthreads();
   }
-#else
-  for (int s = 0; s < nsteps; ++s) {
-    const float* B = lds + (s & 1) * BUF;
-#ifndef DTX_DBG_NOSTAGE
-    if (s + 1 < nsteps) DTX_LOAD_TILE(s + 1);
-#endif
-    // fragment reads run one k-step ahead of the MFMAs that consume them
-    float av[2][RM], bv[2][TN];
-    DTX_LOAD_FRAGS(0, 0);
+
+  if constexpr (TAIL) {
+    // hand the tail rows over in the accumulator layout of a 16x16 block (rows
+    // 8..15 zero) through a wave-private LDS patch, so the epilogues stay generic
+    float* patch = lds + patch_base(RM) + wave * (8 * 16 * TN);
 #pragma unroll
-    for (int ks = 0; ks < kBQ / 4; ++ks) {
-      const int cur = ks & 1;
-#ifdef DTX_DBG_NOFRAG
-      if (ks + 1 < kBQ / 4) {
-        _Pragma("unroll") for (int r = 0; r < RM; ++r) av[cur ^ 1][r] = av[cur][r] + 1.f;
-        _Pragma("unroll") for (int t = 0; t < TN; ++t) bv[cur ^ 1][t] = bv[cur][t] + 1.f;
-      }
-#else
-      if (ks + 1 < kBQ / 4) DTX_LOAD_FRAGS(cur ^ 1, (ks + 1) * 4);
-#endif
-#if DTX_PIPE == 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
+    for (int h = 0; h < TH; ++h)
 #pragma unroll
-      for (int r = 0; r < RM; ++r)
+      for (int e = 0; e < 4; ++e) patch[(4 * tg + e) * (16 * TN) + 32 * h + (lane & 31)] = tacc[h][e];
 #pragma unroll
-        for (int t = 0; t < TN; ++t)
-          acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][r], bv[cur][t], acc[r][t], 0, 0, 0);
-#if DTX_PIPE == 2
-      // interleave: the next k-step's LDS reads are spread between this k-step's MFMAs
-      if (ks + 1 < kBQ / 4) {
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int g = 0; g < (RM + TN + 1) / 2; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, (RM * TN) / ((RM + TN + 1) / 2), 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                // DS read
-        }
-      }
-#elif DTX_PIPE == 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#ifndef DTX_DBG_NOSTAGE
-    if (s + 1 < nsteps) DTX_STORE_TILE((s + 1) & 1);
-    __syncthreads();
-#endif
+      for (int e = 0; e < 4; ++e)
+        acc[RM - 1][t][e] = (kq < 2) ? patch[(4 * kq + e) * (16 * TN) + 16 * t + i] : 0.f;
   }
-#undef DTX_LOAD_FRAGS
-#endif
 #undef DTX_LOAD_TILE
 #undef DTX_GLDS_TILE
 #undef DTX_STORE_X

@@ -21,6 +21,9 @@ using namespace dtx;
 #ifndef DTX_USE_GLDS
 #define DTX_USE_GLDS 1
 #endif
+#ifndef DTX_USE_TAIL
+#define DTX_USE_TAIL 1
+#endif
 
 namespace {
 
@@ -51,7 +54,7 @@ struct DsArgs {
   int Nc, Lp, D, det0, nd, nptiles;
 };
 
-template <int RM, int TN>
+template <int RM, int TN, bool TAIL>
 __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
   constexpr int KT = 16 * RM;
   constexpr int PT = 128 * TN;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // odd RM: LDS row stride == KT == global row stride -> LDS-DMA staging
-  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
+  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS, TAIL>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
                           a.Nc, 0, a.Lp, lds);
 
   // ---------------- epilogue: mean correction, per-detector energy, normalise
@@ -141,32 +144,43 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
 }
 
 template <int RM>
-int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
+int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk, bool tail) {
   constexpr int TN = tn_for(RM);
   constexpr int PT = 128 * TN;
   DsArgs b = a;
   b.nptiles = (int)((a.P + PT - 1) / PT);
   dim3 grid((unsigned)(b.nptiles * nchunk));
-  hipLaunchKernelGGL((ds_mfma_kernel<RM, TN>), grid, dim3(kThreads), 0, ctx->stream, b);
+  if constexpr (RM >= 2) {
+    if (tail) {
+      hipLaunchKernelGGL((ds_mfma_kernel<RM, TN, true>), grid, dim3(kThreads), 0, ctx->stream, b);
+      DTX_HIP(ctx, hipGetLastError());
+      return DTX_OK;
+    }
+  }
+  hipLaunchKernelGGL((ds_mfma_kernel<RM, TN, false>), grid, dim3(kThreads), 0, ctx->stream, b);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }
 
-int launch_tile_rm(dtx_ctx* ctx, int rm, const DsArgs& a, int nchunk) {
+// rows: real rows of the K-tile; the last row block takes the half-cost 4x4 path
+// when it holds at most 8 of them
+int launch_tile_rm(dtx_ctx* ctx, int rm, int rows, const DsArgs& a_, int nchunk) {
+  const bool tail_ = DTX_USE_TAIL && ((rows - 1) % 16) < 8;
+  const DsArgs& a = a_;
   switch (rm) {
-    case 1: return launch_tile<1>(ctx, a, nchunk);
-    case 2: return launch_tile<2>(ctx, a, nchunk);
-    case 3: return launch_tile<3>(ctx, a, nchunk);
-    case 4: return launch_tile<4>(ctx, a, nchunk);
-    case 5: return launch_tile<5>(ctx, a, nchunk);
-    case 6: return launch_tile<6>(ctx, a, nchunk);
-    case 7: return launch_tile<7>(ctx, a, nchunk);
-    case 8: return launch_tile<8>(ctx, a, nchunk);
-    case 9: return launch_tile<9>(ctx, a, nchunk);
-    case 10: return launch_tile<10>(ctx, a, nchunk);
-    case 11: return launch_tile<11>(ctx, a, nchunk);
-    case 12: return launch_tile<12>(ctx, a, nchunk);
-    case 13: return launch_tile<13>(ctx, a, nchunk);
+    case 1: return launch_tile<1>(ctx, a, nchunk, tail_);
+    case 2: return launch_tile<2>(ctx, a, nchunk, tail_);
+    case 3: return launch_tile<3>(ctx, a, nchunk, tail_);
+    case 4: return launch_tile<4>(ctx, a, nchunk, tail_);
+    case 5: return launch_tile<5>(ctx, a, nchunk, tail_);
+    case 6: return launch_tile<6>(ctx, a, nchunk, tail_);
+    case 7: return launch_tile<7>(ctx, a, nchunk, tail_);
+    case 8: return launch_tile<8>(ctx, a, nchunk, tail_);
+    case 9: return launch_tile<9>(ctx, a, nchunk, tail_);
+    case 10: return launch_tile<10>(ctx, a, nchunk, tail_);
+    case 11: return launch_tile<11>(ctx, a, nchunk, tail_);
+    case 12: return launch_tile<12>(ctx, a, nchunk, tail_);
+    case 13: return launch_tile<13>(ctx, a, nchunk, tail_);
   }
   return dtx_fail(ctx, DTX_E_ARG, "bad row-block count %d", rm);
 }
@@ -300,7 +314,7 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
     a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-    if ((rc = launch_tile_rm(ctx, t.rm, a, nchunk))) return rc;
+    if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
