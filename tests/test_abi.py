@@ -69,3 +69,16 @@ def test_sparse_trigger_picker_matches_oracle():
         want = orc.pick_triggers(ds, thr, sr, 0.0) if orc.eval_trig_con(ds.max(), thr) else []
         assert [g[0] for g in got] == [w['index'] for w in want], nm
         assert len(got) == z[key + '_rows'].shape[0], nm
+
+
+def test_header_is_valid_c99(tmp_path):
+    """The boundary header must be consumable from plain C (cgo / JNI / FFI users)."""
+    import subprocess
+    src = tmp_path / 't.c'
+    src.write_text('#include "detex_hip.h"\n'
+                   'int main(void) { uint32_t a, b, c; dtx_cand_unpack(dtx_cand_pack(3, 7, 99), &a, &b, &c);\n'
+                   '  return !(a == 3 && b == 7 && c == 99 && DTX_HIST_BINS == 400); }\n')
+    exe = tmp_path / 't'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic',
+                           '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    assert subprocess.call([str(exe)]) == 0

@@ -1,0 +1,93 @@
+"""Error behaviour of the C ABI on a real device: bad arguments and call-order
+mistakes return an error code with a message (the reference's convention is
+detex.log(level='error') -> raise, detex/__init__.py:131-138); nothing crashes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def raw():
+    from detex_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.dtx_ctx_create(0, None, 1, C.byref(h)) == 0      # own non-blocking stream
+    yield lib, h
+    assert lib.dtx_ctx_destroy(h) == 0
+
+
+def _msg(lib, h):
+    return lib.dtx_last_error(h).decode()
+
+
+def test_call_order_and_arguments(raw):
+    lib, h = raw
+    x = torch.zeros(1000, device='cuda')
+    out = torch.zeros(1000, device='cuda')
+    rc = lib.dtx_subspace_ds(h, C.c_void_p(x.data_ptr()), 1000, 1000, 1, C.c_void_p(out.data_ptr()), 1000)
+    assert rc == -3 and 'no basis' in _msg(lib, h)                # DTX_E_STATE
+    U = np.zeros((3, 30), np.float32)
+    off = np.array([0, 3], np.int32)
+    up = lambda n, Nc, o=off, D=1: lib.dtx_basis_upload(  # noqa: E731
+        h, U.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), D, n, Nc)
+    assert up(30, 4) == -1 and 'multiple of Nc' in _msg(lib, h)
+    assert up(30, 0) == -1
+    assert up(30, 3, np.array([1, 3], np.int32)) == -1 and 'det_off[0]' in _msg(lib, h)
+    assert up(30, 3, np.array([0, 0], np.int32)) == -1
+    assert lib.dtx_basis_upload(h, None, off.ctypes.data_as(C.c_void_p), 1, 30, 3) == -1
+    assert up(30, 3) == 0
+    # block not longer than the template (detect.py:262-266), ldp too small, null pointers
+    rc = lib.dtx_subspace_ds(h, C.c_void_p(x.data_ptr()), 30, 30, 1, C.c_void_p(out.data_ptr()), 1000)
+    assert rc == -1 and 'not longer than the basis' in _msg(lib, h)
+    rc = lib.dtx_subspace_ds(h, C.c_void_p(x.data_ptr()), 300, 300, 1, C.c_void_p(out.data_ptr()), 10)
+    assert rc == -1 and 'ldp' in _msg(lib, h)
+    assert lib.dtx_subspace_ds(h, None, 300, 300, 1, C.c_void_p(out.data_ptr()), 1000) == -1
+    assert lib.dtx_ds_post(h, None, 10, 10, 1, 1, None, None, None, None, None, 0, None) == -1
+    assert lib.dtx_ds_moments(h, C.c_void_p(out.data_ptr()), 10, 10, 1, 1, 1.0, 0.0, 10, None, None) == -1
+    rc = lib.dtx_xcorr_allpairs(h, C.c_void_p(x.data_ptr()), 1, 30, 3, C.c_void_p(out.data_ptr()),
+                                C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr()), 0, 0)
+    assert rc == -1 and 'N >= 2' in _msg(lib, h)
+    rc = lib.dtx_xcorr_allpairs(h, C.c_void_p(x.data_ptr()), 4, 30, 3, C.c_void_p(out.data_ptr()),
+                                C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr()), 0, 7)
+    assert rc == -1 and 'pair range' in _msg(lib, h)
+    ms = C.c_float()
+    assert lib.dtx_last_kernel_ms(h, C.byref(ms)) == -3
+    # a good call still works afterwards, on the context's own stream
+    assert lib.dtx_subspace_ds(h, C.c_void_p(x.data_ptr()), 300, 300, 1, C.c_void_p(out.data_ptr()), 1000) == 0
+    assert lib.dtx_ctx_sync(h) == 0
+    assert lib.dtx_last_kernel_ms(h, C.byref(ms)) == 0 and ms.value >= 0
+    assert lib.dtx_timer_start(h) == 0 and lib.dtx_timer_stop(h, C.byref(ms)) == 0
+
+
+def test_host_entry_points(raw):
+    """dtx_subspace_ds_host / dtx_xcorr_allpairs_host: numpy in, numpy out."""
+    from oracle import detex_oracle as orc
+    lib, h = raw
+    rs = np.random.RandomState(0)
+    Nc, L = 3, 40
+    U = rs.standard_normal((2, Nc * L))
+    U = (U / np.linalg.norm(U, axis=1, keepdims=True)).astype(np.float32)
+    off = np.array([0, 2], np.int32)
+    assert lib.dtx_basis_upload(h, U.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), 1,
+                                Nc * L, Nc) == 0
+    x = rs.standard_normal(Nc * 500).astype(np.float32)
+    P = lib.dtx_num_windows(len(x), Nc * L, Nc)
+    ds = np.empty((1, P), np.float32)
+    assert lib.dtx_subspace_ds_host(h, x.ctypes.data_as(C.c_void_p), len(x),
+                                    ds.ctypes.data_as(C.c_void_p)) == 0
+    assert np.max(np.abs(ds[0] - orc.mpxds_fft(x, U, Nc))) <= 1e-5
+    td = rs.standard_normal((5, Nc * L)).astype(np.float32)
+    cc = np.empty(10, np.float32)
+    lag = np.empty(10, np.int32)
+    ss = np.empty(10, np.float32)
+    assert lib.dtx_xcorr_allpairs_host(h, td.ctypes.data_as(C.c_void_p), 5, Nc * L, Nc,
+                                       cc.ctypes.data_as(C.c_void_p), lag.ctypes.data_as(C.c_void_p),
+                                       ss.ctypes.data_as(C.c_void_p)) == 0
+    rcc, rlag, rss = orc.make_cclags(list(td.astype(np.float64)), Nc)
+    iu = np.triu_indices(5, 1)
+    assert np.max(np.abs(cc - rcc[iu[0], iu[1] - 1])) <= 1e-5
+    assert np.array_equal(lag, rlag[iu[0], iu[1] - 1].astype(np.int32))
