@@ -132,8 +132,15 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     try:
         ctx.upload_basis(U, det_off, Nc)
         data, t0 = fetcher.data[sta]
-        xhost = np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
-        xdev = torch.from_numpy(xhost).to(ctx.device)
+        raw = bool(getattr(fetcher, 'raw', False))
+        if raw:
+            # unfiltered planes stay on the device; each chunk is detrended + band-passed
+            # separately, like the reference's per-chunk _applyFilter (detect.py:231)
+            rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
+            xhost = xdev = None
+        else:
+            xhost = np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
+            xdev = torch.from_numpy(xhost).to(ctx.device)
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
@@ -144,7 +151,15 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         for (i0, i1, stride) in _chunk_batches(bounds):
             s0, cnt = bounds[i0][0], bounds[i0][1]
             M = cnt * Nc
-            ds = ctx.subspace_ds(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc, nchunk=i1 - i0)
+            if raw:
+                planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt]
+                                      for k in range(i0, i1)])
+                mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
+                ds = ctx.subspace_ds(mp)
+                mp_host = mp.cpu().numpy() if estimateMags else None
+            else:
+                ds = ctx.subspace_ds(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc,
+                                     nchunk=i1 - i0)
             res = ctx.ds_post(ds, thr=thr_arr, hist=hist if calcHist else None)
             P = int(ds.shape[2])
             maxds = res['maxds'].cpu().numpy()
@@ -177,7 +192,8 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
                         pem = stm = snr = np.nan
                         if estimateMags:                         # detect.py:422-429
                             c0 = (bounds[i0 + b][0]) * Nc
-                            pem, stm, snr = est_mag(ti, Nc, xhost[c0:c0 + M], ss._bank_mags[name],
+                            mpc = mp_host[b] if raw else xhost[c0:c0 + M]
+                            pem, stm, snr = est_mag(ti, Nc, mpc, ss._bank_mags[name],
                                                     U[det_off[d]:det_off[d + 1]],
                                                     ss._bank_ewf[name], kinds[d] == 'ss')
                         rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),

@@ -63,11 +63,14 @@ class ContinuousFetcher(object):
     the available data.  Defaults 3600 s + 120 s (getdata.py:299)."""
     method = 'memory'
 
-    def __init__(self, sampling_rate, channels, conDatDuration=3600, conBuff=120):
+    def __init__(self, sampling_rate, channels, conDatDuration=3600, conBuff=120, raw=False):
         self.sampling_rate = float(sampling_rate)
         self.channels = list(channels)
         self.conDatDuration = conDatDuration
         self.conBuff = conBuff
+        # raw=True: the arrays are unfiltered; every chunk is detrended and band-passed
+        # on the GPU with the cluster's ``filt`` before the scan (construct.py:1024-1028)
+        self.raw = bool(raw)
         self.data = {}
 
     def add(self, station, data, starttime):

@@ -14,6 +14,18 @@ from . import _lib
 HIST_BINS = 400
 
 
+def bandpass_sos(freqmin, freqmax, df, corners):
+    """Second-order sections of obspy.signal.filter.bandpass (third-party; restated:
+    Butterworth band-pass designed as zpk and converted with zpk2sos)."""
+    from scipy.signal import iirfilter, zpk2sos
+    fe = 0.5 * df
+    low, high = freqmin / fe, freqmax / fe
+    if high - 1.0 > -1e-6 or low > 1:
+        raise ValueError('band-pass corner frequencies must lie below Nyquist')
+    z, p, k = iirfilter(corners, [low, high], btype='band', ftype='butter', output='zpk')
+    return zpk2sos(z, p, k)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -179,6 +191,29 @@ class HipContext(object):
                                          _ptr(ss), int(pair_begin), int(pair_end))
         self._ck(rc, 'dtx_xcorr_allpairs')
         return cc, lag, ss
+
+    # ------------------------------------------------------------ pre-processing
+    def preprocess(self, raw, filt=None, sampling_rate=None, detrend=True, out=None):
+        """Detrend + band-pass + multiplex on the device (construct.py:990-1030).
+
+        raw : [nchunk, Nc, T] float32 CUDA tensor (channels in st.sort() order);
+        filt : [freqmin, freqmax, corners, zerophase] as in the reference, or None.
+        Returns [nchunk, Nc*T] multiplexed float32."""
+        if raw.dtype != torch.float32 or not raw.is_cuda or raw.dim() != 3:
+            raise ValueError('raw must be a [nchunk, Nc, T] float32 CUDA tensor')
+        raw = raw.contiguous()
+        nchunk, Nc, T = (int(s) for s in raw.shape)
+        sos, nsec, zp = None, 0, 0
+        if filt is not None:
+            sos = np.ascontiguousarray(bandpass_sos(filt[0], filt[1], sampling_rate, filt[2]))
+            nsec, zp = len(sos), int(bool(filt[3]))
+        if out is None:
+            out = torch.empty((nchunk, Nc * T), dtype=torch.float32, device=raw.device)
+        rc = self.lib.dtx_preprocess(self.h, _ptr(raw), nchunk, Nc, T, T,
+                                     sos.ctypes.data_as(C.c_void_p) if sos is not None else None,
+                                     nsec, zp, int(bool(detrend)), _ptr(out), int(out.stride(0)))
+        self._ck(rc, 'dtx_preprocess')
+        return out
 
     # ------------------------------------------------------------ timing
     def timer_start(self):

@@ -166,6 +166,26 @@ int dtx_xcorr_allpairs_host(dtx_ctx* ctx, const float* td_host, int N, int n,
                             float* subsamp_host);
 
 /* ------------------------------------------------------------------------
+ * Pre-processing                              (construct.py:990-1030, 928-987)
+ * ------------------------------------------------------------------------ */
+
+/* The numerical part of _applyFilter on the device, in float64: per series
+ * st.detrend('linear') (= scipy.signal.detrend), st.filter('bandpass', ...)
+ * (= sosfilt of the Butterworth band-pass second-order sections, run forward
+ * and, if zerophase, again over the reversed result), then multiplexing
+ * (construct.py:977-978).  The caller designs the filter (host, e.g.
+ * scipy.signal.iirfilter(corners, [lo, hi], btype='band', ftype='butter',
+ * output='sos')) and passes the sections as sos[nsec][6] = b0 b1 b2 a0 a1 a2
+ * (host pointer); nsec = 0 skips the filter.
+ *   raw_dev  [nchunk*Nc] series of T float32 samples, series s at
+ *            raw_dev + s*ser_stride; series s is channel s % Nc of chunk s / Nc
+ *   mp_dev   out: chunk b multiplexed at mp_dev + b*mp_stride, x[Nc*t + c]
+ * Asynchronous. */
+int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc,
+                   int64_t T, int64_t ser_stride, const double* sos, int nsec,
+                   int zerophase, int detrend, float* mp_dev, int64_t mp_stride);
+
+/* ------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py roofline).
  * ------------------------------------------------------------------------ */
 int dtx_timer_start(dtx_ctx* ctx);

@@ -504,3 +504,42 @@ def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
     d1 = np.dot(ConDat, WFU[0])
     d2 = np.dot(WFU[0], WFU[0])
     return mags[0] + d1 / d2, mags[0] + np.log10(np.std(ConDat) / np.std(WFU[0])), SNR
+
+
+# --------------------------------------------------------------------------
+# pre-processing                                   construct.py:990-1030
+# --------------------------------------------------------------------------
+
+def bandpass_sos(freqmin, freqmax, df, corners):
+    """obspy.signal.filter.bandpass design (ObsPy 1.0.2, third-party, absent here;
+    restated from its published algorithm): Butterworth band-pass as zpk ->
+    zpk2sos."""
+    from scipy.signal import iirfilter, zpk2sos
+    fe = 0.5 * df
+    z, p, k = iirfilter(corners, [freqmin / fe, freqmax / fe], btype='band', ftype='butter',
+                        output='zpk')
+    return zpk2sos(z, p, k)
+
+
+def apply_filter(chans, filt, df, detrend=True):
+    """The numerical part of construct.py:1024-1028 on one stream: per channel
+    st.detrend('linear') (ObsPy delegates to scipy.signal.detrend) and
+    st.filter('bandpass', freqmin, freqmax, corners, zerophase) (sosfilt forward
+    and, for zerophase, again over the reversed first pass), float64.
+    PARITY UNPINNED against ObsPy itself (not installable here); pinned against
+    the SciPy routines ObsPy calls."""
+    from scipy.signal import detrend as sp_detrend, sosfilt
+    out = []
+    for c in chans:
+        y = np.asarray(c, dtype=np.float64)
+        if detrend:
+            y = sp_detrend(y, type='linear')
+        if filt is not None:
+            sos = bandpass_sos(filt[0], filt[1], df, filt[2])
+            if filt[3]:
+                first = sosfilt(sos, y)
+                y = sosfilt(sos, first[::-1])[::-1]
+            else:
+                y = sosfilt(sos, y)
+        out.append(y)
+    return out
