@@ -37,6 +37,9 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   const float th = thr ? thr[det] : 0.f;
   const bool do_cand = thr && cand_key && cand_val && ncand;
   int vmax = 0;   // bit pattern; DS >= 0 so integer order == float order, NaN sorts highest
+  // noise windows all fall into the first bins: keep those counts in registers so the
+  // LDS atomics do not serialise on one address
+  unsigned low[4] = {0u, 0u, 0u, 0u};
   const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
   for (int it = 0; it < kPostItems; ++it) {
     const int64_t p = base + (int64_t)it * kPostThreads + tid;
@@ -47,7 +50,10 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
       vmax = max(vmax, bits);
       if (hist) {
         const int b = hist_bin(v);
-        if (b >= 0) atomicAdd(&sh_hist[b], 1u);
+        if (b >= 4) atomicAdd(&sh_hist[b], 1u);
+        else if (b >= 0) {
+          low[0] += (b == 0); low[1] += (b == 1); low[2] += (b == 2); low[3] += (b == 3);
+        }
       }
       if (do_cand && v >= th) {
         const uint32_t slot = atomicAdd(ncand, 1u);
@@ -56,6 +62,15 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
           cand_val[slot] = v;
         }
       }
+    }
+  }
+  if (hist) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned c = low[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+      if ((tid & 63) == 0 && c) atomicAdd(&sh_hist[k], c);
     }
   }
   if (maxds) {

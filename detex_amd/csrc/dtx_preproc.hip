@@ -8,7 +8,7 @@
 // in float64.  Sorting / merging / trimming of ObsPy streams stays on the host.
 //
 // An IIR filter is a linear recurrence along time; it is parallelised by
-// blocks: (1) every block of kPB samples is run from a zero state and its final
+// blocks (memory access coalesced through an LDS tile, see pp_tiled_kernel): (1) every block of kPB samples is run from a zero state and its final
 // state kept, (2) the true state entering each block follows from
 // S_b = M S_{b-1} + f_{b-1} with M the state transition over one block (a tiny
 // sequential pass per series), (3) every block is run again from its true state
@@ -18,7 +18,8 @@
 namespace {
 
 constexpr int kMaxSec = 8;    // biquad sections (bandpass corners <= 8)
-constexpr int kPB = 1024;     // samples per block
+constexpr int kPB = 256;      // samples per block (short blocks: more workgroups in flight)
+constexpr int kTrendSlices = 16;
 
 struct Sos {
   double b0[kMaxSec], b1[kMaxSec], b2[kMaxSec], a1[kMaxSec], a2[kMaxSec];
@@ -36,17 +37,20 @@ __device__ inline double sos_step(const Sos& f, double x, double* z) {
   return x;
 }
 
-// per series: least-squares line a + b t (scipy.signal.detrend type='linear')
+// per series: sums for the least-squares line a + b t (scipy.signal.detrend
+// type='linear'); kTrendSlices workgroups per series add their partial sums of
+// x and x (t - tc) with float64 atomics; trend_of() turns them into (a, b)
 __global__ __launch_bounds__(256) void pp_trend_kernel(const float* __restrict__ raw, int64_t T,
                                                        int64_t ser_stride,
-                                                       double* __restrict__ trend) {
+                                                       double* __restrict__ tsum) {
   __shared__ double sh[8];
-  const int ser = blockIdx.x, tid = threadIdx.x;
+  const int ser = blockIdx.y, tid = threadIdx.x;
   const float* x = raw + (int64_t)ser * ser_stride;
-  // centred abscissa u = t - (T-1)/2 makes the normal equations diagonal
-  const double tc = 0.5 * (double)(T - 1);
+  const double tc = 0.5 * (double)(T - 1);   // centred abscissa: diagonal normal equations
+  const int64_t per = (T + kTrendSlices - 1) / kTrendSlices;
+  const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(t0 + per, T);
   double s0 = 0.0, s1 = 0.0;
-  for (int64_t t = tid; t < T; t += 256) {
+  for (int64_t t = t0 + tid; t < t1; t += 256) {
     const double v = (double)x[t];
     s0 += v;
     s1 += v * ((double)t - tc);
@@ -59,14 +63,17 @@ __global__ __launch_bounds__(256) void pp_trend_kernel(const float* __restrict__
   if ((tid & 63) == 0) { sh[tid >> 6] = s0; sh[4 + (tid >> 6)] = s1; }
   __syncthreads();
   if (tid == 0) {
-    s0 = sh[0] + sh[1] + sh[2] + sh[3];
-    s1 = sh[4] + sh[5] + sh[6] + sh[7];
-    const double n = (double)T;
-    const double suu = n * (n * n - 1.0) / 12.0;          // sum (t - tc)^2
-    const double slope = (T > 1) ? s1 / suu : 0.0;
-    trend[2 * ser] = s0 / n - slope * tc;                 // intercept at t = 0
-    trend[2 * ser + 1] = slope;
+    atomicAdd(&tsum[2 * ser], sh[0] + sh[1] + sh[2] + sh[3]);
+    atomicAdd(&tsum[2 * ser + 1], sh[4] + sh[5] + sh[6] + sh[7]);
   }
+}
+
+// (intercept at t = 0, slope) from the sums
+__device__ inline void trend_of(const double* tsum, int64_t T, double* a, double* b) {
+  const double n = (double)T, tc = 0.5 * (double)(T - 1);
+  const double suu = n * (n * n - 1.0) / 12.0;            // sum (t - tc)^2
+  *b = (T > 1) ? tsum[1] / suu : 0.0;
+  *a = tsum[0] / n - *b * tc;
 }
 
 // input sample i (in filter order) of a series
@@ -74,74 +81,133 @@ template <bool FIRST>
 __device__ inline double pp_input(const float* raw, const double* mid, const double* trend,
                                   int64_t T, int64_t i, bool rev) {
   const int64_t t = rev ? (T - 1 - i) : i;
-  if (FIRST) return (double)raw[t] - (trend ? trend[0] + trend[1] * (double)t : 0.0);
+  if (FIRST) return (double)raw[t] - (trend[0] + trend[1] * (double)t);
   return mid[t];
 }
 
-// pass 1: run every block from a zero state, keep its final state
-template <bool FIRST>
-__global__ __launch_bounds__(256) void pp_block_state_kernel(
+// passes 1 and 3: a workgroup owns 256 consecutive blocks of one series (thread =
+// block).  Samples move through an LDS tile [256 blocks][32 samples]: loaded and
+// stored cooperatively, 32 consecutive samples of a block per 16 lanes (full
+// 128-byte lines of the float32 input / 256 bytes of the float64 intermediate),
+// filtered by the owning thread from LDS.
+//   RUN = false: start from a zero state, keep the final state (pass 1)
+//   RUN = true : start from the true entry state, write the output (pass 3);
+//                LAST selects the multiplexed float32 result x[Nc t + c]
+constexpr int kSub = 32;
+template <bool FIRST, bool RUN, bool LAST>
+__global__ __launch_bounds__(256) void pp_tiled_kernel(
     const float* __restrict__ raw, int64_t ser_stride, const double* __restrict__ mid,
     const double* __restrict__ trend, int64_t T, int nblk, Sos f, bool rev,
-    double* __restrict__ fstate) {
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double* __restrict__ fstate, double* __restrict__ out_mid, float* __restrict__ out_mp, int Nc,
+    int64_t mp_stride) {
+  __shared__ double tile[256][kSub + 1];
+  const int tid = threadIdx.x;
   const int ser = blockIdx.y;
-  if (g >= nblk) return;
+  const int g0 = blockIdx.x * 256;
+  const int g = g0 + tid;
+  const bool valid = g < nblk;
   const float* r = raw ? raw + (int64_t)ser * ser_stride : nullptr;
   const double* m = mid ? mid + (int64_t)ser * T : nullptr;
-  const double* tr = trend ? trend + 2 * ser : nullptr;
+  double trc[2] = {0.0, 0.0};
+  if (FIRST && trend) trend_of(trend + 2 * ser, T, &trc[0], &trc[1]);
+  const double* tr = trc;
+  const int chunk = ser / Nc, c = ser - chunk * Nc;
   double z[2 * kMaxSec];
-  for (int k = 0; k < 2 * f.nsec; ++k) z[k] = 0.0;
-  const int64_t i0 = g * kPB, i1 = min(i0 + (int64_t)kPB, T);
-  for (int64_t i = i0; i < i1; ++i) sos_step(f, pp_input<FIRST>(r, m, tr, T, i, rev), z);
-  double* out = fstate + ((int64_t)ser * nblk + g) * (2 * kMaxSec);
-  for (int k = 0; k < 2 * f.nsec; ++k) out[k] = z[k];
+  double* st = fstate + ((int64_t)ser * nblk + (valid ? g : 0)) * (2 * kMaxSec);
+  for (int k = 0; k < 2 * f.nsec; ++k) z[k] = (RUN && valid) ? st[k] : 0.0;
+
+  for (int jj = 0; jj < kPB; jj += kSub) {
+#pragma unroll 4
+    for (int mm = 0; mm < kSub; ++mm) {
+      const int idx = mm * 256 + tid;
+      const int b = idx / kSub, j = idx - b * kSub;
+      const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
+      tile[b][j] = (g0 + b < nblk && i < T) ? pp_input<FIRST>(r, m, tr, T, i, rev) : 0.0;
+    }
+    __syncthreads();
+    if (valid) {
+      const int64_t i0 = (int64_t)g * kPB + jj;
+#pragma unroll 4
+      for (int j = 0; j < kSub; ++j) {
+        if (i0 + j < T) {
+          const double y = sos_step(f, tile[tid][j], z);
+          if (RUN) tile[tid][j] = y;
+        }
+      }
+    }
+    if (RUN) {
+      __syncthreads();
+#pragma unroll 4
+      for (int mm = 0; mm < kSub; ++mm) {
+        const int idx = mm * 256 + tid;
+        const int b = idx / kSub, j = idx - b * kSub;
+        const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
+        if (g0 + b < nblk && i < T) {
+          const int64_t t = rev ? (T - 1 - i) : i;
+          if (LAST) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)tile[b][j];
+          else out_mid[(int64_t)ser * T + t] = tile[b][j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!RUN && valid)
+    for (int k = 0; k < 2 * f.nsec; ++k) st[k] = z[k];
 }
 
-// pass 2: true entry state of every block, sequential over blocks (one thread per series)
-__global__ void pp_chain_kernel(double* __restrict__ fstate, const double* __restrict__ M, int nblk,
-                                int ns, int nser) {
-  const int ser = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ser >= nser) return;
-  double S[2 * kMaxSec];
-  for (int k = 0; k < ns; ++k) S[k] = 0.0;
-  double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
-  for (int b = 0; b < nblk; ++b) {
-    double fin[2 * kMaxSec], nxt[2 * kMaxSec];
-    for (int k = 0; k < ns; ++k) { fin[k] = fs[b * (2 * kMaxSec) + k]; fs[b * (2 * kMaxSec) + k] = S[k]; }
-    for (int r = 0; r < ns; ++r) {
-      double acc = fin[r];
-      for (int c = 0; c < ns; ++c) acc += M[r * ns + c] * S[c];
-      nxt[r] = acc;
-    }
-    for (int k = 0; k < ns; ++k) S[k] = nxt[k];
+// pass 2: true entry state of every block, S_b = M S_{b-1} + f_{b-1}, by the same
+// three-phase idea one level up.  One wave per series, lane l owns `seg`
+// consecutive blocks: (A) walk them from a zero state (entry states relative to
+// the segment start, in place) and keep the segment's final state; (B) chain the
+// 64 segment states with Mseg = M^seg through shuffles; (C) add the propagated
+// segment entry state h (h <- M h per block) to the relative entry states.
+__device__ inline void matvec(const double* Ms, int ns, const double* v, double* out) {
+  for (int r = 0; r < ns; ++r) {
+    double acc = 0.0;
+    for (int c = 0; c < ns; ++c) acc += Ms[r * ns + c] * v[c];
+    out[r] = acc;
   }
 }
 
-// pass 3: run every block from its true state; write float64 (intermediate) or the
-// multiplexed float32 output x[Nc t + c]
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void pp_block_run_kernel(
-    const float* __restrict__ raw, int64_t ser_stride, const double* __restrict__ mid,
-    const double* __restrict__ trend, int64_t T, int nblk, Sos f, bool rev,
-    const double* __restrict__ fstate, double* __restrict__ out_mid, float* __restrict__ out_mp,
-    int Nc, int64_t mp_stride) {
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int ser = blockIdx.y;
-  if (g >= nblk) return;
-  const float* r = raw ? raw + (int64_t)ser * ser_stride : nullptr;
-  const double* m = mid ? mid + (int64_t)ser * T : nullptr;
-  const double* tr = trend ? trend + 2 * ser : nullptr;
-  double z[2 * kMaxSec];
-  const double* st = fstate + ((int64_t)ser * nblk + g) * (2 * kMaxSec);
-  for (int k = 0; k < 2 * f.nsec; ++k) z[k] = st[k];
-  const int64_t i0 = g * kPB, i1 = min(i0 + (int64_t)kPB, T);
-  const int chunk = ser / Nc, c = ser - chunk * Nc;
-  for (int64_t i = i0; i < i1; ++i) {
-    const double y = sos_step(f, pp_input<FIRST>(r, m, tr, T, i, rev), z);
-    const int64_t t = rev ? (T - 1 - i) : i;
-    if (LAST) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)y;
-    else out_mid[(int64_t)ser * T + t] = y;
+__global__ __launch_bounds__(64) void pp_chain_kernel(double* __restrict__ fstate,
+                                                      const double* __restrict__ M,
+                                                      const double* __restrict__ Mseg, int nblk,
+                                                      int seg, int ns) {
+  __shared__ double Ms[4 * kMaxSec * kMaxSec], Mg[4 * kMaxSec * kMaxSec];
+  const int ser = blockIdx.x, lane = threadIdx.x;
+  for (int k = lane; k < ns * ns; k += 64) { Ms[k] = M[k]; Mg[k] = Mseg[k]; }
+  __syncthreads();
+  double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
+  const int b0 = lane * seg, b1 = min(b0 + seg, nblk);
+  double S[2 * kMaxSec], tmp[2 * kMaxSec];
+  for (int k = 0; k < ns; ++k) S[k] = 0.0;
+  for (int b = b0; b < b1; ++b) {                              // (A)
+    double* p = fs + (int64_t)b * (2 * kMaxSec);
+    matvec(Ms, ns, S, tmp);
+    for (int k = 0; k < ns; ++k) { const double fin = p[k]; p[k] = S[k]; S[k] = tmp[k] + fin; }
+  }
+  // a lane without blocks has S = 0 and must still pass its entry state on: its own
+  // transition is the identity over zero blocks, so only lanes with a full segment apply Mg
+  double G[2 * kMaxSec];                                       // (B) entry state of this segment
+  for (int k = 0; k < ns; ++k) G[k] = 0.0;
+  double carry[2 * kMaxSec];
+  for (int k = 0; k < ns; ++k) carry[k] = 0.0;                 // state leaving segment l-1
+  for (int l = 0; l < 64; ++l) {
+    // carry holds the entry state of segment l (on every lane, kept uniform)
+    if (lane == l)
+      for (int k = 0; k < ns; ++k) G[k] = carry[k];
+    // state leaving segment l = M^(len_l) carry + S_l ; len_l == seg except for the last, whose
+    // exit state nobody needs
+    matvec(Mg, ns, carry, tmp);
+    for (int k = 0; k < ns; ++k) carry[k] = tmp[k] + __shfl(S[k], l, 64);
+  }
+  double h[2 * kMaxSec];                                       // (C)
+  for (int k = 0; k < ns; ++k) h[k] = G[k];
+  for (int b = b0; b < b1; ++b) {
+    double* p = fs + (int64_t)b * (2 * kMaxSec);
+    for (int k = 0; k < ns; ++k) p[k] += h[k];
+    matvec(Ms, ns, h, tmp);
+    for (int k = 0; k < ns; ++k) h[k] = tmp[k];
   }
 }
 
@@ -156,7 +222,11 @@ __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ 
   const float* r = raw + (int64_t)ser * ser_stride;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
     double v = (double)r[t];
-    if (trend) v -= trend[2 * ser] + trend[2 * ser + 1] * (double)t;
+    if (trend) {
+      double a, b;
+      trend_of(trend + 2 * ser, T, &a, &b);
+      v -= a + b * (double)t;
+    }
     out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)v;
   }
 }
@@ -208,7 +278,7 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_tr = carve((size_t)nser * 2 * sizeof(double));
   const size_t o_fs = carve((size_t)nser * nblk * 2 * kMaxSec * sizeof(double));
-  const size_t o_M = carve((size_t)(ns * ns + 1) * sizeof(double));
+  const size_t o_M = carve((size_t)(2 * ns * ns + 2) * sizeof(double));
   const size_t o_mid = carve(zerophase && nsec ? (size_t)nser * T * sizeof(double) : 0);
   int rc;
   if ((rc = dtx_reserve(ctx, ctx->ws_misc3, off))) return rc;
@@ -219,8 +289,9 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   double* mid = (double*)(base + o_mid);
 
   if (detrend) {
-    hipLaunchKernelGGL(pp_trend_kernel, dim3((unsigned)nser), dim3(256), 0, ctx->stream, raw_dev, T,
-                       ser_stride, trend);
+    DTX_HIP(ctx, hipMemsetAsync(trend, 0, (size_t)nser * 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(pp_trend_kernel, dim3(kTrendSlices, (unsigned)nser), dim3(256), 0,
+                       ctx->stream, raw_dev, T, ser_stride, trend);
     DTX_HIP(ctx, hipGetLastError());
   }
   if (nsec == 0) {
@@ -230,34 +301,53 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     DTX_HIP(ctx, hipGetLastError());
     return DTX_OK;
   }
-  DTX_HIP(ctx, hipMemcpyAsync(Mdev, M.data(), (size_t)ns * ns * sizeof(double), hipMemcpyHostToDevice,
-                              ctx->stream));
+  // Mseg = M^seg, seg = blocks per lane in the chain kernel
+  const int seg = (nblk + 63) / 64;
+  {
+    std::vector<double> P((size_t)ns * ns, 0.0), Q((size_t)ns * ns);
+    for (int k = 0; k < ns; ++k) P[(size_t)k * ns + k] = 1.0;
+    for (int e = 0; e < seg; ++e) {
+      for (int r = 0; r < ns; ++r)
+        for (int c = 0; c < ns; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < ns; ++k) acc += M[(size_t)r * ns + k] * P[(size_t)k * ns + c];
+          Q[(size_t)r * ns + c] = acc;
+        }
+      P.swap(Q);
+    }
+    M.insert(M.end(), P.begin(), P.end());
+  }
+  DTX_HIP(ctx, hipMemcpyAsync(Mdev, M.data(), (size_t)2 * ns * ns * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // M is a stack-lifetime host buffer
   dim3 grid((unsigned)((nblk + 255) / 256), (unsigned)nser);
-  dim3 cgrid((unsigned)((nser + 63) / 64));
+  dim3 cgrid((unsigned)nser);
+  const double* nod = nullptr;
+  const float* nof = nullptr;
   // forward pass: raw - trend -> (mid | output)
-  hipLaunchKernelGGL((pp_block_state_kernel<true>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                     ser_stride, (const double*)nullptr, (const double*)trend, T, nblk, f, false, fstate);
+  hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                     ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
+                     (double*)nullptr, (float*)nullptr, Nc, mp_stride);
   hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                     nblk, ns, nser);
+                     (const double*)(Mdev + ns * ns), nblk, seg, ns);
   if (zerophase) {
-    hipLaunchKernelGGL((pp_block_run_kernel<true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, (const double*)nullptr, (const double*)trend, T, nblk, f, false,
-                       (const double*)fstate, mid, (float*)nullptr, Nc, mp_stride);
+    hipLaunchKernelGGL((pp_tiled_kernel<true, true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate, mid,
+                       (float*)nullptr, Nc, mp_stride);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
-    hipLaunchKernelGGL((pp_block_state_kernel<false>), grid, dim3(256), 0, ctx->stream,
-                       (const float*)nullptr, ser_stride, (const double*)mid, (const double*)nullptr,
-                       T, nblk, f, true, fstate);
+    hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
+                       ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
+                       (double*)nullptr, (float*)nullptr, Nc, mp_stride);
     hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                       nblk, ns, nser);
-    hipLaunchKernelGGL((pp_block_run_kernel<false, true>), grid, dim3(256), 0, ctx->stream,
-                       (const float*)nullptr, ser_stride, (const double*)mid, (const double*)nullptr,
-                       T, nblk, f, true, (const double*)fstate, (double*)nullptr, mp_dev, Nc,
-                       mp_stride);
+                       (const double*)(Mdev + ns * ns), nblk, seg, ns);
+    // in place: every thread reads its samples of `mid` into LDS before any store of that tile
+    hipLaunchKernelGGL((pp_tiled_kernel<false, true, true>), grid, dim3(256), 0, ctx->stream, nof,
+                       ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
+                       (double*)nullptr, mp_dev, Nc, mp_stride);
   } else {
-    hipLaunchKernelGGL((pp_block_run_kernel<true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, (const double*)nullptr, (const double*)trend, T, nblk, f, false,
-                       (const double*)fstate, (double*)nullptr, mp_dev, Nc, mp_stride);
+    hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
+                       (double*)nullptr, mp_dev, Nc, mp_stride);
   }
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
