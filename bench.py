@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--sr', type=float, default=100.0)
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
+    ap.add_argument('--engine', default='fp32', choices=['fp32', 'bf16x3'],
+                    help="fp32: exact float32 MFMA; bf16x3: split-bfloat16 MFMA (3 bf16 products "
+                         "per float32 product, float32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-vectors', type=int, default=200,
                     help='basis vectors the CPU baseline sample covers')
@@ -92,6 +95,7 @@ def main():
     D, k = a.detectors, a.basis_per_detector
     K = D * k
     ctx = HipContext(local)
+    ctx.set_engine(a.engine)
 
     # detector basis: built on rank 0, broadcast over RCCL/xGMI (the only collective)
     from detex_amd import parallel

@@ -14,7 +14,7 @@ ABI_VERSION = 1
 # every symbol include/detex_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     'dtx_version', 'dtx_ctx_create', 'dtx_ctx_destroy', 'dtx_ctx_sync',
-    'dtx_ctx_stream', 'dtx_last_error', 'dtx_basis_upload', 'dtx_num_windows',
+    'dtx_ctx_stream', 'dtx_last_error', 'dtx_set_engine', 'dtx_basis_upload', 'dtx_num_windows',
     'dtx_subspace_ds', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms',
@@ -57,6 +57,8 @@ def load():
     lib.dtx_ctx_stream.argtypes = [vp]
     lib.dtx_last_error.restype = C.c_char_p
     lib.dtx_last_error.argtypes = [vp]
+    lib.dtx_set_engine.restype = i32
+    lib.dtx_set_engine.argtypes = [vp, i32]
     lib.dtx_basis_upload.restype = i32
     lib.dtx_basis_upload.argtypes = [vp, vp, vp, i32, i32, i32]
     lib.dtx_num_windows.restype = i64

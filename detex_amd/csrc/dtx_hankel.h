@@ -277,7 +277,9 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
       if constexpr (GL) DTX_STORE_X((s + 1) & 1);
       else DTX_STORE_TILE((s + 1) & 1);
     }
+#ifndef DTX_DBG_NOBARRIER   /* timing-only ablation, results are wrong without it */
     __syncthreads();
+#endif
   }
 
   if constexpr (TAIL) {

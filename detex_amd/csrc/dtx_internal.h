@@ -20,7 +20,8 @@ struct DtxKTile {
   int rows = 0;           // real rows
   int det0 = 0;           // first global detector in this tile
   int nd = 0;             // detectors in this tile
-  float* ut_dev = nullptr;      // [Nc*Lp][KT] transposed basis (rotated, see kernel)
+  float* ut_dev = nullptr;      // [Nc*Lp][KT] transposed, channel-planar basis
+  uint16_t* ut16_dev = nullptr; // split-bf16 image [Nc][Lp/8][2][KT][8]
   float* srow_dev = nullptr;    // [KT] row sums S_k
   int32_t* doff_dev = nullptr;  // [nd+1] detector row offsets local to the tile
 };
@@ -41,7 +42,8 @@ struct dtx_ctx {
   std::vector<DtxKTile> tiles;
 
   // workspaces (grown on demand, never shrunk)
-  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3;
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g;
+  int engine = DTX_ENGINE_FP32;
 
   // timing
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer

@@ -14,6 +14,7 @@
 // registers on the accumulator tile (no LDS round trip, no atomics,
 // deterministic).
 #include "dtx_hankel.h"
+#include "dtx_hankel_bf16.h"
 #include "dtx_internal.h"
 
 using namespace dtx;
@@ -42,6 +43,40 @@ __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x,
   }
 }
 
+// split-bf16 engine: 8 shifted hi / lo bf16 copies of every channel plane,
+// g[b][c][h][m][v] = 16-byte slot holding x_c[8 v + m .. 8 v + m + 7] (0 beyond Tpad)
+__device__ inline unsigned short f32_to_bf16_rne(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__global__ __launch_bounds__(256) void demux16_kernel(const float* __restrict__ xp, int64_t Tpad,
+                                                      int64_t V, i32x4* __restrict__ g) {
+  const int plane = blockIdx.y;                 // b * Nc + c
+  const float* x = xp + (int64_t)plane * Tpad;
+  i32x4* gp = g + (int64_t)plane * 16 * V;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 8 * V;
+       e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / V);
+    const int64_t v = e - (int64_t)m * V;
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t t = 8 * v + m + j;
+      const float val = t < Tpad ? x[t] : 0.f;
+      hi[j] = f32_to_bf16_rne(val);
+      const float hf = __uint_as_float((unsigned)hi[j] << 16);
+      lo[j] = f32_to_bf16_rne(val - hf);
+    }
+    i32x4 H, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      H[j] = (int)((unsigned)hi[2 * j] | ((unsigned)hi[2 * j + 1] << 16));
+      L[j] = (int)((unsigned)lo[2 * j] | ((unsigned)lo[2 * j + 1] << 16));
+    }
+    gp[(int64_t)m * V + v] = H;
+    gp[(int64_t)(8 + m) * V + v] = L;
+  }
+}
+
 struct DsArgs {
   const float* xp;      // [nchunk][Nc][Tpad] channel planes (zero padded)
   const float* ut;      // [Nc*Lp][KT] transposed, channel-planar basis tile
@@ -50,34 +85,23 @@ struct DsArgs {
   const float* mean;    // [nchunk][Ppad]
   const float* den;     // [nchunk][Ppad]  n/(n-1) * sum (w - mu)^2
   float* ds;            // [nchunk][D][ldp]
+  const uint16_t* ut16; // split-bf16 engine: basis image [Nc][Lp/8][2][KT][8]
+  const i32x4* g16;     // split-bf16 engine: shifted stream copies [nchunk][Nc][2][8][V]
+  int64_t V;
   int64_t Tpad, Ppad, ldp, P;
   int Nc, Lp, D, det0, nd, nptiles;
 };
 
-template <int RM, int TN, bool TAIL>
-__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
+// mean correction, per-detector energy (membership MFMA on the accumulator tile),
+// normalisation and store; shared by the float32 and the split-bf16 kernels (same
+// accumulator layout).  `lds` must hold 2*KT + 64 floats and be free.
+template <int RM, int TN>
+__device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& a, int chunk,
+                                            int64_t p0, float* lds) {
   constexpr int KT = 16 * RM;
-  constexpr int PT = 128 * TN;
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
-
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
-  const int chunk = blockIdx.x / a.nptiles;
-  const int pt = blockIdx.x - chunk * a.nptiles;
-  const int64_t p0 = (int64_t)pt * PT;
   const int col0 = wave * 16 * TN;
-
-  f32x4 acc[RM][TN];
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // odd RM: LDS row stride == KT == global row stride -> LDS-DMA staging
-  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS, TAIL>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
-                          a.Nc, 0, a.Lp, lds);
-
-  // ---------------- epilogue: mean correction, per-detector energy, normalise
   float* srow_s = lds;
   int* doff_s = reinterpret_cast<int*>(lds + KT);
   for (int v = tid; v < KT; v += kThreads) srow_s[v] = a.srow[v];
@@ -143,8 +167,62 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
   }
 }
 
+template <int RM, int TN, bool TAIL>
+__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
+  constexpr int KT = 16 * RM;
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
+
+  const int chunk = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - chunk * a.nptiles;
+  const int64_t p0 = (int64_t)pt * PT;
+
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // odd RM: LDS row stride == KT == global row stride -> LDS-DMA staging
+  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS, TAIL>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
+                          a.Nc, 0, a.Lp, lds);
+
+  ds_epilogue<RM, TN>(acc, a, chunk, p0, lds);
+}
+
+// split-bf16 engine (dtx_hankel_bf16.h): same tile, three bf16 MFMAs per product
+template <int RM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel_s(const DsArgs a) {
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes_s(RM)];
+  const int chunk = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - chunk * a.nptiles;
+  const int64_t p0 = (int64_t)pt * PT;
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  hankel_mainloop_bf16x3<RM, TN>(acc, a.ut16, a.Lp, a.g16 + (int64_t)chunk * a.Nc * 16 * a.V, a.V,
+                                 p0 / 8, a.Nc, lds);
+  ds_epilogue<RM, TN>(acc, a, chunk, p0, reinterpret_cast<float*>(lds));
+}
+
+template <int RM>
+int launch_tile_s(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
+  constexpr int TN = tn_s(RM);
+  constexpr int PT = 128 * TN;
+  DsArgs b = a;
+  b.nptiles = (int)((a.P + PT - 1) / PT);
+  dim3 grid((unsigned)(b.nptiles * nchunk));
+  hipLaunchKernelGGL((ds_mfma_kernel_s<RM, TN>), grid, dim3(kThreads), 0, ctx->stream, b);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
 template <int RM>
 int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk, bool tail) {
+  if (a.ut16) return launch_tile_s<RM>(ctx, a, nchunk);
   constexpr int TN = tn_for(RM);
   constexpr int PT = 128 * TN;
   DsArgs b = a;
@@ -183,6 +261,20 @@ int launch_tile_rm(dtx_ctx* ctx, int rm, int rows, const DsArgs& a_, int nchunk)
     case 13: return launch_tile<13>(ctx, a, nchunk, tail_);
   }
   return dtx_fail(ctx, DTX_E_ARG, "bad row-block count %d", rm);
+}
+
+// round-to-nearest-even float32 -> bfloat16 on the host (NaN stays NaN)
+uint16_t host_bf16(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float host_bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float v;
+  std::memcpy(&v, &u, 4);
+  return v;
 }
 
 }  // namespace
@@ -249,11 +341,26 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
         }
       srow[k] = (float)s;
     }
+    // split-bf16 image [c][qb][h][KT][8]: hi = bf16(v), lo = bf16(v - hi)
+    std::vector<uint16_t> ut16((size_t)Nc * (Lp / 8) * 2 * KT * 8, 0);
+    for (int c = 0; c < Nc; ++c)
+      for (int j = 0; j < L; ++j)
+        for (int k = 0; k < t.rows; ++k) {
+          const float v = ut[((size_t)c * Lp + j) * KT + k];
+          const uint16_t hi = host_bf16(v);
+          const uint16_t lo = host_bf16(v - host_bf16_to_f32(hi));
+          const size_t qb = (size_t)c * (Lp / 8) + j / 8;
+          ut16[((qb * 2 + 0) * KT + k) * 8 + j % 8] = hi;
+          ut16[((qb * 2 + 1) * KT + k) * 8 + j % 8] = lo;
+        }
+    DTX_HIP(ctx, hipMalloc(&t.ut16_dev, ut16.size() * sizeof(uint16_t)));
     DTX_HIP(ctx, hipMalloc(&t.ut_dev, ut.size() * sizeof(float)));
     DTX_HIP(ctx, hipMalloc(&t.srow_dev, srow.size() * sizeof(float)));
     DTX_HIP(ctx, hipMalloc(&t.doff_dev, doff.size() * sizeof(int32_t)));
     ctx->tiles.push_back(t);  // pushed first so a failed copy still gets freed
     DTX_HIP(ctx, hipMemcpy(t.ut_dev, ut.data(), ut.size() * sizeof(float), hipMemcpyHostToDevice));
+    DTX_HIP(ctx, hipMemcpy(t.ut16_dev, ut16.data(), ut16.size() * sizeof(uint16_t),
+                           hipMemcpyHostToDevice));
     DTX_HIP(ctx, hipMemcpy(t.srow_dev, srow.data(), srow.size() * sizeof(float),
                            hipMemcpyHostToDevice));
     DTX_HIP(ctx, hipMemcpy(t.doff_dev, doff.data(), doff.size() * sizeof(int32_t),
@@ -307,9 +414,20 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     DTX_HIP(ctx, hipGetLastError());
   }
 
+  i32x4* g16 = nullptr;
+  const int64_t V = Tpad / 8;
+  if (ctx->engine == DTX_ENGINE_BF16X3) {
+    if ((rc = dtx_reserve(ctx, ctx->ws_g, (size_t)nchunk * Nc * 16 * V * sizeof(i32x4)))) return rc;
+    g16 = (i32x4*)ctx->ws_g.p;
+    dim3 grid((unsigned)std::min<int64_t>((8 * V + 255) / 256, 8192), (unsigned)(nchunk * Nc));
+    hipLaunchKernelGGL(demux16_kernel, grid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad, V, g16);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   for (const DtxKTile& t : ctx->tiles) {
     DsArgs a;
+    a.ut16 = g16 ? t.ut16_dev : nullptr; a.g16 = g16; a.V = V;
     a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
@@ -318,6 +436,14 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
+  return DTX_OK;
+}
+
+int dtx_set_engine(dtx_ctx* ctx, int engine) {
+  if (!ctx) return DTX_E_ARG;
+  if (engine != DTX_ENGINE_FP32 && engine != DTX_ENGINE_BF16X3)
+    return dtx_fail(ctx, DTX_E_ARG, "unknown engine %d", engine);
+  ctx->engine = engine;
   return DTX_OK;
 }
 

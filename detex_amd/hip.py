@@ -5,6 +5,7 @@ plumbing only; all arithmetic happens in the hand-written HIP kernels of
 libdetexhip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -47,6 +48,11 @@ class HipContext(object):
         _lib.check(self.lib, None, rc, 'dtx_ctx_create')
         self.h = h
         self.D = self.n = self.Nc = 0
+        self.engine = 'fp32'
+        # DETEX_AMD_ENGINE=fp32|bf16x3 selects the arithmetic engine of new contexts
+        env = os.environ.get('DETEX_AMD_ENGINE')
+        if env:
+            self.set_engine(env)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -61,6 +67,13 @@ class HipContext(object):
 
     def _ck(self, rc, what):
         _lib.check(self.lib, self.h, rc, what)
+
+    def set_engine(self, engine):
+        """'fp32' (exact float32 MFMA, default) or 'bf16x3' (split-bfloat16 MFMA,
+        float32-level accuracy, several times faster)."""
+        code = {'fp32': 0, 'bf16x3': 1}[engine]
+        self._ck(self.lib.dtx_set_engine(self.h, code), 'dtx_set_engine')
+        self.engine = engine
 
     def sync(self):
         self._ck(self.lib.dtx_ctx_sync(self.h), 'dtx_ctx_sync')

@@ -1,0 +1,123 @@
+"""The split-bf16 engine (DTX_ENGINE_BF16X3: a*b ~ ahi*bhi + ahi*blo + alo*bhi on
+bf16 MFMAs, float32 accumulate) against the golden vectors and the oracle at the
+same 1e-5 tolerance as the float32 engine, plus a wide-dynamic-range case that
+shows its error is local to a window."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import detex_oracle as orc  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from detex_amd.hip import HipContext
+    c = HipContext(0)
+    c.set_engine('bf16x3')
+    yield c
+    c.close()
+
+
+def _gpu_ds(ctx, x, U, off, Nc):
+    ctx.upload_basis(np.asarray(U, dtype=np.float32), off, Nc)
+    ds = ctx.subspace_ds(torch.from_numpy(np.asarray(x, dtype=np.float32)).cuda())
+    ctx.sync()
+    return ds[0].cpu().numpy()
+
+
+def test_golden_mpxds(ctx):
+    z = np.load(os.path.join(G, 'mpxds.npz'))
+    for nm in z['names']:
+        key = nm.split(':')[0]
+        x, U, Nc = z[key + '_x'], z[key + '_U'], int(z[key + '_Nc'])
+        ref = z[key + '_ds']
+        got = _gpu_ds(ctx, x, U, [0, U.shape[0]], Nc)[0]
+        win = np.lib.stride_tricks.sliding_window_view(np.asarray(x, dtype=np.float64), U.shape[1])[::Nc]
+        live = win.std(axis=1) > 1e-9
+        tol = 3e-5 if x.dtype == np.float32 else 1e-5
+        assert np.max(np.abs(got[live] - ref[live])) <= tol, nm
+        assert np.all(np.isfinite(got)), nm
+
+
+@pytest.mark.parametrize('Nc,L,ks', [
+    (3, 100, [8]), (3, 100, [1] * 5), (1, 128, [16]), (3, 64, [7, 9, 16, 1]), (3, 100, [8] * 25),
+    (6, 50, [64]), (2, 90, [3] * 30), (3, 33, [40, 60, 108]), (3, 47, [1] * 230), (1, 31, [5, 11]),
+])
+def test_ds_vs_oracle_shapes(ctx, Nc, L, ks):
+    rs = np.random.RandomState(sum(ks) + L)
+    n, K = Nc * L, sum(ks)
+    U = rs.standard_normal((K, n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    U[::3] += 0.02
+    off = np.concatenate([[0], np.cumsum(ks)])
+    T = 1500
+    x = rs.standard_normal(Nc * T) + 0.3
+    x[Nc * 400: Nc * 400 + n] += 5 * U[off[1] - 1] * np.sqrt(n)
+    got = _gpu_ds(ctx, x, U, off, Nc)
+    Uf = U.astype(np.float32).astype(np.float64)
+    xf = x.astype(np.float32).astype(np.float64)
+    for d in range(len(ks)):
+        ref = orc.mpxds_fft(xf, Uf[off[d]:off[d + 1]], Nc)
+        assert np.max(np.abs(got[d] - ref)) <= 1e-5, (d, ks[d])
+
+
+def test_dynamic_range_is_local(ctx):
+    """A 10^4 x amplitude burst does not degrade windows that do not contain it."""
+    rs = np.random.RandomState(4)
+    Nc, L, K, T = 3, 300, 8, 9000
+    n = Nc * L
+    A = rs.standard_normal((n, K))
+    A -= A.mean(axis=0)
+    U = np.linalg.qr(A)[0].T
+    x = rs.standard_normal(Nc * T)
+    x[Nc * 4000: Nc * 4200] *= 1e4
+    x[Nc * 1000: Nc * 1000 + n] += 4 * (rs.standard_normal(K) @ U) * np.sqrt(n) / 3
+    got = _gpu_ds(ctx, x, U, [0, K], Nc)[0]
+    ref = orc.mpxds_fft(x.astype(np.float32).astype(np.float64),
+                        U.astype(np.float32).astype(np.float64), Nc)
+    assert np.max(np.abs(got - ref)) <= 1e-5
+    assert abs(int(np.argmax(got[:3000])) - 1000) == 0
+
+
+def test_engines_agree_fullsize(ctx):
+    """configs[1] shape, one chunk: the two engines agree to 2e-6 and pick the
+    same candidates."""
+    from detex_amd import synth
+    from detex_amd.hip import HipContext
+    Nc, L, D, k, T = 3, 3000, 25, 8, 372000
+    n = Nc * L
+    U, off = synth.detector_bank(5, D, k, n)
+    x, plants = synth.continuous_day(9, 1, Nc * T, Nc, U, off, nplant=6)
+    xt = torch.from_numpy(x).cuda()
+    ctx.upload_basis(U, off, Nc)
+    ds_s = ctx.subspace_ds(xt)
+    c32 = HipContext(0)
+    c32.upload_basis(U, off, Nc)
+    ds_f = c32.subspace_ds(xt)
+    ctx.sync()
+    assert float((ds_s - ds_f).abs().max()) <= 5e-6
+    # spot checks of the split engine against the float64 closed form
+    dsh = ds_s.cpu().numpy()
+    rs = np.random.RandomState(1)
+    P = dsh.shape[2]
+    pts = [(b, p, d) for (b, p, d) in plants] + [(0, int(rs.randint(P)), int(rs.randint(D)))
+                                                  for _ in range(10)]
+    worst = 0.0
+    for (b, p, d) in pts:
+        w = x[b, p * Nc: p * Nc + n].astype(np.float64)
+        mu = w.mean()
+        Ud = U[off[d]:off[d + 1]].astype(np.float64)
+        ref = np.sum((Ud @ w - Ud.sum(axis=1) * mu) ** 2) / (n / (n - 1.0) * np.sum((w - mu) ** 2))
+        worst = max(worst, abs(dsh[b, d, p] - ref))
+    assert worst <= 5e-6, worst
+    thr = np.full(D, 0.3, np.float32)
+    a, b = ctx.ds_post(ds_s, thr=thr), c32.ds_post(ds_f, thr=thr)
+    assert np.array_equal(a['cand'][2], b['cand'][2]) and len(a['cand'][2]) >= 6
+    assert int((a['hist'] - b['hist']).abs().sum()) <= 40     # bin-edge flips only
+    c32.close()
