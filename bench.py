@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1 sparse figure)
 
 
 def parse():
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument('--sr', type=float, default=100.0)
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
-    ap.add_argument('--engine', default='fp32', choices=['fp32', 'bf16x3'],
+    ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="fp32: exact float32 MFMA; bf16x3: split-bfloat16 MFMA (3 bf16 products "
                          "per float32 product, float32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -153,7 +154,12 @@ def main():
 
     flops = 2.0 * K * n * P * a.chunks
     rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
-    kname = 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8))
+    if a.engine == 'fp32':
+        kname = 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8))
+        peak, pmc = PEAK_FP32_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel.json'
+    else:
+        kname = 'ds_mfma_kernel_s<%d,%d>' % (rm, 2 if rm >= 9 else 4)
+        peak, pmc = PEAK_BF16_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel_s.json'
     # HBM-side bytes per launch of the dominant kernel: PMC counters collected by
     # scripts/profile.sh (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) for this
     # exact configuration, committed under profiles/; None for any other configuration
@@ -162,7 +168,7 @@ def main():
         (25, 8, 24, 3, 100.0, 3720.0, 30.0)
     if default_cfg:
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_pmc_ds_mfma_kernel.json')))
+        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pmc)))
         if pm:
             with open(pm[-1]) as f:
                 traffic = json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
@@ -171,17 +177,33 @@ def main():
         'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)',
         'value': value, 'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if a.engine == 'fp32' else 'bf16x3 (f32 operands split in 2 bf16, f32 accumulate)',
+        'data': 'synthetic',
         'config': {'workload': '%s%d basis vectors (%d detectors x %d) x %d chunks of '
                                '%g s, %d-ch %g Hz, n=%d, one station-day per GPU'
                                % ('configs[1]: ' if default_cfg else 'custom: ', K, D, k, a.chunks,
                                   a.chunk_seconds, Nc, a.sr, n),
                    'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
         'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
-                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                     'kernel_ms': kms, 'flop_per_launch': flops},
+                     'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                     'kernel_ms': kms, 'flop_per_launch': flops, 'engine': a.engine,
+                     'note': ('algorithmic flop = 2*K*n per window; the split engine issues 3 bf16 '
+                              'MFMAs per float32 product, so its ceiling is peak/3')
+                     if a.engine != 'fp32' else 'algorithmic flop = 2*K*n per window'},
     }
+    if rank == 0 and world == 1 and a.engine != 'fp32' and default_cfg:
+        ctx.set_engine('fp32')                  # the float32-MFMA engine on the same input
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        k32 = ctx.last_kernel_ms()
+        out['fp32_engine'] = {'value': a.chunks * P / dt32, 'unit': 'windows/s', 'kernel_ms': k32,
+                              'frac_of_fp32_mfma_peak': flops / (k32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        ctx.set_engine(a.engine)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
     else:

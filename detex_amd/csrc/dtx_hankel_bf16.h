@@ -35,7 +35,8 @@ namespace dtx {
 
 // column tiles per wave in this engine (B fragments are 4 VGPRs each, so fewer than fp32)
 __host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? 2 : 4; }
-__host__ __device__ constexpr int xs_for(int tn) { return (128 * tn + kBQ) / 8 + 2; }  // slots per copy
+// slots per shifted copy in LDS: NS + 4 == 12 (mod 16) makes the B reads conflict-free
+__host__ __device__ constexpr int xs_for(int tn) { return (128 * tn + kBQ) / 8 + 4; }
 // bytes of LDS one block needs (two buffers of A tile + x image)
 __host__ __device__ constexpr int lds_bytes_s(int rm) {
   const int loop = 2 * (256 * 16 * rm + 2 * 8 * xs_for(tn_s(rm)) * 16);

@@ -43,7 +43,7 @@ struct dtx_ctx {
 
   // workspaces (grown on demand, never shrunk)
   DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g;
-  int engine = DTX_ENGINE_FP32;
+  int engine = DTX_ENGINE_BF16X3;
 
   // timing
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer

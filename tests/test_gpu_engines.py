@@ -1,7 +1,8 @@
-"""The split-bf16 engine (DTX_ENGINE_BF16X3: a*b ~ ahi*bhi + ahi*blo + alo*bhi on
-bf16 MFMAs, float32 accumulate) against the golden vectors and the oracle at the
-same 1e-5 tolerance as the float32 engine, plus a wide-dynamic-range case that
-shows its error is local to a window."""
+"""Both arithmetic engines of the detection statistic against the golden vectors
+and the oracle at the same 1e-5 tolerance: the default split-bf16 engine
+(DTX_ENGINE_BF16X3: a*b ~ ahi*bhi + ahi*blo + alo*bhi on bf16 MFMAs, float32
+accumulate) and the float32-MFMA engine; plus a wide-dynamic-range case that
+shows the split engine's error is local to a window."""
 import os
 
 import numpy as np
@@ -15,11 +16,12 @@ from oracle import detex_oracle as orc  # noqa: E402
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module')
-def ctx():
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32'])
+def ctx(request):
     from detex_amd.hip import HipContext
     c = HipContext(0)
-    c.set_engine('bf16x3')
+    c.set_engine(request.param)
+    assert c.engine == request.param
     yield c
     c.close()
 
@@ -98,6 +100,7 @@ def test_engines_agree_fullsize(ctx):
     ctx.upload_basis(U, off, Nc)
     ds_s = ctx.subspace_ds(xt)
     c32 = HipContext(0)
+    c32.set_engine('fp32' if ctx.engine == 'bf16x3' else 'bf16x3')
     c32.upload_basis(U, off, Nc)
     ds_f = c32.subspace_ds(xt)
     ctx.sync()
