@@ -63,7 +63,8 @@ template <int RM, int TN>
 __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
                                                        const uint16_t* __restrict__ at16, int Lp,
                                                        const i32x4* __restrict__ g16, int64_t V,
-                                                       int64_t v0, int Nc, char* lds) {
+                                                       int64_t v0, int Nc, int jlo, int jhi,
+                                                       char* lds) {
   constexpr int KT = 16 * RM;
   constexpr int PT = 128 * TN;
   constexpr int NS = (PT + kBQ) / 8;               // x slots per copy per step
@@ -79,8 +80,9 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kg = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int col0 = wave * 16 * TN;
-  const int spc = Lp / kBQ;
+  const int spc = (jhi - jlo) / kBQ;               // steps per channel, [jlo, jhi) in 64s
   const int nsteps = Nc * spc;
+  if (nsteps <= 0) return;
   const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
 
   // x-image staging coordinates of this thread
@@ -99,7 +101,7 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
 #define DTX_S_STAGE(s_, buf_)                                                               \
   do {                                                                                      \
     const int c_ = (s_) / spc;                                                              \
-    const int j0_ = ((s_) - c_ * spc) * kBQ;                                                \
+    const int j0_ = jlo + ((s_) - c_ * spc) * kBQ;                                          \
     const char* ab_ = reinterpret_cast<const char*>(at16) +                                 \
                       ((int64_t)c_ * (Lp / 8) + j0_ / 8) * (2 * KT * 16) + lane * 16;        \
     char* ld_ = lds + (buf_) * BUF;                                                         \

@@ -77,6 +77,19 @@ __global__ __launch_bounds__(256) void demux16_kernel(const float* __restrict__ 
   }
 }
 
+}  // namespace
+
+// shared with dtx_xcorr.hip: build the shifted bf16 copies of `nplanes` channel planes
+int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16) {
+  const int64_t V = Tpad / 8;
+  dim3 grid((unsigned)std::min<int64_t>((8 * V + 255) / 256, 8192), (unsigned)nplanes);
+  hipLaunchKernelGGL(demux16_kernel, grid, dim3(256), 0, ctx->stream, xp, Tpad, V, (i32x4*)g16);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+namespace {
+
 struct DsArgs {
   const float* xp;      // [nchunk][Nc][Tpad] channel planes (zero padded)
   const float* ut;      // [Nc*Lp][KT] transposed, channel-planar basis tile
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel_s(const DsArgs a) 
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   hankel_mainloop_bf16x3<RM, TN>(acc, a.ut16, a.Lp, a.g16 + (int64_t)chunk * a.Nc * 16 * a.V, a.V,
-                                 p0 / 8, a.Nc, lds);
+                                 p0 / 8, a.Nc, 0, a.Lp, lds);
   ds_epilogue<RM, TN>(acc, a, chunk, p0, reinterpret_cast<float*>(lds));
 }
 
@@ -419,9 +432,7 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
   if (ctx->engine == DTX_ENGINE_BF16X3) {
     if ((rc = dtx_reserve(ctx, ctx->ws_g, (size_t)nchunk * Nc * 16 * V * sizeof(i32x4)))) return rc;
     g16 = (i32x4*)ctx->ws_g.p;
-    dim3 grid((unsigned)std::min<int64_t>((8 * V + 255) / 256, 8192), (unsigned)(nchunk * Nc));
-    hipLaunchKernelGGL(demux16_kernel, grid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad, V, g16);
-    DTX_HIP(ctx, hipGetLastError());
+    if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
   }
 
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));

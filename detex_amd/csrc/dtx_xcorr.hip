@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "dtx_hankel.h"
+#include "dtx_hankel_bf16.h"
 #include "dtx_internal.h"
 
 using namespace dtx;
@@ -49,6 +50,29 @@ __global__ __launch_bounds__(256) void xc_transpose_kernel(const float* __restri
       float v = 0.f;
       if (e < N && t < L) v = td[(int64_t)e * n + (int64_t)t * Nc + ch];
       xt[((int64_t)kt * rows + q) * kKtMax + k] = v;
+    }
+  }
+}
+
+// split-bf16 image of the event tiles: XT16[kt][ch][Lp/8][h][208][8] (dtx_hankel_bf16.h)
+__global__ __launch_bounds__(256) void xc_transpose16_kernel(const float* __restrict__ td, int N,
+                                                             int n, int Nc, int L, int Lp,
+                                                             uint16_t* __restrict__ xt16) {
+  const int kt = blockIdx.z;
+  const int64_t nqb = (int64_t)Nc * (Lp / 8);
+  for (int64_t qb = blockIdx.x; qb < nqb; qb += gridDim.x) {
+    const int ch = (int)(qb / (Lp / 8)), j8 = (int)(qb - (int64_t)ch * (Lp / 8)) * 8;
+    for (int v = threadIdx.x; v < kKtMax * 8; v += 256) {
+      const int k = v >> 3, j = v & 7;
+      const int e = kt * kKtMax + k, t = j8 + j;
+      float val = 0.f;
+      if (e < N && t < L) val = td[(int64_t)e * n + (int64_t)t * Nc + ch];
+      const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)val);
+      const float hf = __uint_as_float((unsigned)hi << 16);
+      const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(val - hf));
+      uint16_t* base = xt16 + (((int64_t)kt * nqb + qb) * 2) * kKtMax * 8;
+      base[(int64_t)k * 8 + j] = hi;
+      base[(int64_t)kKtMax * 8 + (int64_t)k * 8 + j] = lo;
     }
   }
 }
@@ -111,41 +135,20 @@ struct XcArgs {
   const float* rsw;     // [N][Ppad] 1/sqrt(ssd) of that window, 0 if zero variance
   unsigned long long* keys;  // [npairs] (orderable cc << 32) | ~p
   const int2* items;    // (c, kt) work items of this launch
+  const uint16_t* xt16; // split-bf16 engine: event tiles
+  const i32x4* g16;     // split-bf16 engine: shifted copies of z, [N][Nc][2][8][V]
+  int64_t V;
   int64_t Tz, Ppad, pair_begin, pair_end;
   int N, Nc, L, Lp, S, Pz, nptiles;
 };
 
+// normalise, scrub, max / first argmax over lags; shared by both engines
 template <int RM, int TN>
-__global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
-  constexpr int PT = 128 * TN;
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
-
+__device__ __forceinline__ void xc_epilogue(f32x4 (&acc)[RM][TN], const XcArgs& a, int c, int kt,
+                                            int p0) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
-  const int item = blockIdx.x / a.nptiles;
-  const int pt = blockIdx.x - item * a.nptiles;
-  const int2 it = a.items[item];
-  const int c = it.x, kt = it.y;
-  const int p0 = pt * PT;
   const int col0 = wave * 16 * TN;
-
-  // contraction range with a non-padding z window: S <= p + t < S + L
-  int jlo = a.S - p0 - PT + 1;
-  jlo = jlo > 0 ? (jlo / kBQ) * kBQ : 0;
-  int jhi = a.S + a.L - p0;
-  jhi = min(a.Lp, ((jhi + kBQ - 1) / kBQ) * kBQ);
-
-  f32x4 acc[RM][TN];
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // RM == 13: the 208-wide event tile is copied whole -> LDS-DMA staging
-  hankel_mainloop<RM, TN, RM == kRmMax && DTX_USE_GLDS>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
-                          a.z + (int64_t)c * a.Nc * a.Tz + p0, a.Tz, a.Nc, jlo, jhi, lds);
-
-  // ---------------- epilogue: normalise, scrub, max / first argmax over lags
   float mu[TN], rw[TN];
   const int pcol = p0 + col0 + i;
 #pragma unroll
@@ -188,6 +191,62 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
       }
     }
   }
+}
+
+template <int RM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
+
+  const int item = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - item * a.nptiles;
+  const int2 it = a.items[item];
+  const int c = it.x, kt = it.y;
+  const int p0 = pt * PT;
+
+  // contraction range with a non-padding z window: S <= p + t < S + L
+  int jlo = a.S - p0 - PT + 1;
+  jlo = jlo > 0 ? (jlo / kBQ) * kBQ : 0;
+  int jhi = a.S + a.L - p0;
+  jhi = min(a.Lp, ((jhi + kBQ - 1) / kBQ) * kBQ);
+
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // RM == 13: the 208-wide event tile is copied whole -> LDS-DMA staging
+  hankel_mainloop<RM, TN, RM == kRmMax && DTX_USE_GLDS>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
+                          a.z + (int64_t)c * a.Nc * a.Tz + p0, a.Tz, a.Nc, jlo, jhi, lds);
+
+  xc_epilogue<RM, TN>(acc, a, c, kt, p0);
+}
+
+template <int RM, int TN>
+__global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) {
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes_s(RM)];
+  const int item = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - item * a.nptiles;
+  const int2 it = a.items[item];
+  const int c = it.x, kt = it.y;
+  const int p0 = pt * PT;
+  int jlo = a.S - p0 - PT + 1;
+  jlo = jlo > 0 ? (jlo / kBQ) * kBQ : 0;
+  int jhi = a.S + a.L - p0;
+  jhi = min(a.Lp, ((jhi + kBQ - 1) / kBQ) * kBQ);
+  f32x4 acc[RM][TN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the tile image always has 208 rows per slot-row; RM < 13 cannot use it (row stride), so the
+  // split engine serves the full 208-event tiles and the float32 engine the remainder tiles
+  hankel_mainloop_bf16x3<RM, TN>(
+      acc, a.xt16 + (int64_t)kt * a.Nc * (a.Lp / 8) * 2 * kKtMax * 8, a.Lp,
+      a.g16 + (int64_t)c * a.Nc * 16 * a.V, a.V, p0 / 8, a.Nc, jlo, jhi, lds);
+  xc_epilogue<RM, TN>(acc, a, c, kt, p0);
 }
 
 // One wave per pair: float64 re-evaluation of the winning lag and its two
@@ -266,6 +325,25 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
 
 template <int RM>
 int launch_items(dtx_ctx* ctx, XcArgs a, const int2* items_dev, int nitems) {
+  if constexpr (RM == kRmMax) {
+    if (a.xt16) {                       // split-bf16 engine for the full 208-event tiles
+      constexpr int TNs = tn_s(RM);
+      constexpr int PTs = 128 * TNs;
+      a.items = items_dev;
+      a.nptiles = (a.Pz + PTs - 1) / PTs;
+      const int64_t nblk = (int64_t)a.nptiles * nitems;
+      const int64_t per = ((int64_t)1 << 20) / a.nptiles * a.nptiles;
+      for (int64_t off = 0; off < nblk; off += per) {
+        XcArgs b = a;
+        b.items = items_dev + off / a.nptiles;
+        const int64_t cnt = std::min(per, nblk - off);
+        hipLaunchKernelGGL((xc_mfma_kernel_s<RM, TNs>), dim3((unsigned)cnt), dim3(kThreads), 0,
+                           ctx->stream, b);
+        DTX_HIP(ctx, hipGetLastError());
+      }
+      return DTX_OK;
+    }
+  }
   constexpr int TN = tn_for(RM);
   constexpr int PT = 128 * TN;
   a.items = items_dev;
@@ -365,6 +443,10 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const size_t o_fs = carve((size_t)N * sizeof(float));
   const size_t o_fr = carve((size_t)N * sizeof(float));
   const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
+  const bool split = ctx->engine == DTX_ENGINE_BF16X3;
+  const int64_t Vz = Tz / 8;
+  const size_t o_xt16 = carve(split ? (size_t)nkt * Nc * (Lp / 8) * 2 * kKtMax * 8 * sizeof(uint16_t) : 0);
+  const size_t o_g = carve(split ? (size_t)N * Nc * 16 * Vz * sizeof(i32x4) : 0);
   int rc;
   if ((rc = dtx_reserve(ctx, ctx->ws_misc, off))) return rc;
   char* base = (char*)ctx->ws_misc.p;
@@ -378,6 +460,8 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   float* fsum = (float*)(base + o_fs);
   float* frs = (float*)(base + o_fr);
   unsigned long long* keys = (unsigned long long*)(base + o_keys);
+  uint16_t* xt16 = (uint16_t*)(base + o_xt16);
+  i32x4* g16 = (i32x4*)(base + o_g);
 
   // ---- work items: (c, kt) for every column c and row tile kt that holds a pair in range
   const int64_t b_begin = row_of_index(N, pair_begin);
@@ -389,7 +473,10 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
       const int64_t lo = std::max<int64_t>(r0, b_begin);
       const int64_t hi = std::min<int64_t>({r0 + kKtMax - 1, (int64_t)c - 1, b_end});
       if (lo > hi) continue;
-      const int rm = (int)((hi - r0) / 16 + 1);
+      int rm = (int)((hi - r0) / 16 + 1);
+      // the split engine works on whole 208-row tiles and is ~3.6x faster per row than the
+      // float32 engine: a remainder tile of >= 4 row blocks is cheaper as a full split tile
+      if (ctx->engine == DTX_ENGINE_BF16X3 && rm >= 4) rm = kRmMax;
       items[rm].push_back(make_int2(c, kt));
     }
   }
@@ -418,6 +505,13 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
     hipLaunchKernelGGL(xc_pad_kernel, grid, dim3(256), 0, ctx->stream, td_dev, n, Nc, L, S, Tz, z);
     DTX_HIP(ctx, hipGetLastError());
   }
+  if (split) {
+    dim3 grid((unsigned)std::min<int64_t>((int64_t)Nc * (Lp / 8), 4096), 1, (unsigned)nkt);
+    hipLaunchKernelGGL(xc_transpose16_kernel, grid, dim3(256), 0, ctx->stream, td_dev, N, n, Nc, L,
+                       Lp, xt16);
+    DTX_HIP(ctx, hipGetLastError());
+    if ((rc = dtx_launch_demux16(ctx, z, Tz, N * Nc, g16))) return rc;
+  }
   hipLaunchKernelGGL(xc_event_stats_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, td_dev, n,
                      esum, essd, esq, fsum, frs);
   DTX_HIP(ctx, hipGetLastError());
@@ -432,6 +526,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   // ---- the MFMA launches, one per row-block count
   XcArgs a;
   a.xt = xt; a.z = z; a.fsum = fsum; a.frs = frs; a.mean_w = mean_w; a.rsw = rsw; a.keys = keys;
+  a.xt16 = split ? xt16 : nullptr; a.g16 = g16; a.V = Vz;
   a.items = nullptr; a.Tz = Tz; a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
   a.N = N; a.Nc = Nc; a.L = L; a.Lp = Lp; a.S = S; a.Pz = Pz; a.nptiles = 0;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));

@@ -20,12 +20,14 @@ ap.add_argument('--L', type=int, default=13000)
 ap.add_argument('--nc', type=int, default=3)
 ap.add_argument('--steps', type=int, default=1)
 ap.add_argument('--cpu-pairs', type=int, default=0)
+ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3'])
 a = ap.parse_args()
 N, L, Nc = a.events, a.L, a.nc
 n = Nc * L
 nfam = max(1, N // 20)
 td = synth.event_families(2, nfam, (N + nfam - 1) // nfam, Nc, L)[:N]
 ctx = HipContext(0)
+ctx.set_engine(a.engine)
 t = torch.from_numpy(td).cuda()
 cc, lag, ss = ctx.xcorr_allpairs(t, Nc)      # warm-up (allocates workspaces)
 ctx.sync()
@@ -42,9 +44,10 @@ flops = 2.0 * mac * npairs
 out = {'metric': 'pairs/sec (all-pairs normalised xcorr)', 'value': npairs / dt, 'unit': 'pairs/s',
        'config': {'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs)},
        'seconds': dt,
-       'roofline': {'bound': 'mfma', 'kernel': 'xc_mfma_kernel<13,2> (+ remainder tiles)',
-                    'achieved': flops / (kms * 1e-3) / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
-                    'frac': flops / (kms * 1e-3) / 1e12 / 157.3, 'kernel_ms': kms,
+       'engine': a.engine,
+       'roofline': {'bound': 'mfma', 'kernel': ('xc_mfma_kernel_s<13,2>' if a.engine != 'fp32' else 'xc_mfma_kernel<13,2>') + ' (+ remainder tiles)',
+                    'achieved': flops / (kms * 1e-3) / 1e12, 'peak': 157.3 if a.engine == 'fp32' else 2500.0, 'unit': 'TFLOP/s',
+                    'frac': flops / (kms * 1e-3) / 1e12 / (157.3 if a.engine == 'fp32' else 2500.0), 'kernel_ms': kms,
                     'flop_per_pair': 2.0 * mac},
        'cc_mean': float(cc.mean()), 'cc_max': float(cc.max())}
 if a.cpu_pairs:
