@@ -34,7 +34,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 namespace dtx {
 
 // column tiles per wave in this engine (B fragments are 4 VGPRs each, so fewer than fp32)
-__host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? 2 : 4; }
+#ifndef DTX_TNS_BIG
+#define DTX_TNS_BIG 3
+#endif
+__host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? DTX_TNS_BIG : 4; }
 // slots per shifted copy in LDS: NS + 4 == 12 (mod 16) makes the B reads conflict-free
 __host__ __device__ constexpr int xs_for(int tn) { return (128 * tn + kBQ) / 8 + 4; }
 // bytes of LDS one block needs (two buffers of A tile + x image)
@@ -74,7 +77,6 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
   constexpr int BUF = ABYTES + XBYTES;
   constexpr int UNITS = ABYTES / 1024;             // 1 KiB LDS-DMA units
   constexpr int NGU = (UNITS + 7) / 8;
-  constexpr int NXP = (16 * NS + kThreads - 1) / kThreads;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kg = lane >> 4;
@@ -85,18 +87,19 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
   if (nsteps <= 0) return;
   const unsigned lds_base = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)lds);
 
-  // x-image staging coordinates of this thread
-  int xsrc[NXP], xdst[NXP];
+  // x image by LDS-DMA too: the LDS image [16 copies][XS slots] is linear, unit u
+  // covers slots 64 u .. 64 u + 63; every lane gathers its slot from the copy row
+  // (h*8 + m) of G (pad slots re-read the last real slot)
+  constexpr int NXU = 16 * XS / 64;                // 1 KiB units of the x image
+  static_assert((16 * XS) % 64 == 0, "x image must be whole LDS-DMA units");
+  constexpr int NGX = (NXU + 7) / 8;
+  int xsrc[NGX];
 #pragma unroll
-  for (int m = 0; m < NXP; ++m) {
-    const int e = tid + m * kThreads;
-    const int hm = e / NS, vl = e - hm * NS;       // (h*8 + copy) row, slot vl
-    xdst[m] = (hm * XS + vl) * 16;
-    xsrc[m] = hm * 65536 + vl;                     // packed; unpacked in DTX_S_STAGE
+  for (int m = 0; m < NGX; ++m) {
+    const int pos = (wave + 8 * m) * 64 + lane;
+    const int hm = pos / XS, vl = pos - hm * XS;
+    xsrc[m] = (hm < 16) ? hm * 65536 + (vl < NS ? vl : NS - 1) : 0;
   }
-  i32x4 rx[NXP];
-#pragma unroll
-  for (int m = 0; m < NXP; ++m) rx[m] = (i32x4){0, 0, 0, 0};
 
 #define DTX_S_STAGE(s_, buf_)                                                               \
   do {                                                                                      \
@@ -113,22 +116,17 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
             (__attribute__((address_space(3))) void*)(ld_ + u_ * 1024), 16, 0, 0);          \
     }                                                                                       \
     const i32x4* gx_ = g16 + (int64_t)c_ * (2 * 8) * V + v0 + j0_ / 8;                      \
-    _Pragma("unroll") for (int m = 0; m < NXP; ++m) {                                       \
-      if ((m + 1) * kThreads <= 16 * NS || tid + m * kThreads < 16 * NS)                    \
-        rx[m] = gx_[(int64_t)(xsrc[m] >> 16) * V + (xsrc[m] & 0xFFFF)];                     \
-    }                                                                                       \
-  } while (0)
-#define DTX_S_STORE_X(buf_)                                                                 \
-  do {                                                                                      \
-    char* xd_ = lds + (buf_) * BUF + ABYTES;                                                \
-    _Pragma("unroll") for (int m = 0; m < NXP; ++m) {                                       \
-      if ((m + 1) * kThreads <= 16 * NS || tid + m * kThreads < 16 * NS)                    \
-        *reinterpret_cast<i32x4*>(xd_ + xdst[m]) = rx[m];                                   \
+    _Pragma("unroll") for (int m = 0; m < NGX; ++m) {                                       \
+      const int u_ = wave_u + 8 * m;                                                        \
+      if ((m + 1) * 8 <= NXU || u_ < NXU)                                                   \
+        __builtin_amdgcn_global_load_lds(                                                   \
+            (const __attribute__((address_space(1))) void*)(gx_ + (int64_t)(xsrc[m] >> 16) * V + \
+                                                            (xsrc[m] & 0xFFFF)),            \
+            (__attribute__((address_space(3))) void*)(ld_ + ABYTES + u_ * 1024), 16, 0, 0); \
     }                                                                                       \
   } while (0)
 
   DTX_S_STAGE(0, 0);
-  DTX_S_STORE_X(0);
   __syncthreads();
 
   // per-lane fragment bases (bytes inside a buffer)
@@ -190,11 +188,9 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (s + 1 < nsteps) DTX_S_STORE_X((s + 1) & 1);
     __syncthreads();
   }
 #undef DTX_S_STAGE
-#undef DTX_S_STORE_X
 }
 
 }  // namespace dtx
