@@ -158,7 +158,7 @@ def main():
         kname = 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8))
         peak, pmc = PEAK_FP32_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel.json'
     else:
-        kname = 'ds_mfma_kernel_s<%d,%d>' % (rm, 2 if rm >= 9 else 4)
+        kname = 'ds_mfma_kernel_s<%d,%d>' % (rm, 3 if rm >= 9 else 4)
         peak, pmc = PEAK_BF16_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel_s.json'
     # HBM-side bytes per launch of the dominant kernel: PMC counters collected by
     # scripts/profile.sh (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) for this
