@@ -112,7 +112,8 @@ def main():
     x, plants = synth.continuous_day(1000 * rank + 1, a.chunks, M, Nc, Uh, det_off, nplant=50)
     xt = torch.from_numpy(x).cuda()
     P = ctx.num_windows(M)
-    ds = torch.empty((a.chunks, D, P), dtype=torch.float32, device='cuda')
+    ldp = (P + 63) // 64 * 64              # aligned row pitch
+    ds = torch.empty((a.chunks, D, ldp), dtype=torch.float32, device='cuda')[:, :, :P]
     thr = np.full(D, 0.3, dtype=np.float32)
     hist = torch.zeros((D, 400), dtype=torch.int32, device='cuda')
 

@@ -41,10 +41,24 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   // LDS atomics do not serialise on one address
   unsigned low[4] = {0u, 0u, 0u, 0u};
   const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
-  for (int it = 0; it < kPostItems; ++it) {
-    const int64_t p = base + (int64_t)it * kPostThreads + tid;
-    if (p < P) {
-      const float v = row[p];
+  // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
+  const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
+  for (int it = 0; it < kPostItems / 4; ++it) {
+    const int64_t p4 = base + ((int64_t)it * kPostThreads + tid) * 4;
+    float vv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && p4 + 3 < P) {
+      const float4 q = *reinterpret_cast<const float4*>(row + p4);
+      vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p4 + j < P) vv[j] = row[p4 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = p4 + j;
+      if (p >= P) continue;
+      const float v = vv[j];
       int bits = __float_as_int(v);
       if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
       vmax = max(vmax, bits);

@@ -119,8 +119,11 @@ class HipContext(object):
                 raise ValueError('flat buffer too small for the chunk layout')
         P = self.num_windows(M)
         if out is None:
-            out = torch.empty((nchunk, self.D, max(P, 0)), dtype=torch.float32,
-                              device=x.device)
+            # row pitch padded to 64 floats: 16-byte aligned rows for the post pass and
+            # whole-line stores from the MFMA epilogue
+            ldp = (max(P, 1) + 63) // 64 * 64
+            out = torch.empty((nchunk, self.D, ldp), dtype=torch.float32,
+                              device=x.device)[:, :, :max(P, 0)]
         rc = self.lib.dtx_subspace_ds(self.h, _ptr(x), int(M), int(chunk_stride),
                                       int(nchunk), _ptr(out), int(out.stride(1)))
         self._ck(rc, 'dtx_subspace_ds')
