@@ -82,3 +82,34 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic',
                            '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = tmp_path / 'ds_host'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'ds_host.c'),
+                           '-L', os.path.join(ROOT, 'detex_amd'), '-ldetexhip', '-lm',
+                           '-Wl,-rpath,' + os.path.join(ROOT, 'detex_amd'),
+                           '-Wl,-rpath,/opt/rocm/lib', '-o', str(exe)])
+    return exe
+
+
+def test_c_example_links(lib, tmp_path):
+    """A plain-C program links against the library through the header alone; without
+    a GPU it must fail loudly (exit code 2: context creation error), never fall back."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 2 and 'HIP' in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs(lib, tmp_path):
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'planted at 1500' in r.stdout
