@@ -42,7 +42,7 @@ struct dtx_ctx {
   std::vector<DtxKTile> tiles;
 
   // workspaces (grown on demand, never shrunk)
-  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g;
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum;
   int engine = DTX_ENGINE_BF16X3;
 
   // timing

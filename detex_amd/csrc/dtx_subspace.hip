@@ -29,17 +29,42 @@ using namespace dtx;
 namespace {
 
 // ------------------------------------------------------------------ demux
-// xp[b][c][t] = x_b[Nc*t + c] for the samples the windows touch, 0 beyond.
+// Block mean in float64 (sliced partial sums, float64 atomics).  The statistic is
+// invariant to adding a constant to the data block, but its float32 evaluation is
+// not: with a DC offset much larger than the signal and basis rows of non-zero mean,
+// U.w and S mu cancel catastrophically.  Removing the block mean first (exact in
+// exact arithmetic: U.(w - m) - S (mu - m) = U.w - S mu) keeps float32 safe.
+constexpr int kMeanSlices = 32;
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ x, int64_t M,
+                                                        int64_t chunk_stride,
+                                                        double* __restrict__ csum) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* xb = x + (int64_t)b * chunk_stride;
+  const int64_t per = (M + kMeanSlices - 1) / kMeanSlices;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, M);
+  double s0 = 0.0;
+  for (int64_t i = i0 + tid; i < i1; i += 256) s0 += (double)xb[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
+  if ((tid & 63) == 0) sh[tid >> 6] = s0;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&csum[b], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// xp[b][c][t] = x_b[Nc*t + c] - mean(x_b) for the samples the windows touch, 0 beyond.
 __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x, int64_t M,
                                                     int64_t chunk_stride, int Nc, int64_t Tvalid,
-                                                    int64_t Tpad, float* __restrict__ xp) {
+                                                    int64_t Tpad, const double* __restrict__ csum,
+                                                    float* __restrict__ xp) {
   const int b = blockIdx.z, c = blockIdx.y;
   const float* xb = x + (int64_t)b * chunk_stride;
   float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
+  const float m0 = (float)(csum[b] / (double)M);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tpad;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t src = t * Nc + c;
-    dst[t] = (t < Tvalid && src < M) ? xb[src] : 0.f;
+    dst[t] = (t < Tvalid && src < M) ? xb[src] - m0 : 0.f;
   }
 }
 
@@ -414,8 +439,13 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     const int64_t Tvalid = P + ctx->L - 1;
     dim3 grid((unsigned)std::min<int64_t>((Tpad + 255) / 256, 4096), (unsigned)Nc,
               (unsigned)nchunk);
+    if ((rc = dtx_reserve(ctx, ctx->ws_csum, (size_t)nchunk * sizeof(double)))) return rc;
+    double* csum = (double*)ctx->ws_csum.p;
+    DTX_HIP(ctx, hipMemsetAsync(csum, 0, (size_t)nchunk * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
+                       ctx->stream, x_dev, M, chunk_stride, csum);
     hipLaunchKernelGGL(demux_kernel, grid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
-                       Tvalid, Tpad, xp);
+                       Tvalid, Tpad, (const double*)csum, xp);
     DTX_HIP(ctx, hipGetLastError());
   }
   {
