@@ -338,39 +338,46 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
                                                         float* __restrict__ mean,
                                                         float* __restrict__ ssd) {
   constexpr int E = kStatsPB / 256;  // windows per thread
-  __shared__ double sh1[4], sh2[4];
-  __shared__ double anchor[2];
+  __shared__ double sh1[4], sh2[4], sh3[4];
+  __shared__ double anchor[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
   const float* xb = planes + (int64_t)b * Nc * plane_stride;
   const int64_t p0 = (int64_t)blockIdx.x * kStatsPB;
   if (p0 >= P) return;
 
-  double s1 = 0.0, s2 = 0.0;
+  // third running quantity: the number of sample-to-sample changes inside the window
+  // (per channel).  It is an exact integer, so "the window is constant" -- the
+  // zero-variance case the statistic defines as 0 -- is decided exactly, however much
+  // round-off the float64 sliding sums have picked up from large values elsewhere.
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int c = 0; c < Nc; ++c) {
     const float* w0 = xb + (int64_t)c * plane_stride + p0;
     for (int j = tid; j < L; j += 256) {
       const double v = (double)w0[j];
       s1 += v;
       s2 += v * v;
+      if (j > 0) s3 += (w0[j] != w0[j - 1]) ? 1.0 : 0.0;
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s1 += __shfl_down(s1, off, 64);
     s2 += __shfl_down(s2, off, 64);
+    s3 += __shfl_down(s3, off, 64);
   }
-  if (lane == 0) { sh1[wv] = s1; sh2[wv] = s2; }
+  if (lane == 0) { sh1[wv] = s1; sh2[wv] = s2; sh3[wv] = s3; }
   __syncthreads();
   if (tid == 0) {
     anchor[0] = sh1[0] + sh1[1] + sh1[2] + sh1[3];
     anchor[1] = sh2[0] + sh2[1] + sh2[2] + sh2[3];
+    anchor[2] = sh3[0] + sh3[1] + sh3[2] + sh3[3];
   }
   __syncthreads();
 
   // local element e turns window (p0 + E*tid + e) into the next one
-  double l1[E], l2[E];
-  double r1 = 0.0, r2 = 0.0;
+  double l1[E], l2[E], l3[E];
+  double r1 = 0.0, r2 = 0.0, r3 = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int64_t pw = p0 + (int64_t)E * tid + e;
@@ -380,32 +387,45 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
         const double vo = (double)o[0], vn = (double)o[L];
         r1 += vn - vo;
         r2 += vn * vn - vo * vo;
+        // changes entering (between samples L-1 and L) and leaving (between 0 and 1)
+        if (L > 1) r3 += ((o[L] != o[L - 1]) ? 1.0 : 0.0) - ((o[1] != o[0]) ? 1.0 : 0.0);
       }
     }
     l1[e] = r1;
     l2[e] = r2;
+    l3[e] = r3;
   }
-  const double i1 = wave_incl_scan(r1, lane), i2 = wave_incl_scan(r2, lane);
+  const double i1 = wave_incl_scan(r1, lane), i2 = wave_incl_scan(r2, lane),
+               i3 = wave_incl_scan(r3, lane);
   __syncthreads();
-  if (lane == 63) { sh1[wv] = i1; sh2[wv] = i2; }
+  if (lane == 63) { sh1[wv] = i1; sh2[wv] = i2; sh3[wv] = i3; }
   __syncthreads();
-  double off1 = i1 - r1, off2 = i2 - r2;  // exclusive within the wave
-  for (int w = 0; w < wv; ++w) { off1 += sh1[w]; off2 += sh2[w]; }
-  const double a1 = anchor[0], a2 = anchor[1];
+  double off1 = i1 - r1, off2 = i2 - r2, off3 = i3 - r3;  // exclusive within the wave
+  for (int w = 0; w < wv; ++w) { off1 += sh1[w]; off2 += sh2[w]; off3 += sh3[w]; }
+  const double a1 = anchor[0], a2 = anchor[1], a3 = anchor[2];
   const double dn = (double)Nc * (double)L;
   float* mo = mean + (int64_t)b * Ppad;
   float* so = ssd + (int64_t)b * Ppad;
+  // a window is constant iff no sample changes inside any channel and all channels
+  // start from the same value
+  auto constant = [&](int64_t pw, double nchg) {
+    if (nchg > 0.5) return false;
+    const float v0 = xb[pw];
+    for (int c = 1; c < Nc; ++c)
+      if (xb[(int64_t)c * plane_stride + pw] != v0) return false;
+    return true;
+  };
   if (tid == 0) {
     mo[p0] = (float)(a1 / dn);
-    so[p0] = stats_out(scale, clamp_var(a2, a1, dn));
+    so[p0] = constant(p0, a3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(a2, a1, dn));
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int64_t pw = p0 + (int64_t)E * tid + e + 1;
     if (pw < P && pw < p0 + kStatsPB) {
-      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e];
+      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
       mo[pw] = (float)(S1 / dn);
-      so[pw] = stats_out(scale, clamp_var(S2, S1, dn));
+      so[pw] = constant(pw, S3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
     }
   }
 }

@@ -54,6 +54,8 @@ struct dtx_ctx {
 int dtx_fail(dtx_ctx* ctx, int code, const char* fmt, ...);
 int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes);
 void dtx_free_tiles_internal(dtx_ctx* c);
+// shortest template (samples per channel) the split-bf16 engine is used for
+constexpr int kSplitMinL = 64;
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

@@ -29,27 +29,69 @@ using namespace dtx;
 namespace {
 
 // ------------------------------------------------------------------ demux
-// Block mean in float64 (sliced partial sums, float64 atomics).  The statistic is
+// Block offset in float64 (sliced partial sums, float64 atomics).  The statistic is
 // invariant to adding a constant to the data block, but its float32 evaluation is
 // not: with a DC offset much larger than the signal and basis rows of non-zero mean,
-// U.w and S mu cancel catastrophically.  Removing the block mean first (exact in
-// exact arithmetic: U.(w - m) - S (mu - m) = U.w - S mu) keeps float32 safe.
+// U.w and S mu cancel catastrophically.  Removing an offset first (exact in exact
+// arithmetic: U.(w - m) - S (mu - m) = U.w - S mu) keeps float32 safe.  The offset is
+// the mean of the block's "ordinary" samples: pass 0 takes sum, sum of squares and
+// count of the non-zero samples (zero-filled gaps, getdata fillZeros, must not pull
+// it), pass 1 repeats the mean over the non-zero samples within 3 sigma of the pass-0
+// mean, so that a spike of any size cannot move it either.
+// csum[b] = {sum, sumsq, count, sum', count'}
 constexpr int kMeanSlices = 32;
+constexpr int kCsum = 5;
+template <int PASS>
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ x, int64_t M,
                                                         int64_t chunk_stride,
                                                         double* __restrict__ csum) {
-  __shared__ double sh[4];
+  __shared__ double sh[3][4];
   const int b = blockIdx.y, tid = threadIdx.x;
   const float* xb = x + (int64_t)b * chunk_stride;
+  double* cs = csum + (int64_t)b * kCsum;
   const int64_t per = (M + kMeanSlices - 1) / kMeanSlices;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, M);
-  double s0 = 0.0;
-  for (int64_t i = i0 + tid; i < i1; i += 256) s0 += (double)xb[i];
+  double m1 = 0.0, band = 0.0;
+  if (PASS == 1) {
+    const double cnt = cs[2];
+    if (cnt < 0.5) return;
+    m1 = cs[0] / cnt;
+    band = 3.0 * sqrt(fmax(cs[1] / cnt - m1 * m1, 0.0));
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = i0 + tid; i < i1; i += 256) {
+    const float vf = xb[i];
+    const double v = (double)vf;
+    if (PASS == 0) {
+      if (vf != 0.f) { s0 += v; s1 += v * v; s2 += 1.0; }
+    } else {
+      if (vf != 0.f && fabs(v - m1) <= band) { s0 += v; s2 += 1.0; }
+    }
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s0 += __shfl_down(s0, off, 64);
-  if ((tid & 63) == 0) sh[tid >> 6] = s0;
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s0; sh[1][tid >> 6] = s1; sh[2][tid >> 6] = s2; }
   __syncthreads();
-  if (tid == 0) atomicAdd(&csum[b], sh[0] + sh[1] + sh[2] + sh[3]);
+  if (tid == 0) {
+    const double t0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    const double t1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double t2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    if (PASS == 0) {
+      atomicAdd(&cs[0], t0); atomicAdd(&cs[1], t1); atomicAdd(&cs[2], t2);
+    } else {
+      atomicAdd(&cs[3], t0); atomicAdd(&cs[4], t2);
+    }
+  }
+}
+
+__device__ inline float block_offset(const double* __restrict__ cs) {
+  if (cs[4] >= 0.5) return (float)(cs[3] / cs[4]);
+  if (cs[2] >= 0.5) return (float)(cs[0] / cs[2]);   // every sample equal: sigma 0 keeps them all,
+  return 0.f;                                        // so this is only the all-zero block
 }
 
 // xp[b][c][t] = x_b[Nc*t + c] - mean(x_b) for the samples the windows touch, 0 beyond.
@@ -60,7 +102,7 @@ __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x,
   const int b = blockIdx.z, c = blockIdx.y;
   const float* xb = x + (int64_t)b * chunk_stride;
   float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
-  const float m0 = (float)(csum[b] / (double)M);
+  const float m0 = block_offset(csum + (int64_t)b * kCsum);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tpad;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t src = t * Nc + c;
@@ -439,10 +481,13 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     const int64_t Tvalid = P + ctx->L - 1;
     dim3 grid((unsigned)std::min<int64_t>((Tpad + 255) / 256, 4096), (unsigned)Nc,
               (unsigned)nchunk);
-    if ((rc = dtx_reserve(ctx, ctx->ws_csum, (size_t)nchunk * sizeof(double)))) return rc;
+    const size_t cbytes = (size_t)nchunk * kCsum * sizeof(double);
+    if ((rc = dtx_reserve(ctx, ctx->ws_csum, cbytes))) return rc;
     double* csum = (double*)ctx->ws_csum.p;
-    DTX_HIP(ctx, hipMemsetAsync(csum, 0, (size_t)nchunk * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
+    DTX_HIP(ctx, hipMemsetAsync(csum, 0, cbytes, ctx->stream));
+    hipLaunchKernelGGL(chunk_sum_kernel<0>, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
+                       ctx->stream, x_dev, M, chunk_stride, csum);
+    hipLaunchKernelGGL(chunk_sum_kernel<1>, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
                        ctx->stream, x_dev, M, chunk_stride, csum);
     hipLaunchKernelGGL(demux_kernel, grid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
                        Tvalid, Tpad, (const double*)csum, xp);
@@ -459,7 +504,10 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
 
   i32x4* g16 = nullptr;
   const int64_t V = Tpad / 8;
-  if (ctx->engine == DTX_ENGINE_BF16X3) {
+  // templates shorter than kSplitMinL samples per channel stay on the float32 engine:
+  // with so few products per window the split products' 2^-17 errors do not average out
+  // (and the padding of L to the 32-sample steps of the bf16 MFMA would dominate anyway)
+  if (ctx->engine == DTX_ENGINE_BF16X3 && ctx->L >= kSplitMinL) {
     if ((rc = dtx_reserve(ctx, ctx->ws_g, (size_t)nchunk * Nc * 16 * V * sizeof(i32x4)))) return rc;
     g16 = (i32x4*)ctx->ws_g.p;
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;

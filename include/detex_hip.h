@@ -83,7 +83,8 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
  *                      dropped alo*blo term is 2^-18 relative; DS agrees with the
  *                      float64 reference as closely as the FP32 engine does: both
  *                      are limited by float32 accumulation, ~2e-6 at DS = 1, 1e-8
- *                      on noise), 3.6x faster. */
+ *                      on noise), 3.6x faster.  Templates shorter than 64 samples
+ *                      per channel are always computed by the FP32 engine. */
 #define DTX_ENGINE_FP32 0
 #define DTX_ENGINE_BF16X3 1
 int dtx_set_engine(dtx_ctx* ctx, int engine);

@@ -37,8 +37,18 @@ def test_random_scan(ctx, seed):
     T = int(rs.randint(L + 1, L + 2500))
     M = Nc * T - int(rs.randint(0, Nc))                # ragged tail
     stride = int(rs.randint(Nc, M + 1) // Nc * Nc)
-    buf = rs.standard_normal((nchunk - 1) * stride + M) * float(10 ** rs.uniform(-6, 3)) + \
-        float(rs.choice([0, 0, 5]))
+    amp = float(10 ** rs.uniform(-6, 3))
+    dc = float(rs.choice([0, 0, 5]))
+    buf = rs.standard_normal((nchunk - 1) * stride + M) * amp + dc
+    if rs.rand() < 0.35 and len(buf) > 6 * n:
+        # dead stretch: the reference zero-fills gaps BEFORE detrend + band-pass
+        # (construct.py:1005-1028), so in the scan input a gap sits at the data's DC level
+        g0 = int(rs.randint(0, len(buf) - 3 * n))
+        buf[g0: g0 + int(rs.randint(n, 3 * n))] = dc
+    spike = -1
+    if rs.rand() < 0.35:                                    # spike 10^4 x the noise level
+        spike = int(rs.randint(len(buf)))
+        buf[spike] += 1e4 * amp
     ctx.set_engine('bf16x3' if seed % 2 else 'fp32')
     ctx.upload_basis(U.astype(np.float32), off, Nc)
     ds = ctx.subspace_ds(torch.from_numpy(buf.astype(np.float32)).cuda(), M=M,
@@ -53,9 +63,21 @@ def test_random_scan(ctx, seed):
     for b in range(nchunk):
         xb = bf[b * stride: b * stride + M]
         for d in rows:
-            ref = orc.mpxds_fft(xb, Uf[off[d]:off[d + 1]], Nc)
-            scale = max(1.0, float(np.max(ref)))       # non-orthonormal rows can exceed 1
-            assert np.max(np.abs(ds[b, d] - ref)) <= 1e-5 * scale, (seed, b, d, Nc, L, ks[d])
+            ref = orc.mpxds_direct(xb, Uf[off[d]:off[d + 1]], Nc) if P * n < 3e6 else \
+                orc.mpxds_fft(xb, Uf[off[d]:off[d + 1]], Nc)
+            live = np.lib.stride_tricks.sliding_window_view(xb, n)[::Nc].std(axis=1) > 0
+            assert np.all(ds[b, d][~live] == 0)        # zero-variance windows score 0
+            scale = max(1.0, float(np.max(ref[live])))  # non-orthonormal rows can exceed 1
+            # a window that holds the spike is that one sample times a basis column: nothing
+            # averages the split products' 2^-17 rounding there, so the split engine is held
+            # to 4e-5 on those windows ("accuracy"); everything else to 1e-5
+            tol = np.full(P, 1e-5)
+            if seed % 2 and spike >= 0:
+                w0 = np.arange(P) * Nc + b * stride
+                tol[(w0 <= spike) & (spike < w0 + n)] = 4e-5
+            bad = (np.abs(ds[b, d] - ref) > tol * scale) & live
+            assert not bad.any(), (seed, b, d, Nc, L, ks[d],
+                                   float(np.max(np.abs(ds[b, d] - ref)[live])), scale)
     ctx.set_engine('bf16x3')
 
 
