@@ -16,7 +16,7 @@ SYMBOLS = [
     'dtx_version', 'dtx_ctx_create', 'dtx_ctx_destroy', 'dtx_ctx_sync',
     'dtx_ctx_stream', 'dtx_last_error', 'dtx_set_engine', 'dtx_basis_upload', 'dtx_num_windows',
     'dtx_subspace_ds', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
-    'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_timer_start',
+    'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms',
 ]
 
@@ -77,6 +77,8 @@ def load():
     lib.dtx_xcorr_allpairs_host.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.dtx_preprocess.restype = i32
     lib.dtx_preprocess.argtypes = [vp, vp, i32, i32, i64, i64, vp, i32, i32, i32, vp, i64]
+    lib.dtx_decimate.restype = i32
+    lib.dtx_decimate.argtypes = [vp, vp, i32, i64, i64, vp, i32, i32, vp, i64]
     lib.dtx_timer_start.restype = i32
     lib.dtx_timer_start.argtypes = [vp]
     lib.dtx_timer_stop.restype = i32

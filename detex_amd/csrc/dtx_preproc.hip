@@ -92,14 +92,15 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 // filtered by the owning thread from LDS.
 //   RUN = false: start from a zero state, keep the final state (pass 1)
 //   RUN = true : start from the true entry state, write the output (pass 3);
-//                LAST selects the multiplexed float32 result x[Nc t + c]
+//                LAST selects the float32 result: multiplexed x[Nc t + c] (dec <= 1) or
+//                the series' own plane keeping every dec-th sample (dtx_decimate)
 constexpr int kSub = 32;
 template <bool FIRST, bool RUN, bool LAST>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
     const float* __restrict__ raw, int64_t ser_stride, const double* __restrict__ mid,
     const double* __restrict__ trend, int64_t T, int nblk, Sos f, bool rev,
     double* __restrict__ fstate, double* __restrict__ out_mid, float* __restrict__ out_mp, int Nc,
-    int64_t mp_stride) {
+    int64_t mp_stride, int dec) {
   __shared__ double tile[256][kSub + 1];
   const int tid = threadIdx.x;
   const int ser = blockIdx.y;
@@ -144,8 +145,12 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
         const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
         if (g0 + b < nblk && i < T) {
           const int64_t t = rev ? (T - 1 - i) : i;
-          if (LAST) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)tile[b][j];
-          else out_mid[(int64_t)ser * T + t] = tile[b][j];
+          if (LAST) {
+            if (dec <= 1) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)tile[b][j];
+            else if (t % dec == 0) out_mp[(int64_t)ser * mp_stride + t / dec] = (float)tile[b][j];
+          } else {
+            out_mid[(int64_t)ser * T + t] = tile[b][j];
+          }
         }
       }
     }
@@ -231,32 +236,46 @@ __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ 
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
-                   int64_t ser_stride, const double* sos, int nsec, int zerophase, int detrend,
-                   float* mp_dev, int64_t mp_stride) {
-  if (!ctx) return DTX_E_ARG;
-  if (!raw_dev || !mp_dev || nchunk <= 0 || Nc <= 0 || T <= 0 || ser_stride < T ||
-      mp_stride < T * Nc)
-    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: bad argument");
-  if (nsec < 0 || nsec > kMaxSec || (nsec > 0 && !sos))
-    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: 0..%d second-order sections supported", kMaxSec);
-  DtxDeviceGuard g(ctx->device);
-  const int nser = nchunk * Nc;
-  const int nblk = (int)((T + kPB - 1) / kPB);
-  const int ns = 2 * nsec;
-
+// host-side preparation shared by dtx_preprocess and dtx_decimate: normalised sections,
+// block transition matrix M and M^seg, workspace carving
+struct PpPlan {
   Sos f;
+  int nser, nblk, ns, seg;
+  double *trend, *fstate, *Mdev, *mid;
+};
+
+int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser, int64_t T,
+            bool need_mid, PpPlan* pl) {
+  if (nsec < 0 || nsec > kMaxSec || (nsec > 0 && !sos))
+    return dtx_fail(ctx, DTX_E_ARG, "%s: 0..%d second-order sections supported", who, kMaxSec);
+  pl->nser = nser;
+  pl->nblk = (int)((T + kPB - 1) / kPB);
+  pl->ns = 2 * nsec;
+  pl->seg = (pl->nblk + 63) / 64;     // blocks per lane in the chain kernel
+  const int ns = pl->ns, nblk = pl->nblk;
+  Sos& f = pl->f;
   f.nsec = nsec;
   for (int s = 0; s < nsec; ++s) {
     const double a0 = sos[6 * s + 3];
-    if (a0 == 0.0) return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: sos a0 == 0");
+    if (a0 == 0.0) return dtx_fail(ctx, DTX_E_ARG, "%s: sos a0 == 0", who);
     f.b0[s] = sos[6 * s + 0] / a0; f.b1[s] = sos[6 * s + 1] / a0; f.b2[s] = sos[6 * s + 2] / a0;
     f.a1[s] = sos[6 * s + 4] / a0; f.a2[s] = sos[6 * s + 5] / a0;
   }
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_tr = carve((size_t)nser * 2 * sizeof(double));
+  const size_t o_fs = carve((size_t)nser * nblk * 2 * kMaxSec * sizeof(double));
+  const size_t o_M = carve((size_t)(2 * ns * ns + 2) * sizeof(double));
+  const size_t o_mid = carve(need_mid ? (size_t)nser * T * sizeof(double) : 0);
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_misc3, off))) return rc;
+  char* base = (char*)ctx->ws_misc3.p;
+  pl->trend = (double*)(base + o_tr);
+  pl->fstate = (double*)(base + o_fs);
+  pl->Mdev = (double*)(base + o_M);
+  pl->mid = (double*)(base + o_mid);
+  if (nsec == 0) return DTX_OK;
+
   // state transition over one block: column k = free response of unit state k
   std::vector<double> M((size_t)ns * ns, 0.0);
   for (int k = 0; k < ns; ++k) {
@@ -273,20 +292,46 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     }
     for (int r = 0; r < ns; ++r) M[(size_t)r * ns + k] = z[r];
   }
+  {  // Mseg = M^seg
+    std::vector<double> P((size_t)ns * ns, 0.0), Q((size_t)ns * ns);
+    for (int k = 0; k < ns; ++k) P[(size_t)k * ns + k] = 1.0;
+    for (int e = 0; e < pl->seg; ++e) {
+      for (int r = 0; r < ns; ++r)
+        for (int c = 0; c < ns; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < ns; ++k) acc += M[(size_t)r * ns + k] * P[(size_t)k * ns + c];
+          Q[(size_t)r * ns + c] = acc;
+        }
+      P.swap(Q);
+    }
+    M.insert(M.end(), P.begin(), P.end());
+  }
+  DTX_HIP(ctx, hipMemcpyAsync(pl->Mdev, M.data(), (size_t)2 * ns * ns * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // M is a stack-lifetime host buffer
+  return DTX_OK;
+}
 
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_tr = carve((size_t)nser * 2 * sizeof(double));
-  const size_t o_fs = carve((size_t)nser * nblk * 2 * kMaxSec * sizeof(double));
-  const size_t o_M = carve((size_t)(2 * ns * ns + 2) * sizeof(double));
-  const size_t o_mid = carve(zerophase && nsec ? (size_t)nser * T * sizeof(double) : 0);
+}  // namespace
+
+extern "C" {
+
+int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
+                   int64_t ser_stride, const double* sos, int nsec, int zerophase, int detrend,
+                   float* mp_dev, int64_t mp_stride) {
+  if (!ctx) return DTX_E_ARG;
+  if (!raw_dev || !mp_dev || nchunk <= 0 || Nc <= 0 || T <= 0 || ser_stride < T ||
+      mp_stride < T * Nc)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: bad argument");
+  DtxDeviceGuard g(ctx->device);
+  const int nser = nchunk * Nc;
+  PpPlan pl;
   int rc;
-  if ((rc = dtx_reserve(ctx, ctx->ws_misc3, off))) return rc;
-  char* base = (char*)ctx->ws_misc3.p;
-  double* trend = detrend ? (double*)(base + o_tr) : nullptr;
-  double* fstate = (double*)(base + o_fs);
-  double* Mdev = (double*)(base + o_M);
-  double* mid = (double*)(base + o_mid);
+  if ((rc = pp_plan(ctx, "dtx_preprocess", sos, nsec, nser, T, zerophase && nsec, &pl))) return rc;
+  const Sos& f = pl.f;
+  const int nblk = pl.nblk, ns = pl.ns, seg = pl.seg;
+  double* trend = detrend ? pl.trend : nullptr;
+  double *fstate = pl.fstate, *Mdev = pl.Mdev, *mid = pl.mid;
 
   if (detrend) {
     DTX_HIP(ctx, hipMemsetAsync(trend, 0, (size_t)nser * 2 * sizeof(double), ctx->stream));
@@ -301,25 +346,6 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     DTX_HIP(ctx, hipGetLastError());
     return DTX_OK;
   }
-  // Mseg = M^seg, seg = blocks per lane in the chain kernel
-  const int seg = (nblk + 63) / 64;
-  {
-    std::vector<double> P((size_t)ns * ns, 0.0), Q((size_t)ns * ns);
-    for (int k = 0; k < ns; ++k) P[(size_t)k * ns + k] = 1.0;
-    for (int e = 0; e < seg; ++e) {
-      for (int r = 0; r < ns; ++r)
-        for (int c = 0; c < ns; ++c) {
-          double acc = 0.0;
-          for (int k = 0; k < ns; ++k) acc += M[(size_t)r * ns + k] * P[(size_t)k * ns + c];
-          Q[(size_t)r * ns + c] = acc;
-        }
-      P.swap(Q);
-    }
-    M.insert(M.end(), P.begin(), P.end());
-  }
-  DTX_HIP(ctx, hipMemcpyAsync(Mdev, M.data(), (size_t)2 * ns * ns * sizeof(double),
-                              hipMemcpyHostToDevice, ctx->stream));
-  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // M is a stack-lifetime host buffer
   dim3 grid((unsigned)((nblk + 255) / 256), (unsigned)nser);
   dim3 cgrid((unsigned)nser);
   const double* nod = nullptr;
@@ -327,28 +353,57 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   // forward pass: raw - trend -> (mid | output)
   hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
-                     (double*)nullptr, (float*)nullptr, Nc, mp_stride);
+                     (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
   hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
                      (const double*)(Mdev + ns * ns), nblk, seg, ns);
   if (zerophase) {
     hipLaunchKernelGGL((pp_tiled_kernel<true, true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                        ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate, mid,
-                       (float*)nullptr, Nc, mp_stride);
+                       (float*)nullptr, Nc, mp_stride, 0);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
     hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
                        ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
-                       (double*)nullptr, (float*)nullptr, Nc, mp_stride);
+                       (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
     hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
                        (const double*)(Mdev + ns * ns), nblk, seg, ns);
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
     hipLaunchKernelGGL((pp_tiled_kernel<false, true, true>), grid, dim3(256), 0, ctx->stream, nof,
                        ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
-                       (double*)nullptr, mp_dev, Nc, mp_stride);
+                       (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   } else {
     hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
                        ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
-                       (double*)nullptr, mp_dev, Nc, mp_stride);
+                       (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   }
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+// Trace.decimate of construct.py:1016-1017: causal low-pass (forward sosfilt of the
+// caller's sections, no detrend) and every factor-th sample kept, per series plane
+int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_t ser_stride,
+                 const double* sos, int nsec, int factor, float* out_dev, int64_t out_stride) {
+  if (!ctx) return DTX_E_ARG;
+  if (!raw_dev || !out_dev || nser <= 0 || T <= 0 || ser_stride < T || factor < 1 ||
+      out_stride < (T + factor - 1) / factor)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_decimate: bad argument");
+  if (nsec < 1) return dtx_fail(ctx, DTX_E_ARG, "dtx_decimate: needs >= 1 low-pass section");
+  DtxDeviceGuard g(ctx->device);
+  PpPlan pl;
+  int rc;
+  if ((rc = pp_plan(ctx, "dtx_decimate", sos, nsec, nser, T, false, &pl))) return rc;
+  dim3 grid((unsigned)((pl.nblk + 255) / 256), (unsigned)nser);
+  const double* nod = nullptr;
+  hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                     ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
+                     (float*)nullptr, 1, out_stride, 0);
+  hipLaunchKernelGGL(pp_chain_kernel, dim3((unsigned)nser), dim3(64), 0, ctx->stream, pl.fstate,
+                     (const double*)pl.Mdev, (const double*)(pl.Mdev + pl.ns * pl.ns), pl.nblk,
+                     pl.seg, pl.ns);
+  // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
+  hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                     ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
+                     out_dev, 1, out_stride, factor);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

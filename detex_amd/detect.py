@@ -102,6 +102,11 @@ def _chunk_batches(bounds):
     return batches
 
 
+def _dec_len(cnt, dec):
+    """samples left of cnt after data[::dec]"""
+    return (cnt + dec - 1) // dec
+
+
 def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
                  useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=False):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
@@ -133,11 +138,14 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         ctx.upload_basis(U, det_off, Nc)
         data, t0 = fetcher.data[sta]
         raw = bool(getattr(fetcher, 'raw', False))
+        dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
         if raw:
-            # unfiltered planes stay on the device; each chunk is detrended + band-passed
-            # separately, like the reference's per-chunk _applyFilter (detect.py:231)
+            # unfiltered planes stay on the device; each chunk is decimated, detrended and
+            # band-passed separately, like the reference's per-chunk _applyFilter
+            # (detect.py:231); after decimation everything runs at sr / decimate (detect.py:239)
             rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
             xhost = xdev = None
+            sr_raw, sr = sr, sr / dec
         else:
             xhost = np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
             xdev = torch.from_numpy(xhost).to(ctx.device)
@@ -145,15 +153,18 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
-        bounds = [b for b in bounds if b[1] * Nc > n and (b[1] * Nc - n) // Nc + 1 >= 10]
+        bounds = [b for b in bounds
+                  if _dec_len(b[1], dec) * Nc > n and (_dec_len(b[1], dec) * Nc - n) // Nc + 1 >= 10]
         LTA = triggerLTATime * sr
         STA = triggerSTATime * sr
         for (i0, i1, stride) in _chunk_batches(bounds):
             s0, cnt = bounds[i0][0], bounds[i0][1]
-            M = cnt * Nc
+            M = _dec_len(cnt, dec) * Nc
             if raw:
                 planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt]
                                       for k in range(i0, i1)])
+                if dec > 1:                                      # construct.py:1016-1017
+                    planes = ctx.decimate(planes, dec, sr_raw)
                 mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
                 ds = ctx.subspace_ds(mp)
                 mp_host = mp.cpu().numpy() if estimateMags else None

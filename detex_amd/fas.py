@@ -88,19 +88,47 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             sr = fetcher.sampling_rate
             n = U.shape[1]
             data, _t0 = fetcher.data[sta]
-            bounds = [b for b in fetcher.chunk_bounds(sta) if b[1] * Nc > n]
+            raw = bool(getattr(fetcher, 'raw', False))
+            dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
+            sr_raw, sr = sr, sr / dec                              # detect.py:239
+
+            def declen(cnt):
+                return (cnt + dec - 1) // dec
+            bounds = [b for b in fetcher.chunk_bounds(sta) if declen(b[1]) * Nc > n]
             if not bounds:
                 raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
             # fas.py:92-93: ask for 4x more chunks than needed, in random order
             order = rs.permutation(len(bounds))[:conDatNum * 4]
+            if raw:
+                rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
+            else:
+                xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)),
+                                                             dtype=np.float32)).to(ctx.device)
+            cache = {}
+
+            def chunk_mp(k):
+                """multiplexed, pre-processed chunk k on the device (fas.py:101) + its
+                channels on the host for the STA/LTA screen"""
+                if k not in cache:
+                    s, cnt, _ = bounds[k]
+                    if raw:
+                        planes = rawdev[None, :, s:s + cnt]
+                        if dec > 1:
+                            planes = ctx.decimate(planes, dec, sr_raw)
+                        mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
+                        chans = mp[0].reshape(-1, Nc).t().cpu().numpy()
+                    else:
+                        mp = xdev[None, s * Nc:(s + cnt) * Nc]
+                        chans = data[:, s:s + cnt]
+                    cache[k] = (mp, chans)
+                return cache[k]
 
             def pick(limit):
                 chosen, count = [], 0
                 for k in order:
-                    s, cnt, _ = bounds[k]
                     count += 1
-                    if not _checkSTALTA(data[:, s:s + cnt], fetcher.channels, sr, STATime,
-                                        LTATime, limit):
+                    if limit is not None and not _checkSTALTA(chunk_mp(k)[1], fetcher.channels, sr,
+                                                              STATime, LTATime, limit):
                         continue
                     if len(chosen) >= conDatNum:
                         break
@@ -111,13 +139,11 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
                 chosen, count = pick(None)
             ctx.upload_basis(U, det_off, Nc)
             D = len(names)
-            xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)),
-                                                         dtype=np.float32)).to(ctx.device)
             hist = torch.zeros((D, numBins - 1), dtype=torch.int32, device=ctx.device)
             sums = torch.zeros((D, 5), dtype=torch.float64, device=ctx.device)
             for k in chosen:
-                s, cnt, _ = bounds[k]
-                ds = ctx.subspace_ds(xdev[s * Nc:], M=cnt * Nc, chunk_stride=cnt * Nc, nchunk=1)
+                mp = chunk_mp(k)[0]
+                ds = ctx.subspace_ds(mp)
                 ctx.ds_moments(ds, lo=-.01, hi=1.0, nbins=numBins - 1, hist=hist, sums=sums)
             ctx.sync()
             h = hist.cpu().numpy()

@@ -27,6 +27,26 @@ def bandpass_sos(freqmin, freqmax, df, corners):
     return zpk2sos(z, p, k)
 
 
+def decimate_sos(df, factor, maxorder=12):
+    """Second-order sections of the anti-alias filter of obspy Trace.decimate(factor)
+    (construct.py:1016-1017; third-party, restated): lowpass_cheby_2 with the stop band
+    at the new Nyquist frequency df/(2 factor), 96 dB attenuation, 1 dB pass-band ripple;
+    the pass band edge is lowered 1 % at a time until the order is <= maxorder."""
+    from scipy.signal import cheb2ord, cheby2, zpk2sos
+    if factor > 16:                      # obspy refuses: decimate in several steps
+        raise ValueError('automatic filter design is unstable for decimation factors above 16')
+    nyquist = df * 0.5
+    freq = df * 0.5 / float(factor)
+    rp, rs, order = 1, 96, 1e99
+    ws = min(freq / nyquist, 1.0)
+    wp = ws
+    while order > maxorder:
+        wp = wp * 0.99
+        order, wn = cheb2ord(wp, ws, rp, rs, analog=0)
+    z, p, k = cheby2(order, rs, wn, btype='low', analog=0, output='zpk')
+    return zpk2sos(z, p, k)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -229,6 +249,25 @@ class HipContext(object):
                                      sos.ctypes.data_as(C.c_void_p) if sos is not None else None,
                                      nsec, zp, int(bool(detrend)), _ptr(out), int(out.stride(0)))
         self._ck(rc, 'dtx_preprocess')
+        return out
+
+    def decimate(self, raw, factor, sampling_rate):
+        """Trace.decimate(factor) on the device (construct.py:1016-1017): causal
+        Chebyshev-II low-pass, then every factor-th sample.
+
+        raw : [..., T] float32 CUDA tensor of series planes -> [..., ceil(T/factor)]"""
+        if raw.dtype != torch.float32 or not raw.is_cuda:
+            raise ValueError('raw must be a float32 CUDA tensor')
+        factor = int(factor)
+        raw = raw.contiguous()
+        T = int(raw.shape[-1])
+        nser = int(raw.numel() // max(T, 1))
+        To = (T + factor - 1) // factor
+        out = torch.empty(tuple(raw.shape[:-1]) + (To,), dtype=torch.float32, device=raw.device)
+        sos = np.ascontiguousarray(decimate_sos(sampling_rate, factor), dtype=np.float64)
+        rc = self.lib.dtx_decimate(self.h, _ptr(raw), nser, T, T, sos.ctypes.data_as(C.c_void_p),
+                                   len(sos), factor, _ptr(out), To)
+        self._ck(rc, 'dtx_decimate')
         return out
 
     # ------------------------------------------------------------ timing

@@ -407,8 +407,10 @@ class SubSpace(object):
         Returns {'ss_df': DataFrame, 'sg_df': DataFrame} with the reference's
         columns (detect.py:397-398) and writes them, the histograms and the
         detector info to the SQLite file ``subspaceDB`` (None: no file).
-        ``estimateMags`` (detect.py:447-499) is not part of this round: Mag, SNR
-        and ProEnMag are NaN as with estimateMags=False in the reference."""
+        ``estimateMags`` (detect.py:447-499) fills Mag, SNR and ProEnMag at every
+        trigger (detect.est_mag); they are NaN with estimateMags=False as in the
+        reference.  A raw ContinuousFetcher is decimated (clusters.decimate),
+        detrended and band-passed (clusters.filt) chunk by chunk on the device."""
         from .detect import scan_station
         if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
             _error('multiprocessing and trigcon other than 0 not supported')

@@ -200,6 +200,19 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc,
                    int64_t T, int64_t ser_stride, const double* sos, int nsec,
                    int zerophase, int detrend, float* mp_dev, int64_t mp_stride);
 
+/* Trace.decimate(factor) of _applyFilter (construct.py:1016-1017), which runs
+ * BEFORE the detrend / band-pass above: ObsPy (third-party, not vendored)
+ * low-passes causally with a Chebyshev-II filter (sosfilt, forward only) and
+ * keeps every factor-th sample, data[::factor].  The caller designs the
+ * low-pass (detex_amd.hip.decimate_sos restates ObsPy's lowpass_cheby_2
+ * design) and passes sos[nsec][6] as for dtx_preprocess; float64 arithmetic.
+ *   raw_dev  nser series of T float32 samples, series s at raw_dev + s*ser_stride
+ *   out_dev  out: series s at out_dev + s*out_stride, ceil(T/factor) samples
+ * Asynchronous. */
+int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T,
+                 int64_t ser_stride, const double* sos, int nsec, int factor,
+                 float* out_dev, int64_t out_stride);
+
 /* ------------------------------------------------------------------------
  * Timing helper: HIP events on the context's stream (bench.py roofline).
  * ------------------------------------------------------------------------ */

@@ -543,3 +543,22 @@ def apply_filter(chans, filt, df, detrend=True):
                 y = sosfilt(sos, y)
         out.append(y)
     return out
+
+
+def decimate(chans, factor, df, maxorder=12):
+    """construct.py:1016-1017 ``st.decimate(decimate)`` on one stream: ObsPy 1.0.2
+    Trace.decimate (third-party, absent here; restated from its published
+    algorithm) = filter('lowpass_cheby_2', freq=df/2/factor, maxorder=12), a causal
+    sosfilt, then ``data[::factor]``.  lowpass_cheby_2: stop band at ``freq`` with
+    96 dB attenuation, 1 dB ripple, pass-band edge lowered by 1 % steps until
+    cheb2ord gives an order <= maxorder.  PARITY UNPINNED against ObsPy itself."""
+    from scipy.signal import cheb2ord, cheby2, zpk2sos, sosfilt
+    nyquist = df * 0.5
+    ws = min((df * 0.5 / float(factor)) / nyquist, 1.0)
+    wp, order = ws, 1e99
+    while order > maxorder:
+        wp *= 0.99
+        order, wn = cheb2ord(wp, ws, 1, 96, analog=0)
+    z, p, k = cheby2(order, 96, wn, btype='low', analog=0, output='zpk')
+    sos = zpk2sos(z, p, k)
+    return [sosfilt(sos, np.asarray(c, dtype=np.float64))[::factor] for c in chans]

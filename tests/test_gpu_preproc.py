@@ -61,42 +61,87 @@ def test_preprocess_feeds_the_scan(ctx):
     assert np.max(np.abs(ds[0, 0].cpu().numpy() - want)) <= 1e-5
 
 
-def test_detex_on_raw_continuous_data(ctx):
-    """SubSpace.detex with a raw ContinuousFetcher: per-chunk device filtering
-    feeds the scan; triggers equal those of the pre-filtered path run through the
-    oracle filter chunk by chunk."""
+@pytest.mark.parametrize('dec', [None, 2])
+def test_detex_on_raw_continuous_data(ctx, dec):
+    """SubSpace.detex / getFAS with a raw ContinuousFetcher: per-chunk device
+    decimation (dec) + filtering feeds the scan; triggers equal those of the oracle's
+    decimate -> filter -> DS chain run chunk by chunk, and everything downstream runs
+    at the decimated rate (detect.py:239)."""
     from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
     from detex_amd.getdata import multiplex
     rs = np.random.RandomState(12)
-    sr, Nc, L = 20.0, 3, 160
+    q = dec or 1
+    sr, Nc, L = 20.0, 3, 160                 # rate / template length AFTER decimation
+    sr_raw, Lr = sr * q, L * q
     filt = [1, 8, 2, True]
-    wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') *
-           np.exp(-np.arange(L) / 50.0) for _ in range(Nc)]
-    wavf = orc.apply_filter(wav, filt, sr)
+    wav = [np.convolve(rs.standard_normal(Lr + 6 * q), np.hanning(6 * q + 1), 'valid') *
+           np.exp(-np.arange(Lr) / (50.0 * q)) for _ in range(Nc)]
+
+    def prep(chans):
+        chans = [np.asarray(c, dtype=np.float32) for c in chans]
+        if dec:
+            chans = orc.decimate(chans, dec, sr_raw)
+        return orc.apply_filter(chans, filt, sr)
+    wavf = [w[:L] for w in prep(wav)]
     ef = EventFetcher(sr, ['E', 'N', 'Z'])
     for i in range(4):
         ef.add('XX.STA', 'ev%d' % i, np.array([rs.uniform(.5, 2) * w + 0.02 * rs.standard_normal(L)
                                                 for w in wavf]), starttime=100. * i)
-    T = int(1500 * sr)
+    T = int(1500 * sr_raw)
     con = rs.standard_normal((Nc, T)) * 0.3 + 500.0 + 0.001 * np.arange(T)
-    for t in (4000, 13000, 22000):
+    for t in (4000 * q, 13000 * q, 22000 * q):
         for c in range(Nc):
-            con[c, t:t + L] += 3.0 * wav[c]
-    cf = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=60, raw=True)
+            con[c, t:t + Lr] += 3.0 * wav[c]
+    cf = ContinuousFetcher(sr_raw, ['E', 'N', 'Z'], conDatDuration=600, conBuff=60, raw=True)
     cf.add('XX.STA', con.astype(np.float32), starttime=5.0e5)
-    cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, ctx=ctx)
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, decimate=dec, ctx=ctx)
     ss = createSubSpace(clust=cl, conDatFetcher=cf)
     ss.attachPickTimes(0.0, 6.0)
     ss.SVD(selectCriteria=4, selectValue=0, threshold=0.35, useSingles=False)
     res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=True)
     names, kinds, U, off, offsets, thr = ss._detector_bank('XX.STA', useSingles=False)
-    want = []
+    want, alld = [], []
     for chunk, t0 in cf.getConData('XX.STA'):
-        x = multiplex(orc.apply_filter(list(chunk.astype(np.float32)), filt, sr))
+        x = multiplex(prep(list(chunk)))
         ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        alld.append(ds)
         if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
             want += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, t0)]
     got = res['ss_df'].sort_values('STMP')
     assert len(got) == len(want) >= 3
     for (_, g), w in zip(got.iterrows(), sorted(want)):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and np.isfinite(g.SNR)
+    # false-alarm statistics over every chunk of the same raw fetcher (fas.py:88-117)
+    ss.getFAS(conDatNum=len(alld), staltalimit=None, seed=0)
+    fas = ss.subspaces['XX.STA'].FAS.iloc[0]
+    ref = np.histogram(np.concatenate(alld), bins=np.linspace(-.01, 1, 401))[0]
+    assert fas['hist'].sum() == ref.sum()
+    assert np.max(np.abs(np.cumsum(fas['hist']) - np.cumsum(ref))) <= 3    # bin-edge ties only
+
+
+@pytest.mark.parametrize('T,factor,sr,shape', [
+    (5000, 2, 100.0, (2, 3)),
+    (5001, 4, 100.0, (3,)),
+    (1023, 5, 500.0, (1, 6)),      # shorter than one block per series after the split
+    (372000, 4, 100.0, (3,)),      # full chunk length
+    (777, 1, 40.0, (2,)),          # factor 1: causal low-pass only
+    (4096, 16, 200.0, (1,)),
+])
+def test_decimate_matches_scipy(ctx, T, factor, sr, shape):
+    """dtx_decimate (construct.py:1016-1017) against the SciPy arithmetic ObsPy's
+    Trace.decimate delegates to; float32 output, 2e-6 of the peak amplitude."""
+    rs = np.random.RandomState(T + factor)
+    raw = (rs.standard_normal(shape + (T,)) * 50 + 300.0).astype(np.float32)
+    got = ctx.decimate(torch.from_numpy(raw).cuda(), factor, sr)
+    ctx.sync()
+    got = got.cpu().numpy()
+    assert got.shape == shape + ((T + factor - 1) // factor,)
+    flat, gflat = raw.reshape(-1, T), got.reshape(-1, got.shape[-1])
+    want = orc.decimate(list(flat), factor, sr)
+    for s in range(len(flat)):
+        assert np.max(np.abs(gflat[s] - want[s])) <= 2e-6 * np.max(np.abs(want[s])), s
+
+
+def test_decimate_rejects_large_factor(ctx):
+    with pytest.raises(ValueError):
+        ctx.decimate(torch.zeros((1, 100), device='cuda'), 17, 100.0)
