@@ -116,7 +116,6 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None."""
     import pandas as pd
     import torch
-    from .getdata import multiplex
     from .hip import HipContext
     names, kinds, U, det_off, offsets, thr = ss._detector_bank(sta, useSubSpaces, useSingles)
     if not names:
@@ -144,11 +143,14 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
             # band-passed separately, like the reference's per-chunk _applyFilter
             # (detect.py:231); after decimation everything runs at sr / decimate (detect.py:239)
             rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
-            xhost = xdev = None
+            xdev = None
             sr_raw, sr = sr, sr / dec
         else:
-            xhost = np.ascontiguousarray(multiplex(list(data)), dtype=np.float32)
-            xdev = torch.from_numpy(xhost).to(ctx.device)
+            # channel planes go up as they are and are interleaved on the device
+            # (construct.py:977-978; dtx_preprocess without filter or detrend)
+            planes = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
+            xdev = ctx.preprocess(planes[None], filt=None, detrend=False)[0]
+            del planes
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
@@ -178,37 +180,49 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
             if res['ncand'] > len(cv):
                 raise RuntimeError('candidate buffer overflow (%d > %d): threshold far too low'
                                    % (res['ncand'], len(cv)))
-            for b in range(i1 - i0):
+            mp_cache = {}
+            # candidates grouped by (chunk, detector); pairs without one cannot trigger
+            key = cb.astype(np.int64) * D + cd
+            order = np.argsort(key, kind='stable')               # keeps p ascending per pair
+            ks, first = np.unique(key[order], return_index=True)
+            last = np.append(first[1:], len(order))
+            for kk, f0, f1 in zip(ks, first, last):
+                b, d = int(kk // D), int(kk % D)
+                name = names[d]
                 start = bounds[i0 + b][2]
-                for d, name in enumerate(names):
-                    sel = (cb == b) & (cd == d)
-                    trig = pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
-                                                float(maxds[b, d]))
-                    row_dev = ds[b, d]
+                sel = order[f0:f1]
+                trig = pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
+                                            float(maxds[b, d]))
+                row_dev = ds[b, d]
 
-                    def fetch(lo, hi, _r=row_dev):
-                        return np.abs(_r[lo:hi].cpu().numpy().astype(np.float64))
-                    for (ti, coef) in trig:
-                        if coef > 1.05:                          # detect.py:199-204
-                            continue
-                        if fillZeros:                            # detect.py:414-415
+                def fetch(lo, hi, _r=row_dev):
+                    return np.abs(_r[lo:hi].cpu().numpy().astype(np.float64))
+                for (ti, coef) in trig:
+                    if coef > 1.05:                          # detect.py:199-204
+                        continue
+                    if fillZeros:                            # detect.py:414-415
+                        sl = 0.0
+                    else:
+                        try:
+                            sl = stalta_at(fetch, ti, P, LTA, STA)
+                        except IndexError:                   # detect.py:289-295, 417-420
                             sl = 0.0
+                    times = float(ti) / sr + start           # detect.py:413
+                    of = offsets[name]
+                    pem = stm = snr = np.nan
+                    if estimateMags:                         # detect.py:422-429
+                        if raw:
+                            mpc = mp_host[b]
                         else:
-                            try:
-                                sl = stalta_at(fetch, ti, P, LTA, STA)
-                            except IndexError:                   # detect.py:289-295, 417-420
-                                sl = 0.0
-                        times = float(ti) / sr + start           # detect.py:413
-                        of = offsets[name]
-                        pem = stm = snr = np.nan
-                        if estimateMags:                         # detect.py:422-429
-                            c0 = (bounds[i0 + b][0]) * Nc
-                            mpc = mp_host[b] if raw else xhost[c0:c0 + M]
-                            pem, stm, snr = est_mag(ti, Nc, mpc, ss._bank_mags[name],
-                                                    U[det_off[d]:det_off[d + 1]],
-                                                    ss._bank_ewf[name], kinds[d] == 'ss')
-                        rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
-                                               times - np.min(of), stm, snr, pem])
+                            if b not in mp_cache:            # the chunk as the scan saw it
+                                c0 = bounds[i0 + b][0] * Nc
+                                mp_cache[b] = xdev[c0:c0 + M].cpu().numpy()
+                            mpc = mp_cache[b]
+                        pem, stm, snr = est_mag(ti, Nc, mpc, ss._bank_mags[name],
+                                                U[det_off[d]:det_off[d + 1]],
+                                                ss._bank_ewf[name], kinds[d] == 'ss')
+                    rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
+                                           times - np.min(of), stm, snr, pem])
         ctx.sync()
         h = hist.cpu().numpy()
     finally:
