@@ -11,3 +11,4 @@ from ._lib import DetexHipError  # noqa: F401
 from .construct import createCluster, createSubSpace  # noqa: F401,E402
 from .getdata import ContinuousFetcher, EventFetcher, multiplex  # noqa: F401,E402
 from .subspace import Cluster, ClusterStream, SubSpace  # noqa: F401,E402
+from .results import detResults, SSResults  # noqa: F401,E402

@@ -448,15 +448,27 @@ class SubSpace(object):
             for k, df in out.items():
                 if len(df):
                     df.to_sql(k, con, if_exists='append', index=False)
+            # subspace.py:1905-1953 _getInfoDF: ss_info / sg_info (events comma-separated)
+            def beta_of(fas):
+                bd = (fas or {}).get('betadist') if isinstance(fas, dict) else None
+                return (bd[0], bd[1]) if bd is not None and len(bd) > 1 else (np.nan, np.nan)
             info = []
             for sta in self.ssStations:
                 for _, r in self.subspaces[sta].iterrows():
-                    info.append(dict(Sta=sta, Name=r.Name, Events='-'.join(r.Events),
+                    b1, b2 = beta_of(r.FAS)
+                    info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
                                      Threshold=r.Threshold, NumBasisUsed=r.NumBasis,
-                                     beta1=(r.FAS or {}).get('betadist', [np.nan])[0],
-                                     beta2=(r.FAS or {}).get('betadist', [np.nan] * 2)[1]))
+                                     beta1=b1, beta2=b2))
             if info:
                 pd.DataFrame(info).to_sql('ss_info', con, if_exists='replace', index=False)
+            info = []
+            for sta in self.singStations:
+                for _, r in self.singles[sta].iterrows():
+                    b1, b2 = beta_of(r.FAS)
+                    info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
+                                     Threshold=r.Threshold, beta1=b1, beta2=b2))
+            if info:
+                pd.DataFrame(info).to_sql('sg_info', con, if_exists='replace', index=False)
             for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
                 rows = [dict(Sta=sta, Name=name, Value=' '.join(str(int(v)) for v in h))
                         for sta, d in hd.items() for name, h in (d or {}).items()]

@@ -74,6 +74,7 @@ def import_reference():
         int(n), center=center).mean().values
     pd.rolling_std = lambda x, n: pd.Series(x).rolling(int(n)).std().values
     pd.rolling_var = lambda x, n: pd.Series(x).rolling(int(n)).var().values
+    pd.DataFrame.iteritems = pd.DataFrame.items     # removed in pandas 2.0 (util.py:925)
     scipy.real = np.real
     scipy.dot = np.dot
     np.NAN = np.NaN = np.nan

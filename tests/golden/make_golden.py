@@ -20,6 +20,9 @@ Reference entry points exercised (file:line in /root/reference):
   detex/detect.py:390-445     _CreateCoeffArray, 545-557 _downPlay..., 526-543
                               _evalTrigCon   -> trig.npz
   detex/detect.py:447-499     _estMag (+637-664) -> estmag.npz
+  detex/results.py:371-400    _deleteDetDups, 403-458 _associateDetections,
+                              476-503 _createDetTable / _createAutoTable,
+                              231-293 _verifyEvents -> assoc.json
 """
 import os
 import sys
@@ -346,6 +349,101 @@ def gen_estmag():
     print('estmag.npz written', {k: v for k, v in out.items() if k[:2] in ('ss', 'sg')})
 
 
+# ---------------------------------------------------------------------------
+# results: per-station reduction, cross-station association, verification
+# ---------------------------------------------------------------------------
+
+class _UTC(object):
+    """The two things the association code needs of obspy.UTCDateTime (absent
+    here): ``.timestamp`` of a float / ISO string, and ``str()`` ->
+    'YYYY-MM-DDTHH:MM:SS.ffffffZ'."""
+
+    def __init__(self, x=0.0):
+        import datetime
+        if isinstance(x, _UTC):
+            x = x.timestamp
+        if isinstance(x, str):
+            fmt = '%Y-%m-%dT%H:%M:%S.%f' if '.' in x else '%Y-%m-%dT%H:%M:%S'
+            x = datetime.datetime.strptime(x.rstrip('Z'), fmt).replace(
+                tzinfo=datetime.timezone.utc).timestamp()
+        self.timestamp = float(x)
+
+    def __str__(self):
+        import datetime
+        d = datetime.datetime.fromtimestamp(round(self.timestamp, 6), datetime.timezone.utc)
+        return d.strftime('%Y-%m-%dT%H:%M:%S.%f') + 'Z'
+
+
+def gen_assoc():
+    import json
+    import sqlite3
+    import tempfile
+    res = detex.results
+    res.obspy.UTCDateTime = _UTC
+    res.obspy.core.UTCDateTime = _UTC
+    cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
+            'ProEnMag']
+    cases = []
+    for seed in range(6):
+        rs = np.random.RandomState(100 + seed)
+        stas = ['TA.M17A', 'TA.M18A', 'UU.BRPU', 'UU.CWU', 'UU.SRU'][:3 + seed % 3]
+        t_events = 1.4e9 + np.cumsum(rs.uniform(3, 900, 14))
+        rows = {'ss_df': [], 'sg_df': []}
+        for t in t_events:
+            for sta in stas:
+                if rs.rand() < 0.35:
+                    continue
+                for nm in ['SS0', 'SS1', 'SG0'][:rs.randint(1, 4)]:
+                    tt = t + rs.uniform(-.4, .4)
+                    mag = rs.uniform(0, 3) if rs.rand() < .7 else np.nan
+                    rows['sg_df' if nm.startswith('SG') else 'ss_df'].append(
+                        [rs.uniform(.3, .95), rs.uniform(2, 9), tt, nm, sta,
+                         tt - rs.uniform(1.5, 2.5), tt - rs.uniform(.2, 1.2), mag,
+                         rs.uniform(1, 20), rs.uniform(0, 3) if rs.rand() < .7 else np.nan])
+        temkey = pd.DataFrame({'NAME': ['tem%d' % i for i in range(3)],
+                               'TIME': [float(t_events[i]) - 1.4 for i in (1, 5, 9)],
+                               'LAT': [40., 41., 42.], 'LON': [-110., -111., -112.],
+                               'MAG': [1., 2., 3.], 'DEPTH': [5., 6., 7.]})
+        veri = pd.DataFrame({'TIME': [float(t_events[i]) - 1.2 for i in (2, 5, 11)] + [1.39e9],
+                             'LAT': [1., 2., 3., 4.], 'LON': [5., 6., 7., 8.],
+                             'MAG': [.5, 1.5, 2.5, 3.5], 'DEPTH': [1., 2., 3., 4.],
+                             'NAME': ['v0', 'v1', 'v2', 'v3'], 'EXTRA': ['a', 'b', 'c', 'd']})
+        req = 2 + seed % 2
+        exc = [None, 0.9, {'TA.M17A': 0.85}][seed % 3]
+        with tempfile.TemporaryDirectory() as tmp:
+            db = os.path.join(tmp, 'ss.db')
+            con = sqlite3.connect(db)
+            for k, v in rows.items():
+                pd.DataFrame(v, columns=cols).to_sql(k, con, index=False)
+            con.close()
+            ssdf = res._deleteDetDups(db, 0, 0, 1, None, None, None, 'ss_df', PfKey=None)
+            sgdf = res._deleteDetDups(db, 0, 0, 2.5, None, None, None, 'sg_df', PfKey=None)
+            df = pd.concat([ssdf, sgdf], ignore_index=True)
+            Dets, Autos = res._associateDetections(df.copy(), 0, req, 1, None, temkey.copy(), exc)
+            vpath = os.path.join(tmp, 'veri.csv')       # _readVeriFile reads files only
+            veri.to_csv(vpath, index=False)
+            Vers = res._verifyEvents(Dets, Autos, vpath, 1, True)
+
+        def table(t):
+            out = []
+            for _, r in t.iterrows():
+                d = {c: (r[c] if not isinstance(r[c], (np.floating, float)) else float(r[c]))
+                     for c in t.columns if c != 'Dets'}
+                d['members'] = [[m.Sta, m.Name, float(m.STMP)] for _, m in r.Dets.iterrows()]
+                out.append(d)
+            return out
+        cases.append(dict(
+            seed=seed, requiredNumStations=req, exceptionalThreshold=exc,
+            ss_df=rows['ss_df'], sg_df=rows['sg_df'], temkey=temkey.to_dict('list'),
+            veri=veri.to_dict('list'),
+            reduced=[[r.Sta, r.Name, float(r.STMP)] for _, r in df.iterrows()],
+            Dets=table(Dets), Autos=table(Autos),
+            Vers=[[r.Event, r.VerName, float(r.VerMag), r.EXTRA] for _, r in Vers.iterrows()]))
+    with open(os.path.join(HERE, 'assoc.json'), 'w') as f:
+        json.dump(dict(cols=cols, cases=cases), f, indent=0, allow_nan=True)
+    print('assoc.json written', [(len(c['Dets']), len(c['Autos']), len(c['Vers'])) for c in cases])
+
+
 if __name__ == '__main__':
     gen_ccx2()
     gen_cclags()
@@ -353,3 +451,4 @@ if __name__ == '__main__':
     gen_mpxds()
     gen_trig()
     gen_estmag()
+    gen_assoc()

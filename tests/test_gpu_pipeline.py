@@ -127,10 +127,17 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
     # SQLite output with the reference's tables
     con = sqlite3.connect(db)
     tabs = set(r[0] for r in con.execute("select name from sqlite_master where type='table'"))
-    assert {'ss_df', 'ss_info', 'ss_hist', 'sg_hist', 'filt_params'} <= tabs
+    assert {'ss_df', 'ss_info', 'sg_info', 'ss_hist', 'sg_hist', 'filt_params'} <= tabs
     n_db = con.execute('select count(*) from ss_df').fetchone()[0]
     con.close()
     assert n_db == len(res['ss_df'])
+    # downstream consumer (results.py): one station, so every detection is its own event;
+    # the planted copies are new detections, none coincides with a template origin time
+    from detex_amd import detResults
+    assoc = detResults(ssDB=db, templateKey=workflow['ef'], requiredNumStations=1)
+    assert len(assoc.Autos) == 0 and len(assoc.Dets) >= len(workflow['plants']) - 1
+    assert assoc.info is not None and set(assoc.info.Sta) == {'TA.M17A'}
+    assert all(',' in e or len(e) for e in assoc.info.Events)
 
 
 def test_fas_matches_scipy(workflow):
