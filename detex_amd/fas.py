@@ -141,10 +141,20 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             D = len(names)
             hist = torch.zeros((D, numBins - 1), dtype=torch.int32, device=ctx.device)
             sums = torch.zeros((D, 5), dtype=torch.float64, device=ctx.device)
+            # chunks of equal length go through the scan together (one launch fills the chip
+            # better than one launch per chunk); batches bounded to ~4 GB of DS
+            bylen = {}
             for k in chosen:
-                mp = chunk_mp(k)[0]
-                ds = ctx.subspace_ds(mp)
-                ctx.ds_moments(ds, lo=-.01, hi=1.0, nbins=numBins - 1, hist=hist, sums=sums)
+                bylen.setdefault(int(chunk_mp(k)[0].shape[1]), []).append(k)
+            for M, ks in sorted(bylen.items()):
+                per = max(1, int(4e9 // (4.0 * D * max(1, (M - n) // Nc + 1))))
+                for i in range(0, len(ks), per):
+                    grp = ks[i:i + per]
+                    mp = chunk_mp(grp[0])[0] if len(grp) == 1 else \
+                        torch.cat([chunk_mp(k)[0] for k in grp], dim=0)
+                    ds = ctx.subspace_ds(mp)
+                    ctx.ds_moments(ds, lo=-.01, hi=1.0, nbins=numBins - 1, hist=hist, sums=sums)
+                    del ds
             ctx.sync()
             h = hist.cpu().numpy()
             sm = sums.cpu().numpy()
