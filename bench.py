@@ -78,6 +78,18 @@ def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as a child job (one process per
+        # GPU, RCCL rendezvous on the loopback address) before anything here touches a GPU
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+               '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))

@@ -78,7 +78,7 @@ int dtx_ctx_create(int device, void* stream, int own_stream, dtx_ctx** out) {
   for (auto ev : evs) {
     e = hipEventCreate(ev);
     if (e != hipSuccess) {
-      delete c;
+      (void)dtx_ctx_destroy(c);          // releases the stream and the events made so far
       return dtx_fail(nullptr, DTX_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
     }
   }
