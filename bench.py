@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1 sparse figure)
+# what a registers-only bf16 MFMA loop sustains on this chip with random operands (the power
+# limit clocks it down to 1.96 GHz; 2479 with all-zero operands): scripts/probe/mfma_peak.hip,
+# profiles/p1_mfma_peak.txt.  Reported next to the nominal peak, never instead of it.
+SUSTAINED_BF16_MFMA_TFLOPS = 2057.0
 
 
 def parse():
@@ -202,9 +206,17 @@ def main():
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                      'kernel_ms': kms, 'flop_per_launch': flops, 'engine': a.engine,
                      'note': ('algorithmic flop = 2*K*n per window; the split engine issues 3 bf16 '
-                              'MFMAs per float32 product, so its ceiling is peak/3')
+                              'MFMAs per float32 product, so its ceiling is peak/3; issued_mfma_tflops '
+                              'counts those 3 MFMAs on the zero-padded 16-row blocks and is to be read '
+                              'against sustained_peak (measured power-limited rate of a registers-only '
+                              'bf16 MFMA loop on random operands, profiles/p1_mfma_peak.txt)')
                      if a.engine != 'fp32' else 'algorithmic flop = 2*K*n per window'},
     }
+    if a.engine != 'fp32':
+        issued = 3.0 * achieved * (16.0 * rm) / min(K, 208) if K <= 208 else None
+        out['roofline']['sustained_peak'] = SUSTAINED_BF16_MFMA_TFLOPS
+        out['roofline']['issued_mfma_tflops'] = issued
+        out['roofline']['issued_frac_of_sustained'] = issued / SUSTAINED_BF16_MFMA_TFLOPS if issued else None
     if rank == 0 and world == 1 and a.engine != 'fp32' and default_cfg:
         ctx.set_engine('fp32')                  # the float32-MFMA engine on the same input
         step()

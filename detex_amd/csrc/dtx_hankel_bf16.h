@@ -38,7 +38,19 @@ namespace dtx {
 #define DTX_TNS_BIG 3
 #endif
 __host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? DTX_TNS_BIG : 4; }
-// slots per shifted copy in LDS: NS + 4 == 12 (mod 16) makes the B reads conflict-free
+// "wide" variant for the big K-tiles (-DDTX_WIDE=1): 4 waves per block, one per SIMD, with
+// the whole 512-entry register file each -> twice the column tiles per wave (same block
+// tile), i.e. every A fragment read from LDS feeds twice the MFMAs (-41 % LDS reads).
+// Measured (profiles/README.md, "power"): on noise it ties with the 8-wave kernel
+// (58.6 vs 59.1 ms) because both sit on the chip's power limit; on all-zero data, where
+// nothing throttles, one wave per SIMD hides less latency (51.4 vs 46.7 ms).  Off by default.
+#ifndef DTX_WIDE
+#define DTX_WIDE 0
+#endif
+__host__ __device__ constexpr int nw_s(int rm) { return (DTX_WIDE && rm >= 9) ? 4 : 8; }
+__host__ __device__ constexpr int tnw_s(int rm) { return tn_s(rm) * 8 / nw_s(rm); }
+// slots per shifted copy in LDS (block tile of 128 * tn columns): NS + 4 == 12 (mod 16)
+// makes the B reads conflict-free
 __host__ __device__ constexpr int xs_for(int tn) { return (128 * tn + kBQ) / 8 + 4; }
 // bytes of LDS one block needs (two buffers of A tile + x image)
 __host__ __device__ constexpr int lds_bytes_s(int rm) {
@@ -62,21 +74,40 @@ __device__ __forceinline__ void lds_wait() {
 
 // g16: shifted bf16 copies of this block's stream planes, [Nc][2][8][V] slots of 16 B,
 // already offset to the block's chunk; v0 = p0 / 8 is added inside.
-template <int RM, int TN>
+// One bf16 MFMA into an accumulator tile.  The 8-wave kernels let hipcc allocate (VGPR
+// accumulators).  The 4-wave "wide" kernels own 256 VGPRs + 256 AGPRs per wave; hipcc
+// selects ONE accumulator register class per function and, past 256 accumulator
+// registers, copies tiles in and out of AGPRs around every MFMA -- so there the class is
+// fixed per tile through the asm constraint: tiles [0, 64) in AGPRs, the rest in VGPRs.
+template <int MODE>   // 0: builtin, 1: AGPR tile, 2: VGPR tile
+__device__ __forceinline__ void mfma_bf16(f32x4& c, const i32x4& a, const i32x4& b) {
+  if constexpr (MODE == 0) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  } else if constexpr (MODE == 1) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+}
+
+// NW waves per block, TN column tiles per wave: block tile [16 RM] x [16 TN NW]
+template <int RM, int TN, int NW = 8>
 __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
                                                        const uint16_t* __restrict__ at16, int Lp,
                                                        const i32x4* __restrict__ g16, int64_t V,
                                                        int64_t v0, int Nc, int jlo, int jhi,
                                                        char* lds) {
   constexpr int KT = 16 * RM;
-  constexpr int PT = 128 * TN;
+  constexpr int PT = 16 * TN * NW;
+  static_assert(PT % 128 == 0, "block tile is a multiple of 128 columns");
   constexpr int NS = (PT + kBQ) / 8;               // x slots per copy per step
-  constexpr int XS = xs_for(TN);                   // padded slot stride of a copy in LDS
+  constexpr int XS = xs_for(PT / 128);             // padded slot stride of a copy in LDS
   constexpr int ABYTES = 256 * KT;                 // A tile of one step
   constexpr int XBYTES = 2 * 8 * XS * 16;
   constexpr int BUF = ABYTES + XBYTES;
   constexpr int UNITS = ABYTES / 1024;             // 1 KiB LDS-DMA units
-  constexpr int NGU = (UNITS + 7) / 8;
+  constexpr int NGU = (UNITS + NW - 1) / NW;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kg = lane >> 4;
@@ -92,11 +123,11 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
   // (h*8 + m) of G (pad slots re-read the last real slot)
   constexpr int NXU = 16 * XS / 64;                // 1 KiB units of the x image
   static_assert((16 * XS) % 64 == 0, "x image must be whole LDS-DMA units");
-  constexpr int NGX = (NXU + 7) / 8;
+  constexpr int NGX = (NXU + NW - 1) / NW;
   int xsrc[NGX];
 #pragma unroll
   for (int m = 0; m < NGX; ++m) {
-    const int pos = (wave + 8 * m) * 64 + lane;
+    const int pos = (wave + NW * m) * 64 + lane;
     const int hm = pos / XS, vl = pos - hm * XS;
     xsrc[m] = (hm < 16) ? hm * 65536 + (vl < NS ? vl : NS - 1) : 0;
   }
@@ -109,16 +140,16 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
                       ((int64_t)c_ * (Lp / 8) + j0_ / 8) * (2 * KT * 16) + lane * 16;        \
     char* ld_ = lds + (buf_) * BUF;                                                         \
     _Pragma("unroll") for (int m = 0; m < NGU; ++m) {                                       \
-      const int u_ = wave_u + 8 * m;                                                        \
-      if ((m + 1) * 8 <= UNITS || u_ < UNITS)                                               \
+      const int u_ = wave_u + NW * m;                                                       \
+      if ((m + 1) * NW <= UNITS || u_ < UNITS)                                              \
         __builtin_amdgcn_global_load_lds(                                                   \
             (const __attribute__((address_space(1))) void*)(ab_ + u_ * 1024),               \
             (__attribute__((address_space(3))) void*)(ld_ + u_ * 1024), 16, 0, 0);          \
     }                                                                                       \
     const i32x4* gx_ = g16 + (int64_t)c_ * (2 * 8) * V + v0 + j0_ / 8;                      \
     _Pragma("unroll") for (int m = 0; m < NGX; ++m) {                                       \
-      const int u_ = wave_u + 8 * m;                                                        \
-      if ((m + 1) * 8 <= NXU || u_ < NXU)                                                   \
+      const int u_ = wave_u + NW * m;                                                       \
+      if ((m + 1) * NW <= NXU || u_ < NXU)                                                 \
         __builtin_amdgcn_global_load_lds(                                                   \
             (const __attribute__((address_space(1))) void*)(gx_ + (int64_t)(xsrc[m] >> 16) * V + \
                                                             (xsrc[m] & 0xFFFF)),            \
@@ -160,20 +191,18 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
                   : (u + 1 < NU ? 2 : 0) +
                         ((u >= 1 && (u - 1) % RM == 0 && (u - 1) / RM + 1 < 2) ? 2 * TN : 0);
       lds_wait<younger>();
-      const bf16x8 ahi = __builtin_bit_cast(bf16x8, ar[u % 3][0]);
-      const bf16x8 alo = __builtin_bit_cast(bf16x8, ar[u % 3][1]);
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            alo, __builtin_bit_cast(bf16x8, br[kk & 1][t][0]), acc[r][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            ahi, __builtin_bit_cast(bf16x8, br[kk & 1][t][1]), acc[r][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            ahi, __builtin_bit_cast(bf16x8, br[kk & 1][t][0]), acc[r][t], 0, 0, 0);
+      static_for<0, TN>([&](auto tc) {
+        constexpr int t = tc, md = NW == 8 ? 0 : (r * TN + t < 64 ? 1 : 2);
+        mfma_bf16<md>(acc[r][t], ar[u % 3][1], br[kk & 1][t][0]);
+      });
+      static_for<0, TN>([&](auto tc) {
+        constexpr int t = tc, md = NW == 8 ? 0 : (r * TN + t < 64 ? 1 : 2);
+        mfma_bf16<md>(acc[r][t], ar[u % 3][0], br[kk & 1][t][1]);
+      });
+      static_for<0, TN>([&](auto tc) {
+        constexpr int t = tc, md = NW == 8 ? 0 : (r * TN + t < 64 ? 1 : 2);
+        mfma_bf16<md>(acc[r][t], ar[u % 3][0], br[kk & 1][t][0]);
+      });
       // issue: B of the next kk when this iteration opens a kk, then A(u + 2)
       if constexpr (r == 0 && kk + 1 < 2) {
         static_for<0, TN>([&](auto tc) {
@@ -190,6 +219,9 @@ __device__ __forceinline__ void hankel_mainloop_bf16x3(f32x4 (&acc)[RM][TN],
     });
     __syncthreads();
   }
+  // the asm MFMAs are opaque to hipcc's hazard recogniser: let the last ones retire
+  // before anything reads the accumulators
+  if constexpr (NW != 8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #undef DTX_S_STAGE
 }
 

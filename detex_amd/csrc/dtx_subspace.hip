@@ -175,10 +175,11 @@ struct DsArgs {
 // mean correction, per-detector energy (membership MFMA on the accumulator tile),
 // normalisation and store; shared by the float32 and the split-bf16 kernels (same
 // accumulator layout).  `lds` must hold 2*KT + 64 floats and be free.
-template <int RM, int TN>
+template <int RM, int TN, int NW = 8>
 __device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& a, int chunk,
                                             int64_t p0, float* lds) {
   constexpr int KT = 16 * RM;
+  constexpr int kThreads = 64 * NW;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int col0 = wave * 16 * TN;
@@ -271,9 +272,9 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
 }
 
 // split-bf16 engine (dtx_hankel_bf16.h): same tile, three bf16 MFMAs per product
-template <int RM, int TN>
-__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel_s(const DsArgs a) {
-  constexpr int PT = 128 * TN;
+template <int RM, int TN, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void ds_mfma_kernel_s(const DsArgs a) {
+  constexpr int PT = 16 * TN * NW;
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes_s(RM)];
   const int chunk = blockIdx.x / a.nptiles;
   const int pt = blockIdx.x - chunk * a.nptiles;
@@ -283,19 +284,20 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel_s(const DsArgs a) 
   for (int r = 0; r < RM; ++r)
 #pragma unroll
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  hankel_mainloop_bf16x3<RM, TN>(acc, a.ut16, a.Lp, a.g16 + (int64_t)chunk * a.Nc * 16 * a.V, a.V,
-                                 p0 / 8, a.Nc, 0, a.Lp, lds);
-  ds_epilogue<RM, TN>(acc, a, chunk, p0, reinterpret_cast<float*>(lds));
+  hankel_mainloop_bf16x3<RM, TN, NW>(acc, a.ut16, a.Lp, a.g16 + (int64_t)chunk * a.Nc * 16 * a.V,
+                                     a.V, p0 / 8, a.Nc, 0, a.Lp, lds);
+  ds_epilogue<RM, TN, NW>(acc, a, chunk, p0, reinterpret_cast<float*>(lds));
 }
 
 template <int RM>
 int launch_tile_s(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
-  constexpr int TN = tn_s(RM);
-  constexpr int PT = 128 * TN;
+  constexpr int NW = nw_s(RM);
+  constexpr int TN = tnw_s(RM);
+  constexpr int PT = 16 * TN * NW;
   DsArgs b = a;
   b.nptiles = (int)((a.P + PT - 1) / PT);
   dim3 grid((unsigned)(b.nptiles * nchunk));
-  hipLaunchKernelGGL((ds_mfma_kernel_s<RM, TN>), grid, dim3(kThreads), 0, ctx->stream, b);
+  hipLaunchKernelGGL((ds_mfma_kernel_s<RM, TN, NW>), grid, dim3(64 * NW), 0, ctx->stream, b);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }
