@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--sr', type=float, default=100.0)
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
-    ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3'],
+    ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3', 'fft'],
                     help="fp32: exact float32 MFMA; bf16x3: split-bfloat16 MFMA (3 bf16 products "
                          "per float32 product, float32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -41,6 +41,7 @@ void dtx_free_tiles_internal(dtx_ctx* c) {
     if (t.doff_dev) (void)hipFree(t.doff_dev);
   }
   c->tiles.clear();
+  dtx_fft_free(c);
 }
 
 extern "C" {
@@ -92,7 +93,8 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   dtx_free_tiles_internal(ctx);
   DtxBuf* bufs[] = {&ctx->ws_xp, &ctx->ws_mean, &ctx->ws_den,
-                    &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3, &ctx->ws_g, &ctx->ws_csum};
+                    &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3, &ctx->ws_g, &ctx->ws_csum,
+                    &ctx->ws_xhat};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
   hipEvent_t evs[4] = {ctx->ev_t0, ctx->ev_t1, ctx->ev_k0, ctx->ev_k1};

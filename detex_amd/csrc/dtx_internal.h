@@ -26,6 +26,23 @@ struct DtxKTile {
   int32_t* doff_dev = nullptr;  // [nd+1] detector row offsets local to the tile
 };
 
+// Frequency-domain engine (dtx_fft.hip): pair spectra of the basis, built on first use
+#ifndef DTX_FFT_N
+#define DTX_FFT_N 8192
+#endif
+struct DtxFft {
+  bool ok = false;
+  int V = 0;                   // windows per block (block advance), a multiple of 512
+  int nunits = 0, npairs = 0;
+  void* W_dev = nullptr;       // [npairs][Nc][DTX_FFT_N] complex64
+  void* tab_dev = nullptr;     // [DTX_FFT_N] twiddle table
+  void* unit_dev = nullptr;    // [nunits] int4
+  void* pinfo_dev = nullptr;   // [npairs] float4
+};
+// templates (samples per channel) the frequency-domain engine takes; others fall back
+constexpr int kFftMinL = 2;
+constexpr int kFftMaxL = DTX_FFT_N - 2048 + 1;
+
 struct DtxBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -40,9 +57,12 @@ struct dtx_ctx {
   // basis
   int D = 0, n = 0, Nc = 0, L = 0, Lp = 0, Ktot = 0;
   std::vector<DtxKTile> tiles;
+  std::vector<float> hU;        // host copy of the stacked basis [Ktot][n] (for lazily built images)
+  std::vector<int32_t> hdoff;   // [D+1]
+  DtxFft fft;
 
   // workspaces (grown on demand, never shrunk)
-  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum;
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat;
   int engine = DTX_ENGINE_BF16X3;
 
   // timing
@@ -56,6 +76,11 @@ int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes);
 void dtx_free_tiles_internal(dtx_ctx* c);
 // shortest template (samples per channel) the split-bf16 engine is used for
 constexpr int kSplitMinL = 64;
+void dtx_fft_free(dtx_ctx* ctx);
+bool dtx_fft_eligible(int L);
+int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n, int Nc);
+int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp);
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

@@ -394,6 +394,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
 
   dtx_free_tiles_internal(ctx);
   ctx->D = D; ctx->n = n; ctx->Nc = Nc; ctx->L = L; ctx->Lp = Lp; ctx->Ktot = Ktot;
+  ctx->hdoff.assign(det_off, det_off + D + 1);
 
   // greedy packing of whole detectors into K-tiles of <= 208 rows
   int d = 0;
@@ -449,6 +450,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
                            hipMemcpyHostToDevice));
     d = dend;
   }
+  ctx->hU.swap(hU);   // kept for the images that are built on first use (frequency-domain engine)
   return DTX_OK;
 }
 
@@ -504,12 +506,19 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     DTX_HIP(ctx, hipGetLastError());
   }
 
+  if (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) {
+    if (!ctx->fft.ok &&
+        (rc = dtx_fft_basis_build(ctx, ctx->hU.data(), ctx->hdoff.data(), ctx->D, n, Nc)))
+      return rc;
+    return dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp);
+  }
+
   i32x4* g16 = nullptr;
   const int64_t V = Tpad / 8;
   // templates shorter than kSplitMinL samples per channel stay on the float32 engine:
   // with so few products per window the split products' 2^-17 errors do not average out
   // (and the padding of L to the 32-sample steps of the bf16 MFMA would dominate anyway)
-  if (ctx->engine == DTX_ENGINE_BF16X3 && ctx->L >= kSplitMinL) {
+  if (ctx->engine != DTX_ENGINE_FP32 && ctx->L >= kSplitMinL) {
     if ((rc = dtx_reserve(ctx, ctx->ws_g, (size_t)nchunk * Nc * 16 * V * sizeof(i32x4)))) return rc;
     g16 = (i32x4*)ctx->ws_g.p;
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
@@ -532,7 +541,7 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
 
 int dtx_set_engine(dtx_ctx* ctx, int engine) {
   if (!ctx) return DTX_E_ARG;
-  if (engine != DTX_ENGINE_FP32 && engine != DTX_ENGINE_BF16X3)
+  if (engine != DTX_ENGINE_FP32 && engine != DTX_ENGINE_BF16X3 && engine != DTX_ENGINE_FFT)
     return dtx_fail(ctx, DTX_E_ARG, "unknown engine %d", engine);
   ctx->engine = engine;
   return DTX_OK;

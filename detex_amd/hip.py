@@ -91,7 +91,7 @@ class HipContext(object):
     def set_engine(self, engine):
         """'bf16x3' (default: split-bfloat16 MFMA, float32-level accuracy, 3.6x
         faster) or 'fp32' (float32 MFMA, products bitwise an fma chain)."""
-        code = {'fp32': 0, 'bf16x3': 1}[engine]
+        code = {'fp32': 0, 'bf16x3': 1, 'fft': 2}[engine]
         self._ck(self.lib.dtx_set_engine(self.h, code), 'dtx_set_engine')
         self.engine = engine
 

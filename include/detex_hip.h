@@ -84,9 +84,17 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
  *                      float64 reference as closely as the FP32 engine does: both
  *                      are limited by float32 accumulation, ~2e-6 at DS = 1, 1e-8
  *                      on noise), 3.6x faster.  Templates shorter than 64 samples
- *                      per channel are always computed by the FP32 engine. */
+ *                      per channel are always computed by the FP32 engine.
+ *   DTX_ENGINE_FFT     frequency-domain (overlap-save) evaluation of the same statistic,
+ *                      the reference's own route (detect.py:559-578: ifft(ssFD * xFD)):
+ *                      8192-point float32 transforms in LDS, two basis vectors per
+ *                      complex transform, ~150x fewer flops than the contraction.
+ *                      Float32 error grows with log(8192) instead of sqrt(n): ~2e-7 at
+ *                      DS = 1.  Templates longer than 6145 samples per channel fall
+ *                      back to DTX_ENGINE_BF16X3. */
 #define DTX_ENGINE_FP32 0
 #define DTX_ENGINE_BF16X3 1
+#define DTX_ENGINE_FFT 2
 int dtx_set_engine(dtx_ctx* ctx, int engine);
 
 /* Number of detection windows for a data block of M multiplexed samples:

@@ -16,7 +16,7 @@ from oracle import detex_oracle as orc  # noqa: E402
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'fp32'])
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'fft'])
 def ctx(request):
     from detex_amd.hip import HipContext
     c = HipContext(0)
@@ -100,7 +100,7 @@ def test_engines_agree_fullsize(ctx):
     ctx.upload_basis(U, off, Nc)
     ds_s = ctx.subspace_ds(xt)
     c32 = HipContext(0)
-    c32.set_engine('fp32' if ctx.engine == 'bf16x3' else 'bf16x3')
+    c32.set_engine('fp32' if ctx.engine != 'fp32' else 'bf16x3')
     c32.upload_basis(U, off, Nc)
     ds_f = c32.subspace_ds(xt)
     ctx.sync()
