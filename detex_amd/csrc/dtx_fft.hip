@@ -42,6 +42,16 @@ namespace {
 constexpr int kN = DTX_FFT_N;        // transform length (complex points)
 constexpr int kT = 512;              // threads per workgroup, 16 points each
 constexpr int kLdsC = kN + kN / 32;  // complex slots of the padded LDS image
+constexpr int kXh = kN / 2 + 8;      // complex slots of one stored half spectrum (f = 0 .. kN/2)
+// L2-sized tiles of the (unit, block) work space: the workgroups an XCD runs together
+// share kTileU units' spectra and kTileB blocks' spectra (see ds_fft_kernel)
+constexpr int kTileU = 2, kTileB = 16, kTile = kTileU * kTileB;
+#ifndef DTX_FFT_WAVES
+#define DTX_FFT_WAVES 2              // waves per SIMD the scan kernel is compiled for (2: one workgroup per CU,
+#endif                               // 256 registers; 4 -> 128 registers spills and measured 19 % slower)
+#ifndef DTX_FFT_BATCH
+#define DTX_FFT_BATCH 1              // channels whose spectra are loaded together ahead of their MACs
+#endif
 static_assert(kN == 8192, "radix plan 16 x 8 x 8 x 8 is for 8192 points");
 
 typedef float2 c32;
@@ -57,55 +67,84 @@ __device__ __forceinline__ c32 muli(c32 a) {
   return SG > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
 
-// natural-order DFTs with kernel e^{SG 2 pi i s q / R}
-template <int SG>
-__device__ __forceinline__ void dft4(c32& u0, c32& u1, c32& u2, c32& u3) {
-  const c32 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = muli<SG>(csub(u1, u3));
-  u0 = cadd(a0, a2); u1 = cadd(a1, a3); u2 = csub(a0, a2); u3 = csub(a1, a3);
-}
-template <int SG>
-__device__ __forceinline__ void dft8(c32 (&u)[8]) {
-  c32 e0 = u[0], e1 = u[2], e2 = u[4], e3 = u[6], o0 = u[1], o1 = u[3], o2 = u[5], o3 = u[7];
-  dft4<SG>(e0, e1, e2, e3);
-  dft4<SG>(o0, o1, o2, o3);
-  constexpr float h = 0.70710678118654752440f;
-  const float sg = (float)SG;
-  o1 = make_float2((o1.x - sg * o1.y) * h, (o1.y + sg * o1.x) * h);     // * (1 + SG i) / sqrt 2
-  o2 = muli<SG>(o2);
-  o3 = make_float2((-o3.x - sg * o3.y) * h, (-o3.y + sg * o3.x) * h);   // * (-1 + SG i) / sqrt 2
-  u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
-  u[1] = cadd(e1, o1); u[5] = csub(e1, o1);
-  u[2] = cadd(e2, o2); u[6] = csub(e2, o2);
-  u[3] = cadd(e3, o3); u[7] = csub(e3, o3);
-}
-template <int SG>
-__device__ __forceinline__ void dft16(c32 (&u)[16]) {
-  c32 e[8], o[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { e[q] = u[2 * q]; o[q] = u[2 * q + 1]; }
-  dft8<SG>(e);
-  dft8<SG>(o);
-  // cos / sin (pi q / 8)
-  constexpr float cs[8] = {1.f, 0.92387953251128675613f, 0.70710678118654752440f,
-                           0.38268343236508977173f, 0.f, -0.38268343236508977173f,
-                           -0.70710678118654752440f, -0.92387953251128675613f};
-  constexpr float sn[8] = {0.f, 0.38268343236508977173f, 0.70710678118654752440f,
-                           0.92387953251128675613f, 1.f, 0.92387953251128675613f,
-                           0.70710678118654752440f, 0.38268343236508977173f};
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const c32 t = cmul(o[q], make_float2(cs[q], (float)SG * sn[q]));
-    u[q] = cadd(e[q], t);
-    u[q + 8] = csub(e[q], t);
+// In-place radix-2 decimation-in-frequency DFT of R = 8 or 16 register values, kernel
+// e^{SG 2 pi i s q / R}; the result is left in BIT-REVERSED order (X[q] = u[rev(q)]), which
+// costs nothing: the callers index their stores with compile-time constants.  Working in
+// place stage by stage keeps the live set at R values plus one temporary -- the natural-
+// order split-radix form needed 238 registers for the 8192-point transform, this one fits
+// the 128 of two workgroups per CU.
+template <int SG, int LEN, int Q>
+__device__ __forceinline__ c32 mul_root(c32 t) {   // t * e^{SG 2 pi i Q / LEN}
+  if constexpr (Q == 0) {
+    return t;
+  } else if constexpr (4 * Q == LEN) {
+    return muli<SG>(t);
+  } else if constexpr (8 * Q == LEN) {             // (1 + SG i) / sqrt 2
+    constexpr float h = 0.70710678118654752440f;
+    return SG > 0 ? make_float2((t.x - t.y) * h, (t.y + t.x) * h)
+                  : make_float2((t.x + t.y) * h, (t.y - t.x) * h);
+  } else if constexpr (8 * Q == 3 * LEN) {         // (-1 + SG i) / sqrt 2
+    constexpr float h = 0.70710678118654752440f;
+    return SG > 0 ? make_float2((-t.x - t.y) * h, (t.x - t.y) * h)
+                  : make_float2((t.y - t.x) * h, (-t.x - t.y) * h);
+  } else {
+    static_assert(LEN == 16, "general roots only in the 16-point stage");
+    constexpr float cs[8] = {1.f, 0.92387953251128675613f, 0.70710678118654752440f,
+                             0.38268343236508977173f, 0.f, -0.38268343236508977173f,
+                             -0.70710678118654752440f, -0.92387953251128675613f};
+    constexpr float sn[8] = {0.f, 0.38268343236508977173f, 0.70710678118654752440f,
+                             0.92387953251128675613f, 1.f, 0.92387953251128675613f,
+                             0.70710678118654752440f, 0.38268343236508977173f};
+    return cmul(t, make_float2(cs[Q], (float)SG * sn[Q]));
   }
 }
+template <int SG, int R, int LEN>
+__device__ __forceinline__ void dif_stage(c32 (&u)[R]) {
+  constexpr int H = LEN / 2;
+  dtx::static_for<0, R / 2>([&](auto bc) {
+    constexpr int b = bc, blk = (b / H) * LEN, q = b % H;
+    const c32 x = u[blk + q], y = u[blk + q + H];
+    u[blk + q] = cadd(x, y);
+    u[blk + q + H] = mul_root<SG, LEN, q>(csub(x, y));
+  });
+}
+template <int SG, int R>
+__device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
+  if constexpr (R >= 16) dif_stage<SG, R, 16>(u);
+  dif_stage<SG, R, 8>(u);
+  dif_stage<SG, R, 4>(u);
+  dif_stage<SG, R, 2>(u);
+}
+__host__ __device__ constexpr int rev3(int q) { return ((q & 1) << 2) | (q & 2) | ((q >> 2) & 1); }
+__host__ __device__ constexpr int rev4(int q) {
+  return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q >> 3) & 1);
+}
 
-__device__ __forceinline__ int lpad(int a) { return a + (a >> 5); }
+// LDS image: complex slot a lives at a + (a >> 5) (one pad slot per 32: the pass-1 scatter,
+// 16 consecutive slots per thread, and every gather are then conflict-free).  All the
+// addresses below are one per-thread base plus compile-time offsets:
+//   gather      point tid + 512 m                  -> gbase + 528 m
+//   scatter 1   slot 16 tid + s                    -> s1 + s                  (s < 16)
+//   scatter 2   j + 16 s, j = 8 (i - k) + k, k = i & 15,  i = tid + 512 h
+//                                                  -> s2 + 4224 h + 16 s + (s >> 1)
+//   scatter 3   j + 128 s, k = i & 127             -> s3 + 4224 h + 132 s
+struct LdsBases {
+  int g, s1, s2, s3;
+};
+__device__ __forceinline__ LdsBases lds_bases(int tid) {
+  LdsBases b;
+  b.g = tid + (tid >> 5);
+  b.s1 = 16 * tid + (tid >> 1);
+  const int k2 = tid & 15, k3 = tid & 127;
+  b.s2 = 8 * (tid - k2) + k2 + 4 * (tid >> 4);
+  b.s3 = 8 * (tid - k3) + k3 + (tid - k3) / 4 + (k3 >> 5);
+  return b;
+}
 
-// twiddles of one workgroup thread: w^1, w^2, w^4 of the three radix-8 passes (the last
-// pass has different ones for its two butterflies), already conjugated for SG < 0
+// twiddles of one workgroup thread: w^1, w^2, w^4 of the three radix-8 passes, already
+// conjugated for SG < 0
 struct Twid {
-  c32 p2[3], p3[3], p4[2][3];
+  c32 p2[3], p3[3], p4[3];   // the second butterfly of pass 4 (point tid + 512) derives its own
 };
 template <int SG>
 __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ tab, int tid) {
@@ -119,68 +158,77 @@ __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ t
   for (int e = 0; e < 3; ++e) {
     w.p2[e] = ld(k2 << e);
     w.p3[e] = ld(k3 << e);
-    w.p4[0][e] = ld(tid << e);
-    w.p4[1][e] = ld((tid + 512) << e);
+    w.p4[e] = ld(tid << e);
   }
 }
 
-// one radix-8 pass over the thread's two butterflies (points 2 s + h, s = 0..7)
-template <int SG>
-__device__ __forceinline__ void pass8(c32 (&v)[16], const c32 (&wa)[3], const c32 (&wb)[3]) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const c32 w1 = h ? wb[0] : wa[0], w2 = h ? wb[1] : wa[1], w4 = h ? wb[2] : wa[2];
-    const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+// one radix-8 butterfly of a pass: points v[2 s + H], s = 0..7, twiddled by w^s; the
+// transform is left bit-reversed in u
+template <int SG, int H>
+__device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c32 w2, c32 w4) {
+  u[0] = v[H];
+  u[1] = cmul(v[2 + H], w1);
+  u[2] = cmul(v[4 + H], w2);
+  u[4] = cmul(v[8 + H], w4);
+  const c32 w3 = cmul(w1, w2);
+  u[3] = cmul(v[6 + H], w3);
+  u[7] = cmul(v[14 + H], cmul(w3, w4));
+  u[5] = cmul(v[10 + H], cmul(w1, w4));
+  u[6] = cmul(v[12 + H], cmul(w2, w4));
+  dft_bitrev<SG, 8>(u);
+}
+
+// radix-8 pass whose finished sub-transform length is 16 (OFF = 16 s + (s >> 1)) or 128
+// (OFF = 132 s): both butterflies, results scattered to LDS
+template <int SG, int P>
+__device__ __forceinline__ void pass8_scatter(const c32 (&v)[16], c32* sb, const c32 (&w)[3]) {
+  dtx::static_for<0, 2>([&](auto hc) {
+    constexpr int h = hc;
     c32 u[8];
-    u[0] = v[h];
-    u[1] = cmul(v[2 + h], w1);
-    u[2] = cmul(v[4 + h], w2);
-    u[3] = cmul(v[6 + h], w3);
-    u[4] = cmul(v[8 + h], w4);
-    u[5] = cmul(v[10 + h], w5);
-    u[6] = cmul(v[12 + h], w6);
-    u[7] = cmul(v[14 + h], w7);
-    dft8<SG>(u);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) v[2 * s + h] = u[s];
-  }
-}
-
-__device__ __forceinline__ void gather(c32 (&v)[16], const c32* lds, int tid) {
-#pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = lds[lpad(tid + 512 * m)];
-}
-// scatter of a radix-8 pass whose finished sub-transform length is p (16 or 128)
-template <int P>
-__device__ __forceinline__ void scatter8(const c32 (&v)[16], c32* lds, int tid) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int i = tid + 512 * h, k = i & (P - 1), j = (i - k) * 8 + k;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) lds[lpad(j + s * P)] = v[2 * s + h];
-  }
+    bfly8<SG, h>(v, u, w[0], w[1], w[2]);
+    dtx::static_for<0, 8>([&](auto sc) {
+      constexpr int s = sc, off = 4224 * h + (P == 16 ? 16 * s + (s >> 1) : 132 * s);
+      sb[off] = u[rev3(s)];
+    });
+  });
 }
 
 // v[m] = point (tid + 512 m) in, natural-order transform point (tid + 512 m) out
-template <int SG>
-__device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, int tid, const Twid& w) {
-  dft16<SG>(v);                                   // pass 1: radix 16, no twiddles
-#pragma unroll
-  for (int s = 0; s < 16; ++s) lds[lpad(16 * tid + s)] = v[s];
+// `mid(stage)` runs after each of the three exchanges: the scan kernel hides the next
+// pair's global loads there
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int SG, class Hook = NoHook>
+__device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb, const Twid& w,
+                                        Hook&& mid = NoHook()) {
+  dft_bitrev<SG, 16>(v);                          // pass 1: radix 16, no twiddles
+  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds[lb.s1 + s] = v[rev4(s)]; });
   __syncthreads();
-  gather(v, lds, tid);
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
   __syncthreads();
-  pass8<SG>(v, w.p2, w.p2);                       // pass 2: sub-transforms of 16 -> 128
-  scatter8<16>(v, lds, tid);
+  mid(0);
+  pass8_scatter<SG, 16>(v, lds + lb.s2, w.p2);    // pass 2: sub-transforms of 16 -> 128
   __syncthreads();
-  gather(v, lds, tid);
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
   __syncthreads();
-  pass8<SG>(v, w.p3, w.p3);                       // pass 3: 128 -> 1024
-  scatter8<128>(v, lds, tid);
+  mid(1);
+  pass8_scatter<SG, 128>(v, lds + lb.s3, w.p3);   // pass 3: 128 -> 1024
   __syncthreads();
-  gather(v, lds, tid);
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
   __syncthreads();
-  pass8<SG>(v, w.p4[0], w.p4[1]);                 // pass 4: 1024 -> 8192, output in place
+  mid(2);
+  // pass 4: 1024 -> 8192, output in place: point tid + 512 (2 s + h).  Butterfly h = 1 is
+  // point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick up e^{i pi/8},
+  // e^{i pi/4}, e^{i pi/2}
+  c32 u0[8], u1[8];
+  bfly8<SG, 0>(v, u0, w.p4[0], w.p4[1], w.p4[2]);
+  bfly8<SG, 1>(v, u1, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
+  dtx::static_for<0, 8>([&](auto sc) {
+    constexpr int s = sc;
+    v[2 * s] = u0[rev3(s)];
+    v[2 * s + 1] = u1[rev3(s)];
+  });
 }
 
 // ---------------------------------------------------------------- block spectra
@@ -193,6 +241,7 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
   const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
   Twid w;
   load_twiddles<-1>(w, tab, tid);
+  const LdsBases lb = lds_bases(tid);
   const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
   const int64_t t0 = (int64_t)blk * V;
   c32 v[16];
@@ -201,15 +250,17 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     const int64_t t = t0 + tid + 512 * m;
     v[m] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
   }
-  fft8192<-1>(v, lds, tid, w);
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kN;
+  fft8192<-1>(v, lds, lb, w);
+  // x is real: only f <= kN / 2 is kept (X[kN - f] = conj X[f])
+  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) dst[tid + 512 * m] = v[m];
+  for (int m = 0; m < 8; ++m) dst[tid + 512 * m] = v[m];
+  if (tid == 0) dst[kN / 2] = v[8];
 }
 
 // ---------------------------------------------------------------- the scan
 struct FftArgs {
-  const c32* xh;        // [nchunk][nblk][Nc][kN]
+  const c32* xh;        // [nchunk * nblk][Nc][kXh] half spectra
   const c32* W;         // [npairs][Nc][kN]
   const c32* tab;       // [kN] e^{+2 pi i m / kN}
   const int4* unit;     // [nunits] {first pair, pairs, detector of slot 0, detector of slot 1 or -1}
@@ -219,66 +270,115 @@ struct FftArgs {
   float* ds;            // [nchunk][D][ldp]
   int64_t Ppad, ldp, P;
   int Nc, D, V, nblk, nchunk;
+  int nunits, ntile_b, per_xcd;   // tiling of the grid (launch_fft)
 };
 
-template <int VM>   // VM = V / 512 outputs kept per thread
-__global__ __launch_bounds__(kT, 2) void ds_fft_kernel(const FftArgs a) {
+// epilogue of one pair (uses z, pr, ui, mean, acc0, acc1 of the enclosing kernel)
+#define DTX_FFT_EPILOGUE \
+    const float4 pi = a.pinfo[ui.x + pr]; \
+    const bool two = TWO && pi.z != 0.f; \
+_Pragma("unroll") \
+    for (int m = 0; m < VM; ++m) { \
+      const float mu = mean[512 * m]; \
+      const float re = z[m].x - pi.x * mu, im = z[m].y - pi.y * mu; \
+      acc0[m] += re * re + (two ? 0.f : im * im); \
+      if (TWO) acc1[m] += two ? im * im : 0.f; \
+    }
+
+// VM = V / 512 outputs kept per thread; TWO: some unit holds two single-vector detectors
+// NCH: reserved (0)
+template <int VM, bool TWO, int NCH>
+__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs a) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x;
-  const int per_unit = a.nchunk * a.nblk;
-  const int unit = blockIdx.x / per_unit;
-  const int rem = blockIdx.x - unit * per_unit;
-  const int chunk = rem / a.nblk, blk = rem - chunk * a.nblk;
+  // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
+  // every XCD a contiguous run of the logical work list, and order that list in tiles of
+  // kTileU units x kTileB blocks: the ~32 workgroups an XCD runs at a time then read the
+  // same kTileU * (pairs * Nc * 64 KB) of basis spectra and kTileB * (Nc * 32 KB) of block
+  // spectra -- ~3 MB, L2 resident -- instead of 32 different blocks' spectra (7 MB).
+  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  const int tile = logical / kTile, slot = logical - tile * kTile;
+  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
+  const int unit = tu * kTileU + slot % kTileU;
+  const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
+  if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
+  const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;
   const int4 ui = a.unit[unit];
   const int64_t p0 = (int64_t)blk * a.V;
-  if (p0 >= a.P) return;
 
   Twid w;
   load_twiddles<1>(w, a.tab, tid);
-  float mu[VM], dn[VM], acc0[VM], acc1[VM];
+  const LdsBases lb = lds_bases(tid);
+  float acc0[VM], acc1[TWO ? VM : 1];
 #pragma unroll
   for (int m = 0; m < VM; ++m) {
-    const int64_t p = p0 + tid + 512 * m;
-    const bool ok = p < a.P;
-    mu[m] = ok ? a.mean[(int64_t)chunk * a.Ppad + p] : 0.f;
-    dn[m] = ok ? a.den[(int64_t)chunk * a.Ppad + p] : 0.f;
     acc0[m] = 0.f;
-    acc1[m] = 0.f;
+    if (TWO) acc1[m] = 0.f;
   }
-  const c32* xh = a.xh + ((int64_t)chunk * a.nblk + blk) * a.Nc * kN + tid;
+  // p0 + 512 VM <= Ppad + V: mean / den are read unguarded (rows are padded, see dtx_fft_scan)
+  const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0 + tid;
+  const float* den = a.den + (int64_t)chunk * a.Ppad + p0 + tid;
+  // the thread's 16 frequencies f = tid + 512 m in the stored half spectrum: f itself, or
+  // kN - f with the imaginary part negated
+  const c32* xh = a.xh + (int64_t)cb * a.Nc * kXh;
+  const int xlo = tid, xhi = (tid == 0) ? kN / 2 : kN / 2 - tid;   // m < 8: xlo + 512 m; m >= 8: xhi - 512 (m - 8)
+  const float xsg8 = (tid == 0) ? 1.f : -1.f;                      // m == 8, tid == 0 is f = kN / 2 itself
+  auto load_x = [&](int c, int m) {
+    c32 xx = xh[(int64_t)c * kXh + (m < 8 ? xlo + 512 * m : xhi - 512 * (m - 8))];
+    if (m == 8) xx.y *= xsg8;
+    if (m > 8) xx.y = -xx.y;
+    return xx;
+  };
+  // MAC of one channel: z += W_c X_c at the thread's 16 frequencies
+  auto mac16 = [&](c32 (&z)[16], const c32 (&ww)[16], const c32 (&xx)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      z[m].x += ww[m].x * xx[m].x - ww[m].y * xx[m].y;
+      z[m].y += ww[m].x * xx[m].y + ww[m].y * xx[m].x;
+    }
+  };
+  auto load16 = [&](c32 (&ww)[16], c32 (&xx)[16], const c32* wp, int c) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      ww[m] = wp[(int64_t)c * kN + 512 * m];
+      xx[m] = load_x(c, m);
+    }
+  };
+  c32 z[16];
   for (int pr = 0; pr < ui.y; ++pr) {
     const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN + tid;
-    c32 z[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-    for (int c = 0; c < a.Nc; ++c) {
+    // whole channel batches of loads (2 x 16 per channel, DTX_FFT_BATCH channels in flight)
+    // ahead of their MACs: memory-level parallelism is what this phase lives on -- the
+    // same loop with each load next to its MAC ran 40 % slower
+    int c = 0;
+    for (; c + DTX_FFT_BATCH <= a.Nc; c += DTX_FFT_BATCH) {
+      c32 pw[DTX_FFT_BATCH][16], px[DTX_FFT_BATCH][16];
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const c32 ww = wp[(int64_t)c * kN + 512 * m], xx = xh[(int64_t)c * kN + 512 * m];
-        z[m].x += ww.x * xx.x - ww.y * xx.y;
-        z[m].y += ww.x * xx.y + ww.y * xx.x;
-      }
-    }
-    fft8192<1>(z, lds, tid, w);
-    const float4 pi = a.pinfo[ui.x + pr];
-    const bool two = pi.z != 0.f;
+      for (int q = 0; q < DTX_FFT_BATCH; ++q) load16(pw[q], px[q], wp, c + q);
 #pragma unroll
-    for (int m = 0; m < VM; ++m) {
-      const float re = z[m].x - pi.x * mu[m], im = z[m].y - pi.y * mu[m];
-      acc0[m] += re * re + (two ? 0.f : im * im);
-      acc1[m] += two ? im * im : 0.f;
+      for (int q = 0; q < DTX_FFT_BATCH; ++q) mac16(z, pw[q], px[q]);
     }
+    for (; c < a.Nc; ++c) {
+      c32 pw[16], px[16];
+      load16(pw, px, wp, c);
+      mac16(z, pw, px);
+    }
+    fft8192<1>(z, lds, lb, w);
+    DTX_FFT_EPILOGUE
     __syncthreads();   // the LDS image is reused by the next pair's first scatter
   }
 #pragma unroll
   for (int m = 0; m < VM; ++m) {
     const int64_t p = p0 + tid + 512 * m;
     if (p < a.P) {
-      float v0 = (dn[m] > 0.f) ? acc0[m] / dn[m] : 0.f;
+      const float dn = den[512 * m];
+      float v0 = (dn > 0.f) ? acc0[m] / dn : 0.f;
       if (__builtin_isinf(v0)) v0 = 0.f;
       a.ds[((int64_t)chunk * a.D + ui.z) * a.ldp + p] = v0;
-      if (ui.w >= 0) {
-        float v1 = (dn[m] > 0.f) ? acc1[m] / dn[m] : 0.f;
+      if (TWO && ui.w >= 0) {
+        float v1 = (dn > 0.f) ? acc1[m] / dn : 0.f;
         if (__builtin_isinf(v1)) v1 = 0.f;
         a.ds[((int64_t)chunk * a.D + ui.w) * a.ldp + p] = v1;
       }
@@ -287,8 +387,12 @@ __global__ __launch_bounds__(kT, 2) void ds_fft_kernel(const FftArgs a) {
 }
 
 template <int VM>
-void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid) {
-  hipLaunchKernelGGL((ds_fft_kernel<VM>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
+  if (two) {          // rare layout (single-vector detectors): one generic instance
+    hipLaunchKernelGGL((ds_fft_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL((ds_fft_kernel<VM, false, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  }
 }
 
 // float64 radix-2 transform on the host, kernel e^{+2 pi i j f / n}, unnormalised
@@ -351,6 +455,7 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
     u.x = (int)pinfo.size();
     if (k == 1 && d + 1 < D && det_off[d + 2] - det_off[d + 1] == 1) {
       u.y = 1; u.z = d; u.w = d + 1;
+      f.two = true;
       pinfo.push_back(make_float4(rowsum(r0), rowsum(r0 + 1), 1.f, 0.f));
       prow.push_back(r0); prow.push_back(r0 + 1);
       d += 2;
@@ -407,10 +512,13 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
   const int Nc = ctx->Nc, V = f.V;
   const int nblk = (int)((P + V - 1) / V);
-  const int64_t grid = (int64_t)f.nunits * nchunk * nblk;
+  const int ntile_u = (f.nunits + kTileU - 1) / kTileU;
+  const int ntile_b = (int)(((int64_t)nchunk * nblk + kTileB - 1) / kTileB);
+  const int64_t per_xcd = ((int64_t)ntile_u * ntile_b * kTile + 7) / 8;
+  const int64_t grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;
-  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblk * Nc * kN * sizeof(float2)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblk * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblk, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
                      ctx->stream, xp, Tpad, Nc, V, nblk, (const c32*)f.tab_dev, xh);
@@ -421,22 +529,23 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
+  a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
   switch (V / 512) {
-    case 1: launch_fft<1>(ctx, a, (unsigned)grid); break;
-    case 2: launch_fft<2>(ctx, a, (unsigned)grid); break;
-    case 3: launch_fft<3>(ctx, a, (unsigned)grid); break;
-    case 4: launch_fft<4>(ctx, a, (unsigned)grid); break;
-    case 5: launch_fft<5>(ctx, a, (unsigned)grid); break;
-    case 6: launch_fft<6>(ctx, a, (unsigned)grid); break;
-    case 7: launch_fft<7>(ctx, a, (unsigned)grid); break;
-    case 8: launch_fft<8>(ctx, a, (unsigned)grid); break;
-    case 9: launch_fft<9>(ctx, a, (unsigned)grid); break;
-    case 10: launch_fft<10>(ctx, a, (unsigned)grid); break;
-    case 11: launch_fft<11>(ctx, a, (unsigned)grid); break;
-    case 12: launch_fft<12>(ctx, a, (unsigned)grid); break;
-    case 13: launch_fft<13>(ctx, a, (unsigned)grid); break;
-    case 14: launch_fft<14>(ctx, a, (unsigned)grid); break;
-    case 15: launch_fft<15>(ctx, a, (unsigned)grid); break;
+    case 1: launch_fft<1>(ctx, a, (unsigned)grid, f.two); break;
+    case 2: launch_fft<2>(ctx, a, (unsigned)grid, f.two); break;
+    case 3: launch_fft<3>(ctx, a, (unsigned)grid, f.two); break;
+    case 4: launch_fft<4>(ctx, a, (unsigned)grid, f.two); break;
+    case 5: launch_fft<5>(ctx, a, (unsigned)grid, f.two); break;
+    case 6: launch_fft<6>(ctx, a, (unsigned)grid, f.two); break;
+    case 7: launch_fft<7>(ctx, a, (unsigned)grid, f.two); break;
+    case 8: launch_fft<8>(ctx, a, (unsigned)grid, f.two); break;
+    case 9: launch_fft<9>(ctx, a, (unsigned)grid, f.two); break;
+    case 10: launch_fft<10>(ctx, a, (unsigned)grid, f.two); break;
+    case 11: launch_fft<11>(ctx, a, (unsigned)grid, f.two); break;
+    case 12: launch_fft<12>(ctx, a, (unsigned)grid, f.two); break;
+    case 13: launch_fft<13>(ctx, a, (unsigned)grid, f.two); break;
+    case 14: launch_fft<14>(ctx, a, (unsigned)grid, f.two); break;
+    case 15: launch_fft<15>(ctx, a, (unsigned)grid, f.two); break;
     default: return dtx_fail(ctx, DTX_E_STATE, "FFT engine: bad block advance %d", V);
   }
   DTX_HIP(ctx, hipGetLastError());

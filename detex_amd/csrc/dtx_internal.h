@@ -32,6 +32,7 @@ struct DtxKTile {
 #endif
 struct DtxFft {
   bool ok = false;
+  bool two = false;            // some unit pairs two single-vector detectors
   int V = 0;                   // windows per block (block advance), a multiple of 512
   int nunits = 0, npairs = 0;
   void* W_dev = nullptr;       // [npairs][Nc][DTX_FFT_N] complex64

@@ -475,8 +475,9 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
   const int64_t Tpad = Ppad + ctx->Lp + 64;
   int rc;
   if ((rc = dtx_reserve(ctx, ctx->ws_xp, (size_t)nchunk * Nc * Tpad * sizeof(float)))) return rc;
-  if ((rc = dtx_reserve(ctx, ctx->ws_mean, (size_t)nchunk * Ppad * sizeof(float)))) return rc;
-  if ((rc = dtx_reserve(ctx, ctx->ws_den, (size_t)nchunk * Ppad * sizeof(float)))) return rc;
+  // + DTX_FFT_N: the frequency-domain engine reads whole blocks of window statistics past P
+  if ((rc = dtx_reserve(ctx, ctx->ws_mean, ((size_t)nchunk * Ppad + DTX_FFT_N) * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_den, ((size_t)nchunk * Ppad + DTX_FFT_N) * sizeof(float)))) return rc;
   float* xp = (float*)ctx->ws_xp.p;
   float* mean = (float*)ctx->ws_mean.p;
   float* den = (float*)ctx->ws_den.p;
