@@ -43,9 +43,11 @@ def parse():
     ap.add_argument('--sr', type=float, default=100.0)
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
-    ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3', 'fft'],
-                    help="fp32: exact float32 MFMA; bf16x3: split-bfloat16 MFMA (3 bf16 products "
-                         "per float32 product, float32 accumulate)")
+    ap.add_argument('--engine', default='auto', choices=['auto', 'fft', 'bf16x3', 'fp32'],
+                    help="auto (library default): fft for templates of 256..6145 samples per channel, "
+                         "else bf16x3; fft: frequency-domain overlap-save engine (float32 transforms in "
+                         "LDS); bf16x3: split-bfloat16 MFMA contraction (3 bf16 products per float32 "
+                         "product, float32 accumulate); fp32: exact float32 MFMA contraction")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-vectors', type=int, default=200,
                     help='basis vectors the CPU baseline sample covers')
@@ -78,6 +80,67 @@ def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
     return dict(value=P / full, unit='windows/s', cores=1, kind='port',
                 sample='1 chunk (%d samples) x %d of %d basis vectors, float64 FFT path, '
                        '%.1f s measured, scaled linearly to %d vectors' % (len(x), done, K, dt, K))
+
+
+def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
+    """Roofline object of the dominant kernel of one engine (kms: its average launch
+    duration from HIP events on the launch stream)."""
+    import glob
+    rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
+    def pmc(pattern):
+        # HBM-side bytes per launch: PMC counters collected by scripts/profile.sh (separate
+        # --pmc passes, gfx950 FETCH_SIZE x2 correction) for the default configuration only
+        if not default_cfg:
+            return None
+        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+        if not pm:
+            return None
+        with open(pm[-1]) as f:
+            return json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
+    if eng == 'fft':
+        N = 8192
+        V = (N - L + 1) // 512 * 512
+        nblk = (P + V - 1) // V
+        npairs = D * ((K // D + 1) // 2) if K % D == 0 else (K + 1) // 2
+        nfft = npairs * nblk * chunks
+        # algorithmic HBM bytes (SURVEY 8d): the stream once (4 Nc B/window) + DS once (4 D B/window)
+        bytes_alg = (4.0 * Nc + 4.0 * D) * P * chunks
+        # what the kernel computes: one 8192-point complex transform (5 N log2 N) and Nc complex
+        # MACs per frequency (8 flop each) per (pair, block)
+        flop_fft = nfft * (5.0 * N * 13 + 8.0 * Nc * N)
+        gbs = bytes_alg / (kms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'kernel': 'ds_fft_kernel<%d>' % (V // 512), 'achieved': gbs, 'peak': 8000.0,
+                'unit': 'GB/s', 'frac': gbs / 8000.0, 'traffic': pmc('*_bench_pmc_ds_fft_kernel.json'),
+                'kernel_ms': kms, 'bytes_per_launch': bytes_alg, 'engine': 'fft',
+                'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
+                            'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
+                            'frac': flop_fft / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                            'contraction_equivalent': flops / (kms * 1e-3) / 1e12},
+                'note': 'overlap-save engine: %d transforms of 8192 complex points per launch in LDS; '
+                        'neither HBM- nor MFMA-bound -- the algorithmic HBM bytes (112 B/window) are '
+                        'what the schema asks for, `compute` prices the transforms against the f32 '
+                        'vector peak, `contraction_equivalent` is the direct contraction it replaces '
+                        '(2*K*n flop per window); DESIGN.md 4.1c has the L2 / LDS / latency budget' % nfft}
+    if eng == 'fp32':
+        ach = flops / (kms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8)),
+                'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc('*_bench_pmc_ds_mfma_kernel.json'),
+                'kernel_ms': kms, 'flop_per_launch': flops, 'engine': 'fp32',
+                'note': 'algorithmic flop = 2*K*n per window'}
+    ach = flops / (kms * 1e-3) / 1e12
+    issued = 3.0 * ach * (16.0 * rm) / min(K, 208) if K <= 208 else None
+    return {'bound': 'mfma', 'kernel': 'ds_mfma_kernel_s<%d,%d>' % (rm, 3 if rm >= 9 else 4),
+            'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': pmc('*_bench_pmc_ds_mfma_kernel_s.json'),
+            'kernel_ms': kms, 'flop_per_launch': flops, 'engine': 'bf16x3',
+            'sustained_peak': SUSTAINED_BF16_MFMA_TFLOPS, 'issued_mfma_tflops': issued,
+            'issued_frac_of_sustained': issued / SUSTAINED_BF16_MFMA_TFLOPS if issued else None,
+            'note': 'algorithmic flop = 2*K*n per window; the split engine issues 3 bf16 MFMAs per '
+                    'float32 product, so its ceiling is peak/3; issued_mfma_tflops counts those 3 MFMAs '
+                    'on the zero-padded 16-row blocks and is to be read against sustained_peak (measured '
+                    'power-limited rate of a registers-only bf16 MFMA loop on random operands, '
+                    'profiles/p1_mfma_peak.txt)'}
 
 
 def main():
@@ -169,65 +232,45 @@ def main():
         sel = (cb == b) & (cd == d) & (np.abs(cp - p) <= 2)
         found += bool(sel.any())
 
-    flops = 2.0 * K * n * P * a.chunks
-    rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
-    if a.engine == 'fp32':
-        kname = 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8))
-        peak, pmc = PEAK_FP32_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel.json'
-    else:
-        kname = 'ds_mfma_kernel_s<%d,%d>' % (rm, 3 if rm >= 9 else 4)
-        peak, pmc = PEAK_BF16_MFMA_TFLOPS, '*_bench_pmc_ds_mfma_kernel_s.json'
-    # HBM-side bytes per launch of the dominant kernel: PMC counters collected by
-    # scripts/profile.sh (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) for this
-    # exact configuration, committed under profiles/; None for any other configuration
-    traffic = None
+    flops = 2.0 * K * n * P * a.chunks       # the contraction's algorithmic flop
     default_cfg = (D, k, a.chunks, Nc, a.sr, a.chunk_seconds, a.template_seconds) == \
         (25, 8, 24, 3, 100.0, 3720.0, 30.0)
-    if default_cfg:
-        import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pmc)))
-        if pm:
-            with open(pm[-1]) as f:
-                traffic = json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
-    achieved = flops / (kms * 1e-3) / 1e12
+    eng = a.engine
+    if eng == 'auto':                        # dtx_internal.h: kFftAutoMinL .. kFftMaxL
+        eng = 'fft' if 256 <= L <= 6145 else 'bf16x3'
+    if eng == 'bf16x3' and L < 64:
+        eng = 'fp32'
     out = {
         'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)',
         'value': value, 'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if a.engine == 'fp32' else 'bf16x3 (f32 operands split in 2 bf16, f32 accumulate)',
+        'dtype': {'fft': 'f32 (complex64 transforms, f64 window statistics)', 'fp32': 'f32',
+                  'bf16x3': 'bf16x3 (f32 operands split in 2 bf16, f32 accumulate)'}[eng],
         'data': 'synthetic',
         'config': {'workload': '%s%d basis vectors (%d detectors x %d) x %d chunks of '
                                '%g s, %d-ch %g Hz, n=%d, one station-day per GPU'
                                % ('configs[1]: ' if default_cfg else 'custom: ', K, D, k, a.chunks,
                                   a.chunk_seconds, Nc, a.sr, n),
+                   'engine': eng if a.engine == eng else '%s -> %s' % (a.engine, eng),
                    'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
-        'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
-                     'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                     'kernel_ms': kms, 'flop_per_launch': flops, 'engine': a.engine,
-                     'note': ('algorithmic flop = 2*K*n per window; the split engine issues 3 bf16 '
-                              'MFMAs per float32 product, so its ceiling is peak/3; issued_mfma_tflops '
-                              'counts those 3 MFMAs on the zero-padded 16-row blocks and is to be read '
-                              'against sustained_peak (measured power-limited rate of a registers-only '
-                              'bf16 MFMA loop on random operands, profiles/p1_mfma_peak.txt)')
-                     if a.engine != 'fp32' else 'algorithmic flop = 2*K*n per window'},
+        'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
     }
-    if a.engine != 'fp32':
-        issued = 3.0 * achieved * (16.0 * rm) / min(K, 208) if K <= 208 else None
-        out['roofline']['sustained_peak'] = SUSTAINED_BF16_MFMA_TFLOPS
-        out['roofline']['issued_mfma_tflops'] = issued
-        out['roofline']['issued_frac_of_sustained'] = issued / SUSTAINED_BF16_MFMA_TFLOPS if issued else None
-    if rank == 0 and world == 1 and a.engine != 'fp32' and default_cfg:
-        ctx.set_engine('fp32')                  # the float32-MFMA engine on the same input
-        step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        dt32 = time.perf_counter() - t1
-        k32 = ctx.last_kernel_ms()
-        out['fp32_engine'] = {'value': a.chunks * P / dt32, 'unit': 'windows/s', 'kernel_ms': k32,
-                              'frac_of_fp32_mfma_peak': flops / (k32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    if rank == 0 and world == 1 and default_cfg:
+        # the other engines on the same input (same step: scan + post pass)
+        for other, key in (('bf16x3', 'mfma_engine'), ('fp32', 'fp32_engine'), ('fft', 'fft_engine')):
+            if other == eng:
+                continue
+            ctx.set_engine(other)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            dto = time.perf_counter() - t1
+            ko = ctx.last_kernel_ms()
+            out[key] = {'value': a.chunks * P / dto, 'unit': 'windows/s',
+                        'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
         ctx.set_engine(a.engine)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)

@@ -43,6 +43,10 @@ struct DtxFft {
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
 constexpr int kFftMaxL = DTX_FFT_N - 2048 + 1;
+// DTX_ENGINE_AUTO: shortest template it hands to the frequency-domain engine (measured
+// crossover with the split-bf16 MFMA engine at 200 basis vectors, Nc = 3: L ~ 220;
+// profiles/f3_crossover.txt)
+constexpr int kFftAutoMinL = 256;
 
 struct DtxBuf {
   void* p = nullptr;
@@ -64,7 +68,7 @@ struct dtx_ctx {
 
   // workspaces (grown on demand, never shrunk)
   DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat;
-  int engine = DTX_ENGINE_BF16X3;
+  int engine = DTX_ENGINE_AUTO;
 
   // timing
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer

@@ -507,7 +507,9 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     DTX_HIP(ctx, hipGetLastError());
   }
 
-  if (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) {
+  const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
+                       (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftMaxL);
+  if (use_fft) {
     if (!ctx->fft.ok &&
         (rc = dtx_fft_basis_build(ctx, ctx->hU.data(), ctx->hdoff.data(), ctx->D, n, Nc)))
       return rc;
@@ -542,7 +544,8 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
 
 int dtx_set_engine(dtx_ctx* ctx, int engine) {
   if (!ctx) return DTX_E_ARG;
-  if (engine != DTX_ENGINE_FP32 && engine != DTX_ENGINE_BF16X3 && engine != DTX_ENGINE_FFT)
+  if (engine != DTX_ENGINE_FP32 && engine != DTX_ENGINE_BF16X3 && engine != DTX_ENGINE_FFT &&
+      engine != DTX_ENGINE_AUTO)
     return dtx_fail(ctx, DTX_E_ARG, "unknown engine %d", engine);
   ctx->engine = engine;
   return DTX_OK;

@@ -443,7 +443,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const size_t o_fs = carve((size_t)N * sizeof(float));
   const size_t o_fr = carve((size_t)N * sizeof(float));
   const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
-  const bool split = ctx->engine == DTX_ENGINE_BF16X3 && L >= kSplitMinL;
+  const bool split = ctx->engine != DTX_ENGINE_FP32 && L >= kSplitMinL;   // FFT / AUTO: scan only
   const int64_t Vz = Tz / 8;
   const size_t o_xt16 = carve(split ? (size_t)nkt * Nc * (Lp / 8) * 2 * kKtMax * 8 * sizeof(uint16_t) : 0);
   const size_t o_g = carve(split ? (size_t)N * Nc * 16 * Vz * sizeof(i32x4) : 0);

@@ -68,8 +68,8 @@ class HipContext(object):
         _lib.check(self.lib, None, rc, 'dtx_ctx_create')
         self.h = h
         self.D = self.n = self.Nc = 0
-        self.engine = 'bf16x3'      # library default (dtx_set_engine)
-        # DETEX_AMD_ENGINE=fp32|bf16x3 selects the arithmetic engine of new contexts
+        self.engine = 'auto'        # library default (dtx_set_engine)
+        # DETEX_AMD_ENGINE=auto|fft|bf16x3|fp32 selects the arithmetic engine of new contexts
         env = os.environ.get('DETEX_AMD_ENGINE')
         if env:
             self.set_engine(env)
@@ -89,9 +89,11 @@ class HipContext(object):
         _lib.check(self.lib, self.h, rc, what)
 
     def set_engine(self, engine):
-        """'bf16x3' (default: split-bfloat16 MFMA, float32-level accuracy, 3.6x
-        faster) or 'fp32' (float32 MFMA, products bitwise an fma chain)."""
-        code = {'fp32': 0, 'bf16x3': 1, 'fft': 2}[engine]
+        """'auto' (default: 'fft' for templates of 256..6145 samples per channel,
+        else 'bf16x3'), 'fft' (frequency-domain overlap-save engine, float32
+        transforms), 'bf16x3' (split-bfloat16 MFMA contraction, float32-level
+        accuracy) or 'fp32' (float32 MFMA, products bitwise an fma chain)."""
+        code = {'fp32': 0, 'bf16x3': 1, 'fft': 2, 'auto': 3}[engine]
         self._ck(self.lib.dtx_set_engine(self.h, code), 'dtx_set_engine')
         self.engine = engine
 

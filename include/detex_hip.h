@@ -74,7 +74,10 @@ const char* dtx_last_error(dtx_ctx* ctx);
 int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
                      int D, int n, int Nc);
 
-/* Arithmetic engine of dtx_subspace_ds (default DTX_ENGINE_BF16X3):
+/* Arithmetic engine of dtx_subspace_ds (default DTX_ENGINE_AUTO):
+ *   DTX_ENGINE_AUTO    DTX_ENGINE_FFT for templates of 256 .. 6145 samples per channel
+ *                      (where it is faster: 6.5x at 3000 samples, 200 basis vectors),
+ *                      DTX_ENGINE_BF16X3 otherwise.
  *   DTX_ENGINE_FP32    v_mfma_f32_16x16x4_f32: exact float32 products, bitwise an
  *                      fma chain.
  *   DTX_ENGINE_BF16X3  every float32 operand split into two bfloat16 parts,
@@ -95,6 +98,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
 #define DTX_ENGINE_FP32 0
 #define DTX_ENGINE_BF16X3 1
 #define DTX_ENGINE_FFT 2
+#define DTX_ENGINE_AUTO 3
 int dtx_set_engine(dtx_ctx* ctx, int engine);
 
 /* Number of detection windows for a data block of M multiplexed samples:

@@ -1,8 +1,9 @@
-"""Both arithmetic engines of the detection statistic against the golden vectors
-and the oracle at the same 1e-5 tolerance: the default split-bf16 engine
-(DTX_ENGINE_BF16X3: a*b ~ ahi*bhi + ahi*blo + alo*bhi on bf16 MFMAs, float32
-accumulate) and the float32-MFMA engine; plus a wide-dynamic-range case that
-shows the split engine's error is local to a window."""
+"""Every arithmetic engine of the detection statistic against the golden vectors
+and the oracle at the same 1e-5 tolerance: the frequency-domain overlap-save engine
+(DTX_ENGINE_FFT), the split-bf16 MFMA contraction (DTX_ENGINE_BF16X3: a*b ~ ahi*bhi +
+ahi*blo + alo*bhi on bf16 MFMAs, float32 accumulate), the float32-MFMA contraction, and
+the default DTX_ENGINE_AUTO that picks between the first two by template length; plus a
+wide-dynamic-range case that shows the errors are local to a window."""
 import os
 
 import numpy as np
@@ -16,7 +17,7 @@ from oracle import detex_oracle as orc  # noqa: E402
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'fft'])
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'fft', 'auto'])
 def ctx(request):
     from detex_amd.hip import HipContext
     c = HipContext(0)
