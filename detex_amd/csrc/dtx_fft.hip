@@ -41,16 +41,19 @@ namespace {
 
 constexpr int kN = DTX_FFT_N;        // transform length (complex points)
 constexpr int kT = 512;              // threads per workgroup, 16 points each
-constexpr int kLdsC = kN + kN / 32;  // complex slots of the padded LDS image
-constexpr int kXh = kN / 2 + 8;      // complex slots of one stored half spectrum (f = 0 .. kN/2)
+constexpr int kLdsC = kN;            // complex slots of the (swizzled, unpadded) LDS image
+// one stored half spectrum of a real series: slots f = 1 .. kN/2 - 1 hold X[f]; slot 0 holds
+// (X[0], X[kN/2]), both real; X[kN - f] = conj X[f] is never stored
+constexpr int kXh = kN / 2;
+constexpr int kXlMax = 3;            // channels whose block spectra fit in LDS beside the image
 // L2-sized tiles of the (unit, block) work space: the workgroups an XCD runs together
 // share kTileU units' spectra and kTileB blocks' spectra (see ds_fft_kernel)
 constexpr int kTileU = 2, kTileB = 16, kTile = kTileU * kTileB;
 #ifndef DTX_FFT_WAVES
 #define DTX_FFT_WAVES 2              // waves per SIMD the scan kernel is compiled for (2: one workgroup per CU,
 #endif                               // 256 registers; 4 -> 128 registers spills and measured 19 % slower)
-#ifndef DTX_FFT_BATCH
-#define DTX_FFT_BATCH 1              // channels whose spectra are loaded together ahead of their MACs
+#ifndef DTX_FFT_XLDS
+#define DTX_FFT_XLDS 1               // Nc = 1, 3: keep the block's spectra in LDS across the unit's pairs
 #endif
 static_assert(kN == 8192, "radix plan 16 x 8 x 8 x 8 is for 8192 points");
 
@@ -120,24 +123,28 @@ __host__ __device__ constexpr int rev4(int q) {
   return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q >> 3) & 1);
 }
 
-// LDS image: complex slot a lives at a + (a >> 5) (one pad slot per 32: the pass-1 scatter,
-// 16 consecutive slots per thread, and every gather are then conflict-free).  All the
-// addresses below are one per-thread base plus compile-time offsets:
-//   gather      point tid + 512 m                  -> gbase + 528 m
-//   scatter 1   slot 16 tid + s                    -> s1 + s                  (s < 16)
-//   scatter 2   j + 16 s, j = 8 (i - k) + k, k = i & 15,  i = tid + 512 h
-//                                                  -> s2 + 4224 h + 16 s + (s >> 1)
-//   scatter 3   j + 128 s, k = i & 127             -> s3 + 4224 h + 132 s
+// LDS image: complex slot a lives at a ^ g(a >> 5), g(u) = (u & 15) ^ ((u & 4) << 2): an XOR
+// swizzle instead of padding (the image is exactly 64 KB, which is what lets three channels
+// of block spectra sit beside it in the 160 KB).  Every access of the transform is
+// conflict-free under it (64 banks x 4 B, ds_*_b64 in half-waves: 32 lanes must hit 32
+// different slots mod 32 -- checked exhaustively, scripts/fft_swizzle_check.py), and every
+// address is one per-thread base combined with a compile-time constant:
+//   gather      point tid + 512 m                                -> g + 512 m
+//   scatter 1   slot 16 tid + s                                  -> s1 ^ s
+//   scatter 2   j + 16 s, j = 8 (i - k) + k, k = i & 15, i = tid + 512 h
+//                                       -> (s2 ^ ((s >> 1) | 16 (s & 1) | 32 (s >> 1))) + 4096 h
+//   scatter 3   j + 128 s, k = i & 127  -> (s3 ^ (4 (s & 3) | 16 (s & 1) | 128 s)) + 4096 h
 struct LdsBases {
   int g, s1, s2, s3;
 };
+__device__ __forceinline__ int swz_g(int u) { return (u & 15) ^ ((u & 4) << 2); }
 __device__ __forceinline__ LdsBases lds_bases(int tid) {
   LdsBases b;
-  b.g = tid + (tid >> 5);
-  b.s1 = 16 * tid + (tid >> 1);
-  const int k2 = tid & 15, k3 = tid & 127;
-  b.s2 = 8 * (tid - k2) + k2 + 4 * (tid >> 4);
-  b.s3 = 8 * (tid - k3) + k3 + (tid - k3) / 4 + (k3 >> 5);
+  b.g = tid ^ swz_g(tid >> 5);
+  b.s1 = (16 * tid) ^ swz_g(tid >> 1);
+  const int k2 = tid & 15, c = (tid >> 4) & 3, k3 = tid & 127;
+  b.s2 = 128 * (tid >> 4) + (k2 ^ (4 * c) ^ (16 * (c & 1)));
+  b.s3 = 1024 * (tid >> 7) + (k3 & 96) + ((k3 & 31) ^ (k3 >> 5));
   return b;
 }
 
@@ -181,14 +188,16 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
 // radix-8 pass whose finished sub-transform length is 16 (OFF = 16 s + (s >> 1)) or 128
 // (OFF = 132 s): both butterflies, results scattered to LDS
 template <int SG, int P>
-__device__ __forceinline__ void pass8_scatter(const c32 (&v)[16], c32* sb, const c32 (&w)[3]) {
+__device__ __forceinline__ void pass8_scatter(const c32 (&v)[16], c32* lds, int sb, const c32 (&w)[3]) {
   dtx::static_for<0, 2>([&](auto hc) {
     constexpr int h = hc;
     c32 u[8];
     bfly8<SG, h>(v, u, w[0], w[1], w[2]);
     dtx::static_for<0, 8>([&](auto sc) {
-      constexpr int s = sc, off = 4224 * h + (P == 16 ? 16 * s + (s >> 1) : 132 * s);
-      sb[off] = u[rev3(s)];
+      constexpr int s = sc;
+      constexpr int imm = P == 16 ? ((s >> 1) | (16 * (s & 1)) | (32 * (s >> 1)))
+                                  : ((4 * (s & 3)) | (16 * (s & 1)) | (128 * s));
+      lds[(sb ^ imm) + 4096 * h] = u[rev3(s)];
     });
   });
 }
@@ -203,19 +212,19 @@ template <int SG, class Hook = NoHook>
 __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb, const Twid& w,
                                         Hook&& mid = NoHook()) {
   dft_bitrev<SG, 16>(v);                          // pass 1: radix 16, no twiddles
-  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds[lb.s1 + s] = v[rev4(s)]; });
+  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds[lb.s1 ^ s] = v[rev4(s)]; });
   __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
   __syncthreads();
   mid(0);
-  pass8_scatter<SG, 16>(v, lds + lb.s2, w.p2);    // pass 2: sub-transforms of 16 -> 128
+  pass8_scatter<SG, 16>(v, lds, lb.s2, w.p2);    // pass 2: sub-transforms of 16 -> 128
   __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
   __syncthreads();
   mid(1);
-  pass8_scatter<SG, 128>(v, lds + lb.s3, w.p3);   // pass 3: 128 -> 1024
+  pass8_scatter<SG, 128>(v, lds, lb.s3, w.p3);   // pass 3: 128 -> 1024
   __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 528 * m]; });
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
   __syncthreads();
   mid(2);
   // pass 4: 1024 -> 8192, output in place: point tid + 512 (2 s + h).  Butterfly h = 1 is
@@ -251,11 +260,11 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     v[m] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
   }
   fft8192<-1>(v, lds, lb, w);
-  // x is real: only f <= kN / 2 is kept (X[kN - f] = conj X[f])
+  // x is real: only f < kN / 2 is kept (X[kN - f] = conj X[f]); X[kN / 2] rides in slot 0
   c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh;
+  if (tid == 0) v[0].y = v[8].x;
 #pragma unroll
   for (int m = 0; m < 8; ++m) dst[tid + 512 * m] = v[m];
-  if (tid == 0) dst[kN / 2] = v[8];
 }
 
 // ---------------------------------------------------------------- the scan
@@ -271,6 +280,7 @@ struct FftArgs {
   int64_t Ppad, ldp, P;
   int Nc, D, V, nblk, nchunk;
   int nunits, ntile_b, per_xcd;   // tiling of the grid (launch_fft)
+  int* guard;           // [1 + nchunk * nblk]: count, then chunk * nblk + blk of blocks to recompute
 };
 
 // epilogue of one pair (uses z, pr, ui, mean, acc0, acc1 of the enclosing kernel)
@@ -286,10 +296,12 @@ _Pragma("unroll") \
     }
 
 // VM = V / 512 outputs kept per thread; TWO: some unit holds two single-vector detectors
-// NCH: reserved (0)
+// NCH > 0: Nc == NCH <= 3 and the block's spectra stay in LDS beside the image (64 + 32 NCH
+// KB: with three channels exactly the CU's 160 KB), so each pair reads only its basis
+// spectra from L2 -- half the bytes; NCH == 0: any Nc, block spectra re-read per pair
 template <int VM, bool TWO, int NCH>
 __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs a) {
-  __shared__ c32 lds[kLdsC];
+  __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
   const int tid = threadIdx.x;
   // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
   // every XCD a contiguous run of the logical work list, and order that list in tiles of
@@ -318,17 +330,26 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   // p0 + 512 VM <= Ppad + V: mean / den are read unguarded (rows are padded, see dtx_fft_scan)
   const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0 + tid;
   const float* den = a.den + (int64_t)chunk * a.Ppad + p0 + tid;
-  // the thread's 16 frequencies f = tid + 512 m in the stored half spectrum: f itself, or
-  // kN - f with the imaginary part negated
-  const c32* xh = a.xh + (int64_t)cb * a.Nc * kXh;
-  const int xlo = tid, xhi = (tid == 0) ? kN / 2 : kN / 2 - tid;   // m < 8: xlo + 512 m; m >= 8: xhi - 512 (m - 8)
-  const float xsg8 = (tid == 0) ? 1.f : -1.f;                      // m == 8, tid == 0 is f = kN / 2 itself
-  auto load_x = [&](int c, int m) {
-    c32 xx = xh[(int64_t)c * kXh + (m < 8 ? xlo + 512 * m : xhi - 512 * (m - 8))];
-    if (m == 8) xx.y *= xsg8;
+  // the thread's 16 frequencies f = tid + 512 m in a stored half spectrum (kXh slots per
+  // channel): m < 8: slot f; m > 8: slot kN - f, conjugated; m == 8: slot kN/2 - tid,
+  // conjugated -- except thread 0, whose f = 0 and f = kN/2 are the two reals of slot 0
+  const int xlo = tid, xhi = kN / 2 - tid, x8 = (tid == 0) ? 0 : kN / 2 - tid;
+  auto fix_x = [&](c32 xx, int m) {
+    if (m == 0 && tid == 0) xx.y = 0.f;
+    if (m == 8) xx = (tid == 0) ? make_float2(xx.y, 0.f) : make_float2(xx.x, -xx.y);
     if (m > 8) xx.y = -xx.y;
     return xx;
   };
+  auto x_slot = [&](int m) { return m < 8 ? xlo + 512 * m : (m == 8 ? x8 : xhi - 512 * (m - 8)); };
+  const c32* xh = a.xh + (int64_t)cb * a.Nc * kXh;
+  c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
+  if constexpr (NCH > 0) {
+    const float4* src = reinterpret_cast<const float4*>(xh);
+    float4* dst = reinterpret_cast<float4*>(xs);
+#pragma unroll
+    for (int q = 0; q < NCH * kXh / 2 / kT; ++q) dst[tid + kT * q] = src[tid + kT * q];
+    __syncthreads();
+  }
   // MAC of one channel: z += W_c X_c at the thread's 16 frequencies
   auto mac16 = [&](c32 (&z)[16], const c32 (&ww)[16], const c32 (&xx)[16]) {
 #pragma unroll
@@ -337,32 +358,22 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       z[m].y += ww[m].x * xx[m].y + ww[m].y * xx[m].x;
     }
   };
-  auto load16 = [&](c32 (&ww)[16], c32 (&xx)[16], const c32* wp, int c) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      ww[m] = wp[(int64_t)c * kN + 512 * m];
-      xx[m] = load_x(c, m);
-    }
-  };
   c32 z[16];
   for (int pr = 0; pr < ui.y; ++pr) {
     const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN + tid;
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-    // whole channel batches of loads (2 x 16 per channel, DTX_FFT_BATCH channels in flight)
-    // ahead of their MACs: memory-level parallelism is what this phase lives on -- the
-    // same loop with each load next to its MAC ran 40 % slower
-    int c = 0;
-    for (; c + DTX_FFT_BATCH <= a.Nc; c += DTX_FFT_BATCH) {
-      c32 pw[DTX_FFT_BATCH][16], px[DTX_FFT_BATCH][16];
-#pragma unroll
-      for (int q = 0; q < DTX_FFT_BATCH; ++q) load16(pw[q], px[q], wp, c + q);
-#pragma unroll
-      for (int q = 0; q < DTX_FFT_BATCH; ++q) mac16(z, pw[q], px[q]);
-    }
-    for (; c < a.Nc; ++c) {
+    // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
+    // this phase lives on (the same loop with each load next to its MAC ran 40 % slower).
+    // NCH > 0: only the basis spectra come from L2, the block's own are LDS reads.
+#pragma nounroll
+    for (int c = 0; c < (NCH > 0 ? NCH : a.Nc); ++c) {
       c32 pw[16], px[16];
-      load16(pw, px, wp, c);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) pw[m] = wp[(int64_t)c * kN + 512 * m];
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+        px[m] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(m)] : xh[(int64_t)c * kXh + x_slot(m)], m);
       mac16(z, pw, px);
     }
     fft8192<1>(z, lds, lb, w);
@@ -384,12 +395,39 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       }
     }
   }
+  // dynamic-range guard (see dtx_subspace_ds): the workgroup of unit 0 lists its block when
+  // the loudest window holds > kFftGuard^2 times the energy of the quietest live one
+  if (unit == 0) {
+    float mn = 3.0e38f, mx = 0.f;
+#pragma unroll
+    for (int m = 0; m < VM; ++m) {
+      const float dn = (p0 + tid + 512 * m < a.P) ? den[512 * m] : 0.f;
+      if (dn > 0.f) { mn = fminf(mn, dn); mx = fmaxf(mx, dn); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    float* red = reinterpret_cast<float*>(lds);      // free: the pair loop ended on a barrier
+    if ((tid & 63) == 0) { red[tid >> 6] = mn; red[8 + (tid >> 6)] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 1; q < kT / 64; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[8 + q]); }
+      if (mx > kFftGuard * kFftGuard * mn) a.guard[1 + atomicAdd(a.guard, 1)] = cb;
+    }
+  }
 }
 
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   if (two) {          // rare layout (single-vector detectors): one generic instance
     hipLaunchKernelGGL((ds_fft_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  } else if (a.Nc == 3 && DTX_FFT_XLDS) {
+    hipLaunchKernelGGL((ds_fft_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  } else if (a.Nc == 1 && DTX_FFT_XLDS) {
+    hipLaunchKernelGGL((ds_fft_kernel<VM, false, 1>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   } else {
     hipLaunchKernelGGL((ds_fft_kernel<VM, false, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   }
@@ -507,7 +545,7 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
 
 // xp / mean / den: the channel planes and window statistics dtx_subspace_ds prepared
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp) {
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list) {
   DtxFft& f = ctx->fft;
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
   const int Nc = ctx->Nc, V = f.V;
@@ -530,6 +568,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
+  a.guard = guard_list;
   switch (V / 512) {
     case 1: launch_fft<1>(ctx, a, (unsigned)grid, f.two); break;
     case 2: launch_fft<2>(ctx, a, (unsigned)grid, f.two); break;

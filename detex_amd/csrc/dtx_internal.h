@@ -67,7 +67,7 @@ struct dtx_ctx {
   DtxFft fft;
 
   // workspaces (grown on demand, never shrunk)
-  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat;
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat, ws_flag;
   int engine = DTX_ENGINE_AUTO;
 
   // timing
@@ -85,7 +85,9 @@ void dtx_fft_free(dtx_ctx* ctx);
 bool dtx_fft_eligible(int L);
 int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n, int Nc);
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp);
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
+// a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared
+constexpr float kFftGuard = 1000.f;
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

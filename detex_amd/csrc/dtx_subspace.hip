@@ -170,6 +170,10 @@ struct DsArgs {
   int64_t V;
   int64_t Tpad, Ppad, ldp, P;
   int Nc, Lp, D, det0, nd, nptiles;
+  // list mode (repair pass behind the frequency-domain engine): recompute only the column
+  // tiles that overlap the listed blocks; list[0] = count, list[1 + e] = chunk * lnblk + block
+  const int* list;
+  int lV, lnblk;
 };
 
 // mean correction, per-detector energy (membership MFMA on the accumulator tile),
@@ -249,15 +253,8 @@ __device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& 
 }
 
 template <int RM, int TN, bool TAIL>
-__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
+__device__ __forceinline__ void ds_mfma_tile(const DsArgs& a, int chunk, int64_t p0, float* lds) {
   constexpr int KT = 16 * RM;
-  constexpr int PT = 128 * TN;
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
-
-  const int chunk = blockIdx.x / a.nptiles;
-  const int pt = blockIdx.x - chunk * a.nptiles;
-  const int64_t p0 = (int64_t)pt * PT;
-
   f32x4 acc[RM][TN];
 #pragma unroll
   for (int r = 0; r < RM; ++r)
@@ -269,6 +266,31 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
                           a.Nc, 0, a.Lp, lds);
 
   ds_epilogue<RM, TN>(acc, a, chunk, p0, lds);
+}
+
+template <int RM, int TN, bool TAIL>
+__global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
+  constexpr int PT = 128 * TN;
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
+  if (a.list == nullptr) {
+    const int chunk = blockIdx.x / a.nptiles;
+    const int pt = blockIdx.x - chunk * a.nptiles;
+    ds_mfma_tile<RM, TN, TAIL>(a, chunk, (int64_t)pt * PT, lds);
+    return;
+  }
+  // list mode: a small persistent grid walks (listed block) x (column tiles overlapping it)
+  const int nlist = a.list[0];
+  const int tpb = a.lV / PT + 2;                     // tiles that can overlap one block
+  for (int e = blockIdx.x; e < nlist * tpb; e += gridDim.x) {
+    const int cb = a.list[1 + e / tpb];
+    const int chunk = cb / a.lnblk, blk = cb - chunk * a.lnblk;
+    const int64_t w0 = (int64_t)blk * a.lV, w1 = w0 + a.lV;      // windows of the block
+    const int64_t pt = w0 / PT + (e % tpb);
+    const int64_t p0 = pt * PT;
+    if (p0 >= w1 || p0 >= a.P) continue;             // uniform over the workgroup
+    ds_mfma_tile<RM, TN, TAIL>(a, chunk, p0, lds);
+    __syncthreads();
+  }
 }
 
 // split-bf16 engine (dtx_hankel_bf16.h): same tile, three bf16 MFMAs per product
@@ -304,12 +326,12 @@ int launch_tile_s(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
 
 template <int RM>
 int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk, bool tail) {
-  if (a.ut16) return launch_tile_s<RM>(ctx, a, nchunk);
+  if (a.ut16 && !a.list) return launch_tile_s<RM>(ctx, a, nchunk);
   constexpr int TN = tn_for(RM);
   constexpr int PT = 128 * TN;
   DsArgs b = a;
   b.nptiles = (int)((a.P + PT - 1) / PT);
-  dim3 grid((unsigned)(b.nptiles * nchunk));
+  dim3 grid(a.list ? 256u : (unsigned)(b.nptiles * nchunk));   // list mode: one workgroup per CU
   if constexpr (RM >= 2) {
     if (tail) {
       hipLaunchKernelGGL((ds_mfma_kernel<RM, TN, true>), grid, dim3(kThreads), 0, ctx->stream, b);
@@ -513,7 +535,29 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     if (!ctx->fft.ok &&
         (rc = dtx_fft_basis_build(ctx, ctx->hU.data(), ctx->hdoff.data(), ctx->D, n, Nc)))
       return rc;
-    return dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp);
+    // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
+    // amplitude in an 8192-sample block, not to the window: a block whose loudest window
+    // holds more than kFftGuard^2 times the energy of its quietest one (a 10^3-sigma burst)
+    // would put >~1e-6 of error on the quiet windows.  The scan kernel lists such blocks
+    // and the float32 MFMA contraction -- whose error is local to a window -- recomputes
+    // them right behind it: a 256-workgroup launch that finds an empty list on ordinary data.
+    const int fV = ctx->fft.V;
+    const int fnblk = (int)((P + fV - 1) / fV);
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
+    int* list = (int*)ctx->ws_flag.p;
+    DTX_HIP(ctx, hipMemsetAsync(list, 0, sizeof(int), ctx->stream));
+    if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, list))) return rc;
+    for (const DtxKTile& t : ctx->tiles) {
+      DsArgs a;
+      a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
+      a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
+      a.mean = mean; a.den = den; a.ds = ds_dev;
+      a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
+      a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
+      a.list = list; a.lV = fV; a.lnblk = fnblk;
+      if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
+    }
+    return DTX_OK;
   }
 
   i32x4* g16 = nullptr;
@@ -535,6 +579,7 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
     a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
+    a.list = nullptr; a.lV = 0; a.lnblk = 0;
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));

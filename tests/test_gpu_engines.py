@@ -88,6 +88,32 @@ def test_dynamic_range_is_local(ctx):
     assert abs(int(np.argmax(got[:3000])) - 1000) == 0
 
 
+def test_extreme_burst_stays_local(ctx):
+    """10^6 x burst: far beyond what float32 transforms of a whole block can carry (the
+    frequency-domain engine's error is relative to the loudest amplitude in its 8192-sample
+    block), so its dynamic-range guard hands the block to the float32 MFMA contraction;
+    the quiet windows hold 1e-5 under every engine."""
+    rs = np.random.RandomState(14)
+    Nc, L, K, T = 3, 300, 8, 20000
+    n = Nc * L
+    A = rs.standard_normal((n, K))
+    A -= A.mean(axis=0)
+    U = np.linalg.qr(A)[0].T
+    x = rs.standard_normal(Nc * T)
+    x[Nc * 9000: Nc * 9200] *= 1e6
+    x[Nc * 1000: Nc * 1000 + n] += 4 * (rs.standard_normal(K) @ U) * np.sqrt(n) / 3
+    x[Nc * 15000: Nc * 15000 + n] += 4 * (rs.standard_normal(K) @ U) * np.sqrt(n) / 3
+    got = _gpu_ds(ctx, x, U, [0, K], Nc)[0]
+    ref = orc.mpxds_fft(x.astype(np.float32).astype(np.float64),
+                        U.astype(np.float32).astype(np.float64), Nc)
+    P = len(ref)
+    quiet = np.ones(P, bool)
+    quiet[9000 - L:9200] = False          # windows that contain burst samples
+    assert np.max(np.abs(got - ref)[quiet]) <= 1e-5
+    assert np.max(np.abs(got - ref)[~quiet]) <= 4e-5
+    assert int(np.argmax(got[:3000])) == 1000 and int(np.argmax(got[12000:])) == 3000
+
+
 def test_engines_agree_fullsize(ctx):
     """configs[1] shape, one chunk: the two engines agree to 2e-6 and pick the
     same candidates."""
