@@ -289,7 +289,7 @@ struct FftArgs {
     const bool two = TWO && pi.z != 0.f; \
 _Pragma("unroll") \
     for (int m = 0; m < VM; ++m) { \
-      const float mu = mean[512 * m]; \
+      const float mu = (mean + 512 * m)[tid]; \
       const float re = z[m].x - pi.x * mu, im = z[m].y - pi.y * mu; \
       acc0[m] += re * re + (two ? 0.f : im * im); \
       if (TWO) acc1[m] += two ? im * im : 0.f; \
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     if (TWO) acc1[m] = 0.f;
   }
   // p0 + 512 VM <= Ppad + V: mean / den are read unguarded (rows are padded, see dtx_fft_scan)
-  const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0 + tid;
-  const float* den = a.den + (int64_t)chunk * a.Ppad + p0 + tid;
+  const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0;   // uniform bases, indexed + tid
+  const float* den = a.den + (int64_t)chunk * a.Ppad + p0;
   // the thread's 16 frequencies f = tid + 512 m in a stored half spectrum (kXh slots per
   // channel): m < 8: slot f; m > 8: slot kN - f, conjugated; m == 8: slot kN/2 - tid,
   // conjugated -- except thread 0, whose f = 0 and f = kN/2 are the two reals of slot 0
@@ -360,20 +360,24 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   };
   c32 z[16];
   for (int pr = 0; pr < ui.y; ++pr) {
-    const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN + tid;
+    const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN;   // uniform
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
     // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
-    // this phase lives on (the same loop with each load next to its MAC ran 40 % slower).
-    // NCH > 0: only the basis spectra come from L2, the block's own are LDS reads.
+    // this phase lives on (the same loop with each load next to its MAC ran 40 % slower;
+    // all three channels in one batch spill and ran 65 % slower).  NCH > 0: only the basis
+    // spectra come from L2, the block's own are LDS reads.  Addresses are kept as
+    // (uniform base) + tid so they stay in SGPRs + one VGPR offset.
 #pragma nounroll
     for (int c = 0; c < (NCH > 0 ? NCH : a.Nc); ++c) {
       c32 pw[16], px[16];
+      const c32* wc = wp + (int64_t)c * kN;
+      const c32* xc = xh + (int64_t)c * kXh;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) pw[m] = wp[(int64_t)c * kN + 512 * m];
+      for (int m = 0; m < 16; ++m) pw[m] = (wc + 512 * m)[tid];
 #pragma unroll
       for (int m = 0; m < 16; ++m)
-        px[m] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(m)] : xh[(int64_t)c * kXh + x_slot(m)], m);
+        px[m] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(m)] : xc[x_slot(m)], m);
       mac16(z, pw, px);
     }
     fft8192<1>(z, lds, lb, w);
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   for (int m = 0; m < VM; ++m) {
     const int64_t p = p0 + tid + 512 * m;
     if (p < a.P) {
-      const float dn = den[512 * m];
+      const float dn = (den + 512 * m)[tid];
       float v0 = (dn > 0.f) ? acc0[m] / dn : 0.f;
       if (__builtin_isinf(v0)) v0 = 0.f;
       a.ds[((int64_t)chunk * a.D + ui.z) * a.ldp + p] = v0;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     float mn = 3.0e38f, mx = 0.f;
 #pragma unroll
     for (int m = 0; m < VM; ++m) {
-      const float dn = (p0 + tid + 512 * m < a.P) ? den[512 * m] : 0.f;
+      const float dn = (p0 + tid + 512 * m < a.P) ? (den + 512 * m)[tid] : 0.f;
       if (dn > 0.f) { mn = fminf(mn, dn); mx = fmaxf(mx, dn); }
     }
 #pragma unroll
