@@ -114,44 +114,66 @@ __device__ __forceinline__ void dif_stage(c32 (&u)[R]) {
 template <int SG, int R>
 __device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
   if constexpr (R >= 16) dif_stage<SG, R, 16>(u);
-  dif_stage<SG, R, 8>(u);
+  if constexpr (R >= 8) dif_stage<SG, R, 8>(u);
   dif_stage<SG, R, 4>(u);
   dif_stage<SG, R, 2>(u);
 }
+__host__ __device__ constexpr int rev2(int q) { return ((q & 1) << 1) | (q >> 1); }
 __host__ __device__ constexpr int rev3(int q) { return ((q & 1) << 2) | (q & 2) | ((q >> 2) & 1); }
 __host__ __device__ constexpr int rev4(int q) {
   return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q >> 3) & 1);
 }
 
-// LDS image: complex slot a lives at a ^ g(a >> 5), g(u) = (u & 15) ^ ((u & 4) << 2): an XOR
-// swizzle instead of padding (the image is exactly 64 KB, which is what lets three channels
-// of block spectra sit beside it in the 160 KB).  Every access of the transform is
-// conflict-free under it (64 banks x 4 B, ds_*_b64 in half-waves: 32 lanes must hit 32
-// different slots mod 32 -- checked exhaustively, scripts/fft_swizzle_check.py), and every
-// address is one per-thread base combined with a compile-time constant:
-//   gather      point tid + 512 m                                -> g + 512 m
-//   scatter 1   slot 16 tid + s                                  -> s1 ^ s
-//   scatter 2   j + 16 s, j = 8 (i - k) + k, k = i & 15, i = tid + 512 h
-//                                       -> (s2 ^ ((s >> 1) | 16 (s & 1) | 32 (s >> 1))) + 4096 h
-//   scatter 3   j + 128 s, k = i & 127  -> (s3 ^ (4 (s & 3) | 16 (s & 1) | 128 s)) + 4096 h
+// The 8192-point transform, decimated over the workgroup's 8 waves:  n = 8 n2 + w.
+//   phase A  wave w transforms ITS 1024-point subsequence z[8 n2 + w] alone: 16 points per
+//            lane (lane l, register r <-> n2 = l + 64 r), Stockham radices 16 x 16 x 4, two
+//            exchanges through the wave's own 8 KB of the LDS image.  A wave's LDS
+//            instructions execute in order, so these exchanges need no s_barrier: the waves
+//            of a workgroup drift apart and one wave's L2 loads overlap another's butterflies.
+//   phase B  one exchange across the waves (Y_w[k2] at slot 1024 w + k2), then thread tid
+//            combines Y_0..7[k2] for k2 = tid, tid + 512 with twiddles e^{2 pi i w k2 / N} in a
+//            radix-8 pass: X[k2 + 1024 k1] -> register m = 2 k1 + h holds point tid + 512 m,
+//            which is what the epilogue's coalesced DS stores want.
+// Two workgroup barriers per transform (before the first scatter: the previous transform's
+// phase-B reads are done; before the phase-B reads) instead of seven.
+//
+// LDS image: in-region slot a lives at a ^ g(a), g(a) = ((a >> 5) & 15) ^ (((a >> 8) & 1) << 4):
+// an XOR swizzle instead of padding (the image is exactly 64 KB, which is what lets three
+// channels of block spectra sit beside it in the 160 KB).  Every access is conflict-free
+// under it (64 banks x 4 B, ds_*_b64 in half-waves; checked exhaustively by
+// scripts/fft_swizzle_check.py) and every address is a per-lane base combined with a
+// compile-time constant:
+//   gather / phase-B write   point l + 64 r             -> (g ^ (2 (r & 7) | 16 ((r >> 2) & 1))) + 64 r
+//   scatter 1                slot 16 l + s              -> s1 ^ s
+//   scatter 2                256 (l >> 4) + (l & 15) + 16 s  -> s2 ^ (16 s ^ (s >> 1))
+//   phase-B read             region w', point tid + 512 h    -> f + 512 h + 1024 w'
 struct LdsBases {
-  int g, s1, s2, s3;
+  int g, s1, s2, f;
 };
-__device__ __forceinline__ int swz_g(int u) { return (u & 15) ^ ((u & 4) << 2); }
 __device__ __forceinline__ LdsBases lds_bases(int tid) {
+  const int l = tid & 63, region = (tid >> 6) * 1024, hb = (l >> 4) & 1;
   LdsBases b;
-  b.g = tid ^ swz_g(tid >> 5);
-  b.s1 = (16 * tid) ^ swz_g(tid >> 1);
-  const int k2 = tid & 15, c = (tid >> 4) & 3, k3 = tid & 127;
-  b.s2 = 128 * (tid >> 4) + (k2 ^ (4 * c) ^ (16 * (c & 1)));
-  b.s3 = 1024 * (tid >> 7) + (k3 & 96) + ((k3 & 31) ^ (k3 >> 5));
+  b.g = region + (l ^ (l >> 5));
+  b.s1 = region + ((16 * l) ^ (((l >> 1) & 15) ^ (hb << 4)));
+  b.s2 = region + ((256 * (l >> 4) + (l & 15)) ^ (24 * hb));
+  b.f = tid ^ (((tid >> 5) & 15) ^ (((tid >> 8) & 1) << 4));
   return b;
 }
+__host__ __device__ constexpr int swz_gr(int r) { return (2 * (r & 7)) | (16 * ((r >> 2) & 1)); }
 
-// twiddles of one workgroup thread: w^1, w^2, w^4 of the three radix-8 passes, already
-// conjugated for SG < 0
+// a wave's LDS writes are visible to its own later reads (in-order LDS pipeline); this only
+// keeps hipcc from moving the accesses across the exchange point
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// twiddles of one thread, already conjugated for SG < 0
 struct Twid {
-  c32 p2[3], p3[3], p4[3];   // the second butterfly of pass 4 (point tid + 512) derives its own
+  c32 a[4];    // pass 2 (radix 16, sub-transforms of 16): w, w^2, w^4, w^8, w = e^{2 pi i (l & 15) / 256}
+  c32 b[2];    // pass 3 (radix 4, sub-transforms of 256), butterfly 0: w, w^2, w = e^{2 pi i l / 1024}
+  c32 p4[3];   // phase B (radix 8): w, w^2, w^4, w = e^{2 pi i tid / 8192}; point tid + 512 derives its own
 };
 template <int SG>
 __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ tab, int tid) {
@@ -160,16 +182,16 @@ __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ t
     if (SG < 0) t.y = -t.y;
     return t;
   };
-  const int k2 = (tid & 15) * (kN / 128), k3 = (tid & 127) * (kN / 1024);
+  const int l = tid & 63;
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    w.p2[e] = ld(k2 << e);
-    w.p3[e] = ld(k3 << e);
-    w.p4[e] = ld(tid << e);
-  }
+  for (int e = 0; e < 4; ++e) w.a[e] = ld(((l & 15) * (kN / 256)) << e);
+  w.b[0] = ld(l * (kN / 1024));
+  w.b[1] = ld(l * (kN / 512));
+#pragma unroll
+  for (int e = 0; e < 3; ++e) w.p4[e] = ld(tid << e);
 }
 
-// one radix-8 butterfly of a pass: points v[2 s + H], s = 0..7, twiddled by w^s; the
+// one radix-8 butterfly of phase B: points v[2 s + H], s = 0..7, twiddled by w^s; the
 // transform is left bit-reversed in u
 template <int SG, int H>
 __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c32 w2, c32 w4) {
@@ -185,51 +207,67 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
   dft_bitrev<SG, 8>(u);
 }
 
-// radix-8 pass whose finished sub-transform length is 16 (OFF = 16 s + (s >> 1)) or 128
-// (OFF = 132 s): both butterflies, results scattered to LDS
-template <int SG, int P>
-__device__ __forceinline__ void pass8_scatter(const c32 (&v)[16], c32* lds, int sb, const c32 (&w)[3]) {
-  dtx::static_for<0, 2>([&](auto hc) {
-    constexpr int h = hc;
-    c32 u[8];
-    bfly8<SG, h>(v, u, w[0], w[1], w[2]);
-    dtx::static_for<0, 8>([&](auto sc) {
-      constexpr int s = sc;
-      constexpr int imm = P == 16 ? ((s >> 1) | (16 * (s & 1)) | (32 * (s >> 1)))
-                                  : ((4 * (s & 3)) | (16 * (s & 1)) | (128 * s));
-      lds[(sb ^ imm) + 4096 * h] = u[rev3(s)];
-    });
-  });
-}
-
-// v[m] = point (tid + 512 m) in, natural-order transform point (tid + 512 m) out
-// `mid(stage)` runs after each of the three exchanges: the scan kernel hides the next
-// pair's global loads there
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-template <int SG, class Hook = NoHook>
-__device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb, const Twid& w,
-                                        Hook&& mid = NoHook()) {
-  dft_bitrev<SG, 16>(v);                          // pass 1: radix 16, no twiddles
+// v[r] = point 8 (l + 64 r) + wave in, natural-order transform point (tid + 512 m) out in v[m]
+template <int SG>
+__device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
+                                        const c32* __restrict__ tab, int tid) {
+  // The ~50 swizzled LDS addresses below and the 9 twiddles are loop invariants of the
+  // caller's pair loop; hoisted there they cost 70 registers and the kernel spills.  An opaque
+  // zero keeps them inside (the twiddle loads are L1 / L2 hits, 9 per transform).
+  int opaque;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+  Twid w;
+  load_twiddles<SG>(w, tab, tid + opaque);
+  LdsBases lb;
+  lb.g = lb0.g + opaque; lb.s1 = lb0.s1 + opaque; lb.s2 = lb0.s2 + opaque; lb.f = lb0.f + opaque;
+  // ---- phase A, pass 1: radix 16 over r, no twiddles
+  dft_bitrev<SG, 16>(v);
+  __syncthreads();   // every wave has finished the phase-B reads of the previous transform
   dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds[lb.s1 ^ s] = v[rev4(s)]; });
+  wave_sync();
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds[(lb.g ^ swz_gr(r)) + 64 * r]; });
+  wave_sync();
+  // ---- pass 2: radix 16, sub-transforms of 16 -> 256
+  {
+    const c32 w1 = w.a[0], w2 = w.a[1], w4 = w.a[2], w8 = w.a[3];
+    const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+    v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+    v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+    v[9] = cmul(v[9], cmul(w1, w8)); v[10] = cmul(v[10], cmul(w2, w8));
+    v[11] = cmul(v[11], cmul(w3, w8)); v[12] = cmul(v[12], cmul(w4, w8));
+    v[13] = cmul(v[13], cmul(w5, w8)); v[14] = cmul(v[14], cmul(w6, w8));
+    v[15] = cmul(v[15], cmul(w7, w8));
+  }
+  dft_bitrev<SG, 16>(v);
+  dtx::static_for<0, 16>([&](auto sc) {
+    constexpr int s = sc;
+    lds[lb.s2 ^ ((16 * s) ^ (s >> 1))] = v[rev4(s)];
+  });
+  wave_sync();
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds[(lb.g ^ swz_gr(r)) + 64 * r]; });
+  wave_sync();
+  // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
+  // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
+  dtx::static_for<0, 4>([&](auto bc) {
+    constexpr int b = bc;
+    const c32 w1 = mul_root<SG, 16, b>(w.b[0]), w2 = mul_root<SG, 8, b>(w.b[1]);
+    c32 u[4];
+    u[0] = v[b];
+    u[1] = cmul(v[b + 4], w1);
+    u[2] = cmul(v[b + 8], w2);
+    u[3] = cmul(v[b + 12], cmul(w1, w2));
+    dft_bitrev<SG, 4>(u);
+    dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
+  });
+  // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds[(lb.g ^ swz_gr(r)) + 64 * r] = v[r]; });
   __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
-  __syncthreads();
-  mid(0);
-  pass8_scatter<SG, 16>(v, lds, lb.s2, w.p2);    // pass 2: sub-transforms of 16 -> 128
-  __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
-  __syncthreads();
-  mid(1);
-  pass8_scatter<SG, 128>(v, lds, lb.s3, w.p3);   // pass 3: 128 -> 1024
-  __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds[lb.g + 512 * m]; });
-  __syncthreads();
-  mid(2);
-  // pass 4: 1024 -> 8192, output in place: point tid + 512 (2 s + h).  Butterfly h = 1 is
-  // point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick up e^{i pi/8},
-  // e^{i pi/4}, e^{i pi/2}
+  dtx::static_for<0, 16>([&](auto mc) {
+    constexpr int m = mc;
+    v[m] = lds[lb.f + 512 * (m & 1) + 1024 * (m >> 1)];
+  });
+  // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
+  // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
   c32 u0[8], u1[8];
   bfly8<SG, 0>(v, u0, w.p4[0], w.p4[1], w.p4[2]);
   bfly8<SG, 1>(v, u1, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
@@ -241,30 +279,29 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
 }
 
 // ---------------------------------------------------------------- block spectra
-// Xh[chunk][blk][c][f] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}
+// Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
+// slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w
+// takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0
 __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, int64_t Tpad,
                                                   int Nc, int V, int nblk,
                                                   const c32* __restrict__ tab,
                                                   c32* __restrict__ xh) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
-  Twid w;
-  load_twiddles<-1>(w, tab, tid);
   const LdsBases lb = lds_bases(tid);
   const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
-  const int64_t t0 = (int64_t)blk * V;
+  const int64_t t0 = (int64_t)blk * V + 8 * (tid & 63) + (tid >> 6);
   c32 v[16];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int64_t t = t0 + tid + 512 * m;
-    v[m] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
+  for (int r = 0; r < 16; ++r) {
+    const int64_t t = t0 + 512 * r;
+    v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
   }
-  fft8192<-1>(v, lds, lb, w);
-  // x is real: only f < kN / 2 is kept (X[kN - f] = conj X[f]); X[kN / 2] rides in slot 0
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh;
+  fft8192<-1>(v, lds, lb, tab, tid);
+  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);
   if (tid == 0) v[0].y = v[8].x;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) dst[tid + 512 * m] = v[m];
+  for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
 }
 
 // ---------------------------------------------------------------- the scan
@@ -318,8 +355,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   const int4 ui = a.unit[unit];
   const int64_t p0 = (int64_t)blk * a.V;
 
-  Twid w;
-  load_twiddles<1>(w, a.tab, tid);
   const LdsBases lb = lds_bases(tid);
   float acc0[VM], acc1[TWO ? VM : 1];
 #pragma unroll
@@ -330,17 +365,21 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   // p0 + 512 VM <= Ppad + V: mean / den are read unguarded (rows are padded, see dtx_fft_scan)
   const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0;   // uniform bases, indexed + tid
   const float* den = a.den + (int64_t)chunk * a.Ppad + p0;
-  // the thread's 16 frequencies f = tid + 512 m in a stored half spectrum (kXh slots per
-  // channel): m < 8: slot f; m > 8: slot kN - f, conjugated; m == 8: slot kN/2 - tid,
-  // conjugated -- except thread 0, whose f = 0 and f = kN/2 are the two reals of slot 0
-  const int xlo = tid, xhi = kN / 2 - tid, x8 = (tid == 0) ? 0 : kN / 2 - tid;
-  auto fix_x = [&](c32 xx, int m) {
-    if (m == 0 && tid == 0) xx.y = 0.f;
-    if (m == 8) xx = (tid == 0) ? make_float2(xx.y, 0.f) : make_float2(xx.x, -xx.y);
-    if (m > 8) xx.y = -xx.y;
+  // the thread's 16 frequencies: wave w, lane l, register r <-> f = 8 (l + 64 r) + w.  In a
+  // stored half spectrum (slot(f) = (f & 7) * 512 + (f >> 3), kXh slots per channel):
+  // r < 8: slot 512 w + l + 64 r;  r >= 8: kN - f, conjugated, i.e. slot xhi - 64 r with
+  // xhi = 512 (8 - w) + 1023 - l (w > 0) or 1024 - l (w = 0) -- except thread 0, whose f = 0
+  // and f = kN / 2 are the two reals of slot 0
+  const int wv = tid >> 6, ln = tid & 63;
+  const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
+  auto fix_x = [&](c32 xx, int r) {
+    if (r == 0 && tid == 0) xx.y = 0.f;
+    if (r == 8 && tid == 0) return make_float2(xx.y, 0.f);
+    if (r >= 8) xx.y = -xx.y;
     return xx;
   };
-  auto x_slot = [&](int m) { return m < 8 ? xlo + 512 * m : (m == 8 ? x8 : xhi - 512 * (m - 8)); };
+  auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
+  const int wlo = 1024 * wv + ln;             // basis spectra are stored wave-decimated: [w][n2]
   const c32* xh = a.xh + (int64_t)cb * a.Nc * kXh;
   c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
   if constexpr (NCH > 0) {
@@ -374,15 +413,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       const c32* wc = wp + (int64_t)c * kN;
       const c32* xc = xh + (int64_t)c * kXh;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) pw[m] = (wc + 512 * m)[tid];
+      for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
 #pragma unroll
-      for (int m = 0; m < 16; ++m)
-        px[m] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(m)] : xc[x_slot(m)], m);
+      for (int r = 0; r < 16; ++r)
+        px[r] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(r)] : xc[x_slot(r)], r);
       mac16(z, pw, px);
     }
-    fft8192<1>(z, lds, lb, w);
+    fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
     DTX_FFT_EPILOGUE
-    __syncthreads();   // the LDS image is reused by the next pair's first scatter
   }
 #pragma unroll
   for (int m = 0; m < VM; ++m) {
@@ -413,7 +451,8 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       mn = fminf(mn, __shfl_xor(mn, off, 64));
       mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     }
-    float* red = reinterpret_cast<float*>(lds);      // free: the pair loop ended on a barrier
+    __syncthreads();                                 // the last transform's phase-B reads are done
+    float* red = reinterpret_cast<float*>(lds);
     if ((tid & 63) == 0) { red[tid >> 6] = mn; red[8 + (tid >> 6)] = mx; }
     __syncthreads();
     if (tid == 0) {
@@ -526,8 +565,10 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
                                     rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
       host_fft_pos(z);
       float2* dst = W.data() + ((size_t)pr * Nc + c) * kN;
+      // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
       for (int q = 0; q < kN; ++q)
-        dst[q] = make_float2((float)(z[q].real() / kN), (float)(z[q].imag() / kN));
+        dst[(q & 7) * (kN / 8) + (q >> 3)] =
+            make_float2((float)(z[q].real() / kN), (float)(z[q].imag() / kN));
     }
   std::vector<float2> tab(kN);
   const double pi = 3.14159265358979323846264338327950288;
