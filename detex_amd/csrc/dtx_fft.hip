@@ -17,17 +17,16 @@
 //     bookkeeping;
 //   * one workgroup (512 threads) owns one (unit, chunk, block): a unit is one detector
 //     (or two single-vector detectors sharing a pair).  It loops over the unit's pairs:
-//     16 frequencies per thread x Nc complex MACs straight from L2, an in-LDS 8192-point
-//     FFT, and the epilogue (Y - S_k mu_p)^2 accumulated in registers; DS leaves the
+//     16 frequencies per thread x Nc complex MACs (basis spectra straight from L2), an
+//     in-LDS 8192-point FFT, and the epilogue (Y - S_k mu_p)^2 accumulated in registers; DS leaves the
 //     chip once, already normalised -- the K x P matrix of projections never exists.
 //
-// The FFT: Stockham autosort, radices 16 x 8 x 8 x 8, 16 points per thread in registers,
-// three exchanges through a 66 KB LDS image (two workgroups per CU).  Every pass reads
-// point (tid + 512 m), m = 0..15, so the first pass is fed from registers (the MAC
-// output) and the last pass leaves window (tid + 512 m) in register m: coalesced DS
-// stores, and only m < V / 512 is kept.  Twiddles w^1, w^2, w^4 per pass live in
-// registers (the other powers are products), loaded once per workgroup from a kN-entry
-// float64-built table.
+// The FFT is decimated over the workgroup's 8 waves (n = 8 n2 + w): each wave transforms its
+// own 1024-point subsequence (radices 16 x 16 x 4, 16 points per lane) through wave-private
+// LDS exchanges that need no s_barrier, then one exchange across the waves feeds a radix-8
+// pass that leaves window (tid + 512 m) in register m: coalesced DS stores, and only
+// m < V / 512 is kept.  Basis and block spectra are stored in that wave-major order, the
+// block's own stay in LDS beside the 64 KB image (three channels: exactly the CU's 160 KB).
 //
 // Work: per (pair, block) 13 * 8192 / 2 butterflies instead of 2 * 2 * Nc * L * V MACs --
 // ~150x fewer flops than the direct contraction; float32 error grows with log kN
@@ -398,29 +397,29 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     }
   };
   c32 z[16];
-  for (int pr = 0; pr < ui.y; ++pr) {
-    const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN;   // uniform
+  {
+    for (int pr = 0; pr < ui.y; ++pr) {
+      const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN;   // uniform
 #pragma unroll
-    for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-    // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
-    // this phase lives on (the same loop with each load next to its MAC ran 40 % slower;
-    // all three channels in one batch spill and ran 65 % slower).  NCH > 0: only the basis
-    // spectra come from L2, the block's own are LDS reads.  Addresses are kept as
-    // (uniform base) + tid so they stay in SGPRs + one VGPR offset.
+      for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
+      // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
+      // this phase lives on (the same loop with each load next to its MAC ran 40 % slower).
+      // Addresses are kept as (uniform base) + lane offset: SGPRs + one VGPR.
 #pragma nounroll
-    for (int c = 0; c < (NCH > 0 ? NCH : a.Nc); ++c) {
-      c32 pw[16], px[16];
-      const c32* wc = wp + (int64_t)c * kN;
-      const c32* xc = xh + (int64_t)c * kXh;
+      for (int c = 0; c < (NCH > 0 ? NCH : a.Nc); ++c) {
+        c32 pw[16], px[16];
+        const c32* wc = wp + (int64_t)c * kN;
+        const c32* xc = xh + (int64_t)c * kXh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
+        for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        px[r] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(r)] : xc[x_slot(r)], r);
-      mac16(z, pw, px);
+        for (int r = 0; r < 16; ++r)
+          px[r] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(r)] : xc[x_slot(r)], r);
+        mac16(z, pw, px);
+      }
+      fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
+      DTX_FFT_EPILOGUE
     }
-    fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
-    DTX_FFT_EPILOGUE
   }
 #pragma unroll
   for (int m = 0; m < VM; ++m) {
