@@ -31,7 +31,10 @@
 // Work: per (pair, block) 13 * 8192 / 2 butterflies instead of 2 * 2 * Nc * L * V MACs --
 // ~150x fewer flops than the direct contraction; float32 error grows with log kN
 // instead of sqrt(n) (measured 2e-7 at DS = 1 against 2e-6 for the MFMA engines).
+#include <algorithm>
+#include <atomic>
 #include <complex>
+#include <thread>
 
 #include "dtx_hankel.h"
 #include "dtx_internal.h"
@@ -475,28 +478,36 @@ void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   }
 }
 
-// float64 radix-2 transform on the host, kernel e^{+2 pi i j f / n}, unnormalised
-void host_fft_pos(std::vector<std::complex<double>>& a) {
-  const size_t n = a.size();
-  for (size_t i = 1, j = 0; i < n; ++i) {
-    size_t bit = n >> 1;
-    for (; j & bit; bit >>= 1) j ^= bit;
-    j ^= bit;
-    if (i < j) std::swap(a[i], a[j]);
+// float64 radix-2 transform on the host, kernel e^{+2 pi i j f / kN}, unnormalised
+struct HostFft {
+  std::vector<std::complex<double>> tw;   // e^{+2 pi i k / kN}, k < kN / 2
+  std::vector<int> rev;
+  HostFft() : tw(kN / 2), rev(kN) {
+    const double pi = 3.14159265358979323846264338327950288;
+    for (int k = 0; k < kN / 2; ++k)
+      tw[k] = std::complex<double>(std::cos(2 * pi * k / kN), std::sin(2 * pi * k / kN));
+    int bits = 0;
+    while ((1 << bits) < kN) ++bits;
+    for (int i = 0; i < kN; ++i) {
+      int r = 0;
+      for (int q = 0; q < bits; ++q) r |= ((i >> q) & 1) << (bits - 1 - q);
+      rev[i] = r;
+    }
   }
-  const double pi = 3.14159265358979323846264338327950288;
-  for (size_t len = 2; len <= n; len <<= 1) {
-    std::vector<std::complex<double>> tw(len / 2);
-    for (size_t k = 0; k < len / 2; ++k)
-      tw[k] = std::complex<double>(std::cos(2 * pi * k / len), std::sin(2 * pi * k / len));
-    for (size_t i = 0; i < n; i += len)
-      for (size_t k = 0; k < len / 2; ++k) {
-        const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * tw[k];
-        a[i + k] = u + v;
-        a[i + k + len / 2] = u - v;
-      }
+  void run(std::complex<double>* a) const {
+    for (int i = 0; i < kN; ++i)
+      if (i < rev[i]) std::swap(a[i], a[rev[i]]);
+    for (int len = 2; len <= kN; len <<= 1) {
+      const int half = len / 2, step = kN / len;
+      for (int i = 0; i < kN; i += len)
+        for (int k = 0; k < half; ++k) {
+          const std::complex<double> u = a[i + k], v = a[i + k + half] * tw[k * step];
+          a[i + k] = u + v;
+          a[i + k + half] = u - v;
+        }
+    }
   }
-}
+};
 
 }  // namespace
 
@@ -553,22 +564,38 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
   f.nunits = (int)units.size();
   f.npairs = (int)pinfo.size();
 
+  // pair spectra in float64 on the host, one (pair, channel) transform per task over the
+  // host's cores (300 transforms at configs[1]: ~80 ms on one core)
   std::vector<float2> W((size_t)f.npairs * Nc * kN);
-  std::vector<std::complex<double>> z(kN);
-  for (int pr = 0; pr < f.npairs; ++pr)
-    for (int c = 0; c < Nc; ++c) {
-      const int ra = prow[2 * pr], rb = prow[2 * pr + 1];
-      for (int j = 0; j < kN; ++j) z[j] = 0.0;
-      for (int j = 0; j < L; ++j)
-        z[j] = std::complex<double>((double)hU[(size_t)ra * n + (size_t)j * Nc + c],
-                                    rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
-      host_fft_pos(z);
-      float2* dst = W.data() + ((size_t)pr * Nc + c) * kN;
-      // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
-      for (int q = 0; q < kN; ++q)
-        dst[(q & 7) * (kN / 8) + (q >> 3)] =
-            make_float2((float)(z[q].real() / kN), (float)(z[q].imag() / kN));
-    }
+  {
+    static const HostFft hfft;
+    const int ntask = f.npairs * Nc;
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = std::max(1u, std::min(nthr ? nthr : 1u, 32u));
+    nthr = std::min<unsigned>(nthr, (unsigned)ntask);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      std::vector<std::complex<double>> z(kN);
+      for (int task = next.fetch_add(1); task < ntask; task = next.fetch_add(1)) {
+        const int pr = task / Nc, c = task - pr * Nc;
+        const int ra = prow[2 * pr], rb = prow[2 * pr + 1];
+        for (int j = 0; j < kN; ++j) z[j] = 0.0;
+        for (int j = 0; j < L; ++j)
+          z[j] = std::complex<double>((double)hU[(size_t)ra * n + (size_t)j * Nc + c],
+                                      rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
+        hfft.run(z.data());
+        float2* dst = W.data() + (size_t)task * kN;
+        // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
+        for (int q = 0; q < kN; ++q)
+          dst[(q & 7) * (kN / 8) + (q >> 3)] =
+              make_float2((float)(z[q].real() / kN), (float)(z[q].imag() / kN));
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
   std::vector<float2> tab(kN);
   const double pi = 3.14159265358979323846264338327950288;
   for (int m = 0; m < kN; ++m)
