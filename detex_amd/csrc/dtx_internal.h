@@ -86,8 +86,11 @@ bool dtx_fft_eligible(int L);
 int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n, int Nc);
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
-// a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared
-constexpr float kFftGuard = 1000.f;
+// a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.
+// Calibration (tests/test_gpu_engines.py, scripts/sweep_more.py): the error of a quiet window
+// that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
+// under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
+constexpr float kFftGuard = 200.f;
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

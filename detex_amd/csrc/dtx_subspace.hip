@@ -537,8 +537,8 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
       return rc;
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window
-    // holds more than kFftGuard^2 times the energy of its quietest one (a 10^3-sigma burst)
-    // would put >~1e-6 of error on the quiet windows.  The scan kernel lists such blocks
+    // holds more than kFftGuard^2 = 4e4 times the energy of its quietest one (a 200-sigma
+    // burst) would put > 4e-6 of error on the quiet windows.  The scan kernel lists such blocks
     // and the float32 MFMA contraction -- whose error is local to a window -- recomputes
     // them right behind it: a 256-workgroup launch that finds an empty list on ordinary data.
     const int fV = ctx->fft.V;

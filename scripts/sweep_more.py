@@ -8,13 +8,14 @@ ctx = HipContext(0)
 bad = 0
 for seed in range(24, 24 + int(sys.argv[1])):
     try:
-        t.test_random_scan(ctx, seed)
+        for eng in ('mfma', 'fft'):
+            t.test_random_scan(ctx, seed, eng)
     except Exception as e:
         bad += 1
         print('SCAN seed', seed, repr(e)[:300])
         for tag, c in (('same ctx', ctx), ('new ctx', HipContext(0))):
             try:
-                t.test_random_scan(c, seed)
+                t.test_random_scan(c, seed, 'fft')
                 print('   rerun', tag, 'ok')
             except Exception as e2:
                 print('   rerun', tag, repr(e2)[:300])

@@ -18,8 +18,11 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize('engine', ['mfma', 'fft'])
 @pytest.mark.parametrize('seed', range(24))
-def test_random_scan(ctx, seed):
+def test_random_scan(ctx, seed, engine):
+    """engine 'mfma': the two contraction engines alternate over the seeds; 'fft': the
+    frequency-domain engine forced on the same shapes (dead stretches, spikes, offsets)."""
     rs = np.random.RandomState(1000 + seed)
     Nc = int(rs.choice([1, 2, 3, 4, 6]))
     L = int(rs.randint(4, 260))
@@ -49,7 +52,8 @@ def test_random_scan(ctx, seed):
     if rs.rand() < 0.35:                                    # spike 10^4 x the noise level
         spike = int(rs.randint(len(buf)))
         buf[spike] += 1e4 * amp
-    ctx.set_engine('bf16x3' if seed % 2 else 'fp32')
+    split = engine == 'mfma' and seed % 2 == 1
+    ctx.set_engine('fft' if engine == 'fft' else ('bf16x3' if split else 'fp32'))
     ctx.upload_basis(U.astype(np.float32), off, Nc)
     ds = ctx.subspace_ds(torch.from_numpy(buf.astype(np.float32)).cuda(), M=M,
                          chunk_stride=stride, nchunk=nchunk)
@@ -72,13 +76,13 @@ def test_random_scan(ctx, seed):
             # averages the split products' 2^-17 rounding there, so the split engine is held
             # to 4e-5 on those windows ("accuracy"); everything else to 1e-5
             tol = np.full(P, 1e-5)
-            if seed % 2 and spike >= 0:
+            if split and spike >= 0:
                 w0 = np.arange(P) * Nc + b * stride
                 tol[(w0 <= spike) & (spike < w0 + n)] = 4e-5
             bad = (np.abs(ds[b, d] - ref) > tol * scale) & live
             assert not bad.any(), (seed, b, d, Nc, L, ks[d],
                                    float(np.max(np.abs(ds[b, d] - ref)[live])), scale)
-    ctx.set_engine('bf16x3')
+    ctx.set_engine('auto')
 
 
 @pytest.mark.parametrize('seed', range(8))
@@ -110,4 +114,4 @@ def test_random_xcorr(ctx, seed):
             assert lag[i] == rl, (seed, b, c)
             if abs(rss) <= .5:
                 assert abs(ss[i] - rss) <= 1e-4, (seed, b, c)
-    ctx.set_engine('bf16x3')
+    ctx.set_engine('auto')
