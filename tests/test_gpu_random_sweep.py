@@ -85,6 +85,49 @@ def test_random_scan(ctx, seed, engine):
     ctx.set_engine('auto')
 
 
+@pytest.mark.parametrize('seed', range(14))
+def test_random_scan_long(ctx, seed):
+    """Default engine on templates long enough for the frequency-domain engine (and one just
+    past its limit): every block advance V = 512 .. 7680, several blocks per chunk with a
+    ragged last one, overlapping chunks, Nc = 1 / 3 (block spectra in LDS) and 2 / 4 / 6
+    (streamed), single-vector detectors sharing a pair, a 300-sigma event (guard)."""
+    rs = np.random.RandomState(3000 + seed)
+    Nc = int([3, 1, 2, 3, 6, 3, 4, 1, 3, 2, 3, 3, 6, 3][seed])
+    L = int([256, 300, 700, 1100, 1500, 2100, 2600, 3000, 3700, 4200, 5000, 6145, 6146, 7681][seed])
+    n = Nc * L
+    ks = [[8, 3], [1, 1, 1, 2], [5], [16, 1], [2, 2], [7], [1], [8] * 3, [4, 1, 1], [3], [9], [2, 5], [4], [2]][seed]
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+    U = rs.standard_normal((off[-1], n))
+    U -= U.mean(axis=1, keepdims=True) * (seed % 2)
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    V = (8192 - L + 1) // 512 * 512 if L <= 6145 else 4096
+    nchunk = 1 + seed % 2
+    T = L + int(rs.randint(int(1.2 * V), int(2.7 * V)))
+    M = Nc * T - int(rs.randint(0, Nc))
+    stride = int(rs.randint(M // 2, M + 1) // Nc * Nc)
+    buf = rs.standard_normal((nchunk - 1) * stride + M) * float(10 ** rs.uniform(-3, 3)) + float(rs.choice([0, 7]))
+    p_ev = int(rs.randint(0, (M - n) // Nc))
+    buf[p_ev * Nc: p_ev * Nc + n] += (300.0 if seed % 3 == 0 else 6.0) * np.std(buf) * np.sqrt(n) * U[off[1] - 1]
+    ctx.set_engine('auto')
+    ctx.upload_basis(U.astype(np.float32), off, Nc)
+    ds = ctx.subspace_ds(torch.from_numpy(buf.astype(np.float32)).cuda(), M=M,
+                         chunk_stride=stride, nchunk=nchunk)
+    ctx.sync()
+    ds = ds.cpu().numpy()
+    Uf = U.astype(np.float32).astype(np.float64)
+    bf = buf.astype(np.float32).astype(np.float64)
+    P = (M - n) // Nc + 1
+    assert ds.shape == (nchunk, len(ks), P)
+    for b in range(nchunk):
+        xb = bf[b * stride: b * stride + M]
+        for d in range(len(ks)):
+            ref = orc.mpxds_fft(xb, Uf[off[d]:off[d + 1]], Nc)
+            err = float(np.max(np.abs(ds[b, d] - ref)))
+            assert err <= 1e-5, (seed, b, d, Nc, L, ks[d], err)
+    if seed % 3 == 0 and nchunk == 1:
+        assert abs(int(np.argmax(ds[0, 0])) - p_ev) <= 0
+
+
 @pytest.mark.parametrize('seed', range(8))
 def test_random_xcorr(ctx, seed):
     from detex_amd import synth
