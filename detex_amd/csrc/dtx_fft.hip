@@ -311,8 +311,9 @@ struct FftArgs {
   const c32* xh;        // [nchunk * nblk][Nc][kXh] half spectra
   const c32* W;         // [npairs][Nc][kN]
   const c32* tab;       // [kN] e^{+2 pi i m / kN}
-  const int4* unit;     // [nunits] {first pair, pairs, detector of slot 0, detector of slot 1 or -1}
-  const float4* pinfo;  // [npairs] {S_k, S_k+1, slot of the imaginary part (0 / 1), 0}
+  const int4* unit;     // [nunits] {first pair, pairs, -, -}: consecutive pairs of whole detectors
+  const float4* pinfo;  // [npairs] {S_k, S_k+1, -, -} row sums of the real- and imaginary-part vectors
+  const int2* pdet;     // [npairs] {detector closed by this pair or -1, single-vector detector of the imaginary part or -1}
   const float* mean;    // [nchunk][Ppad]
   const float* den;     // [nchunk][Ppad]
   float* ds;            // [nchunk][D][ldp]
@@ -322,19 +323,41 @@ struct FftArgs {
   int* guard;           // [1 + nchunk * nblk]: count, then chunk * nblk + blk of blocks to recompute
 };
 
-// epilogue of one pair (uses z, pr, ui, mean, acc0, acc1 of the enclosing kernel)
+// epilogue of one pair (uses z, pr, ui, mean, den, acc0, acc1 of the enclosing kernel): add the
+// squared projections; when the pair closes its detector(s) (pdet.x >= 0), normalise and store.
+// pdet.y >= 0: the imaginary part is a different, single-vector detector (acc1).
 #define DTX_FFT_EPILOGUE \
     const float4 pi = a.pinfo[ui.x + pr]; \
-    const bool two = TWO && pi.z != 0.f; \
+    const int2 pd = a.pdet[ui.x + pr]; \
+    const bool two = TWO && pd.y >= 0; \
 _Pragma("unroll") \
     for (int m = 0; m < VM; ++m) { \
       const float mu = (mean + 512 * m)[tid]; \
       const float re = z[m].x - pi.x * mu, im = z[m].y - pi.y * mu; \
       acc0[m] += re * re + (two ? 0.f : im * im); \
       if (TWO) acc1[m] += two ? im * im : 0.f; \
+    } \
+    if (pd.x >= 0) { \
+_Pragma("unroll") \
+      for (int m = 0; m < VM; ++m) { \
+        const int64_t p = p0 + tid + 512 * m; \
+        if (p < a.P) { \
+          const float dn = (den + 512 * m)[tid]; \
+          float v0 = (dn > 0.f) ? acc0[m] / dn : 0.f; \
+          if (__builtin_isinf(v0)) v0 = 0.f; \
+          a.ds[((int64_t)chunk * a.D + pd.x) * a.ldp + p] = v0; \
+          if (two) { \
+            float v1 = (dn > 0.f) ? acc1[m] / dn : 0.f; \
+            if (__builtin_isinf(v1)) v1 = 0.f; \
+            a.ds[((int64_t)chunk * a.D + pd.y) * a.ldp + p] = v1; \
+          } \
+        } \
+        acc0[m] = 0.f; \
+        if (TWO) acc1[m] = 0.f; \
+      } \
     }
 
-// VM = V / 512 outputs kept per thread; TWO: some unit holds two single-vector detectors
+// VM = V / 512 outputs kept per thread; TWO: some pair holds two single-vector detectors
 // NCH > 0: Nc == NCH <= 3 and the block's spectra stay in LDS beside the image (64 + 32 NCH
 // KB: with three channels exactly the CU's 160 KB), so each pair reads only its basis
 // spectra from L2 -- half the bytes; NCH == 0: any Nc, block spectra re-read per pair
@@ -424,21 +447,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       DTX_FFT_EPILOGUE
     }
   }
-#pragma unroll
-  for (int m = 0; m < VM; ++m) {
-    const int64_t p = p0 + tid + 512 * m;
-    if (p < a.P) {
-      const float dn = (den + 512 * m)[tid];
-      float v0 = (dn > 0.f) ? acc0[m] / dn : 0.f;
-      if (__builtin_isinf(v0)) v0 = 0.f;
-      a.ds[((int64_t)chunk * a.D + ui.z) * a.ldp + p] = v0;
-      if (TWO && ui.w >= 0) {
-        float v1 = (dn > 0.f) ? acc1[m] / dn : 0.f;
-        if (__builtin_isinf(v1)) v1 = 0.f;
-        a.ds[((int64_t)chunk * a.D + ui.w) * a.ldp + p] = v1;
-      }
-    }
-  }
   // dynamic-range guard (see dtx_subspace_ds): the workgroup of unit 0 lists its block when
   // the loudest window holds > kFftGuard^2 times the energy of the quietest live one
   if (unit == 0) {
@@ -467,7 +475,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
 
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
-  if (two) {          // rare layout (single-vector detectors): one generic instance
+  if (two && a.Nc == 3 && DTX_FFT_XLDS) {   // some pair holds two single-vector detectors
+    hipLaunchKernelGGL((ds_fft_kernel<VM, true, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  } else if (two) {
     hipLaunchKernelGGL((ds_fft_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   } else if (a.Nc == 3 && DTX_FFT_XLDS) {
     hipLaunchKernelGGL((ds_fft_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
@@ -517,6 +527,7 @@ void dtx_fft_free(dtx_ctx* ctx) {
   if (f.tab_dev) (void)hipFree(f.tab_dev);
   if (f.unit_dev) (void)hipFree(f.unit_dev);
   if (f.pinfo_dev) (void)hipFree(f.pinfo_dev);
+  if (f.pdet_dev) (void)hipFree(f.pdet_dev);
   f = DtxFft();
 }
 
@@ -531,36 +542,48 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
   DtxFft& f = ctx->fft;
   f.V = (kN - L + 1) / 512 * 512;
 
-  // units: one detector each; two consecutive single-vector detectors share a pair
+  // pairs: consecutive vectors of a detector (an odd one out pairs with a zero row); two
+  // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
+  // closed once they hold kUnitPairs (a detector with more pairs is a unit of its own) -- the
+  // block spectra a workgroup stages in LDS serve all its pairs
+  constexpr int kUnitPairs = 4;
   std::vector<int4> units;
   std::vector<float4> pinfo;
+  std::vector<int2> pdet;
   std::vector<int> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
   auto rowsum = [&](int r) {
     double s = 0.0;
     for (int q = 0; q < n; ++q) s += (double)hU[(size_t)r * n + q];
     return (float)s;
   };
+  int ufirst = 0;
+  auto close_unit = [&]() {
+    const int np = (int)pinfo.size() - ufirst;
+    if (np > 0) units.push_back(make_int4(ufirst, np, 0, 0));
+    ufirst = (int)pinfo.size();
+  };
   for (int d = 0; d < D;) {
     const int r0 = det_off[d], k = det_off[d + 1] - r0;
-    int4 u;
-    u.x = (int)pinfo.size();
-    if (k == 1 && d + 1 < D && det_off[d + 2] - det_off[d + 1] == 1) {
-      u.y = 1; u.z = d; u.w = d + 1;
+    const bool shared = k == 1 && d + 1 < D && det_off[d + 2] - det_off[d + 1] == 1;
+    const int np = shared ? 1 : (k + 1) / 2;
+    if ((int)pinfo.size() - ufirst + np > kUnitPairs) close_unit();
+    if (shared) {
       f.two = true;
-      pinfo.push_back(make_float4(rowsum(r0), rowsum(r0 + 1), 1.f, 0.f));
+      pinfo.push_back(make_float4(rowsum(r0), rowsum(r0 + 1), 0.f, 0.f));
+      pdet.push_back(make_int2(d, d + 1));
       prow.push_back(r0); prow.push_back(r0 + 1);
       d += 2;
     } else {
-      u.y = (k + 1) / 2; u.z = d; u.w = -1;
       for (int q = 0; q < k; q += 2) {
         const bool has2 = q + 1 < k;
         pinfo.push_back(make_float4(rowsum(r0 + q), has2 ? rowsum(r0 + q + 1) : 0.f, 0.f, 0.f));
+        pdet.push_back(make_int2(q + 2 >= k ? d : -1, -1));
         prow.push_back(r0 + q); prow.push_back(has2 ? r0 + q + 1 : -1);
       }
       d += 1;
     }
-    units.push_back(u);
   }
+  close_unit();
   f.nunits = (int)units.size();
   f.npairs = (int)pinfo.size();
 
@@ -605,6 +628,8 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
   DTX_HIP(ctx, hipMalloc(&f.tab_dev, tab.size() * sizeof(float2)));
   DTX_HIP(ctx, hipMalloc(&f.unit_dev, units.size() * sizeof(int4)));
   DTX_HIP(ctx, hipMalloc(&f.pinfo_dev, pinfo.size() * sizeof(float4)));
+  DTX_HIP(ctx, hipMalloc(&f.pdet_dev, pdet.size() * sizeof(int2)));
+  DTX_HIP(ctx, hipMemcpy(f.pdet_dev, pdet.data(), pdet.size() * sizeof(int2), hipMemcpyHostToDevice));
   DTX_HIP(ctx, hipMemcpy(f.W_dev, W.data(), W.size() * sizeof(float2), hipMemcpyHostToDevice));
   DTX_HIP(ctx, hipMemcpy(f.tab_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
   DTX_HIP(ctx, hipMemcpy(f.unit_dev, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -636,6 +661,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
+  a.pdet = (const int2*)f.pdet_dev;
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;

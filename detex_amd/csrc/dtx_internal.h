@@ -39,6 +39,7 @@ struct DtxFft {
   void* tab_dev = nullptr;     // [DTX_FFT_N] twiddle table
   void* unit_dev = nullptr;    // [nunits] int4
   void* pinfo_dev = nullptr;   // [npairs] float4
+  void* pdet_dev = nullptr;    // [npairs] int2
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
