@@ -8,7 +8,8 @@ as 24 chunks of 3720 s, on one MI355X; N GPUs = N station-days, weak scaling).
 
 One "step" = one pass of the hot path over one station-day: for each of the 24
 chunks the detection statistic of all 25 detectors (8 basis vectors each) at
-every window, plus the histogram / max / threshold-candidate pass.  Inputs are
+every window, plus the histogram / max / threshold-candidate pass (one
+dtx_subspace_scan call).  Inputs are
 resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -197,8 +198,8 @@ def main():
     hist = torch.zeros((D, 400), dtype=torch.int32, device='cuda')
 
     def step():
-        ctx.subspace_ds(xt, out=ds)
-        return ctx.ds_post(ds, thr=thr, hist=hist)
+        # detection statistic + histogram / max / threshold candidates (dtx_subspace_scan)
+        return ctx.subspace_scan(xt, out=ds, thr=thr, hist=hist)[1]
 
     def barrier():
         if use_dist:

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 SYMBOLS = [
     'dtx_version', 'dtx_ctx_create', 'dtx_ctx_destroy', 'dtx_ctx_sync',
     'dtx_ctx_stream', 'dtx_last_error', 'dtx_set_engine', 'dtx_basis_upload', 'dtx_num_windows',
-    'dtx_subspace_ds', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
+    'dtx_subspace_ds', 'dtx_subspace_scan', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms',
 ]
@@ -65,6 +65,8 @@ def load():
     lib.dtx_num_windows.argtypes = [i64, i32, i32]
     lib.dtx_subspace_ds.restype = i32
     lib.dtx_subspace_ds.argtypes = [vp, vp, i64, i64, i32, vp, i64]
+    lib.dtx_subspace_scan.restype = i32
+    lib.dtx_subspace_scan.argtypes = [vp, vp, i64, i64, i32, vp, i64, vp, vp, vp, vp, vp, u32, vp]
     lib.dtx_ds_post.restype = i32
     lib.dtx_ds_post.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, u32, vp]
     lib.dtx_ds_moments.restype = i32

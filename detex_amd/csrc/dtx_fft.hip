@@ -307,6 +307,36 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
 }
 
 // ---------------------------------------------------------------- the scan
+// Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when its
+// loudest window holds > kFftGuard^2 times the energy of its quietest live one.  One workgroup
+// per block appends it to list (list[0] = count) for the repair pass.
+__global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ den, int64_t Ppad,
+                                                    int64_t P, int V, int nblk,
+                                                    int* __restrict__ list) {
+  __shared__ float red[8];
+  const int cb = blockIdx.x, tid = threadIdx.x;
+  const int chunk = cb / nblk, blk = cb - chunk * nblk;
+  const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P);
+  const float* d = den + (int64_t)chunk * Ppad;
+  float mn = 3.0e38f, mx = 0.f;
+  for (int64_t p = w0 + tid; p < w1; p += 256) {
+    const float dn = d[p];
+    if (dn > 0.f) { mn = fminf(mn, dn); mx = fmaxf(mx, dn); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  if ((tid & 63) == 0) { red[tid >> 6] = mn; red[4 + (tid >> 6)] = mx; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[4 + q]); }
+    if (mx > kFftGuard * kFftGuard * mn) list[1 + atomicAdd(list, 1)] = cb;
+  }
+}
+
 struct FftArgs {
   const c32* xh;        // [nchunk * nblk][Nc][kXh] half spectra
   const c32* W;         // [npairs][Nc][kN]
@@ -320,7 +350,6 @@ struct FftArgs {
   int64_t Ppad, ldp, P;
   int Nc, D, V, nblk, nchunk;
   int nunits, ntile_b, per_xcd;   // tiling of the grid (launch_fft)
-  int* guard;           // [1 + nchunk * nblk]: count, then chunk * nblk + blk of blocks to recompute
 };
 
 // epilogue of one pair (uses z, pr, ui, mean, den, acc0, acc1 of the enclosing kernel): add the
@@ -333,9 +362,11 @@ struct FftArgs {
 _Pragma("unroll") \
     for (int m = 0; m < VM; ++m) { \
       const float mu = (mean + 512 * m)[tid]; \
-      const float re = z[m].x - pi.x * mu, im = z[m].y - pi.y * mu; \
-      acc0[m] += re * re + (two ? 0.f : im * im); \
-      if (TWO) acc1[m] += two ? im * im : 0.f; \
+      /* explicit fma chain: every instantiation of the kernel rounds the same way */ \
+      const float re = __fmaf_rn(-pi.x, mu, z[m].x), im = __fmaf_rn(-pi.y, mu, z[m].y); \
+      const float i0 = two ? 0.f : im, i1 = two ? im : 0.f; \
+      acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m])); \
+      if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]); \
     } \
     if (pd.x >= 0) { \
 _Pragma("unroll") \
@@ -343,11 +374,11 @@ _Pragma("unroll") \
         const int64_t p = p0 + tid + 512 * m; \
         if (p < a.P) { \
           const float dn = (den + 512 * m)[tid]; \
-          float v0 = (dn > 0.f) ? acc0[m] / dn : 0.f; \
+          float v0 = (dn > 0.f) ? __fdiv_rn(acc0[m], dn) : 0.f; \
           if (__builtin_isinf(v0)) v0 = 0.f; \
           a.ds[((int64_t)chunk * a.D + pd.x) * a.ldp + p] = v0; \
           if (two) { \
-            float v1 = (dn > 0.f) ? acc1[m] / dn : 0.f; \
+            float v1 = (dn > 0.f) ? __fdiv_rn(acc1[m], dn) : 0.f; \
             if (__builtin_isinf(v1)) v1 = 0.f; \
             a.ds[((int64_t)chunk * a.D + pd.y) * a.ldp + p] = v1; \
           } \
@@ -445,30 +476,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       }
       fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
       DTX_FFT_EPILOGUE
-    }
-  }
-  // dynamic-range guard (see dtx_subspace_ds): the workgroup of unit 0 lists its block when
-  // the loudest window holds > kFftGuard^2 times the energy of the quietest live one
-  if (unit == 0) {
-    float mn = 3.0e38f, mx = 0.f;
-#pragma unroll
-    for (int m = 0; m < VM; ++m) {
-      const float dn = (p0 + tid + 512 * m < a.P) ? (den + 512 * m)[tid] : 0.f;
-      if (dn > 0.f) { mn = fminf(mn, dn); mx = fmaxf(mx, dn); }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mn = fminf(mn, __shfl_xor(mn, off, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    }
-    __syncthreads();                                 // the last transform's phase-B reads are done
-    float* red = reinterpret_cast<float*>(lds);
-    if ((tid & 63) == 0) { red[tid >> 6] = mn; red[8 + (tid >> 6)] = mx; }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-      for (int q = 1; q < kT / 64; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[8 + q]); }
-      if (mx > kFftGuard * kFftGuard * mn) a.guard[1 + atomicAdd(a.guard, 1)] = cb;
     }
   }
 }
@@ -657,7 +664,6 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblk, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
                      ctx->stream, xp, Tpad, Nc, V, nblk, (const c32*)f.tab_dev, xh);
   DTX_HIP(ctx, hipGetLastError());
-  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
@@ -665,7 +671,10 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
-  a.guard = guard_list;
+  hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->stream, den,
+                     Ppad, P, V, nblk, guard_list);
+  DTX_HIP(ctx, hipGetLastError());
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {
     case 1: launch_fft<1>(ctx, a, (unsigned)grid, f.two); break;
     case 2: launch_fft<2>(ctx, a, (unsigned)grid, f.two); break;

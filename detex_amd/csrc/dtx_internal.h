@@ -82,6 +82,7 @@ int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes);
 void dtx_free_tiles_internal(dtx_ctx* c);
 // shortest template (samples per channel) the split-bf16 engine is used for
 constexpr int kSplitMinL = 64;
+struct DtxPost;
 void dtx_fft_free(dtx_ctx* ctx);
 bool dtx_fft_eligible(int L);
 int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n, int Nc);
@@ -92,6 +93,8 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
 // under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
 constexpr float kFftGuard = 200.f;
+int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
+                    const DtxPost& po);
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

@@ -3,24 +3,14 @@
 // samples at or above the detector threshold that feeds the reference's
 // trigger-picking loop (detect.py:410).  HBM-bound single pass over DS.
 #include "dtx_internal.h"
+#include "dtx_postdev.h"
 
 namespace {
 
 constexpr int kPostThreads = 256;
 constexpr int kPostItems = 16;   // float4 loads per thread -> 16 KiB of DS per block
 
-// np.histogram(v, np.linspace(0, 1, 401)): bin i holds e_i <= v < e_{i+1}, the
-// last bin also v == 1; edges are e_i = i * (1/400) in float64 and e_400 = 1.
-__device__ inline int hist_bin(float vf) {
-  const double v = (double)vf;
-  if (!(v >= 0.0) || v > 1.0) return -1;          // also drops NaN
-  const double step = 1.0 / 400.0;
-  int i = (int)(v * 400.0);
-  if (i > 399) i = 399;
-  while (i > 0 && v < (double)i * step) --i;
-  while (i < 399 && v >= (double)(i + 1) * step) ++i;
-  return i;
-}
+__device__ inline int hist_bin(float vf) { return dtx_hist_bin(vf); }
 
 __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
@@ -170,6 +160,16 @@ __global__ __launch_bounds__(kPostThreads) void ds_moments_kernel(
 
 }  // namespace
 
+int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
+                    const DtxPost& po) {
+  const int64_t per_block = (int64_t)kPostThreads * kPostItems;
+  dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
+  hipLaunchKernelGGL(ds_post_kernel, grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+                     po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
 extern "C" {
 
 int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
@@ -200,12 +200,10 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int n
   DtxDeviceGuard g(ctx->device);
   if (maxds_dev)
     DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * D * sizeof(float), ctx->stream));
-  const int64_t per_block = (int64_t)kPostThreads * kPostItems;
-  dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
-  hipLaunchKernelGGL(ds_post_kernel, grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
-                     hist_dev, maxds_dev, thr_dev, cand_key_dev, cand_val_dev, cand_cap, ncand_dev);
-  DTX_HIP(ctx, hipGetLastError());
-  return DTX_OK;
+  DtxPost po;
+  po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
+  po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
+  return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, D, po);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include "dtx_hankel.h"
 #include "dtx_hankel_bf16.h"
 #include "dtx_internal.h"
+#include "dtx_postdev.h"
 
 using namespace dtx;
 
@@ -174,6 +175,7 @@ struct DsArgs {
   // tiles that overlap the listed blocks; list[0] = count, list[1 + e] = chunk * lnblk + block
   const int* list;
   int lV, lnblk;
+  int64_t lw0, lw1;     // list mode: only windows [lw0, lw1) of the tile are stored (the listed block's)
 };
 
 // mean correction, per-detector energy (membership MFMA on the accumulator tile),
@@ -242,7 +244,7 @@ __device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int det = 16 * db + 4 * kq + e;
-        if (det < a.nd && p < a.P) {
+        if (det < a.nd && p < a.P && p >= a.lw0 && p < a.lw1) {
           float v = (dn[t] > 0.f) ? out[t][e] / dn[t] : 0.f;
           if (__builtin_isinf(v)) v = 0.f;
           a.ds[((int64_t)chunk * a.D + a.det0 + det) * a.ldp + p] = v;
@@ -288,7 +290,9 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
     const int64_t pt = w0 / PT + (e % tpb);
     const int64_t p0 = pt * PT;
     if (p0 >= w1 || p0 >= a.P) continue;             // uniform over the workgroup
-    ds_mfma_tile<RM, TN, TAIL>(a, chunk, p0, lds);
+    DsArgs b = a;
+    b.lw0 = w0; b.lw1 = w1;
+    ds_mfma_tile<RM, TN, TAIL>(b, chunk, p0, lds);
     __syncthreads();
   }
 }
@@ -476,8 +480,9 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   return DTX_OK;
 }
 
-int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
-                    int nchunk, float* ds_dev, int64_t ldp) {
+// post != NULL: also the histogram / maximum / candidate pass over DS (dtx_ds_post semantics)
+static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                            int nchunk, float* ds_dev, int64_t ldp, const DtxPost* post) {
   if (!ctx) return DTX_E_ARG;
   if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "dtx_subspace_ds: no basis uploaded");
   if (!x_dev || !ds_dev || nchunk <= 0)
@@ -538,7 +543,7 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window
     // holds more than kFftGuard^2 = 4e4 times the energy of its quietest one (a 200-sigma
-    // burst) would put > 4e-6 of error on the quiet windows.  The scan kernel lists such blocks
+    // burst) would put > 4e-6 of error on the quiet windows.  A small kernel lists such blocks
     // and the float32 MFMA contraction -- whose error is local to a window -- recomputes
     // them right behind it: a 256-workgroup launch that finds an empty list on ordinary data.
     const int fV = ctx->fft.V;
@@ -554,9 +559,10 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
       a.mean = mean; a.den = den; a.ds = ds_dev;
       a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
       a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-      a.list = list; a.lV = fV; a.lnblk = fnblk;
+      a.list = list; a.lV = fV; a.lnblk = fnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
       if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
     }
+    if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post);
     return DTX_OK;
   }
 
@@ -579,12 +585,34 @@ int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_s
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
     a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-    a.list = nullptr; a.lV = 0; a.lnblk = 0;
+    a.list = nullptr; a.lV = 0; a.lnblk = 0; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
+  if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post);
   return DTX_OK;
+}
+
+int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                    int nchunk, float* ds_dev, int64_t ldp) {
+  return subspace_ds_impl(ctx, x_dev, M, chunk_stride, nchunk, ds_dev, ldp, nullptr);
+}
+
+int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                      int nchunk, float* ds_dev, int64_t ldp, uint32_t* hist_dev,
+                      float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
+                      float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (nchunk > 65535 || ctx->D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
+  if (maxds_dev && nchunk > 0) {
+    DtxDeviceGuard g(ctx->device);
+    DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->stream));
+  }
+  DtxPost po;
+  po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
+  po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
+  return subspace_ds_impl(ctx, x_dev, M, chunk_stride, nchunk, ds_dev, ldp, &po);
 }
 
 int dtx_set_engine(dtx_ctx* ctx, int engine) {

@@ -111,7 +111,7 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
                  useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=False):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
     detectors in one GPU basis: per batch of chunks the detection statistic
-    (dtx_subspace_ds), histogram / max / candidates (dtx_ds_post), then the
+    (dtx_subspace_scan: detection statistic + histogram / max / candidates), then the
     reference's trigger loop on the sparse candidates.  Returns dict(ss=DataFrame,
     sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None."""
     import pandas as pd
@@ -168,12 +168,12 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
                 if dec > 1:                                      # construct.py:1016-1017
                     planes = ctx.decimate(planes, dec, sr_raw)
                 mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
-                ds = ctx.subspace_ds(mp)
+                ds, res = ctx.subspace_scan(mp, thr=thr_arr, hist=hist if calcHist else None)
                 mp_host = mp.cpu().numpy() if estimateMags else None
             else:
-                ds = ctx.subspace_ds(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc,
-                                     nchunk=i1 - i0)
-            res = ctx.ds_post(ds, thr=thr_arr, hist=hist if calcHist else None)
+                ds, res = ctx.subspace_scan(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc,
+                                            nchunk=i1 - i0, thr=thr_arr,
+                                            hist=hist if calcHist else None)
             P = int(ds.shape[2])
             maxds = res['maxds'].cpu().numpy()
             cb, cd, cp, cv = res['cand']

@@ -151,14 +151,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_ds')
         return out
 
-    def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
-        """Histogram / max / threshold candidates of a DS tensor [nchunk, D, P].
-
-        Returns dict(hist=[D,400] uint32-as-int64 tensor or None, maxds=[nchunk,D],
-        cand=(chunk, det, index, value) numpy arrays sorted by (chunk, det, index),
-        ncand=total found)."""
-        nchunk, D, P = (int(s) for s in ds.shape)
-        dev = ds.device
+    def _post_buffers(self, nchunk, D, dev, thr, hist, want_max, cand_cap):
         if hist is None:
             hist = torch.zeros((D, HIST_BINS), dtype=torch.int32, device=dev)
         maxds = torch.empty((nchunk, D), dtype=torch.float32, device=dev) if want_max else None
@@ -169,10 +162,55 @@ class HipContext(object):
             key = torch.empty((cand_cap,), dtype=torch.int64, device=dev)
             val = torch.empty((cand_cap,), dtype=torch.float32, device=dev)
             cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        return hist, maxds, thr_t, key, val, cnt
+
+    def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None,
+                      hist=None, want_max=True, cand_cap=1 << 20):
+        """subspace_ds + ds_post in one call (dtx_subspace_scan).
+        Returns (ds, result dict as ds_post)."""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError('x must be a float32 CUDA tensor')
+        if M is None:
+            if x.dim() == 1:
+                x = x[None, :]
+            if x.stride(-1) != 1:
+                x = x.contiguous()
+            nchunk, M = int(x.shape[0]), int(x.shape[1])
+            chunk_stride = int(x.stride(0)) if nchunk > 1 else M
+        else:
+            need = (nchunk - 1) * chunk_stride + M
+            if x.numel() < need or not x.is_contiguous():
+                raise ValueError('flat buffer too small for the chunk layout')
+        P = self.num_windows(M)
+        if out is None:
+            ldp = (max(P, 1) + 63) // 64 * 64
+            out = torch.empty((nchunk, self.D, ldp), dtype=torch.float32,
+                              device=x.device)[:, :, :max(P, 0)]
+        hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, self.D, x.device, thr, hist,
+                                                               want_max, cand_cap)
+        rc = self.lib.dtx_subspace_scan(self.h, _ptr(x), int(M), int(chunk_stride), int(nchunk),
+                                        _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
+                                        _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
+        self._ck(rc, 'dtx_subspace_scan')
+        return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
+
+    def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
+        """Histogram / max / threshold candidates of a DS tensor [nchunk, D, P].
+
+        Returns dict(hist=[D,400] uint32-as-int64 tensor or None, maxds=[nchunk,D],
+        cand=(chunk, det, index, value) numpy arrays sorted by (chunk, det, index),
+        ncand=total found)."""
+        nchunk, D, P = (int(s) for s in ds.shape)
+        hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, D, ds.device, thr, hist,
+                                                               want_max, cand_cap)
         rc = self.lib.dtx_ds_post(self.h, _ptr(ds), P, int(ds.stride(1)), nchunk, D,
                                   _ptr(hist), _ptr(maxds), _ptr(thr_t), _ptr(key), _ptr(val),
                                   int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_ds_post')
+        return self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
+
+    @staticmethod
+    def _post_result(hist, maxds, thr, key, val, cnt, cand_cap):
         res = dict(hist=hist, maxds=maxds, cand=None, ncand=0)
         if thr is not None:
             n = int(cnt.item())

@@ -138,6 +138,16 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
                 const float* thr_dev, uint64_t* cand_key_dev,
                 float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* dtx_subspace_ds followed by dtx_ds_post in one call (same arguments, same results).  The
+ * reference does exactly this per chunk (detect.py:259-281, 178-181, 410): detection statistic,
+ * then its histogram, its maximum and the samples at or above the threshold.
+ * maxds_dev is zeroed here; hist_dev / ncand_dev are the caller's
+ * to zero, as for dtx_ds_post.  Asynchronous. */
+int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                      int nchunk, float* ds_dev, int64_t ldp, uint32_t* hist_dev,
+                      float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
+                      float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
+
 /* False-alarm statistics of a DS tensor (detex/fas.py:72-86: np.histogram(dss,
  * np.linspace(-.01, 1, 401)) and scipy.stats.beta.fit(dss, floc=0, fscale=1)).
  *   hist_dev  [D][nbins] uint32, accumulated, uniform np.linspace(lo, hi, nbins+1)

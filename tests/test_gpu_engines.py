@@ -151,3 +151,37 @@ def test_engines_agree_fullsize(ctx):
     assert np.array_equal(a['cand'][2], b['cand'][2]) and len(a['cand'][2]) >= 6
     assert int((a['hist'] - b['hist']).abs().sum()) <= 40     # bin-edge flips only
     c32.close()
+
+
+@pytest.mark.parametrize('burst', [0.0, 3e3])
+def test_fused_scan_equals_two_calls(ctx, burst):
+    """dtx_subspace_scan returns the DS
+    tensor, histogram, maxima and candidates of dtx_subspace_ds + dtx_ds_post, bit for bit --
+    also when the dynamic-range guard hands a block to the repair pass (burst)."""
+    from detex_amd import synth
+    Nc, L, D, k = 3, 700, 5, [8, 1, 1, 3, 2]
+    n = Nc * L
+    rs = np.random.RandomState(21)
+    off = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+    U = np.concatenate([synth.orthonormal_basis(rs, n, kk) for kk in k]).astype(np.float32)
+    nchunk, T = 2, 17000
+    x = rs.standard_normal((nchunk, Nc * T)).astype(np.float32)
+    for b in range(nchunk):
+        p = 2000 + 5000 * b
+        x[b, p * Nc:p * Nc + n] += (6 * np.sqrt(n) * U[off[3]]).astype(np.float32)
+    if burst:
+        x[1, Nc * 9000: Nc * 9100] *= burst
+    xt = torch.from_numpy(x).cuda()
+    thr = np.full(D, 0.25, np.float32)
+    ctx.upload_basis(U, off, Nc)
+    ds1 = ctx.subspace_ds(xt)
+    r1 = ctx.ds_post(ds1, thr=thr)
+    ds2, r2 = ctx.subspace_scan(xt, thr=thr)
+    ctx.sync()
+    assert torch.equal(ds1, ds2)
+    assert torch.equal(r1['hist'], r2['hist'])
+    assert torch.equal(r1['maxds'], r2['maxds'])
+    assert r1['ncand'] == r2['ncand'] and r1['ncand'] >= 2
+    for a_, b_ in zip(r1['cand'], r2['cand']):
+        assert np.array_equal(a_, b_)
+    assert int(r2['hist'].sum()) == nchunk * D * ds2.shape[2]
