@@ -163,6 +163,12 @@ __device__ __forceinline__ LdsBases lds_bases(int tid) {
 }
 __host__ __device__ constexpr int swz_gr(int r) { return (2 * (r & 7)) | (16 * ((r >> 2) & 1)); }
 
+// LDS element at a BYTE offset: the swizzled addresses are formed in bytes (base << 3 once, then
+// XOR / add of compile-time byte constants), so no per-access shift is left for the VALU
+__device__ __forceinline__ c32& lds_at(c32* lds, int byte_off) {
+  return *reinterpret_cast<c32*>(reinterpret_cast<char*>(lds) + byte_off);
+}
+
 // a wave's LDS writes are visible to its own later reads (in-order LDS pipeline); this only
 // keeps hipcc from moving the accesses across the exchange point
 __device__ __forceinline__ void wave_sync() {
@@ -220,14 +226,15 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
   Twid w;
   load_twiddles<SG>(w, tab, tid + opaque);
-  LdsBases lb;
-  lb.g = lb0.g + opaque; lb.s1 = lb0.s1 + opaque; lb.s2 = lb0.s2 + opaque; lb.f = lb0.f + opaque;
+  LdsBases lb;   // in bytes from here on
+  lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
+  lb.f = (lb0.f + opaque) << 3;
   // ---- phase A, pass 1: radix 16 over r, no twiddles
   dft_bitrev<SG, 16>(v);
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
-  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds[lb.s1 ^ s] = v[rev4(s)]; });
+  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
   wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds[(lb.g ^ swz_gr(r)) + 64 * r]; });
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
   // ---- pass 2: radix 16, sub-transforms of 16 -> 256
   {
@@ -243,10 +250,10 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   dft_bitrev<SG, 16>(v);
   dtx::static_for<0, 16>([&](auto sc) {
     constexpr int s = sc;
-    lds[lb.s2 ^ ((16 * s) ^ (s >> 1))] = v[rev4(s)];
+    lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ (s >> 1)))) = v[rev4(s)];
   });
   wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds[(lb.g ^ swz_gr(r)) + 64 * r]; });
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
   // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
   // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
@@ -262,11 +269,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
   });
   // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds[(lb.g ^ swz_gr(r)) + 64 * r] = v[r]; });
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
   __syncthreads();
   dtx::static_for<0, 16>([&](auto mc) {
     constexpr int m = mc;
-    v[m] = lds[lb.f + 512 * (m & 1) + 1024 * (m >> 1)];
+    v[m] = lds_at(lds, lb.f + 8 * (512 * (m & 1) + 1024 * (m >> 1)));
   });
   // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
   // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
