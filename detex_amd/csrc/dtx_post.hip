@@ -10,7 +10,7 @@ namespace {
 constexpr int kPostThreads = 256;
 constexpr int kPostItems = 16;   // float4 loads per thread -> 16 KiB of DS per block
 
-__device__ inline int hist_bin(float vf) { return dtx_hist_bin(vf); }
+__device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
 
 __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,

@@ -32,6 +32,16 @@ __device__ inline int dtx_hist_bin(float vf) {
   return i;
 }
 
+// the same bin; nearly every window is noise in the first four bins: settle those with three
+// compares against the same float64 edges i * (1/400) the general search uses -- no loop, no
+// divergence inside a wave
+__device__ inline int dtx_hist_bin_fast(float vf) {
+  const double vd = (double)vf, step = 1.0 / 400.0;
+  if (vd >= 0.0 && vd < 4.0 * step)
+    return vd < 2.0 * step ? (vd < 1.0 * step ? 0 : 1) : (vd < 3.0 * step ? 2 : 3);
+  return dtx_hist_bin(vf);
+}
+
 // per-thread partial statistics of one (chunk, detector) row; noise windows all fall into the
 // first bins, so those counts stay in registers
 struct DtxPostAcc {
@@ -44,14 +54,7 @@ __device__ inline void dtx_post_value(DtxPostAcc& s, const DtxPost& po, float v,
   if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
   s.vmax = max(s.vmax, bits);
   if (po.hist) {
-    // nearly every window is noise in the first four bins: settle those with three compares
-    // against the same float64 edges i * (1/400) the general search uses, no loop, no divergence
-    const double vd = (double)v, step = 1.0 / 400.0;
-    int b;
-    if (vd >= 0.0 && vd < 4.0 * step)
-      b = vd < 2.0 * step ? (vd < 1.0 * step ? 0 : 1) : (vd < 3.0 * step ? 2 : 3);
-    else
-      b = dtx_hist_bin(v);
+    const int b = dtx_hist_bin_fast(v);
     if (b >= 4) atomicAdd(&po.hist[(int64_t)det * DTX_HIST_BINS + b], 1u);
     else if (b >= 0) {
       s.low[0] += (b == 0); s.low[1] += (b == 1); s.low[2] += (b == 2); s.low[3] += (b == 3);
