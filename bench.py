@@ -100,7 +100,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
             return json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
     if eng == 'fft':
         N = 8192
-        V = (N - L + 1) // 512 * 512
+        V = (N - L + 1) // 512 * 512 if L <= 6145 else 4096      # segmented templates advance by 4096
         nblk = (P + V - 1) // V
         npairs = D * ((K // D + 1) // 2) if K % D == 0 else (K + 1) // 2
         nfft = npairs * nblk * chunks
@@ -237,8 +237,8 @@ def main():
     default_cfg = (D, k, a.chunks, Nc, a.sr, a.chunk_seconds, a.template_seconds) == \
         (25, 8, 24, 3, 100.0, 3720.0, 30.0)
     eng = a.engine
-    if eng == 'auto':                        # dtx_internal.h: kFftAutoMinL .. kFftMaxL
-        eng = 'fft' if 256 <= L <= 6145 else 'bf16x3'
+    if eng == 'auto':                        # dtx_internal.h: kFftAutoMinL .. kFftLongMaxL
+        eng = 'fft' if 256 <= L <= 32768 else 'bf16x3'
     if eng == 'bf16x3' and L < 64:
         eng = 'fp32'
     out = {

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
   }
   fft8192<-1>(v, lds, lb, tab, tid);
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);
+  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);   // nblk: blocks STORED per chunk
   if (tid == 0) v[0].y = v[8].x;
 #pragma unroll
   for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 }
 
 struct FftArgs {
-  const c32* xh;        // [nchunk * nblk][Nc][kXh] half spectra
+  const c32* xh;        // [nchunk][nblkx][Nc][kXh] half spectra, nblkx = nblk + nseg - 1
   const c32* W;         // [npairs][Nc][kN]
   const c32* tab;       // [kN] e^{+2 pi i m / kN}
   const int4* unit;     // [nunits] {first pair, pairs, -, -}: consecutive pairs of whole detectors
@@ -357,6 +357,7 @@ struct FftArgs {
   int64_t Ppad, ldp, P;
   int Nc, D, V, nblk, nchunk;
   int nunits, ntile_b, per_xcd;   // tiling of the grid (launch_fft)
+  int nseg, nblkx;      // template segments (virtual channels per real channel), block spectra stored per chunk
 };
 
 // epilogue of one pair (uses z, pr, ui, mean, den, acc0, acc1 of the enclosing kernel): add the
@@ -443,7 +444,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   };
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
   const int wlo = 1024 * wv + ln;             // basis spectra are stored wave-decimated: [w][n2]
-  const c32* xh = a.xh + (int64_t)cb * a.Nc * kXh;
+  // block spectra of this block; a template longer than one segment also reads the following
+  // blocks': segment s of the template meets the data of block blk + s (advance == segment length)
+  const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
   if constexpr (NCH > 0) {
     const float4* src = reinterpret_cast<const float4*>(xh);
@@ -463,17 +466,19 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   c32 z[16];
   {
     for (int pr = 0; pr < ui.y; ++pr) {
-      const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * kN;   // uniform
+      const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * a.nseg * kN;   // uniform
 #pragma unroll
       for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
       // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
       // this phase lives on (the same loop with each load next to its MAC ran 40 % slower).
       // Addresses are kept as (uniform base) + lane offset: SGPRs + one VGPR.
 #pragma nounroll
-      for (int c = 0; c < (NCH > 0 ? NCH : a.Nc); ++c) {
+      for (int vc = 0; vc < (NCH > 0 ? NCH : a.Nc * a.nseg); ++vc) {
+        // virtual channel vc = (channel c, template segment sg): NCH > 0 implies one segment
+        const int c = NCH > 0 ? vc : vc / a.nseg, sg = NCH > 0 ? 0 : vc - c * a.nseg;
         c32 pw[16], px[16];
-        const c32* wc = wp + (int64_t)c * kN;
-        const c32* xc = xh + (int64_t)c * kXh;
+        const c32* wc = wp + (int64_t)vc * kN;
+        const c32* xc = xh + ((int64_t)sg * a.Nc + c) * kXh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
 #pragma unroll
@@ -489,13 +494,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
 
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
-  if (two && a.Nc == 3 && DTX_FFT_XLDS) {   // some pair holds two single-vector detectors
+  const bool xl = DTX_FFT_XLDS && a.nseg == 1;   // block spectra LDS-resident: single-segment templates
+  if (two && a.Nc == 3 && xl) {   // some pair holds two single-vector detectors
     hipLaunchKernelGGL((ds_fft_kernel<VM, true, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   } else if (two) {
     hipLaunchKernelGGL((ds_fft_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
-  } else if (a.Nc == 3 && DTX_FFT_XLDS) {
+  } else if (a.Nc == 3 && xl) {
     hipLaunchKernelGGL((ds_fft_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
-  } else if (a.Nc == 1 && DTX_FFT_XLDS) {
+  } else if (a.Nc == 1 && xl) {
     hipLaunchKernelGGL((ds_fft_kernel<VM, false, 1>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   } else {
     hipLaunchKernelGGL((ds_fft_kernel<VM, false, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
@@ -545,7 +551,7 @@ void dtx_fft_free(dtx_ctx* ctx) {
   f = DtxFft();
 }
 
-bool dtx_fft_eligible(int L) { return L >= kFftMinL && L <= kFftMaxL; }
+bool dtx_fft_eligible(int L) { return L >= kFftMinL && L <= kFftLongMaxL; }
 
 // hU: the stacked basis [Ktot][n] on the host (multiplexed rows)
 int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n,
@@ -554,7 +560,14 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
   const int L = n / Nc;
   if (!dtx_fft_eligible(L)) return DTX_OK;
   DtxFft& f = ctx->fft;
-  f.V = (kN - L + 1) / 512 * 512;
+  // Templates up to kFftMaxL: one segment, V = 512 floor((kN - L + 1) / 512) windows per block.
+  // Longer ones are cut into segments of kSeg = kN / 2 samples and the block advance is kSeg
+  // too: Y[p] = sum_s corr(segment s, data at p + s kSeg), and with advance == segment length
+  // "data at p + s kSeg" is simply block (blk + s) -- its spectrum is already there.  Each
+  // (channel, segment) is a virtual channel of the MAC.
+  constexpr int kSeg = kN / 2;
+  f.nseg = L <= kFftMaxL ? 1 : (L + kSeg - 1) / kSeg;
+  f.V = f.nseg == 1 ? (kN - L + 1) / 512 * 512 : kSeg;
 
   // pairs: consecutive vectors of a detector (an odd one out pairs with a zero row); two
   // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
@@ -603,10 +616,11 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
 
   // pair spectra in float64 on the host, one (pair, channel) transform per task over the
   // host's cores (300 transforms at configs[1]: ~80 ms on one core)
-  std::vector<float2> W((size_t)f.npairs * Nc * kN);
+  const int nvc = Nc * f.nseg;
+  std::vector<float2> W((size_t)f.npairs * nvc * kN);
   {
     static const HostFft hfft;
-    const int ntask = f.npairs * Nc;
+    const int ntask = f.npairs * nvc;
     unsigned nthr = std::thread::hardware_concurrency();
     nthr = std::max(1u, std::min(nthr ? nthr : 1u, 32u));
     nthr = std::min<unsigned>(nthr, (unsigned)ntask);
@@ -614,12 +628,14 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
     auto work = [&]() {
       std::vector<std::complex<double>> z(kN);
       for (int task = next.fetch_add(1); task < ntask; task = next.fetch_add(1)) {
-        const int pr = task / Nc, c = task - pr * Nc;
+        const int pr = task / nvc, vc = task - pr * nvc;
+        const int c = vc / f.nseg, sg = vc - c * f.nseg;
+        const int j0 = f.nseg == 1 ? 0 : sg * kSeg, j1 = f.nseg == 1 ? L : std::min(L, j0 + kSeg);
         const int ra = prow[2 * pr], rb = prow[2 * pr + 1];
         for (int j = 0; j < kN; ++j) z[j] = 0.0;
-        for (int j = 0; j < L; ++j)
-          z[j] = std::complex<double>((double)hU[(size_t)ra * n + (size_t)j * Nc + c],
-                                      rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
+        for (int j = j0; j < j1; ++j)
+          z[j - j0] = std::complex<double>((double)hU[(size_t)ra * n + (size_t)j * Nc + c],
+                                           rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
         hfft.run(z.data());
         float2* dst = W.data() + (size_t)task * kN;
         // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
@@ -666,10 +682,11 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   const int64_t grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;
-  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblk * Nc * kXh * sizeof(float2)))) return rc;
+  const int nblkx = nblk + f.nseg - 1;   // a segmented template also reads the blocks behind its own
+  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
-  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblk, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                     ctx->stream, xp, Tpad, Nc, V, nblk, (const c32*)f.tab_dev, xh);
+  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
+                     ctx->stream, xp, Tpad, Nc, V, nblkx, (const c32*)f.tab_dev, xh);
   DTX_HIP(ctx, hipGetLastError());
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
@@ -678,6 +695,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
+  a.nseg = f.nseg; a.nblkx = nblkx;
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->stream, den,
                      Ppad, P, V, nblk, guard_list);
   DTX_HIP(ctx, hipGetLastError());

@@ -34,6 +34,7 @@ struct DtxFft {
   bool ok = false;
   bool two = false;            // some unit pairs two single-vector detectors
   int V = 0;                   // windows per block (block advance), a multiple of 512
+  int nseg = 1;                // template segments (> 1: templates longer than kFftMaxL)
   int nunits = 0, npairs = 0;
   void* W_dev = nullptr;       // [npairs][Nc][DTX_FFT_N] complex64
   void* tab_dev = nullptr;     // [DTX_FFT_N] twiddle table
@@ -43,7 +44,8 @@ struct DtxFft {
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
-constexpr int kFftMaxL = DTX_FFT_N - 2048 + 1;
+constexpr int kFftMaxL = DTX_FFT_N - 2048 + 1;     // longest single-segment template
+constexpr int kFftLongMaxL = 8 * (DTX_FFT_N / 2);  // longest template at all (8 segments of 4096)
 // DTX_ENGINE_AUTO: shortest template it hands to the frequency-domain engine (measured
 // crossover with the split-bf16 MFMA engine at 200 basis vectors, Nc = 3: L ~ 220;
 // profiles/f3_crossover.txt)

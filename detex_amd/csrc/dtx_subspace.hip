@@ -535,7 +535,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   }
 
   const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
-                       (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftMaxL);
+                       (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
   if (use_fft) {
     if (!ctx->fft.ok &&
         (rc = dtx_fft_basis_build(ctx, ctx->hU.data(), ctx->hdoff.data(), ctx->D, n, Nc)))

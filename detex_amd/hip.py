@@ -89,7 +89,7 @@ class HipContext(object):
         _lib.check(self.lib, self.h, rc, what)
 
     def set_engine(self, engine):
-        """'auto' (default: 'fft' for templates of 256..6145 samples per channel,
+        """'auto' (default: 'fft' for templates of 256..32768 samples per channel,
         else 'bf16x3'), 'fft' (frequency-domain overlap-save engine, float32
         transforms), 'bf16x3' (split-bfloat16 MFMA contraction, float32-level
         accuracy) or 'fp32' (float32 MFMA, products bitwise an fma chain)."""

@@ -75,8 +75,8 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
                      int D, int n, int Nc);
 
 /* Arithmetic engine of dtx_subspace_ds (default DTX_ENGINE_AUTO):
- *   DTX_ENGINE_AUTO    DTX_ENGINE_FFT for templates of 256 .. 6145 samples per channel
- *                      (where it is faster: 6.5x at 3000 samples, 200 basis vectors),
+ *   DTX_ENGINE_AUTO    DTX_ENGINE_FFT for templates of 256 .. 32768 samples per channel
+ *                      (where it is faster: 8x at 3000 samples, 200 basis vectors),
  *                      DTX_ENGINE_BF16X3 otherwise.
  *   DTX_ENGINE_FP32    v_mfma_f32_16x16x4_f32: exact float32 products, bitwise an
  *                      fma chain.
@@ -93,8 +93,9 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
  *                      8192-point float32 transforms in LDS, two basis vectors per
  *                      complex transform, ~150x fewer flops than the contraction.
  *                      Float32 error grows with log(8192) instead of sqrt(n): ~2e-7 at
- *                      DS = 1.  Templates longer than 6145 samples per channel fall
- *                      back to DTX_ENGINE_BF16X3. */
+ *                      DS = 1.  Templates longer than 6145 samples per channel are cut
+ *                      into segments of 4096 that reuse the block spectra; longer than
+ *                      32768 fall back to DTX_ENGINE_BF16X3. */
 #define DTX_ENGINE_FP32 0
 #define DTX_ENGINE_BF16X3 1
 #define DTX_ENGINE_FFT 2
