@@ -108,7 +108,8 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         bytes_alg = (4.0 * Nc + 4.0 * D) * P * chunks
         # what the kernel computes: one 8192-point complex transform (5 N log2 N) and Nc complex
         # MACs per frequency (8 flop each) per (pair, block)
-        flop_fft = nfft * (5.0 * N * 13 + 8.0 * Nc * N)
+        nseg = 1 if L <= 6145 else (L + 4095) // 4096
+        flop_fft = nfft * (5.0 * N * 13 + 8.0 * Nc * nseg * N)
         gbs = bytes_alg / (kms * 1e-3) / 1e9
         return {'bound': 'hbm', 'kernel': 'ds_fft_kernel<%d>' % (V // 512), 'achieved': gbs, 'peak': 8000.0,
                 'unit': 'GB/s', 'frac': gbs / 8000.0, 'traffic': pmc('*_bench_pmc_ds_fft_kernel.json'),
