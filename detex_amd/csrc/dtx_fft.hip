@@ -36,282 +36,9 @@
 #include <complex>
 #include <thread>
 
-#include "dtx_hankel.h"
-#include "dtx_internal.h"
+#include "dtx_fftcore.h"
 
 namespace {
-
-constexpr int kN = DTX_FFT_N;        // transform length (complex points)
-constexpr int kT = 512;              // threads per workgroup, 16 points each
-constexpr int kLdsC = kN;            // complex slots of the (swizzled, unpadded) LDS image
-// one stored half spectrum of a real series: slots f = 1 .. kN/2 - 1 hold X[f]; slot 0 holds
-// (X[0], X[kN/2]), both real; X[kN - f] = conj X[f] is never stored
-constexpr int kXh = kN / 2;
-constexpr int kXlMax = 3;            // channels whose block spectra fit in LDS beside the image
-// L2-sized tiles of the (unit, block) work space: the workgroups an XCD runs together
-// share kTileU units' spectra and kTileB blocks' spectra (see ds_fft_kernel)
-constexpr int kTileU = 2, kTileB = 16, kTile = kTileU * kTileB;
-#ifndef DTX_FFT_WAVES
-#define DTX_FFT_WAVES 2              // waves per SIMD the scan kernel is compiled for (2: one workgroup per CU,
-#endif                               // 256 registers; 4 -> 128 registers spills and measured 19 % slower)
-#ifndef DTX_FFT_XLDS
-#define DTX_FFT_XLDS 1               // Nc = 1, 3: keep the block's spectra in LDS across the unit's pairs
-#endif
-static_assert(kN == 8192, "radix plan 16 x 8 x 8 x 8 is for 8192 points");
-
-typedef float2 c32;
-
-__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// a * (SG * i)
-template <int SG>
-__device__ __forceinline__ c32 muli(c32 a) {
-  return SG > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
-}
-
-// In-place radix-2 decimation-in-frequency DFT of R = 8 or 16 register values, kernel
-// e^{SG 2 pi i s q / R}; the result is left in BIT-REVERSED order (X[q] = u[rev(q)]), which
-// costs nothing: the callers index their stores with compile-time constants.  Working in
-// place stage by stage keeps the live set at R values plus one temporary -- the natural-
-// order split-radix form needed 238 registers for the 8192-point transform, this one fits
-// the 128 of two workgroups per CU.
-template <int SG, int LEN, int Q>
-__device__ __forceinline__ c32 mul_root(c32 t) {   // t * e^{SG 2 pi i Q / LEN}
-  if constexpr (Q == 0) {
-    return t;
-  } else if constexpr (4 * Q == LEN) {
-    return muli<SG>(t);
-  } else if constexpr (8 * Q == LEN) {             // (1 + SG i) / sqrt 2
-    constexpr float h = 0.70710678118654752440f;
-    return SG > 0 ? make_float2((t.x - t.y) * h, (t.y + t.x) * h)
-                  : make_float2((t.x + t.y) * h, (t.y - t.x) * h);
-  } else if constexpr (8 * Q == 3 * LEN) {         // (-1 + SG i) / sqrt 2
-    constexpr float h = 0.70710678118654752440f;
-    return SG > 0 ? make_float2((-t.x - t.y) * h, (t.x - t.y) * h)
-                  : make_float2((t.y - t.x) * h, (-t.x - t.y) * h);
-  } else {
-    static_assert(LEN == 16, "general roots only in the 16-point stage");
-    constexpr float cs[8] = {1.f, 0.92387953251128675613f, 0.70710678118654752440f,
-                             0.38268343236508977173f, 0.f, -0.38268343236508977173f,
-                             -0.70710678118654752440f, -0.92387953251128675613f};
-    constexpr float sn[8] = {0.f, 0.38268343236508977173f, 0.70710678118654752440f,
-                             0.92387953251128675613f, 1.f, 0.92387953251128675613f,
-                             0.70710678118654752440f, 0.38268343236508977173f};
-    return cmul(t, make_float2(cs[Q], (float)SG * sn[Q]));
-  }
-}
-template <int SG, int R, int LEN>
-__device__ __forceinline__ void dif_stage(c32 (&u)[R]) {
-  constexpr int H = LEN / 2;
-  dtx::static_for<0, R / 2>([&](auto bc) {
-    constexpr int b = bc, blk = (b / H) * LEN, q = b % H;
-    const c32 x = u[blk + q], y = u[blk + q + H];
-    u[blk + q] = cadd(x, y);
-    u[blk + q + H] = mul_root<SG, LEN, q>(csub(x, y));
-  });
-}
-template <int SG, int R>
-__device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
-  if constexpr (R >= 16) dif_stage<SG, R, 16>(u);
-  if constexpr (R >= 8) dif_stage<SG, R, 8>(u);
-  dif_stage<SG, R, 4>(u);
-  dif_stage<SG, R, 2>(u);
-}
-__host__ __device__ constexpr int rev2(int q) { return ((q & 1) << 1) | (q >> 1); }
-__host__ __device__ constexpr int rev3(int q) { return ((q & 1) << 2) | (q & 2) | ((q >> 2) & 1); }
-__host__ __device__ constexpr int rev4(int q) {
-  return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q >> 3) & 1);
-}
-
-// The 8192-point transform, decimated over the workgroup's 8 waves:  n = 8 n2 + w.
-//   phase A  wave w transforms ITS 1024-point subsequence z[8 n2 + w] alone: 16 points per
-//            lane (lane l, register r <-> n2 = l + 64 r), Stockham radices 16 x 16 x 4, two
-//            exchanges through the wave's own 8 KB of the LDS image.  A wave's LDS
-//            instructions execute in order, so these exchanges need no s_barrier: the waves
-//            of a workgroup drift apart and one wave's L2 loads overlap another's butterflies.
-//   phase B  one exchange across the waves (Y_w[k2] at slot 1024 w + k2), then thread tid
-//            combines Y_0..7[k2] for k2 = tid, tid + 512 with twiddles e^{2 pi i w k2 / N} in a
-//            radix-8 pass: X[k2 + 1024 k1] -> register m = 2 k1 + h holds point tid + 512 m,
-//            which is what the epilogue's coalesced DS stores want.
-// Two workgroup barriers per transform (before the first scatter: the previous transform's
-// phase-B reads are done; before the phase-B reads) instead of seven.
-//
-// LDS image: in-region slot a lives at a ^ g(a), g(a) = ((a >> 5) & 15) ^ (((a >> 8) & 1) << 4):
-// an XOR swizzle instead of padding (the image is exactly 64 KB, which is what lets three
-// channels of block spectra sit beside it in the 160 KB).  Every access is conflict-free
-// under it (64 banks x 4 B, ds_*_b64 in half-waves; checked exhaustively by
-// scripts/fft_swizzle_check.py) and every address is a per-lane base combined with a
-// compile-time constant:
-//   gather / phase-B write   point l + 64 r             -> (g ^ (2 (r & 7) | 16 ((r >> 2) & 1))) + 64 r
-//   scatter 1                slot 16 l + s              -> s1 ^ s
-//   scatter 2                256 (l >> 4) + (l & 15) + 16 s  -> s2 ^ (16 s ^ (s >> 1))
-//   phase-B read             region w', point tid + 512 h    -> f + 512 h + 1024 w'
-struct LdsBases {
-  int g, s1, s2, f;
-};
-__device__ __forceinline__ LdsBases lds_bases(int tid) {
-  const int l = tid & 63, region = (tid >> 6) * 1024, hb = (l >> 4) & 1;
-  LdsBases b;
-  b.g = region + (l ^ (l >> 5));
-  b.s1 = region + ((16 * l) ^ (((l >> 1) & 15) ^ (hb << 4)));
-  b.s2 = region + ((256 * (l >> 4) + (l & 15)) ^ (24 * hb));
-  b.f = tid ^ (((tid >> 5) & 15) ^ (((tid >> 8) & 1) << 4));
-  return b;
-}
-__host__ __device__ constexpr int swz_gr(int r) { return (2 * (r & 7)) | (16 * ((r >> 2) & 1)); }
-
-// LDS element at a BYTE offset: the swizzled addresses are formed in bytes (base << 3 once, then
-// XOR / add of compile-time byte constants), so no per-access shift is left for the VALU
-__device__ __forceinline__ c32& lds_at(c32* lds, int byte_off) {
-  return *reinterpret_cast<c32*>(reinterpret_cast<char*>(lds) + byte_off);
-}
-
-// a wave's LDS writes are visible to its own later reads (in-order LDS pipeline); this only
-// keeps hipcc from moving the accesses across the exchange point
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// twiddles of one thread, already conjugated for SG < 0
-struct Twid {
-  c32 a[4];    // pass 2 (radix 16, sub-transforms of 16): w, w^2, w^4, w^8, w = e^{2 pi i (l & 15) / 256}
-  c32 b[2];    // pass 3 (radix 4, sub-transforms of 256), butterfly 0: w, w^2, w = e^{2 pi i l / 1024}
-  c32 p4[3];   // phase B (radix 8): w, w^2, w^4, w = e^{2 pi i tid / 8192}; point tid + 512 derives its own
-};
-template <int SG>
-__device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ tab, int tid) {
-  auto ld = [&](int idx) {
-    c32 t = tab[idx];
-    if (SG < 0) t.y = -t.y;
-    return t;
-  };
-  const int l = tid & 63;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) w.a[e] = ld(((l & 15) * (kN / 256)) << e);
-  w.b[0] = ld(l * (kN / 1024));
-  w.b[1] = ld(l * (kN / 512));
-#pragma unroll
-  for (int e = 0; e < 3; ++e) w.p4[e] = ld(tid << e);
-}
-
-// one radix-8 butterfly of phase B: points v[2 s + H], s = 0..7, twiddled by w^s; the
-// transform is left bit-reversed in u
-template <int SG, int H>
-__device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c32 w2, c32 w4) {
-  u[0] = v[H];
-  u[1] = cmul(v[2 + H], w1);
-  u[2] = cmul(v[4 + H], w2);
-  u[4] = cmul(v[8 + H], w4);
-  const c32 w3 = cmul(w1, w2);
-  u[3] = cmul(v[6 + H], w3);
-  u[7] = cmul(v[14 + H], cmul(w3, w4));
-  u[5] = cmul(v[10 + H], cmul(w1, w4));
-  u[6] = cmul(v[12 + H], cmul(w2, w4));
-  dft_bitrev<SG, 8>(u);
-}
-
-// v[r] = point 8 (l + 64 r) + wave in, natural-order transform point (tid + 512 m) out in v[m]
-template <int SG>
-__device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
-                                        const c32* __restrict__ tab, int tid) {
-  // The ~50 swizzled LDS addresses below and the 9 twiddles are loop invariants of the
-  // caller's pair loop; hoisted there they cost 70 registers and the kernel spills.  An opaque
-  // zero keeps them inside (the twiddle loads are L1 / L2 hits, 9 per transform).
-  int opaque;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
-  Twid w;
-  load_twiddles<SG>(w, tab, tid + opaque);
-  LdsBases lb;   // in bytes from here on
-  lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
-  lb.f = (lb0.f + opaque) << 3;
-  // ---- phase A, pass 1: radix 16 over r, no twiddles
-  dft_bitrev<SG, 16>(v);
-  __syncthreads();   // every wave has finished the phase-B reads of the previous transform
-  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
-  wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
-  wave_sync();
-  // ---- pass 2: radix 16, sub-transforms of 16 -> 256
-  {
-    const c32 w1 = w.a[0], w2 = w.a[1], w4 = w.a[2], w8 = w.a[3];
-    const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
-    v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-    v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
-    v[9] = cmul(v[9], cmul(w1, w8)); v[10] = cmul(v[10], cmul(w2, w8));
-    v[11] = cmul(v[11], cmul(w3, w8)); v[12] = cmul(v[12], cmul(w4, w8));
-    v[13] = cmul(v[13], cmul(w5, w8)); v[14] = cmul(v[14], cmul(w6, w8));
-    v[15] = cmul(v[15], cmul(w7, w8));
-  }
-  dft_bitrev<SG, 16>(v);
-  dtx::static_for<0, 16>([&](auto sc) {
-    constexpr int s = sc;
-    lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ (s >> 1)))) = v[rev4(s)];
-  });
-  wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
-  wave_sync();
-  // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
-  // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
-  dtx::static_for<0, 4>([&](auto bc) {
-    constexpr int b = bc;
-    const c32 w1 = mul_root<SG, 16, b>(w.b[0]), w2 = mul_root<SG, 8, b>(w.b[1]);
-    c32 u[4];
-    u[0] = v[b];
-    u[1] = cmul(v[b + 4], w1);
-    u[2] = cmul(v[b + 8], w2);
-    u[3] = cmul(v[b + 12], cmul(w1, w2));
-    dft_bitrev<SG, 4>(u);
-    dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
-  });
-  // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
-  __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) {
-    constexpr int m = mc;
-    v[m] = lds_at(lds, lb.f + 8 * (512 * (m & 1) + 1024 * (m >> 1)));
-  });
-  // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
-  // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
-  c32 u0[8], u1[8];
-  bfly8<SG, 0>(v, u0, w.p4[0], w.p4[1], w.p4[2]);
-  bfly8<SG, 1>(v, u1, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
-  dtx::static_for<0, 8>([&](auto sc) {
-    constexpr int s = sc;
-    v[2 * s] = u0[rev3(s)];
-    v[2 * s + 1] = u1[rev3(s)];
-  });
-}
-
-// ---------------------------------------------------------------- block spectra
-// Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
-// slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w
-// takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0
-__global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, int64_t Tpad,
-                                                  int Nc, int V, int nblk,
-                                                  const c32* __restrict__ tab,
-                                                  c32* __restrict__ xh) {
-  __shared__ c32 lds[kLdsC];
-  const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
-  const LdsBases lb = lds_bases(tid);
-  const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
-  const int64_t t0 = (int64_t)blk * V + 8 * (tid & 63) + (tid >> 6);
-  c32 v[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t t = t0 + 512 * r;
-    v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
-  }
-  fft8192<-1>(v, lds, lb, tab, tid);
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);   // nblk: blocks STORED per chunk
-  if (tid == 0) v[0].y = v[8].x;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
-}
 
 // ---------------------------------------------------------------- the scan
 // Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when its

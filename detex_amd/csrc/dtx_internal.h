@@ -97,6 +97,13 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
 constexpr float kFftGuard = 200.f;
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
                     const DtxPost& po);
+// shortest events (samples per channel) the all-pairs cross-correlation sends through the
+// frequency domain under DTX_ENGINE_AUTO / DTX_ENGINE_FFT (dtx_xcfft.hip)
+constexpr int kXcFftMinL = 1024;
+int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L, int Pz,
+                  int64_t Ppad, int64_t Tz, const float* z, const float* fsum, const float* frs,
+                  const float* mean_w, const float* rsw, unsigned long long* keys,
+                  int64_t pair_begin, int64_t pair_end, int64_t b_begin, int64_t b_end);
 int dtx_launch_demux16(dtx_ctx* ctx, const float* xp, int64_t Tpad, int nplanes, void* g16);
 
 #define DTX_HIP(ctx, call)                                                    \

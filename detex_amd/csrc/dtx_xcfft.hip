@@ -1,0 +1,252 @@
+// All-pairs normalised cross-correlation through the frequency-domain machinery of the scan
+// (dtx_fftcore.h): replaces the lag-by-lag contraction of dtx_xcorr.hip for long events.
+//
+// For a fixed later event c the reference's _CCX2 (detex/construct.py:425-466) correlates every
+// earlier event b against c at the 2S+1 kept lags.  With c's zero-padded channel planes z_c as
+// the "stream" and the earlier events as "basis vectors" this is the scan's problem:
+//   Y_b[p] = sum_ch sum_j x_b,ch[j] z_c,ch[p + j],   p = 0 .. 2S  (lag index)
+// evaluated by overlap-save blocks of 8192 samples: block spectra of z_c once per event,
+// spectra of event PAIRS (b, b+1) as one complex sequence once per call (two correlations per
+// transform), events longer than 6145 samples cut into segments of 4096 that meet the block
+// spectra at shifted block indices (virtual channels; 12 per pair at L = 13 000).  The epilogue
+// is the contraction kernels' own: cc = (Y - sum(x_b) mu_w) rs_b rs_w, scrub, and the running
+// (max, first argmax) over lags as a 64-bit atomicMax key per pair; the winning lag is then
+// re-evaluated in float64 by xc_finish_kernel exactly as before, so the float32 transforms
+// only have to pick the lag.
+#include "dtx_fftcore.h"
+
+namespace {
+
+constexpr float kScrubTolF = 1e-5f;   // dtx_xcorr.hip: kScrubTol
+constexpr int kSegX = kN / 2;
+constexpr int kUnitX = 4;             // event pairs per workgroup (they share the window statistics)
+
+__device__ inline int64_t condensed_index_x(int64_t N, int64_t b, int64_t c) {
+  return N * b - b * (b + 1) / 2 + (c - b - 1);
+}
+
+// W[pair][vc][wave-major f] = 1/kN sum_j (x_2p,ch[j0 + j] + i x_2p+1,ch[j0 + j]) e^{+2 pi i j f / kN},
+// vc = ch * nseg + seg, j0 = seg * seglen, j < seglen (and j0 + j < L); float32 on the device
+// (2000 events x 12 virtual channels is 12 000 transforms: seconds on the host, < 1 ms here).
+__global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ td, int N, int n,
+                                                      int Nc, int L, int nseg, int seglen,
+                                                      const c32* __restrict__ tab,
+                                                      c32* __restrict__ W) {
+  __shared__ c32 lds[kLdsC];
+  const int tid = threadIdx.x;
+  const int nvc = Nc * nseg;
+  const int pr = blockIdx.x / nvc, vc = blockIdx.x - pr * nvc;
+  const int ch = vc / nseg, sg = vc - ch * nseg;
+  const int a = 2 * pr, b = a + 1;
+  const int j0 = sg * seglen;
+  const LdsBases lb = lds_bases(tid);
+  c32 v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = 8 * ((tid & 63) + 64 * r) + (tid >> 6);     // point index the transform expects
+    float re = 0.f, im = 0.f;
+    if (j < seglen && j0 + j < L) {
+      const int64_t q = (int64_t)(j0 + j) * Nc + ch;
+      re = td[(int64_t)a * n + q];
+      if (b < N) im = td[(int64_t)b * n + q];
+    }
+    v[r] = make_float2(re, im);
+  }
+  fft8192<1>(v, lds, lb, tab, tid);
+  c32* dst = W + ((int64_t)pr * nvc + vc) * kN + (tid & 7) * 1024 + (tid >> 3);
+  const float sc = 1.0f / (float)kN;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) dst[64 * m] = make_float2(v[m].x * sc, v[m].y * sc);
+}
+
+struct XcFftArgs {
+  const c32* xh;        // [N][nblkx][Nc][kXh] block spectra of the padded planes of every event
+  const c32* W;         // [ceil(N/2)][Nc*nseg][kN] pair spectra
+  const c32* tab;
+  const int2* items;    // (c, first pair of the unit)
+  const float* fsum;    // [N] sum(x_b)
+  const float* frs;     // [N] 1/sqrt(ssd(x_b)), 0 for a dead event
+  const float* mean_w;  // [N][Ppad]
+  const float* rsw;     // [N][Ppad]
+  unsigned long long* keys;
+  int64_t Ppad, pair_begin, pair_end;
+  int N, Nc, nseg, nblk, nblkx, V, Pz;
+};
+
+// one workgroup: event c, block blk of its lags, a unit of up to kUnitX earlier-event pairs
+template <int VM>
+__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftArgs a) {
+  __shared__ c32 lds[kLdsC];
+  const int tid = threadIdx.x;
+  const int item = blockIdx.x / a.nblk, blk = blockIdx.x - item * a.nblk;
+  const int2 it = a.items[item];
+  const int c = it.x, pr0 = it.y;
+  const int npr = min(kUnitX, (c + 1) / 2 - pr0);          // pairs with at least one row < c
+  const LdsBases lb = lds_bases(tid);
+  const int p0 = blk * a.V;
+
+  float mu[VM], rw[VM];
+#pragma unroll
+  for (int m = 0; m < VM; ++m) {
+    const int p = p0 + tid + 512 * m;
+    const bool ok = p < a.Pz;
+    mu[m] = ok ? a.mean_w[(int64_t)c * a.Ppad + p] : 0.f;
+    rw[m] = ok ? a.rsw[(int64_t)c * a.Ppad + p] : 0.f;
+  }
+  // the thread's 16 frequencies in a stored half spectrum (see ds_fft_kernel)
+  const int wv = tid >> 6, ln = tid & 63;
+  const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
+  auto fix_x = [&](c32 xx, int r) {
+    if (r == 0 && tid == 0) xx.y = 0.f;
+    if (r == 8 && tid == 0) return make_float2(xx.y, 0.f);
+    if (r >= 8) xx.y = -xx.y;
+    return xx;
+  };
+  auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
+  const int wlo = 1024 * wv + ln;
+  const int nvc = a.Nc * a.nseg;
+  const c32* xh = a.xh + ((int64_t)c * a.nblkx + blk) * a.Nc * kXh;
+
+  for (int q = 0; q < npr; ++q) {
+    const int pr = pr0 + q;
+    const c32* wp = a.W + (int64_t)pr * nvc * kN;
+    c32 z[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
+#pragma nounroll
+    for (int vc = 0; vc < nvc; ++vc) {
+      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
+      c32 pw[16], px[16];
+      const c32* wc = wp + (int64_t)vc * kN;
+      const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        z[m].x += pw[m].x * px[m].x - pw[m].y * px[m].y;
+        z[m].y += pw[m].x * px[m].y + pw[m].y * px[m].x;
+      }
+    }
+    fft8192<1>(z, lds, lb, a.tab, tid);
+    // rows 2 pr (real part) and 2 pr + 1 (imaginary part): normalise, scrub, max / first argmax
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = 2 * pr + h;
+      const bool rowok = b < c;                                   // uniform
+      const float s1 = rowok ? a.fsum[b] : 0.f, r1 = rowok ? a.frs[b] : 0.f;
+      unsigned long long key = 0ull;
+#pragma unroll
+      for (int m = 0; m < VM; ++m) {
+        const int p = p0 + tid + 512 * m;
+        const float y = h ? z[m].y : z[m].x;
+        float cc = (y - s1 * mu[m]) * (r1 * rw[m]);
+        if (cc > 1.f + kScrubTolF || cc < -1.f - kScrubTolF) cc = 0.f;   // construct.py:458-462
+        if (p < a.Pz && cc == cc) {
+          const unsigned bits = __float_as_uint(cc);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          const unsigned long long k2 =
+              ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
+          key = k2 > key ? k2 : key;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+      }
+      if ((tid & 63) == 0 && rowok && r1 > 0.f && key != 0ull) {
+        const int64_t idx = condensed_index_x(a.N, b, c);
+        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+      }
+    }
+  }
+}
+
+template <int VM>
+void launch_xc(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
+  hipLaunchKernelGGL((xc_fft_kernel<VM>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+}
+
+}  // namespace
+
+// Lag search of dtx_xcorr_allpairs through the frequency domain.  z / stats / keys are the
+// buffers dtx_xcorr_allpairs prepared; rows b in [b_begin, b_end] hold the pairs of the range.
+int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L, int Pz,
+                  int64_t Ppad, int64_t Tz, const float* z, const float* fsum, const float* frs,
+                  const float* mean_w, const float* rsw, unsigned long long* keys,
+                  int64_t pair_begin, int64_t pair_end, int64_t b_begin, int64_t b_end) {
+  const int nseg = L <= kFftMaxL ? 1 : (L + kSegX - 1) / kSegX;
+  const int seglen = nseg == 1 ? L : kSegX;
+  const int V = nseg == 1 ? (kN - L + 1) / 512 * 512 : kSegX;
+  const int nblk = (Pz + V - 1) / V, nblkx = nblk + nseg - 1;
+  const int nvc = Nc * nseg, npr = (N + 1) / 2;
+
+  // work items (c, first pair of a unit), unit-major so that concurrent workgroups share the
+  // unit's pair spectra in L2
+  std::vector<int2> items;
+  for (int pr0 = 0; pr0 < npr; pr0 += kUnitX) {
+    const int64_t r_lo = 2 * (int64_t)pr0, r_hi = 2 * (int64_t)(pr0 + kUnitX) - 1;
+    if (r_hi < b_begin || r_lo > b_end) continue;
+    for (int c = std::max<int64_t>(r_lo + 1, 1); c < N; ++c) items.push_back(make_int2(c, pr0));
+  }
+  if (items.empty()) return DTX_OK;
+  const int64_t grid = (int64_t)items.size() * nblk;
+  if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
+
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_w = carve((size_t)npr * nvc * kN * sizeof(float2));
+  const size_t o_x = carve((size_t)N * nblkx * Nc * kXh * sizeof(float2));
+  const size_t o_t = carve((size_t)kN * sizeof(float2));
+  const size_t o_i = carve(items.size() * sizeof(int2));
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, off))) return rc;
+  char* base = (char*)ctx->ws_xhat.p;
+  c32* W = (c32*)(base + o_w);
+  c32* xh = (c32*)(base + o_x);
+  c32* tab = (c32*)(base + o_t);
+  {
+    std::vector<float2> htab(kN);
+    const double pi = 3.14159265358979323846264338327950288;
+    for (int m = 0; m < kN; ++m)
+      htab[m] = make_float2((float)std::cos(2 * pi * m / kN), (float)std::sin(2 * pi * m / kN));
+    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the arena may be in use by queued work
+    DTX_HIP(ctx, hipMemcpy(tab, htab.data(), htab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    DTX_HIP(ctx, hipMemcpy(base + o_i, items.data(), items.size() * sizeof(int2),
+                           hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(xc_wspec_kernel, dim3((unsigned)(npr * nvc)), dim3(kT), 0, ctx->stream, td_dev,
+                     N, n, Nc, L, nseg, seglen, (const c32*)tab, W);
+  DTX_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
+                     ctx->stream, z, Tz, Nc, V, nblkx, (const c32*)tab, xh);
+  DTX_HIP(ctx, hipGetLastError());
+
+  XcFftArgs a;
+  a.xh = xh; a.W = W; a.tab = tab; a.items = (const int2*)(base + o_i);
+  a.fsum = fsum; a.frs = frs; a.mean_w = mean_w; a.rsw = rsw; a.keys = keys;
+  a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
+  a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.nblkx = nblkx; a.V = V; a.Pz = Pz;
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  switch (V / 512) {
+    case 4: launch_xc<4>(ctx, a, (unsigned)grid); break;
+    case 5: launch_xc<5>(ctx, a, (unsigned)grid); break;
+    case 6: launch_xc<6>(ctx, a, (unsigned)grid); break;
+    case 7: launch_xc<7>(ctx, a, (unsigned)grid); break;
+    case 8: launch_xc<8>(ctx, a, (unsigned)grid); break;
+    case 9: launch_xc<9>(ctx, a, (unsigned)grid); break;
+    case 10: launch_xc<10>(ctx, a, (unsigned)grid); break;
+    case 11: launch_xc<11>(ctx, a, (unsigned)grid); break;
+    case 12: launch_xc<12>(ctx, a, (unsigned)grid); break;
+    case 13: launch_xc<13>(ctx, a, (unsigned)grid); break;
+    case 14: launch_xc<14>(ctx, a, (unsigned)grid); break;
+    case 15: launch_xc<15>(ctx, a, (unsigned)grid); break;
+    default: return dtx_fail(ctx, DTX_E_STATE, "xcorr (FFT): bad block advance %d", V);
+  }
+  DTX_HIP(ctx, hipGetLastError());
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  ctx->kernel_timed = true;
+  return DTX_OK;
+}

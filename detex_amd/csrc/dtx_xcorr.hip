@@ -256,17 +256,23 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
     const double* __restrict__ esum, const double* __restrict__ essd,
     const double* __restrict__ esq, int N, int n, int Nc, int S, int Pz, int trunc,
     int64_t pair_begin, int64_t pair_end, float* __restrict__ cc_out, int32_t* __restrict__ lag_out,
-    float* __restrict__ ss_out) {
+    float* __restrict__ ss_out, int T) {
   const int lane = threadIdx.x & 63;
-  const int64_t idx = pair_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (idx >= pair_end) return;
-  // invert the condensed index
-  const double tn1 = 2.0 * N - 1.0;
-  int64_t b = (int64_t)((tn1 - sqrt(tn1 * tn1 - 8.0 * (double)idx)) * 0.5);
-  if (b < 0) b = 0;
-  while (b > 0 && condensed_index(N, b, b + 1) > idx) --b;
-  while (condensed_index(N, b + 1, b + 2) <= idx && b + 2 < N) ++b;
-  const int64_t c = idx - condensed_index(N, b, b + 1) + b + 1;
+  // Pairs are walked tile by tile (T x T events, upper triangle of tiles): the events a tile
+  // touches (2 T n floats: 160 MB at T = 512, n = 39 000) stay in the Infinity Cache while the
+  // tile's T^2 pairs are evaluated.  In plain condensed order every pair streamed its later
+  // event from HBM (312 GB for 2000 events of 39 000 samples: 169 ms).
+  const int per_tile = T * T / 4;                       // blocks per tile, 4 pairs (waves) each
+  int t = (int)(blockIdx.x / per_tile);
+  const int local = (int)(blockIdx.x - (int64_t)t * per_tile) * 4 + (threadIdx.x >> 6);
+  const int ntile = (N + T - 1) / T;
+  int ti = 0;
+  while (t >= ntile - ti) { t -= ntile - ti; ++ti; }    // tile (ti, tj), ti <= tj
+  const int tj = ti + t;
+  const int64_t b = (int64_t)ti * T + local / T, c = (int64_t)tj * T + local % T;
+  if (b >= c || c >= N) return;
+  const int64_t idx = condensed_index(N, b, c);
+  if (idx < pair_begin || idx >= pair_end) return;
 
   const unsigned long long key = keys[idx];
   const double ssd1 = essd[b], sum1 = esum[b];
@@ -279,17 +285,20 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
   const float* x1 = td + b * n;
   const float* x2 = td + c * n;
   double dot[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+  // branch-free: out-of-range lags read a clamped address and contribute 0, so the four loads of
+  // an iteration (and of the unrolled neighbours) are in flight together
+  const int sh0 = (p - 1 - S) * Nc;
+#pragma unroll 4
   for (int j = lane; j < n; j += 64) {
     const double a1 = (double)x1[j];
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
-      const int jj = j + (p - 1 + l - S) * Nc;
-      if (jj >= 0 && jj < n) {
-        const double v = (double)x2[jj];
-        dot[l] += a1 * v;
-        sw[l] += v;
-        sq[l] += v * v;
-      }
+      const int jj = j + sh0 + l * Nc;
+      const bool ok = jj >= 0 && jj < n;
+      const double v = ok ? (double)x2[min(max(jj, 0), n - 1)] : 0.0;
+      dot[l] += a1 * v;
+      sw[l] += v;
+      sq[l] += v * v;
     }
   }
 #pragma unroll
@@ -430,10 +439,14 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const int64_t Tz = Ppad + Lp + 64;
   const int nkt = (N + kKtMax - 1) / kKtMax;
 
+  // AUTO / FFT: events of kXcFftMinL .. kFftLongMaxL samples per channel go through the
+  // frequency domain (dtx_xcfft.hip); the contraction kernels below serve the rest
+  const bool use_fft = (ctx->engine == DTX_ENGINE_AUTO || ctx->engine == DTX_ENGINE_FFT) &&
+                       L >= kXcFftMinL && L <= kFftLongMaxL;
   // ---- workspaces (one arena)
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_xt = carve((size_t)nkt * Nc * Lp * kKtMax * sizeof(float));
+  const size_t o_xt = carve(use_fft ? 0 : (size_t)nkt * Nc * Lp * kKtMax * sizeof(float));
   const size_t o_z = carve((size_t)N * Nc * Tz * sizeof(float));
   const size_t o_mw = carve((size_t)N * Ppad * sizeof(float));
   const size_t o_rw = carve((size_t)N * Ppad * sizeof(float));
@@ -443,7 +456,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const size_t o_fs = carve((size_t)N * sizeof(float));
   const size_t o_fr = carve((size_t)N * sizeof(float));
   const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
-  const bool split = ctx->engine != DTX_ENGINE_FP32 && L >= kSplitMinL;   // FFT / AUTO: scan only
+  const bool split = !use_fft && ctx->engine != DTX_ENGINE_FP32 && L >= kSplitMinL;
   const int64_t Vz = Tz / 8;
   const size_t o_xt16 = carve(split ? (size_t)nkt * Nc * (Lp / 8) * 2 * kKtMax * 8 * sizeof(uint16_t) : 0);
   const size_t o_g = carve(split ? (size_t)N * Nc * 16 * Vz * sizeof(i32x4) : 0);
@@ -467,7 +480,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const int64_t b_begin = row_of_index(N, pair_begin);
   const int64_t b_end = row_of_index(N, pair_end - 1);
   std::vector<std::vector<int2>> items(kRmMax + 1);
-  for (int kt = 0; kt < nkt; ++kt) {           // kt-major: concurrent blocks share the XT tile
+  for (int kt = 0; kt < (use_fft ? 0 : nkt); ++kt) {   // kt-major: concurrent blocks share the XT tile
     const int64_t r0 = (int64_t)kt * kKtMax;
     for (int c = 1; c < N; ++c) {
       const int64_t lo = std::max<int64_t>(r0, b_begin);
@@ -494,7 +507,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   }
 
   // ---- prep kernels
-  {
+  if (!use_fft) {
     dim3 grid((unsigned)std::min<int64_t>(((int64_t)Nc * Lp + 3) / 4, 8192), 1, (unsigned)nkt);
     hipLaunchKernelGGL(xc_transpose_kernel, grid, dim3(256), 0, ctx->stream, td_dev, N, n, Nc, L,
                        Lp, xt);
@@ -529,6 +542,11 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   a.xt16 = split ? xt16 : nullptr; a.g16 = g16; a.V = Vz;
   a.items = nullptr; a.Tz = Tz; a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
   a.N = N; a.Nc = Nc; a.L = L; a.Lp = Lp; a.S = S; a.Pz = Pz; a.nptiles = 0;
+  if (use_fft) {
+    if ((rc = dtx_xcfft_run(ctx, td_dev, N, n, Nc, L, Pz, Ppad, Tz, z, fsum, frs, mean_w, rsw, keys,
+                            pair_begin, pair_end, b_begin, b_end)))
+      return rc;
+  } else {
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   {
     const int2* p = (const int2*)ctx->ws_misc2.p;
@@ -541,11 +559,18 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
+  }
 
-  hipLaunchKernelGGL(xc_finish_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, ctx->stream,
-                     td_dev, (const unsigned long long*)keys, (const double*)esum,
-                     (const double*)essd, (const double*)esq, N, n, Nc, S, Pz, trunc, pair_begin,
-                     pair_end, cc_dev, lag_dev, subsamp_dev);
+  {
+    const int T = std::min(512, (N + 3) / 4 * 4);
+    const int64_t ntile = (N + T - 1) / T;
+    const int64_t fgrid = ntile * (ntile + 1) / 2 * ((int64_t)T * T / 4);
+    if (fgrid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "too many events");
+    hipLaunchKernelGGL(xc_finish_kernel, dim3((unsigned)fgrid), dim3(256), 0, ctx->stream,
+                       td_dev, (const unsigned long long*)keys, (const double*)esum,
+                       (const double*)essd, (const double*)esq, N, n, Nc, S, Pz, trunc, pair_begin,
+                       pair_end, cc_dev, lag_dev, subsamp_dev, T);
+  }
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

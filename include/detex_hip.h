@@ -194,6 +194,8 @@ int dtx_subspace_ds_host(dtx_ctx* ctx, const float* x_host, int64_t M,
  * Only pairs with pair_begin <= idx < pair_end are computed (multi-GPU
  * sharding); outputs are full-size [N*(N-1)/2] arrays, device pointers.
  * Asynchronous. */
+/* (Engine: under DTX_ENGINE_AUTO / DTX_ENGINE_FFT events of 1024 .. 32768 samples per channel use
+ * the frequency-domain lag search; DTX_ENGINE_BF16X3 / DTX_ENGINE_FP32 force the MFMA contraction.) */
 int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc,
                        float* cc_dev, int32_t* lag_dev, float* subsamp_dev,
                        int64_t pair_begin, int64_t pair_end);

@@ -20,7 +20,7 @@ ap.add_argument('--L', type=int, default=13000)
 ap.add_argument('--nc', type=int, default=3)
 ap.add_argument('--steps', type=int, default=1)
 ap.add_argument('--cpu-pairs', type=int, default=0)
-ap.add_argument('--engine', default='bf16x3', choices=['fp32', 'bf16x3'])
+ap.add_argument('--engine', default='auto', choices=['auto', 'fft', 'bf16x3', 'fp32'])
 a = ap.parse_args()
 N, L, Nc = a.events, a.L, a.nc
 n = Nc * L
@@ -45,10 +45,14 @@ out = {'metric': 'pairs/sec (all-pairs normalised xcorr)', 'value': npairs / dt,
        'config': {'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs)},
        'seconds': dt,
        'engine': a.engine,
-       'roofline': {'bound': 'mfma', 'kernel': ('xc_mfma_kernel_s<13,2>' if a.engine != 'fp32' else 'xc_mfma_kernel<13,2>') + ' (+ remainder tiles)',
-                    'achieved': flops / (kms * 1e-3) / 1e12, 'peak': 157.3 if a.engine == 'fp32' else 2500.0, 'unit': 'TFLOP/s',
-                    'frac': flops / (kms * 1e-3) / 1e12 / (157.3 if a.engine == 'fp32' else 2500.0), 'kernel_ms': kms,
-                    'flop_per_pair': 2.0 * mac},
+       'roofline': ({'bound': 'mfma', 'kernel': ('xc_mfma_kernel_s<13,2>' if a.engine != 'fp32' else 'xc_mfma_kernel<13,2>') + ' (+ remainder tiles)',
+                     'achieved': flops / (kms * 1e-3) / 1e12, 'peak': 157.3 if a.engine == 'fp32' else 2500.0, 'unit': 'TFLOP/s',
+                     'frac': flops / (kms * 1e-3) / 1e12 / (157.3 if a.engine == 'fp32' else 2500.0), 'kernel_ms': kms,
+                     'flop_per_pair': 2.0 * mac}
+                    if a.engine in ('fp32', 'bf16x3') or L < 1024 else
+                    {'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
+                     'contraction_equivalent_tflops': flops / (kms * 1e-3) / 1e12,
+                     'note': 'frequency-domain lag search (dtx_xcfft.hip); the direct contraction it replaces is %.3g flop per pair' % (2.0 * mac)}),
        'cc_mean': float(cc.mean()), 'cc_max': float(cc.max())}
 if a.cpu_pairs:
     from oracle import detex_oracle as orc

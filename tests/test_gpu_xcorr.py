@@ -156,3 +156,46 @@ def test_dead_and_degenerate_events(ctx):
     # too short for the central-half truncation (L < 4): all zeros
     cc, lag, ss = _gpu(ctx, rs.standard_normal((3, 6)).astype(np.float32), 2)
     assert not cc.any() and not lag.any() and not ss.any()
+
+
+@pytest.mark.parametrize('Nc,L,N', [(3, 1024, 9), (1, 2500, 12), (3, 3000, 23), (2, 5200, 8),
+                                    (3, 6500, 7), (1, 9000, 10), (3, 13000, 6)])
+def test_long_events_frequency_domain(ctx, Nc, L, N):
+    """Events of >= 1024 samples per channel take the frequency-domain lag search under the
+    default engine (dtx_xcfft.hip; past 6145 samples cut into segments): same answers as the
+    contraction engine and the float64 oracle -- cc 1e-5, lag exact, subsamp 1e-4; includes an
+    odd event count (a pair with a zero row), an identical pair and a dead event."""
+    from detex_amd import synth
+    rs = np.random.RandomState(L + N)
+    nfam = 2
+    td = synth.event_families(L, nfam, (N + nfam - 1) // nfam, Nc, L, maxshift=max(1, L // 40))[:N]
+    td = td * np.float32(10 ** rs.uniform(-3, 3))
+    if N >= 8:
+        td[5] = td[2]                      # identical pair: cc = 1, lag 0
+        td[7] = 0.0                        # dead event: cc 0 with everything
+    ctx.set_engine('auto')
+    cc, lag, ss = _gpu(ctx, td, Nc)
+    ctx.set_engine('bf16x3')
+    cc2, lag2, ss2 = _gpu(ctx, td, Nc)
+    ctx.set_engine('auto')
+    n = Nc * L
+    trunc = n // (2 * Nc) - 1
+    k = 0
+    nchecked = 0
+    for b in range(N):
+        for c in range(b + 1, N):
+            x1 = td[b].astype(np.float64)
+            x2 = td[c].astype(np.float64)
+            raw = orc.ccx2_raw_fft(x1, x2, Nc)
+            rc, rl, rss, res = orc.ccx2_reduce(raw, n, Nc, trunc, SCRUB)
+            assert abs(cc[k] - rc) <= 1e-5, (b, c, cc[k], rc)
+            assert abs(cc[k] - cc2[k]) <= 1e-5, (b, c)
+            fin = np.sort(res[np.isfinite(res)])
+            if len(fin) > 1 and fin[-1] - fin[-2] > 5e-6 and abs(abs(rc) - 1) > 2e-5:
+                assert lag[k] == rl, (b, c, lag[k], rl)
+                assert lag[k] == lag2[k], (b, c)
+                if abs(rss) <= .5:
+                    assert abs(ss[k] - rss) <= 1e-4, (b, c)
+                nchecked += 1
+            k += 1
+    assert nchecked >= N
