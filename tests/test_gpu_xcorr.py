@@ -123,12 +123,13 @@ def test_allpairs_vs_oracle(ctx, N, Nc, L):
     assert nok >= 0.9 * len(pairs)
 
 
-def test_pair_range_sharding(ctx):
+@pytest.mark.parametrize('N,Nc,L', [(30, 3, 48), (21, 3, 1500)])
+def test_pair_range_sharding(ctx, N, Nc, L):
     """Disjoint [pair_begin, pair_end) ranges reproduce the full result (the
-    multi-GPU partition) and leave other entries untouched."""
+    multi-GPU partition) and leave other entries untouched -- on the MFMA contraction
+    (short events) and on the frequency-domain lag search (L >= 1024)."""
     from detex_amd import synth
-    N, Nc, L = 30, 3, 48
-    td = synth.event_families(3, 6, 5, Nc, L, maxshift=6)
+    td = synth.event_families(3, 6, (N + 5) // 6, Nc, L, maxshift=6)[:N]
     full = _gpu(ctx, td, Nc)
     npairs = N * (N - 1) // 2
     cuts = [0, 1, 57, 200, 201, npairs]
