@@ -107,30 +107,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   const int nvc = a.Nc * a.nseg;
   const c32* xh = a.xh + ((int64_t)c * a.nblkx + blk) * a.Nc * kXh;
 
-  for (int q = 0; q < npr; ++q) {
-    const int pr = pr0 + q;
-    const c32* wp = a.W + (int64_t)pr * nvc * kN;
-    c32 z[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-#pragma nounroll
-    for (int vc = 0; vc < nvc; ++vc) {
-      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
-      c32 pw[16], px[16];
-      const c32* wc = wp + (int64_t)vc * kN;
-      const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        z[m].x += pw[m].x * px[m].x - pw[m].y * px[m].y;
-        z[m].y += pw[m].x * px[m].y + pw[m].y * px[m].x;
-      }
-    }
-    fft8192<1>(z, lds, lb, a.tab, tid);
-    // rows 2 pr (real part) and 2 pr + 1 (imaginary part): normalise, scrub, max / first argmax
+  // rows 2 pr (real part) and 2 pr + 1 (imaginary part) of a finished transform: normalise,
+  // scrub, max / first argmax over the block's lags, one atomicMax per row and wave
+  auto reduce_rows = [&](const c32 (&z)[16], int pr) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int b = 2 * pr + h;
@@ -160,6 +139,45 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
         const int64_t idx = condensed_index_x(a.N, b, c);
         if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
       }
+    }
+  };
+  // Pairs are taken two at a time: the block spectra (the operand both share) are loaded once
+  // per virtual channel for two MACs -- the MAC streams 1.2 MB per transform from L2 and is what
+  // bounds this kernel.
+  for (int q = 0; q < npr; q += 2) {
+    const int pr = pr0 + q;
+    const bool has2 = q + 1 < npr;
+    const c32* wpa = a.W + (int64_t)pr * nvc * kN;
+    const c32* wpb = wpa + (has2 ? (int64_t)nvc * kN : 0);
+    c32 z[16], zb[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
+#pragma nounroll
+    for (int vc = 0; vc < nvc; ++vc) {
+      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
+      c32 pa[16], pb[16], px[16];
+      const c32* wca = wpa + (int64_t)vc * kN;
+      const c32* wcb = wpb + (int64_t)vc * kN;
+      const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = (wca + 64 * r)[wlo];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pb[r] = (wcb + 64 * r)[wlo];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        z[m].x += pa[m].x * px[m].x - pa[m].y * px[m].y;
+        z[m].y += pa[m].x * px[m].y + pa[m].y * px[m].x;
+        zb[m].x += pb[m].x * px[m].x - pb[m].y * px[m].y;
+        zb[m].y += pb[m].x * px[m].y + pb[m].y * px[m].x;
+      }
+    }
+    fft8192<1>(z, lds, lb, a.tab, tid);
+    reduce_rows(z, pr);
+    if (has2) {
+      fft8192<1>(zb, lds, lb, a.tab, tid);
+      reduce_rows(zb, pr + 1);
     }
   }
 }
