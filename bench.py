@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--nc', type=int, default=3)
     ap.add_argument('--template-seconds', type=float, default=30.0)  # subspace.py:1462
     ap.add_argument('--engine', default='auto', choices=['auto', 'fft', 'bf16x3', 'fp32'],
-                    help="auto (library default): fft for templates of 256..6145 samples per channel, "
+                    help="auto (library default): fft for templates of 256..32768 samples per channel, "
                          "else bf16x3; fft: frequency-domain overlap-save engine (float32 transforms in "
                          "LDS); bf16x3: split-bfloat16 MFMA contraction (3 bf16 products per float32 "
                          "product, float32 accumulate); fp32: exact float32 MFMA contraction")
@@ -100,7 +100,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
             return json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
     if eng == 'fft':
         N = 8192
-        V = (N - L + 1) // 512 * 512 if L <= 6145 else 4096      # segmented templates advance by 4096
+        V = (N - L + 1) // 512 * 512 if L <= 5633 else 4096      # segmented templates advance by 4096
         nblk = (P + V - 1) // V
         npairs = D * ((K // D + 1) // 2) if K % D == 0 else (K + 1) // 2
         nfft = npairs * nblk * chunks
@@ -108,7 +108,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         bytes_alg = (4.0 * Nc + 4.0 * D) * P * chunks
         # what the kernel computes: one 8192-point complex transform (5 N log2 N) and Nc complex
         # MACs per frequency (8 flop each) per (pair, block)
-        nseg = 1 if L <= 6145 else (L + 4095) // 4096
+        nseg = 1 if L <= 5633 else (L + 4095) // 4096
         flop_fft = nfft * (5.0 * N * 13 + 8.0 * Nc * nseg * N)
         gbs = bytes_alg / (kms * 1e-3) / 1e9
         return {'bound': 'hbm', 'kernel': 'ds_fft_kernel<%d>' % (V // 512), 'achieved': gbs, 'peak': 8000.0,

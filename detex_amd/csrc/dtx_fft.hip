@@ -191,26 +191,63 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     }
   };
   c32 z[16];
-  {
+  if constexpr (NCH == 0) {
+    // Block spectra streamed from L2 (Nc not 1 / 3, or a segmented template): pairs are taken two
+    // at a time so that one load of a block spectrum feeds two MACs -- the MAC's L2 traffic is
+    // what bounds this path (the same step took the cross-correlation kernel from 516 to 402 ms).
+    const int nvc = a.Nc * a.nseg;
+    for (int pr0 = 0; pr0 < ui.y; pr0 += 2) {
+      const bool has2 = pr0 + 1 < ui.y;
+      const c32* wpa = a.W + (int64_t)(ui.x + pr0) * nvc * kN;   // uniform
+      const c32* wpb = wpa + (has2 ? (int64_t)nvc * kN : 0);
+      c32 zb[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
+#pragma nounroll
+      for (int vc = 0; vc < nvc; ++vc) {
+        const int c = vc / a.nseg, sg = vc - c * a.nseg;   // (channel, template segment)
+        c32 pa[16], pb[16], px[16];
+        const c32* wca = wpa + (int64_t)vc * kN;
+        const c32* wcb = wpb + (int64_t)vc * kN;
+        const c32* xc = xh + ((int64_t)sg * a.Nc + c) * kXh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[r] = (wca + 64 * r)[wlo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pb[r] = (wcb + 64 * r)[wlo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
+        mac16(z, pa, px);
+        mac16(zb, pb, px);
+      }
+      {
+        const int pr = pr0;
+        fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
+        DTX_FFT_EPILOGUE
+      }
+      if (has2) {
+        const int pr = pr0 + 1;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) z[m] = zb[m];
+        fft8192<1>(z, lds, lb, a.tab, tid);
+        DTX_FFT_EPILOGUE
+      }
+    }
+  } else {
     for (int pr = 0; pr < ui.y; ++pr) {
-      const c32* wp = a.W + (int64_t)(ui.x + pr) * a.Nc * a.nseg * kN;   // uniform
+      const c32* wp = a.W + (int64_t)(ui.x + pr) * NCH * kN;   // uniform
 #pragma unroll
       for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
       // a whole channel batch of loads ahead of its MACs: memory-level parallelism is what
       // this phase lives on (the same loop with each load next to its MAC ran 40 % slower).
       // Addresses are kept as (uniform base) + lane offset: SGPRs + one VGPR.
 #pragma nounroll
-      for (int vc = 0; vc < (NCH > 0 ? NCH : a.Nc * a.nseg); ++vc) {
-        // virtual channel vc = (channel c, template segment sg): NCH > 0 implies one segment
-        const int c = NCH > 0 ? vc : vc / a.nseg, sg = NCH > 0 ? 0 : vc - c * a.nseg;
+      for (int c = 0; c < NCH; ++c) {
         c32 pw[16], px[16];
-        const c32* wc = wp + (int64_t)vc * kN;
-        const c32* xc = xh + ((int64_t)sg * a.Nc + c) * kXh;
+        const c32* wc = wp + (int64_t)c * kN;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          px[r] = fix_x(NCH > 0 ? xs[c * kXh + x_slot(r)] : xc[x_slot(r)], r);
+        for (int r = 0; r < 16; ++r) px[r] = fix_x(xs[c * kXh + x_slot(r)], r);
         mac16(z, pw, px);
       }
       fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)

@@ -44,7 +44,12 @@ struct DtxFft {
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
-constexpr int kFftMaxL = DTX_FFT_N - 2048 + 1;     // longest single-segment template
+// measured (scripts/seg_ab.sh, 200 basis vectors): two segments of 4096 take 12.8 ms per
+// station-day; one segment takes 11.3 ms at V = 2560 and 13.6 ms at V = 2048
+#ifndef DTX_FFT_SEG_L
+#define DTX_FFT_SEG_L (DTX_FFT_N - 2560 + 1)
+#endif
+constexpr int kFftMaxL = DTX_FFT_SEG_L;            // longest single-segment template
 constexpr int kFftLongMaxL = 8 * (DTX_FFT_N / 2);  // longest template at all (8 segments of 4096)
 // DTX_ENGINE_AUTO: shortest template it hands to the frequency-domain engine (measured
 // crossover with the split-bf16 MFMA engine at 200 basis vectors, Nc = 3: L ~ 220;

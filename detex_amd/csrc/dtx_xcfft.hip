@@ -7,7 +7,7 @@
 //   Y_b[p] = sum_ch sum_j x_b,ch[j] z_c,ch[p + j],   p = 0 .. 2S  (lag index)
 // evaluated by overlap-save blocks of 8192 samples: block spectra of z_c once per event,
 // spectra of event PAIRS (b, b+1) as one complex sequence once per call (two correlations per
-// transform), events longer than 6145 samples cut into segments of 4096 that meet the block
+// transform), events longer than 5633 samples cut into segments of 4096 that meet the block
 // spectra at shifted block indices (virtual channels; 12 per pair at L = 13 000).  The epilogue
 // is the contraction kernels' own: cc = (Y - sum(x_b) mu_w) rs_b rs_w, scrub, and the running
 // (max, first argmax) over lags as a 64-bit atomicMax key per pair; the winning lag is then

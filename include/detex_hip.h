@@ -93,7 +93,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
  *                      8192-point float32 transforms in LDS, two basis vectors per
  *                      complex transform, ~150x fewer flops than the contraction.
  *                      Float32 error grows with log(8192) instead of sqrt(n): ~2e-7 at
- *                      DS = 1.  Templates longer than 6145 samples per channel are cut
+ *                      DS = 1.  Templates longer than 5633 samples per channel are cut
  *                      into segments of 4096 that reuse the block spectra; longer than
  *                      32768 fall back to DTX_ENGINE_BF16X3. */
 #define DTX_ENGINE_FP32 0

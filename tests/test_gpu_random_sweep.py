@@ -90,11 +90,11 @@ def test_random_scan_long(ctx, seed):
     """Default engine on templates long enough for the frequency-domain engine: every block
     advance V = 2048 .. 7680, several blocks per chunk with a ragged last one, overlapping
     chunks, Nc = 1 / 3 (block spectra in LDS) and 2 / 4 / 6 (streamed), single-vector
-    detectors sharing a pair, a 300-sigma event (guard), and templates past 6145 samples that
+    detectors sharing a pair, a 300-sigma event (guard), and templates past 5633 samples that
     are cut into 2 .. 4 segments of 4096 (virtual channels)."""
     rs = np.random.RandomState(3000 + seed)
     Nc = int([3, 1, 2, 3, 6, 3, 4, 1, 3, 2, 3, 3, 6, 3, 1, 3, 2][seed])
-    L = int([256, 300, 700, 1100, 1500, 2100, 2600, 3000, 3700, 4200, 5000, 6145, 6146, 7681, 9000, 13000, 16384][seed])
+    L = int([256, 300, 700, 1100, 1500, 2100, 2600, 3000, 3700, 4200, 5000, 5633, 5634, 7681, 9000, 13000, 16384][seed])
     n = Nc * L
     ks = [[8, 3], [1, 1, 1, 2], [5], [16, 1], [2, 2], [7], [1], [8] * 3, [4, 1, 1], [3], [9], [2, 5], [4], [2],
           [3, 1, 1], [4], [2]][seed]
@@ -102,7 +102,7 @@ def test_random_scan_long(ctx, seed):
     U = rs.standard_normal((off[-1], n))
     U -= U.mean(axis=1, keepdims=True) * (seed % 2)
     U /= np.linalg.norm(U, axis=1, keepdims=True)
-    V = (8192 - L + 1) // 512 * 512 if L <= 6145 else 4096
+    V = (8192 - L + 1) // 512 * 512 if L <= 5633 else 4096
     nchunk = 1 + seed % 2
     T = L + int(rs.randint(int(1.2 * V), int(2.7 * V)))
     M = Nc * T - int(rs.randint(0, Nc))

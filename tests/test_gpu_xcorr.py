@@ -163,7 +163,7 @@ def test_dead_and_degenerate_events(ctx):
                                     (3, 6500, 7), (1, 9000, 10), (3, 13000, 6)])
 def test_long_events_frequency_domain(ctx, Nc, L, N):
     """Events of >= 1024 samples per channel take the frequency-domain lag search under the
-    default engine (dtx_xcfft.hip; past 6145 samples cut into segments): same answers as the
+    default engine (dtx_xcfft.hip; past 5633 samples cut into segments): same answers as the
     contraction engine and the float64 oracle -- cc 1e-5, lag exact, subsamp 1e-4; includes an
     odd event count (a pair with a zero row), an identical pair and a dead event."""
     from detex_amd import synth
