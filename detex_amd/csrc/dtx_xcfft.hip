@@ -25,11 +25,15 @@ __device__ inline int64_t condensed_index_x(int64_t N, int64_t b, int64_t c) {
   return N * b - b * (b + 1) / 2 + (c - b - 1);
 }
 
-// W[pair][vc][wave-major f] = 1/kN sum_j (x_2p,ch[j0 + j] + i x_2p+1,ch[j0 + j]) e^{+2 pi i j f / kN},
+// W[pair][vc][wave-major f] = 1/kN sum_j (u_2p,ch[j0 + j] + i u_2p+1,ch[j0 + j]) e^{+2 pi i j f / kN},
 // vc = ch * nseg + seg, j0 = seg * seglen, j < seglen (and j0 + j < L); float32 on the device
 // (2000 events x 12 virtual channels is 12 000 transforms: seconds on the host, < 1 ms here).
+// u_b = x_b * rs_b, rs_b = 1 / sqrt(ssd(x_b)): the two events of a pair share one complex
+// transform, whose float32 rounding is relative to the larger of the two -- catalogue events
+// differ by orders of magnitude in amplitude, unit-energy rows do not.
 __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ td, int N, int n,
                                                       int Nc, int L, int nseg, int seglen,
+                                                      const float* __restrict__ frs,
                                                       const c32* __restrict__ tab,
                                                       c32* __restrict__ W) {
   __shared__ c32 lds[kLdsC];
@@ -39,6 +43,7 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
   const int ch = vc / nseg, sg = vc - ch * nseg;
   const int a = 2 * pr, b = a + 1;
   const int j0 = sg * seglen;
+  const float ra = frs[a], rb = b < N ? frs[b] : 0.f;
   const LdsBases lb = lds_bases(tid);
   c32 v[16];
 #pragma unroll
@@ -47,8 +52,8 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
     float re = 0.f, im = 0.f;
     if (j < seglen && j0 + j < L) {
       const int64_t q = (int64_t)(j0 + j) * Nc + ch;
-      re = td[(int64_t)a * n + q];
-      if (b < N) im = td[(int64_t)b * n + q];
+      re = td[(int64_t)a * n + q] * ra;
+      if (b < N) im = td[(int64_t)b * n + q] * rb;
     }
     v[r] = make_float2(re, im);
   }
@@ -114,13 +119,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
     for (int h = 0; h < 2; ++h) {
       const int b = 2 * pr + h;
       const bool rowok = b < c;                                   // uniform
-      const float s1 = rowok ? a.fsum[b] : 0.f, r1 = rowok ? a.frs[b] : 0.f;
+      // the pair spectra hold unit-energy rows x_b rs_b: cc = (Y' - (sum x_b) rs_b mu_w) rs_w
+      const float r1 = rowok ? a.frs[b] : 0.f, s1 = rowok ? a.fsum[b] * r1 : 0.f;
       unsigned long long key = 0ull;
 #pragma unroll
       for (int m = 0; m < VM; ++m) {
         const int p = p0 + tid + 512 * m;
         const float y = h ? z[m].y : z[m].x;
-        float cc = (y - s1 * mu[m]) * (r1 * rw[m]);
+        float cc = (y - s1 * mu[m]) * rw[m];
         if (cc > 1.f + kScrubTolF || cc < -1.f - kScrubTolF) cc = 0.f;   // construct.py:458-462
         if (p < a.Pz && cc == cc) {
           const unsigned bits = __float_as_uint(cc);
@@ -236,7 +242,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
                            hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(xc_wspec_kernel, dim3((unsigned)(npr * nvc)), dim3(kT), 0, ctx->stream, td_dev,
-                     N, n, Nc, L, nseg, seglen, (const c32*)tab, W);
+                     N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
   DTX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
                      ctx->stream, z, Tz, Nc, V, nblkx, (const c32*)tab, xh);

@@ -171,6 +171,8 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
     nfam = 2
     td = synth.event_families(L, nfam, (N + nfam - 1) // nfam, Nc, L, maxshift=max(1, L // 40))[:N]
     td = td * np.float32(10 ** rs.uniform(-3, 3))
+    # catalogue events differ by orders of magnitude: neighbours (which share a transform) by 10^6
+    td *= (10.0 ** rs.choice([-3, 0, 3], size=N)).astype(np.float32)[:, None]
     if N >= 8:
         td[5] = td[2]                      # identical pair: cc = 1, lag 0
         td[7] = 0.0                        # dead event: cc 0 with everything
