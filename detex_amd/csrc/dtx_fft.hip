@@ -133,9 +133,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   const int tid = threadIdx.x;
   // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
   // every XCD a contiguous run of the logical work list, and order that list in tiles of
-  // kTileU units x kTileB blocks: the ~32 workgroups an XCD runs at a time then read the
-  // same kTileU * (pairs * Nc * 64 KB) of basis spectra and kTileB * (Nc * 32 KB) of block
-  // spectra -- ~3 MB, L2 resident -- instead of 32 different blocks' spectra (7 MB).
+  // kTileU units x kTileB blocks (1 x 32): the ~32 workgroups an XCD runs at a time then read
+  // the same unit's basis spectra (pairs * Nc * 64 KB = 1.5 MB for eight pairs) and 32 blocks'
+  // spectra (Nc * 32 KB each, 3 MB) instead of unrelated ones.
   const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
   const int tile = logical / kTile, slot = logical - tile * kTile;
   const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
@@ -335,9 +335,9 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
 
   // pairs: consecutive vectors of a detector (an odd one out pairs with a zero row); two
   // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
-  // closed once they hold kUnitPairs (a detector with more pairs is a unit of its own) -- the
+  // closed once they hold kUnitPairs = 8 (a detector with more pairs is a unit of its own) -- the
   // block spectra a workgroup stages in LDS serve all its pairs
-  constexpr int kUnitPairs = 4;
+  constexpr int kUnitPairs = DTX_FFT_UNIT;
   std::vector<int4> units;
   std::vector<float4> pinfo;
   std::vector<int2> pdet;

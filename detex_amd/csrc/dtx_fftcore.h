@@ -19,7 +19,16 @@ constexpr int kXh = kN / 2;
 constexpr int kXlMax = 3;            // channels whose block spectra fit in LDS beside the image
 // L2-sized tiles of the (unit, block) work space: the workgroups an XCD runs together
 // share kTileU units' spectra and kTileB blocks' spectra (see ds_fft_kernel)
-constexpr int kTileU = 2, kTileB = 16, kTile = kTileU * kTileB;
+#ifndef DTX_FFT_UNIT
+#define DTX_FFT_UNIT 8                  // pairs per unit (runs of whole detectors)
+#endif
+#ifndef DTX_FFT_TILEU
+#define DTX_FFT_TILEU 1                 // measured (200 basis vectors): 2 x 16 tiles 6.21 ms, 1 x 32 5.85 ms
+#endif
+#ifndef DTX_FFT_TILE
+#define DTX_FFT_TILE 32
+#endif
+constexpr int kTileU = DTX_FFT_TILEU, kTileB = DTX_FFT_TILE / DTX_FFT_TILEU, kTile = kTileU * kTileB;
 #ifndef DTX_FFT_WAVES
 #define DTX_FFT_WAVES 2              // waves per SIMD the scan kernel is compiled for (2: one workgroup per CU,
 #endif                               // 256 registers; 4 -> 128 registers spills and measured 19 % slower)
