@@ -76,6 +76,7 @@ struct XcFftArgs {
   unsigned long long* keys;
   int64_t Ppad, pair_begin, pair_end;
   int N, Nc, nseg, nblk, nblkx, V, Pz;
+  int64_t per_xcd, nwork;
 };
 
 // one workgroup: event c, block blk of its lags, a unit of up to kUnitX earlier-event pairs
@@ -83,7 +84,11 @@ template <int VM>
 __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftArgs a) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x;
-  const int item = blockIdx.x / a.nblk, blk = blockIdx.x - item * a.nblk;
+  // workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of the
+  // (unit-major) work list so that the workgroups sharing an L2 share a unit's pair spectra
+  const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if (logical >= a.nwork) return;
+  const int item = (int)(logical / a.nblk), blk = (int)(logical - (int64_t)item * a.nblk);
   const int2 it = a.items[item];
   const int c = it.x, pr0 = it.y;
   const int npr = min(kUnitX, (c + 1) / 2 - pr0);          // pairs with at least one row < c
@@ -216,7 +221,8 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
     for (int c = std::max<int64_t>(r_lo + 1, 1); c < N; ++c) items.push_back(make_int2(c, pr0));
   }
   if (items.empty()) return DTX_OK;
-  const int64_t grid = (int64_t)items.size() * nblk;
+  const int64_t nwork = (int64_t)items.size() * nblk;
+  const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
   size_t off = 0;
@@ -253,6 +259,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   a.fsum = fsum; a.frs = frs; a.mean_w = mean_w; a.rsw = rsw; a.keys = keys;
   a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
   a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.nblkx = nblkx; a.V = V; a.Pz = Pz;
+  a.per_xcd = per_xcd; a.nwork = nwork;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   switch (V / 512) {
     case 4: launch_xc<4>(ctx, a, (unsigned)grid); break;
