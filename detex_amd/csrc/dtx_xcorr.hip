@@ -286,24 +286,83 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
     lc = local % T;
   }
   const int64_t b = (int64_t)ti * T + lb, c = (int64_t)tj * T + lc;
-  if (b >= c || c >= N) return;
-  const int64_t idx = condensed_index(N, b, c);
-  if (idx < pair_begin || idx >= pair_end) return;
-
-  const unsigned long long key = keys[idx];
-  const double ssd1 = essd[b], sum1 = esum[b];
-  if (key == 0ull || !(ssd1 > 0.0) || !(esq[c] > 0.0)) {
-    // construct.py:463-464: all-NaN CC vector -> (0, 0, 0)
-    if (lane == 0) { cc_out[idx] = 0.f; lag_out[idx] = 0; ss_out[idx] = 0.f; }
-    return;
+  // the four waves of a block share the earlier event b (lc differs): b is staged through LDS
+  // once per block, and the loop below is organised around ONE pass over the later event c --
+  // per element one global load instead of four (x_b, and x_c at the three lags)
+  constexpr int kCh = 4096, kPad = 64;
+  __shared__ float x1s[kCh + 2 * kPad];
+  const bool stage = Nc <= kPad;                        // uniform; else: the plain loop
+  bool live = b < c && c < N;
+  int64_t idx = 0;
+  if (live) {
+    idx = condensed_index(N, b, c);
+    live = idx >= pair_begin && idx < pair_end;
   }
-  const int p = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-  const float* x1 = td + b * n;
-  const float* x2 = td + c * n;
-  double dot[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+  unsigned long long key = 0ull;
+  double ssd1 = 0.0, sum1 = 0.0;
+  if (live) {
+    key = keys[idx];
+    ssd1 = essd[b]; sum1 = esum[b];
+    if (key == 0ull || !(ssd1 > 0.0) || !(esq[c] > 0.0)) {
+      // construct.py:463-464: all-NaN CC vector -> (0, 0, 0)
+      if (lane == 0) { cc_out[idx] = 0.f; lag_out[idx] = 0; ss_out[idx] = 0.f; }
+      live = false;
+    }
+  }
+  if (!stage && !live) return;
+  const int p = live ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+  const float* x1 = td + (b < N ? b : 0) * (int64_t)n;
+  const float* x2 = td + (c < N ? c : 0) * (int64_t)n;
+  double dot[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sq[3] = {0, 0, 0}, swc = 0.0, sqc = 0.0;
+  const int sh0 = (p - 1 - S) * Nc;                     // lag l pairs x_b[j] with x_c[j + sh0 + l Nc]
+  if (stage) {
+    // index jm = the x_b index of the MIDDLE lag; x_c element t = jm + sh0 + Nc meets
+    // x_b[jm + Nc] (lag 0), x_b[jm] (lag 1), x_b[jm - Nc] (lag 2)
+    const int sh1 = sh0 + Nc;
+    for (int J0 = -Nc; J0 < n + Nc; J0 += kCh) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < kCh + 2 * Nc; i += 256) {
+        const int j = J0 - Nc + i;
+        x1s[i] = (j >= 0 && j < n && b < N) ? x1[j] : 0.f;
+      }
+      __syncthreads();
+      if (live) {
+        const int jend = min(J0 + kCh, n + Nc);
+#pragma unroll 2
+        for (int jb = J0; jb < jend; jb += 64) {        // jb: the iteration's first index (uniform)
+          const int jm = jb + lane, t = jm + sh1;
+          const int i = jm - J0 + Nc;                   // x1s index of x_b[jm]
+          if (jb - Nc >= 0 && jb + 63 + Nc < n && jb + sh1 >= 0 && jb + 63 + sh1 < n) {
+            // interior: every lane valid at all three lags, which all see the same x_c element
+            const double v = (double)x2[t];
+            dot[0] += (double)x1s[i + Nc] * v;
+            dot[1] += (double)x1s[i] * v;
+            dot[2] += (double)x1s[i - Nc] * v;
+            swc += v;
+            sqc += v * v;
+          } else if (jm < jend) {
+            const bool tok = t >= 0 && t < n;
+            const double v = tok ? (double)x2[min(max(t, 0), n - 1)] : 0.0;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+              const int jl = jm + (1 - l) * Nc;
+              const bool ok = tok && jl >= 0 && jl < n;
+              const double a1 = (double)x1s[i + (1 - l) * Nc];
+              const double vv = ok ? v : 0.0;
+              dot[l] += a1 * vv;
+              sw[l] += vv;
+              sq[l] += vv * vv;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { sw[l] += swc; sq[l] += sqc; }
+    if (!live) return;
+  } else {
   // branch-free: out-of-range lags read a clamped address and contribute 0, so the four loads of
   // an iteration (and of the unrolled neighbours) are in flight together
-  const int sh0 = (p - 1 - S) * Nc;
 #pragma unroll 4
   for (int j = lane; j < n; j += 64) {
     const double a1 = (double)x1[j];
@@ -316,6 +375,7 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
       sw[l] += v;
       sq[l] += v * v;
     }
+  }
   }
 #pragma unroll
   for (int l = 0; l < 3; ++l)
