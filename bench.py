@@ -274,6 +274,19 @@ def main():
             out[key] = {'value': a.chunks * P / dto, 'unit': 'windows/s',
                         'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
         ctx.set_engine(a.engine)
+    if rank == 0 and world == 1 and default_cfg:
+        # secondary hot path (SURVEY 8d, configs[2] short variant): all-pairs normalised
+        # cross-correlation of 500 events x 3000 samples x 3 channels; the full 2000 x 13000
+        # configuration is scripts/bench_xcorr.py (0.46 s)
+        tdx = torch.from_numpy(synth.event_families(2, 25, 20, Nc, 3000)).cuda()
+        ctx.xcorr_allpairs(tdx, Nc)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ctx.xcorr_allpairs(tdx, Nc)
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - t1
+        out['xcorr'] = {'value': 500 * 499 / 2 / dtx, 'unit': 'pairs/s', 'seconds': dtx,
+                        'workload': 'configs[2] short variant: 500 events, Nc=3, L=3000, 124750 pairs'}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
     else:
