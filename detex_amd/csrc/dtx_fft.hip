@@ -87,6 +87,14 @@ struct FftArgs {
   int nseg, nblkx;      // template segments (virtual channels per real channel), block spectra stored per chunk
 };
 
+#ifndef DTX_DS_NT
+#define DTX_DS_NT 1
+#endif
+#if DTX_DS_NT
+#define DTX_DS_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define DTX_DS_STORE(v, p) (*(p) = (v))
+#endif
 // epilogue of one pair (uses z, pr, ui, mean, den, acc0, acc1 of the enclosing kernel): add the
 // squared projections; when the pair closes its detector(s) (pdet.x >= 0), normalise and store.
 // pdet.y >= 0: the imaginary part is a different, single-vector detector (acc1).
@@ -111,11 +119,11 @@ _Pragma("unroll") \
           const float dn = (den + 512 * m)[tid]; \
           float v0 = (dn > 0.f) ? __fdiv_rn(acc0[m], dn) : 0.f; \
           if (__builtin_isinf(v0)) v0 = 0.f; \
-          a.ds[((int64_t)chunk * a.D + pd.x) * a.ldp + p] = v0; \
+          DTX_DS_STORE(v0, &a.ds[((int64_t)chunk * a.D + pd.x) * a.ldp + p]); \
           if (two) { \
             float v1 = (dn > 0.f) ? __fdiv_rn(acc1[m], dn) : 0.f; \
             if (__builtin_isinf(v1)) v1 = 0.f; \
-            a.ds[((int64_t)chunk * a.D + pd.y) * a.ldp + p] = v1; \
+            DTX_DS_STORE(v1, &a.ds[((int64_t)chunk * a.D + pd.y) * a.ldp + p]); \
           } \
         } \
         acc0[m] = 0.f; \
