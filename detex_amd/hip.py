@@ -165,9 +165,11 @@ class HipContext(object):
         return hist, maxds, thr_t, key, val, cnt
 
     def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None,
-                      hist=None, want_max=True, cand_cap=1 << 20):
+                      hist=None, want_max=True, cand_cap=1 << 20, lazy=False):
         """subspace_ds + ds_post in one call (dtx_subspace_scan).
-        Returns (ds, result dict as ds_post)."""
+        Returns (ds, result dict as ds_post).  lazy=True returns (ds, fetch) instead, where
+        fetch() synchronises and builds that dict: nothing here then waits for the device, so
+        independent scans (other contexts on other streams) can be enqueued behind each other."""
         if x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError('x must be a float32 CUDA tensor')
         if M is None:
@@ -192,6 +194,8 @@ class HipContext(object):
                                         _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
                                         _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_subspace_scan')
+        if lazy:
+            return out, (lambda: self._post_result(hist, maxds, thr, key, val, cnt, cand_cap))
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
 
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
