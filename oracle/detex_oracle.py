@@ -446,14 +446,63 @@ def used_basis_count(average, selectCriteria, selectValue):
         av = np.array(average, dtype=np.float64)
         av[-1] = 1.00
         return int(np.argmax(av >= selectValue))
-    if selectCriteria == 4:
-        return int(selectValue) + 1
+    if selectCriteria == 4:             # keys[:selectValue + 1]: at most all of them
+        return min(int(selectValue) + 1, len(average) - 1)
     raise ValueError('selectCriteria of %s is not supported' % selectCriteria)
 
 
 def threshold_criteria3(minimum, numbasis, selectValue):
     """subspace.py:1049-1054."""
     return minimum[numbasis] * selectValue
+
+
+# --------------------------------------------------------------------------
+# alignment through the dendrogram (Harris 2006 App. B)   construct.py:710-812
+# --------------------------------------------------------------------------
+
+def _triangular(n):
+    """construct.py:790-795."""
+    return n * (n + 1) // 2
+
+
+def get_delays(link, cx, lags):
+    """construct.py:710-760 (_getDelays, _traceEventDendro, _updateLags, _getDow,
+    _getAcr, _getClustDict) for one cluster of N + 1 events.
+
+    link : linkage(cx); cx : condensed dissimilarities (unique values); lags :
+    condensed pair lags.  Returns the accumulated lag of every event (lagSeries)."""
+    N = len(link)                                            # merges (events - 1)
+    lags = np.array(lags, dtype=np.float64)
+    cx = np.asarray(cx, dtype=np.float64)
+    clust = {i: [i] for i in range(N + 1)}                   # 800-812
+    for a in range(N):
+        clust[N + 1 + a] = clust[int(link[a, 0])] + clust[int(link[a, 1])]
+    iu = np.triu_indices(N + 1, 1)
+    total = np.zeros(N + 1, dtype=np.int64)
+    for a in range(N):
+        height = link[a, 2]
+        k = int(np.flatnonzero(cx == height)[0])             # 727-729: cxdf[cxdf == row.cc]
+        ev1 = int(iu[0][k])                                  # tempdf.index[0]
+        cl22 = clust[int(link[a, 1])] if ev1 in clust[int(link[a, 0])] else clust[int(link[a, 0])]
+        currentLag = int(np.round(lags[k]))                  # 752: CCtoLag[cc]
+        for b in cl22:                                       # 754-756
+            total[b] += currentLag
+            nn = N                                           # _updateLags(b, lags, len(dflink), .)
+            acr = [_triangular(nn) - _triangular(nn - b) + q for q in range(nn - b)]       # 782-788
+            dow = [_triangular(nn - 1) - 1 + b - _triangular(nn - 1 - q) for q in range(b)]  # 773-779
+            for q in acr:
+                lags[q] += currentLag
+            for q in dow:
+                lags[q] -= currentLag
+    return total
+
+
+def align_td(sample_delays, events_td):
+    """construct.py:486-504: events sliced by their (non-negative) sample delays and cut to
+    the common length."""
+    sample_delays = [int(d) for d in sample_delays]
+    TDlengths = len(events_td[0]) - max(sample_delays)
+    return [np.asarray(e)[d:][:TDlengths] for e, d in zip(events_td, sample_delays)]
 
 
 # --------------------------------------------------------------------------

@@ -83,4 +83,42 @@ def import_reference():
     builtins.xrange = range
     sys.path.insert(0, REFERENCE_ROOT)
     import detex  # noqa: E402
+    _py2_container_semantics(detex)
     return detex
+
+
+class ListDict(dict):
+    """Python 2 dict: keys() / values() return lists (sortable, indexable)."""
+
+    def keys(self):
+        return list(dict.keys(self))
+
+    def values(self):
+        return list(dict.values(self))
+
+
+def _py2_container_semantics(detex):
+    """Test-side shims that let the reference's basis-selection and alignment code run
+    UNMODIFIED under Python 3 / pandas 2 (the reference files are not touched):
+
+    * SubSpace._getFracEnergy / _getUsedBasis (subspace.py:968-1013) call
+      ``svdDict.keys().sort()``: their dict argument is handed over as a ListDict;
+    * _getDelays (construct.py:725) stores a list in one DataFrame cell with
+      ``df.loc[row, col] = [...]``, which pandas 0.17 accepted: a scalar/scalar ``.loc``
+      assignment of a list is routed to ``.at``."""
+    SS = detex.subspace.SubSpace
+    fe, ub = SS._getFracEnergy, SS._getUsedBasis
+    SS._getFracEnergy = lambda self, ind, row, svdDict, U: fe(self, ind, row, ListDict(svdDict), U)
+    SS._getUsedBasis = (lambda self, ind, row, svdDict, frac, crit, val:
+                        ub(self, ind, row, ListDict(svdDict), frac, crit, val))
+    from pandas.core.indexing import _LocIndexer
+    orig = _LocIndexer.__setitem__
+
+    def setitem(self, key, value):
+        if (isinstance(value, list) and isinstance(key, tuple) and len(key) == 2 and
+                all(np.isscalar(k) for k in key)):
+            self.obj.at[key[0], key[1]] = value
+            return
+        return orig(self, key, value)
+
+    _LocIndexer.__setitem__ = setitem

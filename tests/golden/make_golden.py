@@ -20,6 +20,13 @@ Reference entry points exercised (file:line in /root/reference):
   detex/detect.py:390-445     _CreateCoeffArray, 545-557 _downPlay..., 526-543
                               _evalTrigCon   -> trig.npz
   detex/detect.py:447-499     _estMag (+637-664) -> estmag.npz
+  detex/subspace.py:786-912   SubSpace.SVD (+ _trimGroups 921-943, _getFracEnergy
+                              968-997, _getUsedBasis 999-1013, _setThresholds
+                              1015-1054 criteria 3 / fixed)  -> svd.npz
+  detex/construct.py:710-760  _getDelays / _traceEventDendro / _updateLags,
+                              486-504 _alignTD (+ _ensureUnique, _makeCC2LagMap,
+                              the createSubSpace lines 273-285 around them)
+                                              -> delays.npz
   detex/results.py:371-400    _deleteDetDups, 403-458 _associateDetections,
                               476-503 _createDetTable / _createAutoTable,
                               231-293 _verifyEvents -> assoc.json
@@ -349,6 +356,120 @@ def gen_estmag():
     print('estmag.npz written', {k: v for k, v in out.items() if k[:2] in ('ss', 'sg')})
 
 
+# ---------------------------------------------------------------- SVD / basis selection
+def gen_svd():
+    """SubSpace.SVD of the reference itself (subspace.py:786-912), run through the
+    ListDict shim of _ref_import.py: left singular vectors, singular values, fractional
+    energy capture, the selected basis and the thresholds of criteria 3 / a fixed
+    threshold.  Criteria 2 / 4 thresholds need continuous data (getFAS) and are pinned
+    separately through the detection statistic + scipy.stats.beta."""
+    SS = detex.subspace.SubSpace
+    out = {}
+    names = []
+    cols = ['Name', 'Events', 'AlignedTD', 'SVD', 'UsedSVDKeys', 'FracEnergy', 'SVDdefined',
+            'SampleTrims', 'Threshold', 'NumBasis', 'Station']
+    cases = [   # (seed, nev, n, trims, selectCriteria, selectValue, threshold, normalize)
+        (0, 6, 180, (15, 165), 3, 0.9, 0, False),
+        (1, 5, 240, (0, 240), 3, 0.75, 0, True),
+        (2, 8, 150, None, 3, 0.95, 0, False),          # no trims -> whole aligned waveform
+        (3, 4, 300, (30, 270), 2, 0.8, 0.25, False),   # criteria 2 with a fixed threshold
+        (4, 7, 120, (6, 96), 4, 2, 0.3, False),        # criteria 4: selectValue + 1 vectors
+        (5, 3, 90, (0, 90), 4, 9, 0.3, False),         # criteria 4 beyond the event count
+        (6, 6, 200, (21, 150), 3, 1.0, 0, False)]      # selectValue 1: only the forced last element reaches it
+    for case, (seed, nev, n, trims, crit, val, thr, normalize) in enumerate(cases):
+        rs = np.random.RandomState(300 + seed)
+        base = np.array([_bandlimited(rs, n) for _ in range(3)])
+        evs = {}
+        for i in range(nev):
+            evs['ev%02d' % i] = (rs.uniform(.5, 2) * base[i % 2] + rs.uniform(0, .6) * base[2] +
+                                 .25 * rs.randn(n) + rs.uniform(-.2, .2))
+        df = pd.DataFrame(index=[0], columns=cols, dtype=object)
+        df.at[0, 'Name'] = 'SS0'
+        df.at[0, 'Events'] = sorted(evs)
+        df.at[0, 'AlignedTD'] = evs
+        df.at[0, 'SampleTrims'] = ({'Starttime': trims[0], 'Endtime': trims[1]}
+                                   if trims is not None else {})
+        df.at[0, 'SVDdefined'] = False
+        df.at[0, 'Station'] = 'NET.STA'
+        ss = SS({}, {'NET.STA': df}, None, 'double', 1e-12, None)
+        ss.SVD(selectCriteria=crit, selectValue=val, threshold=thr, normalize=normalize,
+               useSingles=False)
+        r = ss.subspaces['NET.STA'].iloc[0]
+        svals = sorted(r.SVD.keys(), reverse=True)
+        key = 's%02d' % case
+        names.append('%s:seed=%d,nev=%d,n=%d,trims=%s,crit=%d,val=%g,thr=%g,norm=%d'
+                     % (key, seed, nev, n, trims, crit, val, thr, normalize))
+        out[key + '_events'] = np.array([evs[k] for k in sorted(evs)])
+        out[key + '_trims'] = np.array(trims if trims is not None else (-1, -1), dtype=np.int64)
+        out[key + '_has_trims'] = np.bool_(trims is not None)
+        out[key + '_crit'] = np.int64(crit)
+        out[key + '_val'] = np.float64(val)
+        out[key + '_thr_in'] = np.float64(thr)
+        out[key + '_normalize'] = np.bool_(normalize)
+        out[key + '_s'] = np.array(svals, dtype=np.float64)
+        out[key + '_U'] = np.array([r.SVD[k] for k in svals]).T        # columns, descending s
+        out[key + '_frac'] = np.array([r.FracEnergy[k] for k in sorted(evs)], dtype=np.float64)
+        out[key + '_average'] = np.asarray(r.FracEnergy['Average'], dtype=np.float64)
+        out[key + '_minimum'] = np.asarray(r.FracEnergy['Minimum'], dtype=np.float64)
+        out[key + '_used'] = np.array(list(r.UsedSVDKeys), dtype=np.float64)
+        out[key + '_numbasis'] = np.int64(r.NumBasis)
+        out[key + '_threshold'] = np.float64(r.Threshold)
+        case += 1
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'svd.npz'), **out)
+    print('svd.npz: %d cases' % len(cases), [int(out['s%02d_numbasis' % i]) for i in range(len(cases))])
+
+
+# ---------------------------------------------------------------- alignment delays
+def gen_delays():
+    """createSubSpace lines 270-285 of the reference on one cluster: stored CC / lag
+    frames -> dissimilarities -> _ensureUnique -> linkage -> _getDelays (dendrogram walk
+    with lag propagation, Harris 2006 App. B) -> _alignTD."""
+    out = {}
+    names = []
+    cases = [(7, 1, 5, 3, 120, 10), (8, 2, 4, 1, 96, 12), (9, 1, 9, 3, 80, 8), (10, 3, 3, 2, 64, 6),
+             (11, 1, 3, 3, 60, 5)]
+    for case, (seed, nfam, nper, Nc, L, maxshift) in enumerate(cases):
+        rs = np.random.RandomState(seed)
+        evs, fam = _family_events(rs, nfam, nper, Nc, L, maxshift, 8.0)
+        evnames = ['ev%02d' % i for i in range(len(evs))]
+        row = pd.Series({
+            'MPtd': dict(zip(evnames, evs)),
+            'MPfd': {k: scipy.fftpack.fft(v, n=2 ** int(2 * len(v)).bit_length())
+                     for k, v in zip(evnames, evs)},
+            'Channels': {k: ['C%d' % c for c in range(Nc)] for k in evnames},
+            'Station': 'NET.STA'})
+        DFcc, DFlag, _ = construct._makeDFcclags(evnames, row)
+        cxdf = 1.0000001 - DFcc
+        cx = construct._flatNoNan(cxdf)
+        cx, cxdf = construct._ensureUnique(cx, cxdf)
+        lags = construct._flatNoNan(DFlag)
+        lags_in = np.array(lags, dtype=np.float64)
+        link = linkage(cx)
+        CCtoLag = construct._makeCC2LagMap(cx, lags)
+        delays, dflink = construct._getDelays(link, CCtoLag, cx, lags, cxdf)
+        delayNP = -1 * np.min(delays)
+        delayDF = pd.DataFrame(delays + delayNP, columns=['SampleDelays'])
+        delayDF['Events'] = [evnames[x] for x in delayDF.index]
+        aligned = construct._alignTD(delayDF, row)
+        key = 'd%02d' % case
+        names.append('%s:seed=%d,nfam=%d,nper=%d,Nc=%d,L=%d' % (key, seed, nfam, nper, Nc, L))
+        out[key + '_events'] = np.array(evs)
+        out[key + '_Nc'] = np.int64(Nc)
+        out[key + '_cc'] = DFcc.values.astype(np.float64)
+        out[key + '_lag'] = DFlag.values.astype(np.float64)
+        out[key + '_cx'] = np.asarray(cx, dtype=np.float64)
+        out[key + '_lags_in'] = lags_in
+        out[key + '_link'] = link
+        out[key + '_delays'] = np.asarray(delays.values, dtype=np.int64)        # raw accumulated lags
+        out[key + '_sample_delays'] = delayDF.SampleDelays.values.astype(np.int64)
+        out[key + '_aligned'] = np.array([aligned[k] for k in evnames])
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'delays.npz'), **out)
+    print('delays.npz: %d cases' % len(cases),
+          [out['d%02d_sample_delays' % i].tolist() for i in range(len(cases))])
+
+
 # ---------------------------------------------------------------------------
 # results: per-station reduction, cross-station association, verification
 # ---------------------------------------------------------------------------
@@ -451,4 +572,6 @@ if __name__ == '__main__':
     gen_mpxds()
     gen_trig()
     gen_estmag()
+    gen_svd()
+    gen_delays()
     gen_assoc()

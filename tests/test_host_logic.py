@@ -154,6 +154,80 @@ def test_svd_basis_selection_and_thresholds():
         ss.detex(multiprocess=True)
 
 
+def _subspace_from_golden(z, k):
+    """A one-subspace SubSpace of the product holding the fixture's aligned events."""
+    import pandas as pd
+    from detex_amd.subspace import SubSpace
+    ev, t, ht = z[k + '_events'], z[k + '_trims'], bool(z[k + '_has_trims'])
+    names = ['ev%02d' % i for i in range(len(ev))]
+    row = dict(Name='SS0', Station='NET.STA', Events=names, AlignedTD=dict(zip(names, ev)), SVD=None,
+               UsedSVDKeys=None, FracEnergy=None, SVDdefined=False,
+               SampleTrims={'Starttime': int(t[0]), 'Endtime': int(t[1])} if ht else {},
+               Threshold=np.nan, FAS=None, NumBasis=0, Offsets=[0, 0, 0],
+               Stats={n: dict(magnitude=1.0) for n in names}, numEvents=len(names))
+    return SubSpace({}, {'NET.STA': pd.DataFrame([row], dtype=object)}, None, 'double', 1e-12, None)
+
+
+def test_SubSpace_SVD_matches_reference_golden():
+    """SubSpace.SVD of the product against the reference's own SubSpace.SVD
+    (tests/golden/svd.npz, subspace.py:786-1054)."""
+    z = np.load(os.path.join(G, 'svd.npz'))
+    for nm in z['names']:
+        k = nm.split(':')[0]
+        ss = _subspace_from_golden(z, k)
+        thr = float(z[k + '_thr_in'])
+        ss.SVD(selectCriteria=int(z[k + '_crit']),
+               selectValue=float(z[k + '_val']) if int(z[k + '_crit']) != 4 else int(z[k + '_val']),
+               threshold=thr if thr > 0 else None, normalize=bool(z[k + '_normalize']),
+               useSingles=False)
+        row = ss.subspaces['NET.STA'].iloc[0]
+        U, s = row.SVD['U'], row.SVD['s']
+        assert np.allclose(s, z[k + '_s'], rtol=1e-12), nm
+        sg = np.sign(np.sum(U * z[k + '_U'], axis=0))
+        assert np.allclose(U * sg, z[k + '_U'], atol=1e-9), nm
+        assert int(row.NumBasis) == int(z[k + '_numbasis']), nm
+        assert np.allclose(row.UsedSVDKeys, z[k + '_used'], rtol=1e-12), nm
+        assert np.allclose(row.FracEnergy['Average'], z[k + '_average'], atol=1e-12), nm
+        assert np.allclose(row.FracEnergy['Minimum'], z[k + '_minimum'], atol=1e-12), nm
+        for i, e in enumerate(row.Events):
+            assert np.allclose(row.FracEnergy[e], z[k + '_frac'][i], atol=1e-12), nm
+        assert np.isclose(float(row.Threshold), float(z[k + '_threshold']), rtol=1e-12), nm
+        # the stacked detector the scan uploads: the selected vectors, as rows
+        names, kinds, Ub, off, _, th = ss._detector_bank('NET.STA')
+        nb = int(z[k + '_numbasis'])
+        assert Ub.shape[0] == nb and list(off) == [0, nb]
+        assert np.allclose(Ub * sg[:nb, None], z[k + '_U'][:, :nb].T, atol=1e-9), nm
+
+
+def test_getDelays_alignTD_match_reference_golden():
+    """construct._getDelays / _alignTD of the product against the reference's own
+    (tests/golden/delays.npz, construct.py:710-760, 486-504), and the same through
+    createCluster -> createSubSpace on the fixture's events."""
+    z = np.load(os.path.join(G, 'delays.npz'))
+    for nm in z['names']:
+        k = nm.split(':')[0]
+        ev, Nc = z[k + '_events'], int(z[k + '_Nc'])
+        d = construct._getDelays(z[k + '_link'], z[k + '_cx'], z[k + '_lags_in'], len(ev))
+        assert np.array_equal(d, z[k + '_delays']), nm
+        names = ['ev%02d' % i for i in range(len(ev))]
+        ali = construct._alignTD(d - d.min(), names, dict(zip(names, ev)))
+        assert np.array_equal(np.array([ali[n] for n in names]), z[k + '_aligned']), nm
+        if 'nfam=1' not in nm:
+            continue
+        # one family = one cluster: the whole construction path reproduces the alignment
+        f = EventFetcher(100.0, ['C%d' % c for c in range(Nc)])
+        for n_, e in zip(names, ev):
+            f.add('NET.STA', n_, e.reshape(-1, Nc).T, starttime=50.0, origintime=48.0)
+        cl = createCluster(CCreq=0.05, fetch_arg=f, ctx=OracleCtx())
+        assert len(cl['STA'].clusts) == 1 and len(cl['STA'].clusts[0]) == len(ev)
+        ss = createSubSpace(clust=cl)
+        row = ss.subspaces['NET.STA'].iloc[0]
+        assert np.array_equal(np.array([row.AlignedTD[n_] for n_ in names]), z[k + '_aligned']), nm
+        sd = z[k + '_sample_delays']
+        st = np.array([row.Stats[n_]['starttime'] for n_ in names])
+        assert np.allclose(st, 50.0 + sd / (100.0 * Nc), atol=1e-12)        # construct.py:346-366
+
+
 def test_chunk_geometry():
     """getdata.py:509-518, 869-886: starts on multiples of conDatDuration, each
     chunk conDatDuration + conBuff long, the last trimmed to the data."""

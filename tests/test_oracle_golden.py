@@ -151,9 +151,49 @@ def test_trigger_picking_matches_reference():
             assert g['index'] == int(round((r[2] - start) * sr))
 
 
+def test_svd_matches_reference_golden():
+    """svd.npz: SubSpace.SVD of the reference itself (subspace.py:786-1054, run through the
+    ListDict shim of tests/golden/_ref_import.py): singular values / vectors, fractional
+    energy capture, selected basis, criteria-3 thresholds."""
+    z = np.load(os.path.join(G, 'svd.npz'))
+    for nm in z['names']:
+        k = nm.split(':')[0]
+        ev, t, ht = z[k + '_events'], z[k + '_trims'], bool(z[k + '_has_trims'])
+        arr = orc.trim_groups(list(ev), max(t[0], 0) if ht else None, t[1] if ht else None)
+        U, s = orc.svd_basis(arr, normalize=bool(z[k + '_normalize']))
+        assert np.allclose(s, z[k + '_s'], rtol=1e-12), nm
+        sg = np.sign(np.sum(U * z[k + '_U'], axis=0))            # singular vectors: sign is free
+        assert np.allclose(U * sg, z[k + '_U'], atol=1e-9), nm
+        wf = [e[t[0]:t[1]] if ht else e for e in ev]
+        fr, av, mn = orc.frac_energy(U, wf)
+        assert np.allclose(fr, z[k + '_frac'], atol=1e-12), nm
+        assert np.allclose(mn, z[k + '_minimum'], atol=1e-12), nm
+        crit, val = int(z[k + '_crit']), float(z[k + '_val'])
+        nb = orc.used_basis_count(av, crit, val)
+        assert nb == int(z[k + '_numbasis']), nm
+        assert np.allclose(s[:nb], z[k + '_used'], rtol=1e-12), nm
+        if float(z[k + '_thr_in']) == 0:                           # criteria 3 threshold
+            assert np.isclose(orc.threshold_criteria3(mn, nb, val), float(z[k + '_threshold']),
+                              rtol=1e-12), nm
+
+
+def test_delays_match_reference_golden():
+    """delays.npz: _getDelays / _alignTD of the reference itself (construct.py:710-760,
+    486-504) on five clusters."""
+    z = np.load(os.path.join(G, 'delays.npz'))
+    for nm in z['names']:
+        k = nm.split(':')[0]
+        d = orc.get_delays(z[k + '_link'], z[k + '_cx'], z[k + '_lags_in'])
+        assert np.array_equal(d, z[k + '_delays']), nm
+        sd = d - d.min()
+        assert np.array_equal(sd, z[k + '_sample_delays']), nm
+        al = orc.align_td(sd, list(z[k + '_events']))
+        assert np.array_equal(np.array(al), z[k + '_aligned']), nm
+
+
 def test_svd_basis_properties():
-    """No runnable reference for SubSpace.SVD under py3 (dict.keys().sort());
-    follow subspace.py:886-1013 and check the defining properties."""
+    """Defining properties of the basis selection (subspace.py:886-1013), beside the
+    reference-run vectors of test_svd_matches_reference_golden."""
     rs = np.random.RandomState(3)
     base = rs.randn(3, 240)
     ali = [rs.uniform(.5, 2) * base[i % 2] + 0.2 * base[2] * rs.randn() +
