@@ -35,8 +35,8 @@ SUSTAINED_BF16_MFMA_TFLOPS = 2057.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--detectors', type=int, default=25)
     ap.add_argument('--basis-per-detector', type=int, default=8)
     ap.add_argument('--chunks', type=int, default=24)
@@ -50,6 +50,15 @@ def parse():
                          "LDS); bf16x3: split-bfloat16 MFMA contraction (3 bf16 products per float32 "
                          "product, float32 accumulate); fp32: exact float32 MFMA contraction")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary fields (other engines, configs[2] / configs[4], PCIe-inclusive '
+                         'rate): what the profiling scripts use')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 4],
+                    help='2 (default): BASELINE configs[1], one station-day per GPU and step (weak scaling); '
+                         '4: BASELINE configs[3], 8 stations x 30 days dealt round-robin over the GPUs, one '
+                         'step = all 240 station-days (strong scaling)')
+    ap.add_argument('--stations', type=int, default=8)
+    ap.add_argument('--days', type=int, default=30)
     ap.add_argument('--cpu-vectors', type=int, default=200,
                     help='basis vectors the CPU baseline sample covers')
     return ap.parse_args()
@@ -78,9 +87,23 @@ def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
     dt = time.perf_counter() - t0
     P = (len(x) - n) // Nc + 1
     full = dt * K / done                                    # seconds per chunk, all K vectors
-    return dict(value=P / full, unit='windows/s', cores=1, kind='port',
+    from oracle import cpu_bench
+    model, ncores, logical = cpu_bench.cpu_info()
+    return dict(value=P / full, unit='windows/s', cores=1, kind='port', cpu_model=model,
+                physical_cores=ncores, os_cpu_count=logical,
                 sample='1 chunk (%d samples) x %d of %d basis vectors, float64 FFT path, '
                        '%.1f s measured, scaled linearly to %d vectors' % (len(x), done, K, dt, K))
+
+
+def cpu_baseline_allcores(U, det_off, x, Nc):
+    """The same CPU restatement on every physical core of the host (SURVEY.md 8d / BASELINE.md 3):
+    one worker process per core, each one chunk x 24 basis vectors.  The reference itself is
+    single-threaded; this is the generous CPU figure."""
+    from oracle import cpu_bench
+    try:
+        return cpu_bench.allcores_baseline(U, det_off, x, Nc, nvec_per_worker=24, timeout=240.0)
+    except Exception as e:          # a bounded leg: never take the bench line down
+        return dict(value=None, unit='windows/s', error=repr(e))
 
 
 def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
@@ -145,6 +168,233 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
                     'profiles/p1_mfma_peak.txt)'}
 
 
+def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
+    """The same step with the station-day handed over as a HOST buffer: pinned memory, the next
+    day's H2D copy on a second stream under the current day's scan (two device buffers), results
+    (candidates, maxima, histograms -- a few KB) fetched every step, DS left on the device."""
+    xp = torch.from_numpy(x).pin_memory()
+    bufs = [torch.empty(x.shape, dtype=torch.float32, device='cuda') for _ in range(2)]
+    copy = torch.cuda.Stream()
+    ready = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    main = torch.cuda.current_stream()
+
+    def upload(i):
+        with torch.cuda.stream(copy):
+            copy.wait_event(done[i])
+            bufs[i].copy_(xp, non_blocking=True)
+            ready[i].record(copy)
+
+    for i in range(2):
+        done[i].record(main)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    upload(0)
+    for i in range(steps):
+        cur = i & 1
+        if i + 1 < steps:
+            upload(1 - cur)
+        main.wait_event(ready[cur])
+        _, fetch = ctx.subspace_scan(bufs[cur], out=ds, thr=thr, hist=hist, lazy=True)
+        done[cur].record(main)
+        fetch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': windows * steps / dt, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt / steps,
+            'steps': steps,
+            'note': 'host buffers: %.0f MB per station-day from pinned memory, double-buffered on a copy '
+                    'stream; candidate list / maxima / histograms copied back, DS stays in HBM'
+                    % (x.nbytes / 1e6)}
+
+
+def xcorr_full(ctx, synth, Nc):
+    """BASELINE configs[2] at full size: 2000 events x (3 x 13000) samples, 1 999 000 pairs."""
+    N, L = 2000, 13000
+    n = Nc * L
+    td = torch.from_numpy(synth.event_families(2, 100, 20, Nc, L)).cuda()
+    npairs = N * (N - 1) // 2
+    S = L - L // 2
+    flop_pair = 2.0 * Nc * ((2 * S + 1) * L - S * (S + 1))        # SURVEY 8d: 0.7605 GFLOP
+    res = {}
+    for eng in ('auto', 'bf16x3'):
+        ctx.set_engine(eng)
+        ctx.xcorr_allpairs(td, Nc)
+        ctx.sync()
+        t1 = time.perf_counter()
+        cc, lag, ss = ctx.xcorr_allpairs(td, Nc)
+        ctx.sync()
+        res[eng] = (time.perf_counter() - t1, ctx.last_kernel_ms(), float(cc.mean()))
+    ctx.set_engine('auto')
+    dt, kms, ccm = res['auto']
+    dtm, kmsm, _ = res['bf16x3']
+    # frequency-domain lag search (dtx_xcfft.hip): per (later event c, lag block, event pair)
+    # one 8192-point complex transform and a MAC over Nc * nseg virtual channels
+    nseg = (L + 4095) // 4096
+    nblk = (2 * S + 1 + 4095) // 4096
+    nfft = (npairs / 2.0) * nblk
+    flop_fft = nfft * (5.0 * 8192 * 13 + 8.0 * Nc * nseg * 8192)
+    l2_bytes = nfft * Nc * nseg * (8192 * 8 + 4096 * 8 / 2.0)      # pair spectrum + half of a shared block spectrum
+    bytes_alg = 4.0 * N * n + 12.0 * npairs                        # SURVEY 8d: events once + 12 B per pair
+    return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,
+            'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs),
+            'cc_mean': ccm,
+            'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
+                         'achieved': bytes_alg / (kms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                         'bytes_per_launch': bytes_alg,
+                         'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
+                                     'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
+                                     'frac': flop_fft / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                     'contraction_equivalent': flop_pair * npairs / (kms * 1e-3) / 1e12},
+                         'l2': {'unit': 'TB/s', 'model_bytes': l2_bytes,
+                                'achieved': l2_bytes / (kms * 1e-3) / 1e12, 'peak': 34.5,
+                                'frac': l2_bytes / (kms * 1e-3) / 1e12 / 34.5},
+                         'note': 'frequency-domain lag search: %.3g transforms of 8192 points, each with a MAC '
+                                 'over %d virtual channels whose spectra stream from L2 (model: one 64 KB pair '
+                                 'spectrum per transform and channel, block spectra shared by two pairs); '
+                                 'algorithmic HBM bytes = events once + 12 B per pair' % (nfft, Nc * nseg)},
+            'mfma_engine': {'value': npairs / dtm, 'unit': 'pairs/s', 'seconds': dtm,
+                            'roofline': {'bound': 'mfma', 'kernel': 'xc_mfma_kernel_s<13,2>', 'kernel_ms': kmsm,
+                                         'achieved': flop_pair * npairs / (kmsm * 1e-3) / 1e12,
+                                         'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': flop_pair * npairs / (kmsm * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                         'flop_per_pair': flop_pair,
+                                         'note': 'split-bf16 contraction (3 MFMAs per product: ceiling peak / 3)'}}}
+
+
+def config5(ctx, synth):
+    """BASELINE configs[4]: 500 Hz 6-channel borehole array, one 64-dimensional subspace, 2 s
+    window (n = 6000), one hour of data."""
+    Nc, L, K, T = 6, 1000, 64, 1800000
+    n = Nc * L
+    U, off = synth.detector_bank(5, 1, K, n)
+    x, plants = synth.continuous_day(5, 1, Nc * T, Nc, U, off, nplant=10)
+    xt = torch.from_numpy(x).cuda()
+    thr = np.full(1, 0.3, np.float32)
+    res = {}
+    for eng in ('auto', 'fp32'):
+        ctx.set_engine(eng)
+        ctx.upload_basis(U, off, Nc)
+        ds, r = ctx.subspace_scan(xt, thr=thr)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ds, r = ctx.subspace_scan(xt, out=ds, thr=thr)
+        ctx.sync()
+        res[eng] = ((time.perf_counter() - t1) / 5, ctx.last_kernel_ms())
+        cb, cd, cp, cv = r['cand']
+        assert all(((cp - p) == 0).any() for (_, p, _) in plants), 'config5: planted event missed'
+    ctx.set_engine('auto')
+    P = T - L + 1
+    flops = 2.0 * K * n * P
+    return {'value': P / res['auto'][0], 'unit': 'windows/s', 'ms_per_hour_of_data': 1e3 * res['auto'][0],
+            'kernel_ms': res['auto'][1],
+            'workload': 'configs[4]: 500 Hz, 6 channels, K=64, n=6000, 1 h (%d windows)' % P,
+            'fp32_mfma_engine': {'value': P / res['fp32'][0], 'unit': 'windows/s', 'kernel_ms': res['fp32'][1],
+                                 'roofline': {'bound': 'mfma', 'achieved': flops / (res['fp32'][1] * 1e-3) / 1e12,
+                                              'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                              'frac': flops / (res['fp32'][1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}}
+
+
+def run_config4(a, rank, world, local, use_dist):
+    """BASELINE configs[3]: `stations` x `days` station-days of the configs[1] workload, dealt
+    round-robin over the GPUs (detex_amd.parallel.shard_units); every station has its own
+    detector basis, built on rank 0 and broadcast over RCCL / xGMI.  One step = every rank scans
+    all its station-days (strong scaling: the total is fixed as N grows).  Inputs (noise drawn on
+    the device per (station, day) seed + planted events) are resident in HBM before the timed
+    region; each station's basis images are uploaded once, before it."""
+    import torch.distributed as dist
+    from detex_amd import parallel, synth
+    from detex_amd.hip import HipContext
+    dev = torch.device('cuda', local)
+    Nc = a.nc
+    L = int(round(a.template_seconds * a.sr))
+    n = Nc * L
+    M = int(round(a.chunk_seconds * a.sr)) * Nc
+    D, k = a.detectors, a.basis_per_detector
+    units = [(s, d) for s in range(a.stations) for d in range(a.days)]
+    mine = [units[i] for i in parallel.shard_units(len(units), rank, world)]
+    ctxs, bases = {}, {}
+    t_up = time.perf_counter()
+    for s in range(a.stations):
+        U, off = synth.detector_bank(100 + s, D, k, n) if rank == 0 else (None, None)
+        Ut, off = parallel.broadcast_basis(U, off, n, dev)          # every rank takes part
+        if any(u[0] == s for u in mine):
+            c = HipContext(local)
+            c.set_engine(a.engine)
+            c.upload_basis(Ut, off, Nc)
+            ctxs[s], bases[s] = c, (Ut.cpu().numpy(), off)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t_up
+    gen = torch.Generator(device=dev)
+    data, plants = {}, {}
+    for (s, d) in mine:
+        gen.manual_seed(1000 * s + d)                               # SURVEY 8d cfg 4
+        x = torch.randn((a.chunks, M), generator=gen, device=dev, dtype=torch.float32)
+        rs = np.random.RandomState(1000 * s + d)
+        Uh, off = bases[s]
+        pl = []
+        for _ in range(5):
+            b, dd = int(rs.randint(a.chunks)), int(rs.randint(D))
+            while True:
+                p = int(rs.randint(0, (M - n) // Nc))
+                if all(pb != b or abs(pp - p) >= 2 * L for (pb, pp, _) in pl):
+                    break
+            coef = rs.standard_normal(k)
+            coef /= np.linalg.norm(coef)
+            w = (rs.uniform(5, 20) * np.sqrt(n) * (coef @ Uh[off[dd]:off[dd + 1]])).astype(np.float32)
+            x[b, p * Nc:p * Nc + n] += torch.from_numpy(w).to(dev)
+            pl.append((b, p, dd))
+        data[(s, d)], plants[(s, d)] = x, pl
+    P = next(iter(ctxs.values())).num_windows(M) if ctxs else (M - n) // Nc + 1
+    ldp = (P + 63) // 64 * 64
+    ds = torch.empty((a.chunks, D, ldp), dtype=torch.float32, device=dev)[:, :, :P]
+    thr = np.full(D, 0.3, dtype=np.float32)
+    hists = {s: torch.zeros((D, 400), dtype=torch.int32, device=dev) for s in ctxs}
+
+    def step(check=False):
+        fetches = []
+        for (s, d) in mine:
+            _, f = ctxs[s].subspace_scan(data[(s, d)], out=ds, thr=thr, hist=hists[s], lazy=True)
+            if check:
+                cb, cd, cp, cv = f()['cand']
+                for (b, p, dd) in plants[(s, d)]:
+                    assert ((cb == b) & (cd == dd) & (np.abs(cp - p) <= 2)).any(), (s, d, b, p, dd)
+            else:
+                fetches.append(f)
+        return [f() for f in fetches[-1:]]        # the last fetch synchronises the stream
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(check=True)
+    for _ in range(max(a.warmup - 1, 0)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    windows = len(units) * a.chunks * P * a.steps
+    return {'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)', 'value': windows / dt,
+            'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32 (reference default f64)', 'data': 'synthetic',
+            'config': {'workload': 'configs[3]: %d stations x %d days = %d station-days of %d basis vectors '
+                                   '(%d x %d) x %d chunks of %g s, %d-ch %g Hz, dealt round-robin over %d GPUs'
+                                   % (a.stations, a.days, len(units), D * k, D, k, a.chunks, a.chunk_seconds,
+                                      Nc, a.sr, world),
+                       'engine': a.engine, 'station_days_per_gpu_max': -(-len(units) // world),
+                       'basis_broadcast_and_upload_s': t_up}}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'RANK' not in os.environ:
@@ -176,6 +426,13 @@ def main():
     M = int(round(a.chunk_seconds * a.sr)) * Nc
     D, k = a.detectors, a.basis_per_detector
     K = D * k
+    if a.config == 4:
+        out = run_config4(a, rank, world, local, use_dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     ctx = HipContext(local)
     ctx.set_engine(a.engine)
 
@@ -233,6 +490,7 @@ def main():
     for (b, p, d) in plants:
         sel = (cb == b) & (cd == d) & (np.abs(cp - p) <= 2)
         found += bool(sel.any())
+    assert found == len(plants), 'planted events missed: %d of %d found' % (found, len(plants))
 
     flops = 2.0 * K * n * P * a.chunks       # the contraction's algorithmic flop
     default_cfg = (D, k, a.chunks, Nc, a.sr, a.chunk_seconds, a.template_seconds) == \
@@ -247,8 +505,11 @@ def main():
         'value': value, 'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': {'fft': 'f32 (complex64 transforms, f64 window statistics)', 'fp32': 'f32',
-                  'bf16x3': 'bf16x3 (f32 operands split in 2 bf16, f32 accumulate)'}[eng],
+        # the reference defaults to float64 (construct.py:27-34 dtype='double', 'single' = float32);
+        # north_star prescribes float32 within 1e-5 of that path
+        'dtype': {'fft': 'f32 (complex64 transforms, f64 window statistics; reference default f64)',
+                  'fp32': 'f32 (reference default f64)',
+                  'bf16x3': 'bf16x3 (f32 operands split in 2 bf16, f32 accumulate; reference default f64)'}[eng],
         'data': 'synthetic',
         'config': {'workload': '%s%d basis vectors (%d detectors x %d) x %d chunks of '
                                '%g s, %d-ch %g Hz, n=%d, one station-day per GPU'
@@ -258,7 +519,8 @@ def main():
                    'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
         'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
     }
-    if rank == 0 and world == 1 and default_cfg:
+    extras = rank == 0 and world == 1 and default_cfg and not a.no_extras
+    if extras:
         # the other engines on the same input (same step: scan + post pass)
         for other, key in (('bf16x3', 'mfma_engine'), ('fp32', 'fp32_engine'), ('fft', 'fft_engine')):
             if other == eng:
@@ -274,21 +536,14 @@ def main():
             out[key] = {'value': a.chunks * P / dto, 'unit': 'windows/s',
                         'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
         ctx.set_engine(a.engine)
-    if rank == 0 and world == 1 and default_cfg:
-        # secondary hot path (SURVEY 8d, configs[2] short variant): all-pairs normalised
-        # cross-correlation of 500 events x 3000 samples x 3 channels; the full 2000 x 13000
-        # configuration is scripts/bench_xcorr.py (0.46 s)
-        tdx = torch.from_numpy(synth.event_families(2, 25, 20, Nc, 3000)).cuda()
-        ctx.xcorr_allpairs(tdx, Nc)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ctx.xcorr_allpairs(tdx, Nc)
-        torch.cuda.synchronize()
-        dtx = time.perf_counter() - t1
-        out['xcorr'] = {'value': 500 * 499 / 2 / dtx, 'unit': 'pairs/s', 'seconds': dtx,
-                        'workload': 'configs[2] short variant: 500 events, Nc=3, L=3000, 124750 pairs'}
+        out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, min(a.steps, 50))
+        out['xcorr_full'] = xcorr_full(ctx, synth, Nc)
+        out['config5'] = config5(ctx, synth)
+        ctx.upload_basis(Ut, det_off, Nc)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
+        if default_cfg and not a.no_extras:
+            out['cpu_baseline']['all_cores'] = cpu_baseline_allcores(Uh, det_off, x, Nc)
     else:
         out['cpu_baseline'] = None
     if rank == 0:

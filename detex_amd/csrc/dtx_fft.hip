@@ -41,21 +41,28 @@
 namespace {
 
 // ---------------------------------------------------------------- the scan
-// Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when its
-// loudest window holds > kFftGuard^2 times the energy of its quietest live one.  One workgroup
-// per block appends it to list (list[0] = count) for the repair pass.
+// Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when the
+// loudest window over the samples its transforms read holds > kFftGuard^2 times the energy of
+// its quietest live own window.  One workgroup per block appends it to list (list[0] = count)
+// for the repair pass.  wspan: windows whose samples the block's transforms cover -- V for a
+// single-segment template (xhat_kernel zeroes the tail no kept output reads), 2 V for a
+// segmented one (segment s meets block blk + s: samples up to (nseg + 1) V are transformed, and
+// windows w0 .. w0 + 2 V - 1 reach sample w0 + 2 V + L - 2 >= w0 + (nseg + 1) V - 1).
 __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ den, int64_t Ppad,
-                                                    int64_t P, int V, int nblk,
+                                                    int64_t P, int V, int nblk, int wspan,
                                                     int* __restrict__ list) {
   __shared__ float red[8];
   const int cb = blockIdx.x, tid = threadIdx.x;
   const int chunk = cb / nblk, blk = cb - chunk * nblk;
-  const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P);
+  const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P), w2 = min(w0 + wspan, P);
   const float* d = den + (int64_t)chunk * Ppad;
   float mn = 3.0e38f, mx = 0.f;
-  for (int64_t p = w0 + tid; p < w1; p += 256) {
+  for (int64_t p = w0 + tid; p < w2; p += 256) {
     const float dn = d[p];
-    if (dn > 0.f) { mn = fminf(mn, dn); mx = fmaxf(mx, dn); }
+    if (dn > 0.f) {
+      if (p < w1) mn = fminf(mn, dn);
+      mx = fmaxf(mx, dn);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -457,8 +464,9 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   const int nblkx = nblk + f.nseg - 1;   // a segmented template also reads the blocks behind its own
   if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
+  const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                     ctx->stream, xp, Tpad, Nc, V, nblkx, (const c32*)f.tab_dev, xh);
+                     ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh);
   DTX_HIP(ctx, hipGetLastError());
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
@@ -469,7 +477,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
   a.nseg = f.nseg; a.nblkx = nblkx;
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->stream, den,
-                     Ppad, P, V, nblk, guard_list);
+                     Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list);
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {

@@ -268,21 +268,26 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
 // ---------------------------------------------------------------- block spectra
 // Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
 // slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w
-// takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0
+// takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0.
+// keep: samples of a block that can reach a kept output (V + L - 1 for a single-segment
+// template: window p < V reads samples p .. p + L - 1); the rest of the 8192 are transformed as
+// zeros -- exact, and it keeps a burst that lies only in that tail out of this block's float32
+// rounding (the dynamic-range guard looks at the block's own windows).  kN: no masking.
 __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, int64_t Tpad,
-                                                  int Nc, int V, int nblk,
+                                                  int Nc, int V, int nblk, int keep,
                                                   const c32* __restrict__ tab,
                                                   c32* __restrict__ xh) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
   const LdsBases lb = lds_bases(tid);
   const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
-  const int64_t t0 = (int64_t)blk * V + 8 * (tid & 63) + (tid >> 6);
+  const int tb = 8 * (tid & 63) + (tid >> 6);          // sample within the block
+  const int64_t t0 = (int64_t)blk * V + tb;
   c32 v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t t = t0 + 512 * r;
-    v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
+    v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
   }
   fft8192<-1>(v, lds, lb, tab, tid);
   c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);   // nblk: blocks STORED per chunk

@@ -251,7 +251,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
                      N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
   DTX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
-                     ctx->stream, z, Tz, Nc, V, nblkx, (const c32*)tab, xh);
+                     ctx->stream, z, Tz, Nc, V, nblkx, kN, (const c32*)tab, xh);
   DTX_HIP(ctx, hipGetLastError());
 
   XcFftArgs a;

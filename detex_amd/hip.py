@@ -195,7 +195,10 @@ class HipContext(object):
                                         _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
-            return out, (lambda: self._post_result(hist, maxds, thr, key, val, cnt, cand_cap))
+            def fetch():
+                self.sync()          # the context's stream, whatever torch's current stream is now
+                return self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
+            return out, fetch
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
 
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):

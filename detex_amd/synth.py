@@ -23,8 +23,10 @@ def detector_bank(seed, D, k, n):
 def continuous_day(seed, nchunk, M, Nc, U=None, det_off=None, nplant=50, amp=(5.0, 20.0)):
     """nchunk data blocks of M multiplexed samples: N(0,1) noise plus planted
     events (random combinations of one detector's basis, scaled to `amp` times
-    the noise sigma per sample) at channel-aligned positions.  Returns x
-    [nchunk, M] float32 and the list of (chunk, window index, detector)."""
+    the noise sigma per sample) at channel-aligned positions; planted events never
+    overlap each other (a 20-sigma event on top of a 5-sigma one would bury it: every
+    plant must be detectable on its own).  Returns x [nchunk, M] float32 and the list
+    of (chunk, window index, detector)."""
     rs = np.random.RandomState(seed)
     x = rs.standard_normal((nchunk, M)).astype(np.float32)
     plants = []
@@ -38,7 +40,10 @@ def continuous_day(seed, nchunk, M, Nc, U=None, det_off=None, nplant=50, amp=(5.
             coef = rs.standard_normal(rows.shape[0])
             coef /= np.linalg.norm(coef)
             a = rs.uniform(*amp) * np.sqrt(n)
-            p = int(rs.randint(0, (M - n) // Nc))
+            while True:
+                p = int(rs.randint(0, (M - n) // Nc))
+                if all(pb != b or abs(pp - p) >= 2 * (n // Nc) for (pb, pp, _) in plants):
+                    break
             pos = p * Nc
             plants.append((b, p, d))
             x[b, pos:pos + n] += (a * (coef @ rows)).astype(np.float32)

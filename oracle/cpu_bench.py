@@ -1,0 +1,152 @@
+"""All-cores leg of bench.py's ``cpu_baseline`` -- TEST / MEASUREMENT INFRASTRUCTURE, not
+product code (only bench.py's cpu_baseline leg imports this).
+
+The reference scans single-threaded (detex/subspace.py:1843-1845 rejects ``multiprocess``);
+SURVEY.md section 8(d) asks for the same CPU restatement on all physical cores as well: one
+worker process per physical core, each running the reference's FFT algorithm
+(oracle.detex_oracle.mpxds_fft, detex/detect.py:559-578) on its own chunk for a slice of the
+basis vectors.  Workers are plain child processes (``python -m oracle.cpu_bench <dir> <i>``,
+numpy / scipy only -- they never touch the GPU and do not re-import the parent's main
+module); a file gate starts them together once all have finished importing, and the rate is
+the work of all workers over the wall clock from the gate to the last finish.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cpu_info():
+    """(model name, physical cores usable by this process, logical cpus)."""
+    model, phys = 'unknown', set()
+    try:
+        pid = cid = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name') and model == 'unknown':
+                    model = line.split(':', 1)[1].strip()
+                elif line.startswith('physical id'):
+                    pid = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    cid = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    nphys = len(phys) if phys else logical
+    return model, max(1, min(nphys, usable)), logical
+
+
+def _mem_available_gb():
+    try:
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable'):
+                    return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 8.0
+
+
+def _worker(workdir, i):
+    """One worker: the reference algorithm on one chunk and a slice of the detectors (its own
+    stream FFT, then one 2^21-point IFFT per basis vector)."""
+    import scipy.fftpack
+    sys.path.insert(0, ROOT)
+    from oracle import detex_oracle as orc
+    z = np.load(os.path.join(workdir, 'task%d.npz' % i))
+    x, U, off, Nc = z['x'].astype(np.float64), z['U'].astype(np.float64), z['off'], int(z['Nc'])
+    n = U.shape[1]
+    rbi = 2 ** int(len(x) + n).bit_length()
+    open(os.path.join(workdir, 'ready%d' % i), 'w').close()
+    deadline = time.time() + 600
+    while not os.path.exists(os.path.join(workdir, 'go')):      # the start gate
+        if time.time() > deadline:
+            sys.exit(2)
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    xFD = scipy.fftpack.fft(x, n=rbi)                            # detect.py:255-256
+    nv = 0
+    for d in range(len(off) - 1):
+        orc.mpxds_fft(x, U[off[d]:off[d + 1]], Nc, rbi=rbi, xFD=xFD)
+        nv += int(off[d + 1] - off[d])
+    dt = time.perf_counter() - t0
+    with open(os.path.join(workdir, 'done%d.json' % i), 'w') as f:
+        json.dump(dict(nvec=nv, seconds=dt), f)
+
+
+def allcores_baseline(U, det_off, x_chunks, Nc, nvec_per_worker=40, max_workers=None,
+                      timeout=600.0):
+    """windows/s of the reference algorithm with one worker per physical core, each on one
+    chunk x ``nvec_per_worker`` basis vectors; the rate is scaled linearly to all K vectors
+    (the cost is one IFFT per vector and chunk)."""
+    model, ncores, logical = cpu_info()
+    # ~1.2 GB peak per worker (8-vector detector: spectra, products and inverse transforms
+    # of 2^21 complex128 points each)
+    workers = max(1, min(ncores, int(_mem_available_gb() / 1.5)))
+    if max_workers:
+        workers = min(workers, int(max_workers))
+    D = len(det_off) - 1
+    K, n = U.shape
+    x_chunks = np.atleast_2d(x_chunks)
+    procs = []
+    with tempfile.TemporaryDirectory(prefix='dtx_cpu_') as wd:
+        d = 0
+        for w in range(workers):
+            rows, off = [], [0]
+            while off[-1] < nvec_per_worker:
+                rows.append(U[det_off[d]:det_off[d + 1]])
+                off.append(off[-1] + rows[-1].shape[0])
+                d = (d + 1) % D
+            np.savez(os.path.join(wd, 'task%d.npz' % w), x=x_chunks[w % len(x_chunks)],
+                     U=np.concatenate(rows), off=np.array(off), Nc=Nc)
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        try:
+            for w in range(workers):
+                procs.append(subprocess.Popen([sys.executable, '-m', 'oracle.cpu_bench', wd, str(w)],
+                                              cwd=ROOT, env=env))
+            t_end = time.time() + timeout
+            while not all(os.path.exists(os.path.join(wd, 'ready%d' % w)) for w in range(workers)):
+                if time.time() > t_end or any(p.poll() not in (None, 0) for p in procs):
+                    raise RuntimeError('cpu_bench workers failed to start')
+                time.sleep(0.01)
+            t0 = time.perf_counter()
+            open(os.path.join(wd, 'go'), 'w').close()
+            for p in procs:
+                p.wait(timeout=max(1.0, t_end - time.time()))
+            wall = time.perf_counter() - t0
+            res = []
+            for w in range(workers):
+                with open(os.path.join(wd, 'done%d.json' % w)) as f:
+                    res.append(json.load(f))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    nvec = sum(r['nvec'] for r in res)
+    P = (x_chunks.shape[1] - n) // Nc + 1
+    # nvec (vector, chunk) units done in `wall` seconds; a full chunk needs K of them
+    value = P * (nvec / float(K)) / wall
+    return dict(value=value, unit='windows/s', cores=workers, kind='port', cpu_model=model,
+                physical_cores=ncores, os_cpu_count=logical,
+                sample='%d worker processes (one per physical core) x 1 chunk x %d basis vectors '
+                       'each, float64 FFT path, %.1f s wall (slowest worker %.1f s), scaled linearly '
+                       'to %d vectors' % (workers, nvec // workers, wall,
+                                          max(r['seconds'] for r in res), K))
+
+
+if __name__ == '__main__':
+    _worker(sys.argv[1], int(sys.argv[2]))

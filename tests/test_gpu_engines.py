@@ -114,6 +114,38 @@ def test_extreme_burst_stays_local(ctx):
     assert int(np.argmax(got[:3000])) == 1000 and int(np.argmax(got[12000:])) == 3000
 
 
+@pytest.mark.parametrize('L,burst', [(300, (8000, 8100)), (6000, (10500, 10600)),
+                                      (3000, (8150, 8190)), (513, (8150, 8192))])
+def test_burst_in_the_unused_tail_of_a_block(ctx, L, burst):
+    """A 10^6 x burst that lies only in the part of block 0's 8192-sample transform no kept
+    output of block 0 reads (samples >= V + L - 1; for a segmented template: beyond the reach of
+    block 0's own windows but inside the following block's transform, which block 0's segments
+    also use).  The block's own window energies do not see it, so the guard alone would not
+    repair block 0: single-segment templates transform that tail as zeros, segmented ones let
+    the guard look one block further.  Every quiet window holds 1e-5."""
+    rs = np.random.RandomState(15)
+    Nc, K, T = 3, 6, 26000
+    n = Nc * L
+    A = rs.standard_normal((n, K))
+    A -= A.mean(axis=0)
+    U = np.linalg.qr(A)[0].T
+    x = rs.standard_normal(Nc * T)
+    b0, b1 = burst
+    x[Nc * b0: Nc * b1] *= 1e6
+    x[Nc * 500: Nc * 500 + n] += 4 * (rs.standard_normal(K) @ U) * np.sqrt(n) / 3
+    got = _gpu_ds(ctx, x, U, [0, K], Nc)[0]
+    ref = orc.mpxds_fft(x.astype(np.float32).astype(np.float64),
+                        U.astype(np.float32).astype(np.float64), Nc)
+    P = len(ref)
+    quiet = np.ones(P, bool)
+    quiet[max(b0 - L + 1, 0):b1] = False      # windows that contain burst samples
+    V = (8192 - L + 1) // 512 * 512 if L <= 5633 else 4096
+    assert b0 - L + 1 >= V                    # no window of block 0 contains the burst
+    assert np.max(np.abs(got - ref)[quiet]) <= 1e-5
+    assert np.max(np.abs(got - ref)[~quiet]) <= 4e-5
+    assert int(np.argmax(got[:V])) == 500
+
+
 def test_engines_agree_fullsize(ctx):
     """configs[1] shape, one chunk: the two engines agree to 2e-6 and pick the
     same candidates."""

@@ -112,3 +112,224 @@ def test_xcorr_config3_scale(ctx):
             assert lag[i] == rl, (b, c)
             if abs(rss) <= .5:
                 assert abs(ss[i] - rss) <= 1e-4, (b, c)
+
+
+# --------------------------------------------------------------------------
+# configs[2] at its real size: 2000 events x n = 39 000, all 1 999 000 pairs
+# --------------------------------------------------------------------------
+
+def _cidx(N, b, c):
+    return N * b - b * (b + 1) // 2 + (c - b - 1)
+
+
+@pytest.fixture(scope='module')
+def config3_events():
+    """configs[2]: 100 families x 20 events, Nc = 3, L = 13 000, with known answers planted
+    across the tile borders of every kernel on the path: the 208-event row tiles of the MFMA
+    contraction, the 512 x 512-event tiles and 16-event L2 groups of the finishing kernel, the
+    eight-pair units of the frequency-domain search."""
+    Nc, L = 3, 13000
+    td = synth.event_families(2, 100, 20, Nc, L)
+    rs = np.random.RandomState(11)
+    known = {}
+
+    def delayed(src, sh):
+        base = td[src].reshape(L, Nc)
+        pad = rs.standard_normal((abs(sh), Nc)).astype(np.float32) * 1e-3
+        out = np.vstack([pad, base[:-sh]]) if sh > 0 else np.vstack([base[-sh:], pad])
+        return out.reshape(-1)
+
+    for (b, c, sh) in [(207, 208, 37), (511, 512, -25), (1023, 1024, 5), (15, 16, 101),
+                       (1535, 1536, -64), (623, 624, 3)]:
+        td[c] = delayed(b, sh)
+        known[(b, c)] = sh * Nc
+    td[416] = 2.5 * td[415]                 # scaled copy across the second row-tile border
+    known[(415, 416)] = 0
+    td[1999] = td[0]                        # identical events at the two ends of the matrix
+    known[(0, 1999)] = 0
+    return Nc, L, td, known
+
+
+def _spot_pairs(N, rs, count=200):
+    edges = [16, 208, 416, 512, 624, 832, 1024, 1040, 1248, 1456, 1536, 1664, 1872, 1984]
+    pairs = set()
+    for e in edges:
+        for b, c in [(e - 1, e), (e, e + 1), (e - 2, e - 1), (0, e), (e, N - 1), (e - 1, N - 1),
+                     (e - 1, e + 15), (e - 1, e + 16), (e // 2, e)]:
+            if 0 <= b < c < N:
+                pairs.add((b, c))
+    for e1 in edges:
+        for e2 in edges:
+            if e1 < e2:
+                pairs.add((e1 - 1, e2))
+    pairs |= {(0, 1), (0, N - 1), (N - 2, N - 1), (1, 2), (7, 8), (8, 9)}
+    pairs = sorted(pairs)
+    if len(pairs) > count - 40:
+        keep = rs.permutation(len(pairs))[:count - 40]
+        pairs = [pairs[i] for i in sorted(keep)]
+    while len(pairs) < count:
+        b, c = sorted(rs.randint(0, N, 2))
+        if b != c and (b, c) not in pairs:
+            pairs.append((int(b), int(c)))
+    return pairs
+
+
+def test_xcorr_config3_full(ctx, config3_events):
+    """All 1 999 000 pairs of configs[2] under the default engine and under the MFMA
+    contraction: range / alignment properties on every pair, the planted known answers, 200
+    spot pairs against the reference's FFT algorithm (oracle), and engine against engine."""
+    Nc, L, td, known = config3_events
+    N = td.shape[0]
+    tdd = torch.from_numpy(td).cuda()
+    out = {}
+    for eng in ('auto', 'bf16x3'):
+        ctx.set_engine(eng)
+        cc, lag, ss = ctx.xcorr_allpairs(tdd, Nc)
+        ctx.sync()
+        out[eng] = (cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy())
+    ctx.set_engine('auto')
+    del tdd
+    S = L - L // 2
+    for eng, (cc, lag, ss) in out.items():
+        assert cc.shape == (N * (N - 1) // 2,), eng
+        assert np.all(np.isfinite(cc)) and np.all(np.isfinite(ss)), eng
+        assert np.all(np.abs(cc) <= 1 + 1e-5), eng
+        assert np.all(lag % Nc == 0) and np.all(np.abs(lag) <= S * Nc), eng
+        inner = np.abs(lag) < S * Nc                # _subSamp is 0 at the ends of the lag range
+        assert np.all(ss[~inner] == 0), eng
+        for (b, c), want in known.items():
+            i = _cidx(N, b, c)
+            assert lag[i] == want, (eng, b, c, lag[i], want)
+            assert cc[i] > 0.99, (eng, b, c, cc[i])
+        for (b, c) in [(415, 416), (0, 1999)]:
+            i = _cidx(N, b, c)
+            assert abs(cc[i] - 1) <= 1e-5 and abs(ss[i]) < 1e-3, (eng, b, c)
+        # family structure: same-family pairs (20 consecutive events) correlate, others do not
+        fam = np.arange(N) // 20
+        iu = np.triu_indices(N, 1)
+        same = fam[iu[0]] == fam[iu[1]]
+        assert np.median(cc[same]) > 0.8 and np.percentile(cc[~same], 99.9) < 0.3, eng
+    # engine against engine on every pair (both re-evaluate the winning lag in float64)
+    (c0, l0, s0), (c1, l1, s1) = out['auto'], out['bf16x3']
+    assert np.max(np.abs(c0 - c1)) <= 2e-5
+    differ = l0 != l1
+    assert differ.mean() < 1e-3                      # only near-ties between lags may differ
+    assert np.all(np.abs(c0[differ] - c1[differ]) <= 1e-5)
+    # oracle spot pairs
+    rs = np.random.RandomState(5)
+    pairs = _spot_pairs(N, rs, 200)
+    assert len(pairs) >= 200
+    fd_cache = {}
+
+    def fd(e):
+        if e not in fd_cache:
+            if len(fd_cache) > 64:
+                fd_cache.clear()
+            fd_cache[e] = orc.get_freq_domain(td[e].astype(np.float64))
+        return fd_cache[e]
+
+    for (b, c) in pairs:
+        rc, rl, rss, res = orc.ccx2_fft(td[b], td[c], Nc, fd(b), fd(c), scrub_tol=1e-5)
+        i = _cidx(N, b, c)
+        srt = np.sort(res[np.isfinite(res)])
+        for eng, (cc, lag, ss) in out.items():
+            assert abs(cc[i] - rc) <= 1e-5, (eng, b, c, cc[i], rc)
+            if srt[-1] - srt[-2] > 5e-6:
+                assert lag[i] == rl, (eng, b, c, lag[i], rl)
+                if abs(rss) <= .5:
+                    assert abs(ss[i] - rss) <= 1e-4, (eng, b, c, ss[i], rss)
+
+
+# --------------------------------------------------------------------------
+# configs[0] at its real size, through the reference's workflow names
+# --------------------------------------------------------------------------
+
+def _bandpassed(rs, T, sr, lo=1.0, hi=10.0):
+    from scipy.signal import butter, sosfiltfilt
+    sos = butter(2, [lo / (sr / 2), hi / (sr / 2)], btype='band', output='sos')
+    return sosfiltfilt(sos, rs.standard_normal(T + 200))[100:100 + T]
+
+
+def test_config1_full_workflow(tmp_path):
+    """configs[0]: 10 templates (2 families x 5), 3-ch 100 Hz, trim [10, 120] -> L = 13 000
+    (n = 39 000), one hour (+ 120 s) of continuous data; createCluster -> createSubSpace ->
+    attachPickTimes -> SVD -> detex on the GPU against the same workflow on the CPU oracle."""
+    import pandas as pd
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
+    from detex_amd.getdata import multiplex
+    SR, NC, L = 100.0, 3, 13000
+    rs = np.random.RandomState(0)
+    env = np.exp(-np.arange(L + 100) / (0.08 * L))
+    fams = [[_bandpassed(rs, L + 100, SR) * env for _ in range(NC)] for _ in range(2)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    n = 0
+    for f, wav in enumerate(fams):
+        for _ in range(5):
+            sh = int(rs.randint(0, 101))
+            amp = rs.uniform(.5, 2)
+            data = np.array([amp * w[sh:sh + L] + _bandpassed(rs, L, SR) * np.std(w[:2000]) / 5
+                             for w in wav])
+            ef.add('TA.M17A', 'ev%02d' % n, data, starttime=5000.0 + 500 * n,
+                   origintime=4990.0 + 500 * n, magnitude=1.0 + 0.2 * n)
+            n += 1
+    T = int(3720 * SR)
+    con = np.array([_bandpassed(rs, T, SR) for _ in range(NC)]) * 0.02
+    plants = [(30000, 0, 1.0), (90000, 1, 0.7), (150000, 0, 0.5), (152500, 1, 0.9),
+              (270000, 0, 1.2), (355000, 1, 0.6)]          # the last lies in the 120 s overlap
+    for (t, f, a) in plants:
+        for c in range(NC):
+            con[c, t:t + 4000] += a * fams[f][c][50:4050]
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])       # 3600 s + 120 s chunks
+    cf.add('TA.M17A', con.astype(np.float32), starttime=1.2e6)
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, device=0)
+    c = cl['TA.M17A']
+    assert sorted(map(sorted, c.clusts)) == [['ev%02d' % i for i in range(5)],
+                                             ['ev%02d' % i for i in range(5, 10)]]
+    # similarity matrix (45 pairs of n = 39 000) against the oracle
+    row = cl.trdf.iloc[0]
+    td = [multiplex(list(ef.events['TA.M17A'][e]['data'].astype(np.float32))) for e in row.Events]
+    cc, lag, ssub = orc.make_cclags(td, NC)
+    assert np.nanmax(np.abs(row.CCs.values.astype(float) - cc)) <= 1e-5
+    assert np.array_equal(np.nan_to_num(row.Lags.values.astype(float), nan=-1),
+                          np.nan_to_num(lag, nan=-1))
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=0.0, defaultDuration=30)        # subspace.py:1462 -> n = 9000
+    ss.SVD(selectCriteria=3, selectValue=0.8, threshold=None, useSingles=False)
+    db = str(tmp_path / 'SubSpace.db')
+    res = ss.detex(subspaceDB=db, triggerLTATime=5, triggerSTATime=0, estimateMags=True)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A', useSingles=False)
+    assert kinds == ['ss', 'ss'] and U.shape[1] == 9000
+    want = []
+    hist = {nm: np.zeros(400, dtype=np.int64) for nm in names}
+    nchunks = 0
+    for chunk, t0 in cf.getConData('TA.M17A'):
+        x = multiplex(list(chunk)).astype(np.float64)
+        if len(x) <= U.shape[1]:
+            continue
+        nchunks += 1
+        for d, nm in enumerate(names):
+            ds = orc.mpxds_fft(x, U[off[d]:off[d + 1]].astype(np.float32), NC)
+            ds, maxds = orc.scrub_ds(ds)
+            hist[nm] += orc.ds_histogram(ds)
+            if orc.eval_trig_con(maxds, np.float32(thr[nm])):
+                sl = orc.get_stalta(ds, 5 * SR, 0)
+                for t in orc.pick_triggers(ds, np.float32(thr[nm]), SR, t0, offsets[nm], stalta=sl):
+                    if t['DS'] <= 1.05:
+                        mg = orc.est_mag(t['index'], NC, x, ss._bank_mags[nm],
+                                         U[off[d]:off[d + 1]], ss._bank_ewf[nm], True)
+                        want.append((nm, t['STMP'], t['DS'], t['DS_STALTA'], mg))
+    assert nchunks == 2
+    got = res['ss_df'].sort_values(['Name', 'STMP']).reset_index(drop=True)
+    want.sort(key=lambda r: (r[0], r[1]))
+    assert len(got) == len(want) and len(want) >= len(plants)
+    for (_, g), w in zip(got.iterrows(), want):
+        assert g.Name == w[0] and g.STMP == w[1]                   # trigger index bit-exact
+        assert abs(g.DS - w[2]) <= 1e-5
+        assert abs(g.DS_STALTA - w[3]) <= 1e-3 * max(1, abs(w[3]))
+        assert np.allclose([g.ProEnMag, g.Mag, g.SNR], list(w[4]), rtol=1e-5, equal_nan=True)
+    for (t, f, a) in plants:
+        hit = got[np.abs(got.STMP - (1.2e6 + (t + 50) / SR)) < 2.0]
+        assert len(hit) >= 1, (t, f, a)
+    for nm in names:
+        h = ss.histSubSpaces['TA.M17A'][nm]
+        assert h.sum() == hist[nm].sum() and np.abs(h - hist[nm]).sum() <= 8

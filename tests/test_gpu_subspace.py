@@ -175,3 +175,39 @@ def test_post_hist_max_triggers(ctx):
     assert nfound >= len(plants) - 1     # the two plants 12 s apart merge into one
     for (b, p, d) in plants:
         assert dsh[b, d, p] > 0.5
+
+
+def test_golden_triggers_through_device_post(ctx):
+    """trig.npz (the reference's _evalTrigCon / _CreateCoeffArray / _downPlayArrayAroundMax /
+    _getStaLtaArray outputs, detect.py:390-445, 501-557) with the DS vectors fed through the
+    DEVICE candidate list: dtx_ds_post -> pick_triggers_sparse -> stalta_at, against the
+    reference rows -- near-edge peaks, peaks < 20 s apart, ties, max == threshold (>= vs >),
+    nothing above threshold, DS > 1.05."""
+    from detex_amd.detect import pick_triggers_sparse, stalta_at
+    z = np.load(os.path.join(G, 'trig.npz'))
+    sr, start, offsets = float(z['sr']), float(z['start']), z['offsets']
+    for nm in z['names']:
+        key = nm.split(':')[0]
+        ds64, thr, rows = z[key + '_ds'], float(z[key + '_thr']), z[key + '_rows']
+        ds = torch.from_numpy(ds64.astype(np.float32)).cuda()[None, None, :].contiguous()
+        P = ds.shape[2]
+        res = ctx.ds_post(ds, thr=np.array([thr], np.float32))
+        ctx.sync()
+        assert np.array_equal(res['hist'].cpu().numpy()[0],
+                              np.histogram(ds64.astype(np.float32).astype(np.float64),
+                                           bins=np.linspace(0, 1, 401))[0]), nm
+        maxds = float(res['maxds'].cpu().numpy()[0, 0])
+        assert maxds == np.float32(ds64.max()), nm
+        cb, cd, cp, cv = res['cand']
+        assert np.array_equal(cp, np.nonzero(ds64.astype(np.float32) >= np.float32(thr))[0]), nm
+        trig = pick_triggers_sparse(cp, cv, P, float(np.float32(thr)), sr, maxds)
+        assert bool(trig) == bool(z[key + '_trig']), nm
+        assert len(trig) == rows.shape[0], nm
+        dsabs = np.abs(ds64)
+        for (ti, coef), r in zip(trig, rows):
+            assert abs(coef - r[0]) <= 1e-6, nm                   # DS (float32 of the golden value)
+            assert ti / sr + start == r[2], nm                    # STMP: trigger index bit-exact
+            assert (ti / sr + start) - np.max(offsets) == r[3], nm
+            assert (ti / sr + start) - np.min(offsets) == r[4], nm
+            sl = stalta_at(lambda lo, hi: dsabs[lo:hi], ti, P, 5 * sr, 0)
+            assert abs(sl - r[1]) <= 1e-9 * max(1.0, abs(r[1])), nm
