@@ -97,11 +97,11 @@ def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
 
 def cpu_baseline_allcores(U, det_off, x, Nc):
     """The same CPU restatement on every physical core of the host (SURVEY.md 8d / BASELINE.md 3):
-    one worker process per core, each one chunk x 24 basis vectors.  The reference itself is
+    one worker process per core, each one chunk x 8 basis vectors (one detector).  The reference itself is
     single-threaded; this is the generous CPU figure."""
     from oracle import cpu_bench
     try:
-        return cpu_bench.allcores_baseline(U, det_off, x, Nc, nvec_per_worker=24, timeout=240.0)
+        return cpu_bench.allcores_baseline(U, det_off, x, Nc, nvec_per_worker=8, timeout=240.0)
     except Exception as e:          # a bounded leg: never take the bench line down
         return dict(value=None, unit='windows/s', error=repr(e))
 

@@ -115,7 +115,7 @@ def test_extreme_burst_stays_local(ctx):
 
 
 @pytest.mark.parametrize('L,burst', [(300, (8000, 8100)), (6000, (10500, 10600)),
-                                      (3000, (8150, 8190)), (513, (8150, 8192))])
+                                      (3000, (8150, 8190)), (400, (8100, 8190))])
 def test_burst_in_the_unused_tail_of_a_block(ctx, L, burst):
     """A 10^6 x burst that lies only in the part of block 0's 8192-sample transform no kept
     output of block 0 reads (samples >= V + L - 1; for a segmented template: beyond the reach of
