@@ -32,9 +32,7 @@
 // ~150x fewer flops than the direct contraction; float32 error grows with log kN
 // instead of sqrt(n) (measured 2e-7 at DS = 1 against 2e-6 for the MFMA engines).
 #include <algorithm>
-#include <atomic>
-#include <complex>
-#include <thread>
+#include <cmath>
 
 #include "dtx_fftcore.h"
 
@@ -287,36 +285,61 @@ void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   }
 }
 
-// float64 radix-2 transform on the host, kernel e^{+2 pi i j f / kN}, unnormalised
-struct HostFft {
-  std::vector<std::complex<double>> tw;   // e^{+2 pi i k / kN}, k < kN / 2
-  std::vector<int> rev;
-  HostFft() : tw(kN / 2), rev(kN) {
-    const double pi = 3.14159265358979323846264338327950288;
-    for (int k = 0; k < kN / 2; ++k)
-      tw[k] = std::complex<double>(std::cos(2 * pi * k / kN), std::sin(2 * pi * k / kN));
-    int bits = 0;
-    while ((1 << bits) < kN) ++bits;
-    for (int i = 0; i < kN; ++i) {
-      int r = 0;
-      for (int q = 0; q < bits; ++q) r |= ((i >> q) & 1) << (bits - 1 - q);
-      rev[i] = r;
+// Pair spectra in FLOAT64 on the device: W[task][wave-major f] = 1/kN sum_j (u_ra,c[j0 + j] +
+// i u_rb,c[j0 + j]) e^{+2 pi i j f / kN}, task = pair * nvc + (c * nseg + seg).  One workgroup
+// per task; a plain radix-2 transform of 8192 complex128 points in 128 KB of LDS (twiddles from
+// sincospi in float64), rounded to float32 only on the way out -- the same values the host
+// used to build with a float64 FFT (300 transforms at configs[1]: 80 ms on one core, ~0.1 ms here).
+__global__ __launch_bounds__(512) void wspec64_kernel(const float* __restrict__ U, int n, int Nc,
+                                                      int L, int nseg, int seglen,
+                                                      const int2* __restrict__ prow,
+                                                      c32* __restrict__ W) {
+  __shared__ double2 z[kN];
+  const int tid = threadIdx.x;
+  const int nvc = Nc * nseg;
+  const int pr = blockIdx.x / nvc, vc = blockIdx.x - pr * nvc;
+  const int c = vc / nseg, sg = vc - c * nseg;
+  const int j0 = sg * seglen, j1 = min(L, j0 + seglen);
+  const int2 rows = prow[pr];
+  constexpr int kBits = 13;
+  static_assert((1 << kBits) == kN, "bit reversal is for 8192 points");
+  for (int j = tid; j < kN; j += 512) {
+    double re = 0.0, im = 0.0;
+    if (j0 + j < j1) {
+      const size_t q = (size_t)(j0 + j) * Nc + c;
+      re = (double)U[(size_t)rows.x * n + q];
+      if (rows.y >= 0) im = (double)U[(size_t)rows.y * n + q];
     }
+    z[__brev((unsigned)j) >> (32 - kBits)] = make_double2(re, im);
   }
-  void run(std::complex<double>* a) const {
-    for (int i = 0; i < kN; ++i)
-      if (i < rev[i]) std::swap(a[i], a[rev[i]]);
-    for (int len = 2; len <= kN; len <<= 1) {
-      const int half = len / 2, step = kN / len;
-      for (int i = 0; i < kN; i += len)
-        for (int k = 0; k < half; ++k) {
-          const std::complex<double> u = a[i + k], v = a[i + k + half] * tw[k * step];
-          a[i + k] = u + v;
-          a[i + k + half] = u - v;
-        }
+  __syncthreads();
+  for (int half = 1; half < kN; half <<= 1) {
+    for (int b = tid; b < kN / 2; b += 512) {
+      const int k = b & (half - 1);
+      const int i = ((b - k) << 1) + k;
+      double sn, cs;
+      sincospi((double)k / (double)half, &sn, &cs);        // e^{+i pi k / half}
+      const double2 u = z[i], w = z[i + half];
+      const double2 v = make_double2(w.x * cs - w.y * sn, w.x * sn + w.y * cs);
+      z[i] = make_double2(u.x + v.x, u.y + v.y);
+      z[i + half] = make_double2(u.x - v.x, u.y - v.y);
     }
+    __syncthreads();
   }
-};
+  c32* dst = W + (size_t)blockIdx.x * kN;
+  // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
+  for (int q = tid; q < kN; q += 512)
+    dst[(q & 7) * (kN / 8) + (q >> 3)] = make_float2((float)(z[q].x / kN), (float)(z[q].y / kN));
+}
+
+// pinfo[pair] = {S_ra, S_rb, 0, 0} from the row sums
+__global__ void pinfo_kernel(const int2* __restrict__ prow, const float* __restrict__ srow, int npairs,
+                             float4* __restrict__ pinfo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const int2 r = prow[p];
+  pinfo[p] = make_float4(srow[r.x], r.y >= 0 ? srow[r.y] : 0.f, 0.f, 0.f);
+}
 
 }  // namespace
 
@@ -327,14 +350,15 @@ void dtx_fft_free(dtx_ctx* ctx) {
   if (f.unit_dev) (void)hipFree(f.unit_dev);
   if (f.pinfo_dev) (void)hipFree(f.pinfo_dev);
   if (f.pdet_dev) (void)hipFree(f.pdet_dev);
+  if (f.prow_dev) (void)hipFree(f.prow_dev);
   f = DtxFft();
 }
 
 bool dtx_fft_eligible(int L) { return L >= kFftMinL && L <= kFftLongMaxL; }
 
-// hU: the stacked basis [Ktot][n] on the host (multiplexed rows)
-int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n,
-                        int Nc) {
+// Units / pairs of the uploaded basis (host, from det_off alone) and their spectra (device, from
+// the context's device copy of U and its row sums)
+int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int Nc) {
   dtx_fft_free(ctx);
   const int L = n / Nc;
   if (!dtx_fft_eligible(L)) return DTX_OK;
@@ -354,96 +378,67 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, i
   // block spectra a workgroup stages in LDS serve all its pairs
   constexpr int kUnitPairs = DTX_FFT_UNIT;
   std::vector<int4> units;
-  std::vector<float4> pinfo;
   std::vector<int2> pdet;
-  std::vector<int> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
-  auto rowsum = [&](int r) {
-    double s = 0.0;
-    for (int q = 0; q < n; ++q) s += (double)hU[(size_t)r * n + q];
-    return (float)s;
-  };
+  std::vector<int2> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
   int ufirst = 0;
   auto close_unit = [&]() {
-    const int np = (int)pinfo.size() - ufirst;
+    const int np = (int)prow.size() - ufirst;
     if (np > 0) units.push_back(make_int4(ufirst, np, 0, 0));
-    ufirst = (int)pinfo.size();
+    ufirst = (int)prow.size();
   };
   for (int d = 0; d < D;) {
     const int r0 = det_off[d], k = det_off[d + 1] - r0;
     const bool shared = k == 1 && d + 1 < D && det_off[d + 2] - det_off[d + 1] == 1;
     const int np = shared ? 1 : (k + 1) / 2;
-    if ((int)pinfo.size() - ufirst + np > kUnitPairs) close_unit();
+    if ((int)prow.size() - ufirst + np > kUnitPairs) close_unit();
     if (shared) {
       f.two = true;
-      pinfo.push_back(make_float4(rowsum(r0), rowsum(r0 + 1), 0.f, 0.f));
       pdet.push_back(make_int2(d, d + 1));
-      prow.push_back(r0); prow.push_back(r0 + 1);
+      prow.push_back(make_int2(r0, r0 + 1));
       d += 2;
     } else {
       for (int q = 0; q < k; q += 2) {
         const bool has2 = q + 1 < k;
-        pinfo.push_back(make_float4(rowsum(r0 + q), has2 ? rowsum(r0 + q + 1) : 0.f, 0.f, 0.f));
         pdet.push_back(make_int2(q + 2 >= k ? d : -1, -1));
-        prow.push_back(r0 + q); prow.push_back(has2 ? r0 + q + 1 : -1);
+        prow.push_back(make_int2(r0 + q, has2 ? r0 + q + 1 : -1));
       }
       d += 1;
     }
   }
   close_unit();
   f.nunits = (int)units.size();
-  f.npairs = (int)pinfo.size();
+  f.npairs = (int)prow.size();
 
-  // pair spectra in float64 on the host, one (pair, channel) transform per task over the
-  // host's cores (300 transforms at configs[1]: ~80 ms on one core)
   const int nvc = Nc * f.nseg;
-  std::vector<float2> W((size_t)f.npairs * nvc * kN);
-  {
-    static const HostFft hfft;
-    const int ntask = f.npairs * nvc;
-    unsigned nthr = std::thread::hardware_concurrency();
-    nthr = std::max(1u, std::min(nthr ? nthr : 1u, 32u));
-    nthr = std::min<unsigned>(nthr, (unsigned)ntask);
-    std::atomic<int> next(0);
-    auto work = [&]() {
-      std::vector<std::complex<double>> z(kN);
-      for (int task = next.fetch_add(1); task < ntask; task = next.fetch_add(1)) {
-        const int pr = task / nvc, vc = task - pr * nvc;
-        const int c = vc / f.nseg, sg = vc - c * f.nseg;
-        const int j0 = f.nseg == 1 ? 0 : sg * kSeg, j1 = f.nseg == 1 ? L : std::min(L, j0 + kSeg);
-        const int ra = prow[2 * pr], rb = prow[2 * pr + 1];
-        for (int j = 0; j < kN; ++j) z[j] = 0.0;
-        for (int j = j0; j < j1; ++j)
-          z[j - j0] = std::complex<double>((double)hU[(size_t)ra * n + (size_t)j * Nc + c],
-                                           rb >= 0 ? (double)hU[(size_t)rb * n + (size_t)j * Nc + c] : 0.0);
-        hfft.run(z.data());
-        float2* dst = W.data() + (size_t)task * kN;
-        // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
-        for (int q = 0; q < kN; ++q)
-          dst[(q & 7) * (kN / 8) + (q >> 3)] =
-              make_float2((float)(z[q].real() / kN), (float)(z[q].imag() / kN));
-      }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-  }
-  std::vector<float2> tab(kN);
-  const double pi = 3.14159265358979323846264338327950288;
-  for (int m = 0; m < kN; ++m)
-    tab[m] = make_float2((float)std::cos(2 * pi * m / kN), (float)std::sin(2 * pi * m / kN));
-
-  DTX_HIP(ctx, hipMalloc(&f.W_dev, W.size() * sizeof(float2)));
+  static const std::vector<float2> tab = [] {          // e^{+2 pi i m / kN}, once per process
+    std::vector<float2> t(kN);
+    const double pi = 3.14159265358979323846264338327950288;
+    for (int m = 0; m < kN; ++m)
+      t[m] = make_float2((float)std::cos(2 * pi * m / kN), (float)std::sin(2 * pi * m / kN));
+    return t;
+  }();
+  DTX_HIP(ctx, hipMalloc(&f.W_dev, (size_t)f.npairs * nvc * kN * sizeof(float2)));
   DTX_HIP(ctx, hipMalloc(&f.tab_dev, tab.size() * sizeof(float2)));
   DTX_HIP(ctx, hipMalloc(&f.unit_dev, units.size() * sizeof(int4)));
-  DTX_HIP(ctx, hipMalloc(&f.pinfo_dev, pinfo.size() * sizeof(float4)));
+  DTX_HIP(ctx, hipMalloc(&f.pinfo_dev, (size_t)f.npairs * sizeof(float4)));
   DTX_HIP(ctx, hipMalloc(&f.pdet_dev, pdet.size() * sizeof(int2)));
-  DTX_HIP(ctx, hipMemcpy(f.pdet_dev, pdet.data(), pdet.size() * sizeof(int2), hipMemcpyHostToDevice));
-  DTX_HIP(ctx, hipMemcpy(f.W_dev, W.data(), W.size() * sizeof(float2), hipMemcpyHostToDevice));
-  DTX_HIP(ctx, hipMemcpy(f.tab_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
-  DTX_HIP(ctx, hipMemcpy(f.unit_dev, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice));
-  DTX_HIP(ctx, hipMemcpy(f.pinfo_dev, pinfo.data(), pinfo.size() * sizeof(float4),
-                         hipMemcpyHostToDevice));
+  DTX_HIP(ctx, hipMalloc(&f.prow_dev, prow.size() * sizeof(int2)));
+  // small synchronous copies into fresh buffers
+  hipError_t e = hipMemcpy(f.prow_dev, prow.data(), prow.size() * sizeof(int2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f.pdet_dev, pdet.data(), pdet.size() * sizeof(int2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f.tab_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f.unit_dev, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pinfo_kernel, dim3((unsigned)((f.npairs + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int2*)f.prow_dev, (const float*)ctx->srow_all.p, f.npairs,
+                       (float4*)f.pinfo_dev);
+    hipLaunchKernelGGL(wspec64_kernel, dim3((unsigned)(f.npairs * nvc)), dim3(512), 0, ctx->stream,
+                       (const float*)ctx->U_buf.p, n, Nc, L, f.nseg, f.nseg == 1 ? L : kSeg,
+                       (const int2*)f.prow_dev, (c32*)f.W_dev);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess)
+    return dtx_fail(ctx, DTX_E_HIP, "FFT engine: building the pair spectra failed: %s", hipGetErrorString(e));
   f.ok = true;
   return DTX_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -41,6 +42,7 @@ struct DtxFft {
   void* unit_dev = nullptr;    // [nunits] int4
   void* pinfo_dev = nullptr;   // [npairs] float4
   void* pdet_dev = nullptr;    // [npairs] int2
+  void* prow_dev = nullptr;    // [npairs] int2: basis rows of the real / imaginary part
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
@@ -70,12 +72,13 @@ struct dtx_ctx {
   // basis
   int D = 0, n = 0, Nc = 0, L = 0, Lp = 0, Ktot = 0;
   std::vector<DtxKTile> tiles;
-  std::vector<float> hU;        // host copy of the stacked basis [Ktot][n] (for lazily built images)
+  DtxBuf U_buf;                 // device copy of the stacked basis [Ktot][n] (images are built from it on the device)
+  DtxBuf srow_all;              // [Ktot] row sums S_k (float64 sums, stored float32)
   std::vector<int32_t> hdoff;   // [D+1]
   DtxFft fft;
 
   // workspaces (grown on demand, never shrunk)
-  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat, ws_flag;
+  DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat, ws_flag, ws_trig, ws_trig_doff;
   int engine = DTX_ENGINE_AUTO;
 
   // timing
@@ -92,7 +95,7 @@ constexpr int kSplitMinL = 64;
 struct DtxPost;
 void dtx_fft_free(dtx_ctx* ctx);
 bool dtx_fft_eligible(int L);
-int dtx_fft_basis_build(dtx_ctx* ctx, const float* hU, const int32_t* det_off, int D, int n, int Nc);
+int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int Nc);
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
 // a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.

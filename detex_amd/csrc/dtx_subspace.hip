@@ -13,6 +13,8 @@
 // squares is a second, tiny MFMA with a 0/1 detector-membership matrix, done in
 // registers on the accumulator tile (no LDS round trip, no atomics,
 // deterministic).
+#include <hip/hip_bf16.h>
+
 #include "dtx_hankel.h"
 #include "dtx_hankel_bf16.h"
 #include "dtx_internal.h"
@@ -371,18 +373,49 @@ int launch_tile_rm(dtx_ctx* ctx, int rm, int rows, const DsArgs& a_, int nchunk)
   return dtx_fail(ctx, DTX_E_ARG, "bad row-block count %d", rm);
 }
 
-// round-to-nearest-even float32 -> bfloat16 on the host (NaN stays NaN)
-uint16_t host_bf16(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// ---------------------------------------------------------------- basis images (device side)
+// S_k = sum_q U[k][q] in float64, stored float32: one workgroup per row
+__global__ __launch_bounds__(256) void basis_rowsum_kernel(const float* __restrict__ U, int n,
+                                                           float* __restrict__ srow) {
+  __shared__ double red[4];
+  const float* u = U + (size_t)blockIdx.x * n;
+  double s = 0.0;
+  for (int q = threadIdx.x; q < n; q += 256) s += (double)u[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) srow[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
-float host_bf16_to_f32(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float v;
-  std::memcpy(&v, &u, 4);
-  return v;
+
+// One K-tile: ut[(c Lp + j) KT + k] = U[row0 + k][Nc j + c] (0 for k >= rows or j >= L) and the
+// split-bf16 image ut16[c][j / 8][h][KT][8] (hi = bf16(v), lo = bf16(v - hi); the plain casts
+// round to nearest even and keep a NaN a NaN).  Reads go through an LDS tile so that both the
+// row-major source and the k-fastest destination move whole lines.
+__global__ __launch_bounds__(256) void basis_tile_kernel(const float* __restrict__ U, int n, int Nc,
+                                                         int L, int Lp, int row0, int rows, int KT,
+                                                         float* __restrict__ ut,
+                                                         uint16_t* __restrict__ ut16) {
+  __shared__ float tile[16][65];
+  const int c = blockIdx.z, j0 = blockIdx.x * 64, k0 = blockIdx.y * 16;
+  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    const int k = e >> 6, j = e & 63;
+    float v = 0.f;
+    if (k0 + k < rows && j0 + j < L) v = U[(size_t)(row0 + k0 + k) * n + (size_t)(j0 + j) * Nc + c];
+    tile[k][j] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    const int j = e >> 4, k = e & 15;
+    const float v = tile[k][j];
+    const size_t jj = (size_t)j0 + j;
+    ut[((size_t)c * Lp + jj) * KT + k0 + k] = v;
+    const __hip_bfloat16 hi = __float2bfloat16(v);
+    const __hip_bfloat16 lo = __float2bfloat16(v - __bfloat162float(hi));
+    const size_t qb = (size_t)c * (Lp / 8) + jj / 8;
+    ut16[((qb * 2 + 0) * KT + k0 + k) * 8 + jj % 8] = __builtin_bit_cast(uint16_t, hi);
+    ut16[((qb * 2 + 1) * KT + k0 + k) * 8 + jj % 8] = __builtin_bit_cast(uint16_t, lo);
+  }
 }
 
 }  // namespace
@@ -411,18 +444,31 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
       return dtx_fail(ctx, DTX_E_ARG, "detector %d has %d basis vectors (max %d)", d, k, kKtMax);
   }
   DtxDeviceGuard g(ctx->device);
-  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the old images may still be in use
   const int Ktot = det_off[D];
   const int L = n / Nc;
   const int Lp = (int)dtx_round_up(L, kBQ);
-  std::vector<float> hU((size_t)Ktot * n);
-  DTX_HIP(ctx, hipMemcpy(hU.data(), U, hU.size() * sizeof(float), hipMemcpyDefault));
-
+  int rc;
   dtx_free_tiles_internal(ctx);
+  if ((rc = dtx_reserve(ctx, ctx->U_buf, (size_t)Ktot * n * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->srow_all, (size_t)Ktot * sizeof(float)))) return rc;
+  float* Ud = (float*)ctx->U_buf.p;
+  float* srow_all = (float*)ctx->srow_all.p;
+  hipPointerAttribute_t at;
+  const bool on_device = hipPointerGetAttributes(&at, U) == hipSuccess &&
+                         at.type == hipMemoryTypeDevice;
+  (void)hipGetLastError();                           // a plain host pointer is not an error
+  DTX_HIP(ctx, hipMemcpyAsync(Ud, U, (size_t)Ktot * n * sizeof(float), hipMemcpyDefault, ctx->stream));
+  if (!on_device) DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the caller may reuse its buffer
+
   ctx->D = D; ctx->n = n; ctx->Nc = Nc; ctx->L = L; ctx->Lp = Lp; ctx->Ktot = Ktot;
   ctx->hdoff.assign(det_off, det_off + D + 1);
+  hipLaunchKernelGGL(basis_rowsum_kernel, dim3((unsigned)Ktot), dim3(256), 0, ctx->stream,
+                     (const float*)Ud, n, srow_all);
+  DTX_HIP(ctx, hipGetLastError());
 
-  // greedy packing of whole detectors into K-tiles of <= 208 rows
+  // greedy packing of whole detectors into K-tiles of <= 208 rows; every image is built on the
+  // device from the one copy of U (no host pass over the basis, no stream synchronisation)
   int d = 0;
   while (d < D) {
     DtxKTile t;
@@ -435,48 +481,25 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
     t.rm = (t.rows + 15) / 16;
     const int KT = 16 * t.rm;
     const size_t nq = (size_t)Nc * Lp;
-    std::vector<float> ut(nq * KT, 0.f);
-    std::vector<float> srow(KT, 0.f);
     std::vector<int32_t> doff(t.nd + 1);
     for (int e = 0; e <= t.nd; ++e) doff[e] = det_off[d + e] - row0;
-    for (int k = 0; k < t.rows; ++k) {
-      const float* u = hU.data() + (size_t)(row0 + k) * n;
-      double s = 0.0;
-      for (int c = 0; c < Nc; ++c)
-        for (int j = 0; j < L; ++j) {
-          const float v = u[(size_t)j * Nc + c];
-          s += (double)v;
-          ut[((size_t)c * Lp + j) * KT + k] = v;
-        }
-      srow[k] = (float)s;
-    }
-    // split-bf16 image [c][qb][h][KT][8]: hi = bf16(v), lo = bf16(v - hi)
-    std::vector<uint16_t> ut16((size_t)Nc * (Lp / 8) * 2 * KT * 8, 0);
-    for (int c = 0; c < Nc; ++c)
-      for (int j = 0; j < L; ++j)
-        for (int k = 0; k < t.rows; ++k) {
-          const float v = ut[((size_t)c * Lp + j) * KT + k];
-          const uint16_t hi = host_bf16(v);
-          const uint16_t lo = host_bf16(v - host_bf16_to_f32(hi));
-          const size_t qb = (size_t)c * (Lp / 8) + j / 8;
-          ut16[((qb * 2 + 0) * KT + k) * 8 + j % 8] = hi;
-          ut16[((qb * 2 + 1) * KT + k) * 8 + j % 8] = lo;
-        }
-    DTX_HIP(ctx, hipMalloc(&t.ut16_dev, ut16.size() * sizeof(uint16_t)));
-    DTX_HIP(ctx, hipMalloc(&t.ut_dev, ut.size() * sizeof(float)));
-    DTX_HIP(ctx, hipMalloc(&t.srow_dev, srow.size() * sizeof(float)));
+    const size_t ut16_elems = (size_t)Nc * (Lp / 8) * 2 * KT * 8;
+    DTX_HIP(ctx, hipMalloc(&t.ut16_dev, ut16_elems * sizeof(uint16_t)));
+    DTX_HIP(ctx, hipMalloc(&t.ut_dev, nq * KT * sizeof(float)));
+    DTX_HIP(ctx, hipMalloc(&t.srow_dev, KT * sizeof(float)));
     DTX_HIP(ctx, hipMalloc(&t.doff_dev, doff.size() * sizeof(int32_t)));
-    ctx->tiles.push_back(t);  // pushed first so a failed copy still gets freed
-    DTX_HIP(ctx, hipMemcpy(t.ut_dev, ut.data(), ut.size() * sizeof(float), hipMemcpyHostToDevice));
-    DTX_HIP(ctx, hipMemcpy(t.ut16_dev, ut16.data(), ut16.size() * sizeof(uint16_t),
-                           hipMemcpyHostToDevice));
-    DTX_HIP(ctx, hipMemcpy(t.srow_dev, srow.data(), srow.size() * sizeof(float),
-                           hipMemcpyHostToDevice));
+    ctx->tiles.push_back(t);  // pushed first so a failed call still gets freed
+    hipLaunchKernelGGL(basis_tile_kernel, dim3((unsigned)(Lp / 64), (unsigned)t.rm, (unsigned)Nc),
+                       dim3(256), 0, ctx->stream, (const float*)Ud, n, Nc, L, Lp, row0, t.rows, KT,
+                       t.ut_dev, t.ut16_dev);
+    DTX_HIP(ctx, hipGetLastError());
+    DTX_HIP(ctx, hipMemsetAsync(t.srow_dev, 0, KT * sizeof(float), ctx->stream));
+    DTX_HIP(ctx, hipMemcpyAsync(t.srow_dev, srow_all + row0, t.rows * sizeof(float),
+                                hipMemcpyDeviceToDevice, ctx->stream));
     DTX_HIP(ctx, hipMemcpy(t.doff_dev, doff.data(), doff.size() * sizeof(int32_t),
-                           hipMemcpyHostToDevice));
+                           hipMemcpyHostToDevice));   // fresh buffer, a few bytes: synchronous
     d = dend;
   }
-  ctx->hU.swap(hU);   // kept for the images that are built on first use (frequency-domain engine)
   return DTX_OK;
 }
 
@@ -538,7 +561,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
                        (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
   if (use_fft) {
     if (!ctx->fft.ok &&
-        (rc = dtx_fft_basis_build(ctx, ctx->hU.data(), ctx->hdoff.data(), ctx->D, n, Nc)))
+        (rc = dtx_fft_basis_build(ctx, ctx->hdoff.data(), ctx->D, n, Nc)))
       return rc;
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window

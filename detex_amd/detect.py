@@ -49,13 +49,15 @@ def pick_triggers_sparse(idx, val, P, threshold, sr, maxds, buff=20, maxcount=40
 # STA/LTA of the detection statistic at a trigger       detect.py:501-524
 # --------------------------------------------------------------------------
 
-def _centered_mean_at(fetch, i, n, P):
-    """Value at index i of ``replace_nan_with_mean(pd.rolling_mean(|C|, n,
-    center=True))`` (detect.py:509-511, 516-524) without forming the whole
-    vector: ``fetch(lo, hi)`` returns |C|[lo:hi]."""
+def _centered_lo(i, n, P):
+    """First sample of the window whose mean is element i of
+    ``replace_nan_with_mean(pd.rolling_mean(|C|, n, center=True))`` (detect.py:509-511,
+    516-524): -1 if that element is itself a NaN of the rolling mean (the ``first + 1``
+    quirk on very short vectors); IndexError where the reference's indexing fails
+    (its caller then records 0.0, detect.py:289-295, 417-420)."""
     n = int(n)
     if n < 1 or n > P:
-        raise IndexError('window longer than the detection statistic')   # reference: except -> 0.0
+        raise IndexError('window longer than the detection statistic')
     off = (n - 1) // 2
     first = n - 1 - off                 # first index with a full window
     last = first + (P - n)
@@ -64,11 +66,18 @@ def _centered_mean_at(fetch, i, n, P):
         if i > P - 1:
             raise IndexError('arg[first + 1] is out of range')
         if i > last:
-            return float('nan')         # arg[first + 1] is itself a NaN of the rolling mean
+            return -1                   # arg[first + 1] is itself a NaN of the rolling mean
     elif i > last:                      # arg[last + 1:] = arg[last]
         i = last
-    lo = i - first
-    return float(np.mean(fetch(lo, lo + n)))
+    return i - first
+
+
+def _centered_mean_at(fetch, i, n, P):
+    """Value at index i of that vector without forming it: ``fetch(lo, hi)`` returns |C|[lo:hi]."""
+    lo = _centered_lo(i, n, P)
+    if lo < 0:
+        return float('nan')
+    return float(np.mean(fetch(lo, lo + int(n))))
 
 
 def stalta_at(fetch, i, P, LTA, STA):
@@ -107,15 +116,89 @@ def _dec_len(cnt, dec):
     return (cnt + dec - 1) // dec
 
 
+def _warn(msg):
+    """detex.log(level='warning', pri=True): the scan goes on (detect.py:160-174)."""
+    import logging
+    logging.getLogger('detex_amd.detect').warning(msg)
+
+
+def mag_constants(ewf, mags, U, issub):
+    """Per-detector constants of the magnitude estimates (detect.py:367-381, 447-499): sums,
+    stds and self dot products of the training events (as float32, the precision the device
+    holds them in), and var(WFU, axis=1) with WFU = WFs . UtU formed as (WFs U^T) U."""
+    ewf = np.asarray(ewf, dtype=np.float32).astype(np.float64)
+    c = dict(ewf=ewf, mags=np.asarray(mags, dtype=np.float64), sum_e=ewf.sum(axis=1),
+             std_e=ewf.std(axis=1), d2=np.einsum('ij,ij->i', ewf, ewf), var_wfu=None)
+    if issub:
+        Ud = np.asarray(U, dtype=np.float64)
+        c['var_wfu'] = np.var((ewf @ Ud.T) @ Ud, axis=1)
+    return c
+
+
+def mags_from_stats(c, issub, n, o):
+    """(ProEnMag, Mag, SNR) of one trigger (detect.py:447-499, _estPEMag / _estSTDMag 637-664)
+    from its dtx_trigger_stats row ``o``: o[2] mean and o[3] std of the triggering window,
+    o[4] var(U^T U w), o[5] median rolling std of the pre-event noise, o[6 + e] w . event e."""
+    mean_c, std_c, var_s, noise = o[2], o[3], o[4], o[5]
+    with np.errstate(all='ignore'):
+        snr = float(np.divide(std_c, noise))                      # detect.py:472-473
+    mags = c['mags']
+    dots = np.asarray(o[6:6 + len(mags)], dtype=np.float64)
+    if issub:
+        touse = mags > -15
+        if not touse.any():                                       # detect.py:478-482
+            return np.nan, np.nan, snr
+        with np.errstate(all='ignore'):
+            # fast_normcorr(x, ConDat)[0] (construct.py:469-483) from the dot products
+            ec = (dots - c['sum_e'] * mean_c) / (n * c['std_e'] * std_c)
+            we = np.square(ec) * touse
+            proEn = var_s / c['var_wfu']                          # detect.py:463
+            pem = np.sum((mags + np.log10(np.sqrt(proEn)))[touse] * we[touse]) / we.sum()
+            stm = np.sum((mags + np.log10(std_c / c['std_e']))[touse] * we[touse]) / we.sum()
+        return float(pem), float(stm), snr
+    if np.isnan(mags[0]) or mags[0] < -15:                        # detect.py:490-492
+        return np.nan, np.nan, snr
+    with np.errstate(all='ignore'):
+        return (float(mags[0] + dots[0] / c['d2'][0]),
+                float(mags[0] + np.log10(std_c / c['std_e'][0])), snr)
+
+
+class _MagBank(object):
+    """The training events of every detector of a station on the device (for
+    dtx_trigger_stats) and their host-side constants."""
+
+    def __init__(self, ss, names, kinds, U, det_off, device):
+        import torch
+        self.consts = [mag_constants(ss._bank_ewf[nm], ss._bank_mags[nm],
+                                     U[det_off[d]:det_off[d + 1]], kinds[d] == 'ss')
+                       for d, nm in enumerate(names)]
+        eoff = np.concatenate([[0], np.cumsum([len(c['mags']) for c in self.consts])])
+        self.emax = int(max(len(c['mags']) for c in self.consts))
+        self.ewf = torch.from_numpy(np.concatenate([c['ewf'] for c in self.consts])
+                                    .astype(np.float32)).to(device)
+        self.eoff = torch.from_numpy(eoff.astype(np.int32)).to(device)
+
+    def estimate(self, d, issub, n, o):
+        return mags_from_stats(self.consts[d], issub, n, o)
+
+
 def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
-                 useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=False):
+                 useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=True,
+                 planes_dev=None, chunk_sel=None):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
     detectors in one GPU basis: per batch of chunks the detection statistic
-    (dtx_subspace_scan: detection statistic + histogram / max / candidates), then the
-    reference's trigger loop on the sparse candidates.  Returns dict(ss=DataFrame,
-    sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None."""
+    (dtx_subspace_scan: detection statistic + histogram / max / candidates), the
+    reference's trigger loop on the sparse candidates, then ONE dtx_trigger_stats launch
+    for the STA/LTA and magnitude ingredients of all the batch's triggers.  Returns
+    dict(ss=DataFrame, sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None.
+
+    planes_dev: the station's [Nc, T] data already on the device (uploaded ahead by the
+    caller, e.g. from pinned memory on a copy stream); chunk_sel: indices into the station's
+    chunk list this call scans (multi-GPU sharding); a failing batch is logged and skipped
+    like a failing chunk of the reference (detect.py:160-174)."""
     import pandas as pd
     import torch
+    from ._lib import DetexHipError
     from .hip import HipContext
     names, kinds, U, det_off, offsets, thr = ss._detector_bank(sta, useSubSpaces, useSingles)
     if not names:
@@ -138,91 +221,40 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         data, t0 = fetcher.data[sta]
         raw = bool(getattr(fetcher, 'raw', False))
         dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
+        if planes_dev is None:
+            planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
         if raw:
             # unfiltered planes stay on the device; each chunk is decimated, detrended and
             # band-passed separately, like the reference's per-chunk _applyFilter
             # (detect.py:231); after decimation everything runs at sr / decimate (detect.py:239)
-            rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
-            xdev = None
+            rawdev, xdev = planes_dev, None
             sr_raw, sr = sr, sr / dec
         else:
-            # channel planes go up as they are and are interleaved on the device
+            # channel planes are interleaved on the device
             # (construct.py:977-978; dtx_preprocess without filter or detrend)
-            planes = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
-            xdev = ctx.preprocess(planes[None], filt=None, detrend=False)[0]
-            del planes
+            xdev = ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
+        del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
+        if chunk_sel is not None:
+            bounds = [bounds[i] for i in chunk_sel if i < len(bounds)]
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
         bounds = [b for b in bounds
                   if _dec_len(b[1], dec) * Nc > n and (_dec_len(b[1], dec) * Nc - n) // Nc + 1 >= 10]
         LTA = triggerLTATime * sr
         STA = triggerSTATime * sr
+        need_stats = estimateMags or not fillZeros
+        bank = _MagBank(ss, names, kinds, U, det_off, ctx.device) if need_stats else None
         for (i0, i1, stride) in _chunk_batches(bounds):
-            s0, cnt = bounds[i0][0], bounds[i0][1]
-            M = _dec_len(cnt, dec) * Nc
-            if raw:
-                planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt]
-                                      for k in range(i0, i1)])
-                if dec > 1:                                      # construct.py:1016-1017
-                    planes = ctx.decimate(planes, dec, sr_raw)
-                mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
-                ds, res = ctx.subspace_scan(mp, thr=thr_arr, hist=hist if calcHist else None)
-                mp_host = mp.cpu().numpy() if estimateMags else None
-            else:
-                ds, res = ctx.subspace_scan(xdev[s0 * Nc:], M=M, chunk_stride=stride * Nc,
-                                            nchunk=i1 - i0, thr=thr_arr,
-                                            hist=hist if calcHist else None)
-            P = int(ds.shape[2])
-            maxds = res['maxds'].cpu().numpy()
-            cb, cd, cp, cv = res['cand']
-            if res['ncand'] > len(cv):
-                raise RuntimeError('candidate buffer overflow (%d > %d): threshold far too low'
-                                   % (res['ncand'], len(cv)))
-            mp_cache = {}
-            # candidates grouped by (chunk, detector); pairs without one cannot trigger
-            key = cb.astype(np.int64) * D + cd
-            order = np.argsort(key, kind='stable')               # keeps p ascending per pair
-            ks, first = np.unique(key[order], return_index=True)
-            last = np.append(first[1:], len(order))
-            for kk, f0, f1 in zip(ks, first, last):
-                b, d = int(kk // D), int(kk % D)
-                name = names[d]
-                start = bounds[i0 + b][2]
-                sel = order[f0:f1]
-                trig = pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
-                                            float(maxds[b, d]))
-                row_dev = ds[b, d]
-
-                def fetch(lo, hi, _r=row_dev):
-                    return np.abs(_r[lo:hi].cpu().numpy().astype(np.float64))
-                for (ti, coef) in trig:
-                    if coef > 1.05:                          # detect.py:199-204
-                        continue
-                    if fillZeros:                            # detect.py:414-415
-                        sl = 0.0
-                    else:
-                        try:
-                            sl = stalta_at(fetch, ti, P, LTA, STA)
-                        except IndexError:                   # detect.py:289-295, 417-420
-                            sl = 0.0
-                    times = float(ti) / sr + start           # detect.py:413
-                    of = offsets[name]
-                    pem = stm = snr = np.nan
-                    if estimateMags:                         # detect.py:422-429
-                        if raw:
-                            mpc = mp_host[b]
-                        else:
-                            if b not in mp_cache:            # the chunk as the scan saw it
-                                c0 = bounds[i0 + b][0] * Nc
-                                mp_cache[b] = xdev[c0:c0 + M].cpu().numpy()
-                            mpc = mp_cache[b]
-                        pem, stm, snr = est_mag(ti, Nc, mpc, ss._bank_mags[name],
-                                                U[det_off[d]:det_off[d + 1]],
-                                                ss._bank_ewf[name], kinds[d] == 'ss')
-                    rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
-                                           times - np.min(of), stm, snr, pem])
+            try:
+                _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bounds, i0,
+                            i1, stride, raw, dec, rawdev if raw else None, xdev, Nc, n, D, sr,
+                            sr_raw if raw else sr, LTA, STA, fillZeros, estimateMags, bank, rows)
+            except DetexHipError as e:
+                # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
+                _warn('failing to run detector on %s from %s to %s: %s'
+                      % (sta, bounds[i0][2], bounds[i1 - 1][2] + bounds[i1 - 1][1] / sr, e))
         ctx.sync()
         h = hist.cpu().numpy()
     finally:
@@ -234,58 +266,81 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     return out
 
 
-# --------------------------------------------------------------------------
-# magnitude estimates at a trigger                 detect.py:447-499, 637-664
-# --------------------------------------------------------------------------
-
-def _rolling_std_median(pe, n):
-    """median(pd.rolling_std(pe, n)[n-1:]) (ddof=1) by prefix sums in float64."""
-    pe = np.asarray(pe, dtype=np.float64)
-    pe = pe - pe.mean()                      # shift invariance: kills the cancellation
-    c1 = np.concatenate([[0.0], np.cumsum(pe)])
-    c2 = np.concatenate([[0.0], np.cumsum(pe * pe)])
-    s1 = c1[n:] - c1[:-n]
-    s2 = c2[n:] - c2[:-n]
-    var = np.maximum((s2 - s1 * s1 / n) / (n - 1.0), 0.0)
-    return float(np.median(np.sqrt(var)))
-
-
-def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
-    """Projected-energy and standard-deviation magnitude estimates and the SNR
-    of a detection (Chambers et al. 2015; detect.py:447-499).  Same results as
-    the reference without its n x n ``UtU`` (648 MB per detector at n = 9000,
-    detect.py:367): U^T (U w) replaces UtU w, and (WFs U^T) U replaces WFs UtU.
-    Returns (projectedEnergyMag, stdMag, SNR); per trigger, rare, on the host."""
-    MPcon = np.asarray(MPcon)
-    ewf = np.asarray(ewf, dtype=np.float64)
-    mags = np.asarray(mags, dtype=np.float64)
-    WFlen = ewf.shape[1]
-    a = trigIndex * Nc
-    ConDat = np.asarray(MPcon[a: a + WFlen], dtype=np.float64)
-    if a > 5 * WFlen:                                            # detect.py:466-471
-        pe = MPcon[a - 5 * WFlen: a]
+def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bounds, i0, i1, stride,
+                raw, dec, rawdev, xdev, Nc, n, D, sr, sr_raw, LTA, STA, fillZeros, estimateMags, bank,
+                rows):
+    """One launch group of equal-length chunks: scan, trigger picking, trigger-time estimates."""
+    import torch
+    s0, cnt = bounds[i0][0], bounds[i0][1]
+    M = _dec_len(cnt, dec) * Nc
+    nb = i1 - i0
+    if raw:
+        planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt] for k in range(i0, i1)])
+        if dec > 1:                                      # construct.py:1016-1017
+            planes = ctx.decimate(planes, dec, sr_raw)
+        xb = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
+        xarg, xM, xstride = xb, None, None
+        cstride = int(xb.stride(0))
     else:
-        pe = MPcon[a: a + WFlen + 6 * WFlen]
-    SNR = np.std(ConDat) / _rolling_std_median(pe, WFlen)        # detect.py:472-473
-    touse = mags > -15
-    if issubspace:
-        U = np.asarray(U, dtype=np.float64)
-        if not touse.any():                                      # detect.py:478-482
-            return np.nan, np.nan, SNR
-        ssCon = U.T @ (U @ ConDat)                               # = UtU . ConDat
-        WFU = (ewf @ U.T) @ U                                    # = WFs . UtU
-        proEn = np.var(ssCon) / np.var(WFU, axis=1)              # detect.py:463
-        cd = ConDat - ConDat.mean()
-        ec = np.array([np.dot(x - x.mean(), cd) / (len(x) * np.std(x) * np.std(ConDat))
-                       for x in ewf])                            # fast_normcorr(x, ConDat)[0]
-        we = np.square(ec) * touse
-        pem = np.sum((mags + np.log10(np.sqrt(proEn)))[touse] * we[touse]) / we.sum()
-        stm = np.sum((mags + np.log10(np.std(ConDat) / np.std(ewf, axis=1)))[touse] *
-                     we[touse]) / we.sum()
-        return float(pem), float(stm), float(SNR)
-    if np.isnan(mags[0]) or mags[0] < -15:                       # detect.py:490-492
-        return np.nan, np.nan, float(SNR)
-    d1 = np.dot(ConDat, ewf[0])
-    d2 = np.dot(ewf[0], ewf[0])
-    return (float(mags[0] + d1 / d2),
-            float(mags[0] + np.log10(np.std(ConDat) / np.std(ewf[0]))), float(SNR))
+        xb = xdev[s0 * Nc:]
+        xarg, xM, xstride = xb, M, stride * Nc
+        cstride = stride * Nc
+    cap = 1 << 18
+    ds, res = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else nb,
+                                thr=thr_arr, hist=hist if calcHist else None, cand_cap=cap)
+    if res['ncand'] > cap:
+        # the candidate list is sized for ordinary thresholds; one that overflows is listed
+        # again from the DS tensor at the size the device counted (no second scan; the
+        # histogram already holds this batch)
+        _warn('%d samples above threshold on %s in one batch of %d chunks: thresholds very low?'
+              % (res['ncand'], sta, nb))
+        again = ctx.ds_post(ds, thr=thr_arr, want_max=False, cand_cap=int(res['ncand']) + 1024)
+        res['cand'], res['ncand'] = again['cand'], again['ncand']
+    P = int(ds.shape[2])
+    maxds = res['maxds'].cpu().numpy()
+    cb, cd, cp, cv = res['cand']
+    # candidates grouped by (chunk, detector); pairs without one cannot trigger
+    key = cb.astype(np.int64) * D + cd
+    order = np.argsort(key, kind='stable')               # keeps p ascending per pair
+    ks, first = np.unique(key[order], return_index=True)
+    last = np.append(first[1:], len(order))
+    trigs = []                                           # (chunk, det, index, coef)
+    for kk, f0, f1 in zip(ks, first, last):
+        b, d = int(kk // D), int(kk % D)
+        sel = order[f0:f1]
+        for (ti, coef) in pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
+                                               float(maxds[b, d])):
+            if coef > 1.05:                              # detect.py:199-204
+                continue
+            trigs.append((b, d, ti, coef))
+    if not trigs:
+        return
+    stats = None
+    if bank is not None:
+        tab = np.full((len(trigs), 5), -1, dtype=np.int32)
+        bad = np.zeros(len(trigs), dtype=bool)           # IndexError of the reference's indexing -> 0.0
+        for r, (b, d, ti, _) in enumerate(trigs):
+            tab[r, :3] = (b, d, ti)
+            if not fillZeros:
+                try:
+                    tab[r, 3] = ti if STA == 0 else _centered_lo(ti, STA, P)
+                    tab[r, 4] = _centered_lo(ti, LTA, P)
+                except IndexError:
+                    bad[r] = True
+        stats = ctx.trigger_stats(xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
+                                  bank.ewf, bank.eoff, bank.emax).cpu().numpy()
+    for r, (b, d, ti, coef) in enumerate(trigs):
+        name = names[d]
+        start = bounds[i0 + b][2]
+        if fillZeros or bad[r]:                          # detect.py:414-420, 289-295
+            sl = 0.0
+        else:
+            with np.errstate(all='ignore'):
+                sl = float(np.divide(stats[r, 0], stats[r, 1]))
+        times = float(ti) / sr + start                   # detect.py:413
+        of = offsets[name]
+        pem = stm = snr = np.nan
+        if estimateMags:                                 # detect.py:422-429
+            pem, stm, snr = bank.estimate(d, kinds[d] == 'ss', n, stats[r])
+        rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
+                               times - np.min(of), stm, snr, pem])

@@ -256,6 +256,26 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_ds_host')
         return out
 
+    def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax):
+        """dtx_trigger_stats: STA / LTA means and the magnitude / SNR ingredients at triggers.
+
+        x, M, chunk_stride, ds: the buffers of the subspace_scan call the triggers come from;
+        trig: int32 array [ntrig, 5] (chunk, detector, window, STA start or -1, LTA start or -1);
+        ewf: [Etot, n] float32 CUDA tensor, eoff: [D+1] int32 CUDA tensor.
+        Returns a float64 CUDA tensor [ntrig, 6 + emax] (asynchronous)."""
+        trig = np.ascontiguousarray(trig, dtype=np.int32).reshape(-1, 5)
+        nt = len(trig)
+        out = torch.full((nt, 6 + int(emax)), float('nan'), dtype=torch.float64, device=ds.device)
+        if nt == 0:
+            return out
+        tdev = torch.from_numpy(trig).to(ds.device)
+        nchunk, D, P = (int(v) for v in ds.shape)
+        rc = self.lib.dtx_trigger_stats(self.h, _ptr(x), int(M), int(chunk_stride), _ptr(ds), P,
+                                        int(ds.stride(1)), _ptr(tdev), nt, int(sta_len), int(lta_len),
+                                        _ptr(ewf), _ptr(eoff), int(emax), _ptr(out))
+        self._ck(rc, 'dtx_trigger_stats')
+        return out
+
     # ------------------------------------------------------------ xcorr
     def xcorr_allpairs(self, td, Nc, pair_begin=0, pair_end=None):
         """td: [N, n] float32 CUDA tensor of multiplexed events.  Returns

@@ -399,7 +399,7 @@ class SubSpace(object):
     # ------------------------------------------------------------ detex
     def detex(self, utcStart=None, utcEnd=None, subspaceDB='SubSpace.db', trigCon=0,
               triggerLTATime=5, triggerSTATime=0, multiprocess=False, delOldCorrs=True,
-              calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=False,
+              calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=True,
               classifyEvents=None, eventCorFile='EventCors', utcSaves=None, fillZeros=False,
               device=0, ctx=None):
         """subspace.py:1745-1902: run every detector over the continuous data.
@@ -408,7 +408,7 @@ class SubSpace(object):
         columns (detect.py:397-398) and writes them, the histograms and the
         detector info to the SQLite file ``subspaceDB`` (None: no file).
         ``estimateMags`` (detect.py:447-499) fills Mag, SNR and ProEnMag at every
-        trigger (detect.est_mag); they are NaN with estimateMags=False as in the
+        trigger (dtx_trigger_stats + detect.mags_from_stats); they are NaN with estimateMags=False as in the
         reference.  A raw ContinuousFetcher is decimated (clusters.decimate),
         detrended and band-passed (clusters.filt) chunk by chunk on the device."""
         from .detect import scan_station

@@ -13,6 +13,7 @@
  *   detex/detect.py:178-181  np.histogram(DS, linspace(0,1,401))  -> dtx_ds_post (hist)
  *   detex/detect.py:275-281  MaxDS / inf scrub                    -> dtx_ds_post (maxds)
  *   detex/detect.py:410      candidates for the trigger loop      -> dtx_ds_post (cand)
+ *   detex/detect.py:447-499  _estMag at every trigger (+ 501-524 STA/LTA there) -> dtx_trigger_stats
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++ / torch types.
@@ -161,6 +162,32 @@ int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
 int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
                    int nchunk, int D, double lo, double hi, int nbins,
                    uint32_t* hist_dev, double* sums_dev);
+
+/* ------------------------------------------------------------------------
+ * Trigger-time estimates                (detect.py:447-499, 501-524, 637-664)
+ * ------------------------------------------------------------------------ */
+
+/* For each of `ntrig` triggers (rows of trig_dev: chunk, detector, window index p, first DS
+ * sample of the STA window or -1, first DS sample of the LTA window or -1 -- int32 x 5), in
+ * float64, one workgroup per trigger:
+ *   out[0] mean(|DS[sta_lo : sta_lo + sta_len]|)  (NaN if sta_lo < 0)   detect.py:505-511
+ *   out[1] mean(|DS[lta_lo : lta_lo + lta_len]|)  (NaN if lta_lo < 0)
+ *   out[2], out[3]  mean and std (ddof 0) of ConDat = x_chunk[p*Nc : p*Nc + n]   detect.py:456
+ *   out[4] var(U^T (U ConDat)), U = the rows of the trigger's detector (the reference forms
+ *          the n x n matrix UtU = U^T U for this, detect.py:367, 460-463)
+ *   out[5] median of the rolling std (window n, ddof 1) of the 5 n samples before the
+ *          trigger, or of up to 7 n samples from it if there are fewer before   detect.py:466-472
+ *   out[6 + e] ConDat . ewf[ewf_off[det] + e]  for the detector's training events: the lag-0
+ *          numerator of fast_normcorr (construct.py:469-483, detect.py:484) and d1 of 494
+ * x_dev / M / chunk_stride / ds_dev / P / ldp as in dtx_subspace_scan (the same buffers);
+ * ewf_dev [Etot][n] float32 training events, ewf_off_dev [D+1] int32 (device), emax = the
+ * largest event count of a detector; out_dev [ntrig][DTX_TRIG_HEAD + emax] float64.
+ * Uses the basis of the last dtx_basis_upload.  Asynchronous. */
+#define DTX_TRIG_HEAD 6
+int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                      const float* ds_dev, int64_t P, int64_t ldp, const int32_t* trig_dev,
+                      int ntrig, int sta_len, int lta_len, const float* ewf_dev,
+                      const int32_t* ewf_off_dev, int emax, double* out_dev);
 
 static inline uint64_t dtx_cand_pack(uint32_t chunk, uint32_t det, uint32_t p) {
   return ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;

@@ -555,6 +555,31 @@ def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
     return mags[0] + d1 / d2, mags[0] + np.log10(np.std(ConDat) / np.std(WFU[0])), SNR
 
 
+def trigger_stats_row(trigIndex, Nc, MPcon, U, ewf, ds=None, sta_lo=-1, sta_len=1, lta_lo=-1,
+                      lta_len=1):
+    """What dtx_trigger_stats writes for one trigger, in NumPy float64 (the checker of that
+    kernel): means of |DS| over the STA / LTA windows, mean / std of the triggering window,
+    var(UtU . ConDat) with the literal n x n UtU of detect.py:367, the median rolling std of
+    the pre-event noise (detect.py:466-472) and the dot products with the training events."""
+    MPcon = np.asarray(MPcon, dtype=np.float64)
+    U = np.atleast_2d(np.asarray(U, dtype=np.float64))
+    ewf = np.atleast_2d(np.asarray(ewf, dtype=np.float64))
+    n = U.shape[1]
+    a = trigIndex * Nc
+    ConDat = MPcon[a:a + n]
+    UtU = np.dot(U.T, U)
+    ssCon = np.dot(UtU, ConDat)
+    if a > 5 * n:
+        pe = MPcon[a - 5 * n:a]
+    else:
+        pe = MPcon[a:a + n + 6 * n]
+    rs = rolling_std_valid(pe, n) if len(pe) >= n else np.array([np.nan])
+    st = np.mean(np.abs(ds[sta_lo:sta_lo + sta_len])) if (ds is not None and sta_lo >= 0) else np.nan
+    lt = np.mean(np.abs(ds[lta_lo:lta_lo + lta_len])) if (ds is not None and lta_lo >= 0) else np.nan
+    return np.concatenate([[st, lt, ConDat.mean(), ConDat.std(), np.var(ssCon), np.median(rs)],
+                           ewf @ ConDat])
+
+
 # --------------------------------------------------------------------------
 # pre-processing                                   construct.py:990-1030
 # --------------------------------------------------------------------------

@@ -171,3 +171,61 @@ def test_fas_matches_scipy(workflow):
         want = scipy.stats.beta.isf(ss.Pf, ref[0], ref[1], 0, 1)
         assert np.isclose(th, want, rtol=1e-5) or want > .9
     ctx.close()
+
+
+def test_trigger_stats_kernel():
+    """dtx_trigger_stats against the oracle's NumPy restatement of every number it writes,
+    and the magnitudes built from it against the reference's own _estMag outputs
+    (tests/golden/estmag.npz: subspace and singleton detector, < and > 5 template lengths of
+    pre-event data); truncated and even-length noise windows; STA / LTA window means."""
+    from detex_amd import detect
+    from detex_amd.hip import HipContext
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(G, 'estmag.npz'))
+    MPcon, U, ewf, mags, Nc = z['MPcon'], z['U'], z['ewf'], z['mags'], int(z['Nc'])
+    n = U.shape[1]
+    ctx = HipContext(0)
+    # detector 0: the 2-vector subspace with its 4 training events; detector 1: a singleton
+    # (its first event, normalised, not demeaned: detect.py:364)
+    sg = ewf[:1] / np.linalg.norm(ewf[0])
+    Ub = np.concatenate([U, sg]).astype(np.float32)
+    off = [0, 2, 3]
+    ctx.upload_basis(Ub, off, Nc)
+    ev_all = torch.from_numpy(np.concatenate([ewf, ewf[:1]]).astype(np.float32)).cuda()
+    eoff = torch.tensor([0, 4, 5], dtype=torch.int32).cuda()
+    x32 = MPcon.astype(np.float32)
+    for M in (len(x32), 1100, 1101):
+        x = torch.from_numpy(x32[:M]).cuda()[None, :].contiguous()
+        ds = ctx.subspace_ds(x)
+        P = int(ds.shape[2])
+        dsh = ds.cpu().numpy().astype(np.float64)
+        trigs = [int(t) for t in z['trigs'] if t < P] + [10, P - 1, P // 2]
+        tab, want = [], []
+        for d in (0, 1):
+            for ti in trigs:
+                sta_lo = detect._centered_lo(ti, 7, P)
+                lta_lo = detect._centered_lo(ti, 60, P)
+                tab.append([0, d, ti, sta_lo, lta_lo])
+                want.append(orc.trigger_stats_row(
+                    ti, Nc, x32[:M].astype(np.float64), Ub[off[d]:off[d + 1]].astype(np.float64),
+                    (ewf if d == 0 else ewf[:1]).astype(np.float32).astype(np.float64),
+                    ds=dsh[0, d], sta_lo=sta_lo, sta_len=7, lta_lo=lta_lo, lta_len=60))
+        got = ctx.trigger_stats(x, M, M, ds, np.array(tab, np.int32), 7, 60, ev_all, eoff, 4).cpu().numpy()
+        for g, w, t in zip(got, want, tab):
+            ne = 4 if t[1] == 0 else 1
+            assert np.allclose(g[:6], w[:6], rtol=2e-6, atol=1e-12), (M, t, g[:6], w[:6])
+            assert np.allclose(g[6:6 + ne], w[6:], rtol=1e-6, atol=1e-9), (M, t)
+        if M == len(x32):
+            # the reference's own magnitudes (float64 inputs there, float32 here)
+            for tag, trig in zip(['early', 'late'], z['trigs']):
+                for kind, d in (('ss', 0), ('sg', 1)):
+                    r = [i for i, t in enumerate(tab) if t[1] == d and t[2] == int(trig)][0]
+                    c = detect.mag_constants(ewf if d == 0 else ewf[:1], mags if d == 0 else mags[:1],
+                                             U, d == 0)
+                    m = detect.mags_from_stats(c, d == 0, n, got[r])
+                    ref = z['%s_%s' % (kind, tag)]
+                    if d == 0:
+                        assert np.allclose(m, ref, rtol=2e-5), (kind, tag, m, ref)
+                    else:       # the golden singleton ran the reference's non-subspace branch on ewf[0]
+                        assert np.allclose(m, ref, rtol=2e-5), (kind, tag, m, ref)
+    ctx.close()

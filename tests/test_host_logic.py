@@ -283,17 +283,24 @@ def test_classic_sta_lta_restatement():
 
 
 def test_est_mag_matches_reference():
-    """Oracle (literal, with UtU) and product (UtU-free) against the reference."""
+    """Oracle (literal, with UtU) against the reference's _estMag, and the product's host half
+    (detect.mags_from_stats: the scalar formulas applied to a dtx_trigger_stats row) fed with
+    the oracle's restatement of that row; the device half is tests/test_gpu_pipeline.py::
+    test_trigger_stats_kernel."""
     z = np.load(os.path.join(G, 'estmag.npz'))
     MPcon, U, ewf, mags, Nc = z['MPcon'], z['U'], z['ewf'], z['mags'], int(z['Nc'])
+    n = U.shape[1]
     for tag, trig in zip(['early', 'late'], z['trigs']):
         for kind, issub in (('ss', True), ('sg', False)):
             ref = z['%s_%s' % (kind, tag)]
             m = mags if issub else mags[:1]
             e = ewf if issub else ewf[:1]
             o = orc.est_mag(int(trig), Nc, MPcon, m, U, e, issubspace=issub)
-            g = detect.est_mag(int(trig), Nc, MPcon, m, U, e, issubspace=issub)
             assert np.allclose(o, ref, rtol=1e-10), (kind, tag)
-            assert np.allclose(g, ref, rtol=1e-9), (kind, tag)
-    g = detect.est_mag(40, Nc, MPcon, np.array([-99., -99, -99, -99]), U, ewf)
+            row = orc.trigger_stats_row(int(trig), Nc, MPcon, U, e)
+            c = detect.mag_constants(e, m, U, issub)
+            g = detect.mags_from_stats(c, issub, n, row)
+            assert np.allclose(g, ref, rtol=2e-6), (kind, tag)     # events held in float32
+    c = detect.mag_constants(ewf, np.array([-99., -99, -99, -99]), U, True)
+    g = detect.mags_from_stats(c, True, n, orc.trigger_stats_row(40, Nc, MPcon, U, ewf))
     assert np.isnan(g[0]) and np.isnan(g[1]) and g[2] > 0
