@@ -83,12 +83,24 @@ def _makeDFcclags(eventList, row, ctx):
         _error('Number of Channels not equal, cannot perform correlation')      # 429-431
     if len(set(len(row.MPtd[e]) for e in eventList)) != 1:
         _error('Lengths not equal on multiplexed data, cannot correlate')       # 433-436
+    from . import parallel
     Nc = len(row.Channels[eventList[0]])
     td = np.ascontiguousarray([row.MPtd[e] for e in eventList], dtype=np.float32)
-    cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc)
-    ctx.sync()
-    return _frames_from_condensed(len(eventList), cc.cpu().numpy(), lag.cpu().numpy(),
-                                  ss.cpu().numpy())
+    N = len(eventList)
+    rank, world = parallel.dist_info()
+    if world > 1:
+        # one process per GPU: every rank correlates a contiguous range of the condensed pair
+        # list (every pair costs the same), the slices are all-gathered
+        npairs = N * (N - 1) // 2
+        ranges = [parallel.shard_pairs(npairs, r, world) for r in range(world)]
+        b, e = ranges[rank]
+        cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc, b, e)
+        ctx.sync()
+        cc, lag, ss = (parallel.gather_condensed(v, ranges, npairs, ctx.device) for v in (cc, lag, ss))
+    else:
+        cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc)
+        ctx.sync()
+    return _frames_from_condensed(N, cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy())
 
 
 def _flatNoNan(df):

@@ -116,6 +116,11 @@ def _dec_len(cnt, dec):
     return (cnt + dec - 1) // dec
 
 
+# capacity of the device candidate list of one batch (samples at or above threshold); a batch
+# that exceeds it is listed again at the size the device counted
+CAND_CAP = 1 << 18
+
+
 def _warn(msg):
     """detex.log(level='warning', pri=True): the scan goes on (detect.py:160-174)."""
     import logging
@@ -184,7 +189,7 @@ class _MagBank(object):
 
 def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
                  useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=True,
-                 planes_dev=None, chunk_sel=None):
+                 planes_dev=None, chunk_sel=None, bank=None):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
     detectors in one GPU basis: per batch of chunks the detection statistic
     (dtx_subspace_scan: detection statistic + histogram / max / candidates), the
@@ -194,13 +199,16 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
 
     planes_dev: the station's [Nc, T] data already on the device (uploaded ahead by the
     caller, e.g. from pinned memory on a copy stream); chunk_sel: indices into the station's
-    chunk list this call scans (multi-GPU sharding); a failing batch is logged and skipped
-    like a failing chunk of the reference (detect.py:160-174)."""
+    chunk list this call scans (multi-GPU sharding); bank: the station's detector bank if the
+    caller already built (or received) it; a failing batch is logged and skipped like a
+    failing chunk of the reference (detect.py:160-174)."""
     import pandas as pd
     import torch
     from ._lib import DetexHipError
     from .hip import HipContext
-    names, kinds, U, det_off, offsets, thr = ss._detector_bank(sta, useSubSpaces, useSingles)
+    if bank is None:
+        bank = ss._detector_bank(sta, useSubSpaces, useSingles)
+    names, kinds, U, det_off, offsets, thr = bank
     if not names:
         return None
     fetcher = ss.cfetcher
@@ -245,12 +253,12 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         LTA = triggerLTATime * sr
         STA = triggerSTATime * sr
         need_stats = estimateMags or not fillZeros
-        bank = _MagBank(ss, names, kinds, U, det_off, ctx.device) if need_stats else None
+        mbank = _MagBank(ss, names, kinds, U, det_off, ctx.device) if need_stats else None
         for (i0, i1, stride) in _chunk_batches(bounds):
             try:
                 _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bounds, i0,
                             i1, stride, raw, dec, rawdev if raw else None, xdev, Nc, n, D, sr,
-                            sr_raw if raw else sr, LTA, STA, fillZeros, estimateMags, bank, rows)
+                            sr_raw if raw else sr, LTA, STA, fillZeros, estimateMags, mbank, rows)
             except DetexHipError as e:
                 # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
                 _warn('failing to run detector on %s from %s to %s: %s'
@@ -285,7 +293,7 @@ def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bo
         xb = xdev[s0 * Nc:]
         xarg, xM, xstride = xb, M, stride * Nc
         cstride = stride * Nc
-    cap = 1 << 18
+    cap = CAND_CAP
     ds, res = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else nb,
                                 thr=thr_arr, hist=hist if calcHist else None, cand_cap=cap)
     if res['ncand'] > cap:

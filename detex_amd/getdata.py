@@ -81,6 +81,20 @@ class ContinuousFetcher(object):
         self.data[station] = (data, float(starttime))
         return self
 
+    def pin(self):
+        """Move every station's array into page-locked host memory (as float32): the scan then
+        uploads it at PCIe rate on a copy stream, under the previous station's kernels
+        (SubSpace.detex), instead of through a pageable staging copy."""
+        import torch
+        self.pinned = getattr(self, 'pinned', {})
+        for sta, (data, t0) in list(self.data.items()):
+            if sta in self.pinned:
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).pin_memory()
+            self.pinned[sta] = t
+            self.data[sta] = (t.numpy(), t0)          # same memory, NumPy face
+        return self
+
     def chunk_bounds(self, station, utcStart=None, utcEnd=None):
         """[(first sample, number of samples, chunk start time)] of every chunk."""
         data, t0 = self.data[station]

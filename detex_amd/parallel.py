@@ -26,6 +26,33 @@ def shard_units(nunits, rank, world):
     return list(range(rank, nunits, world))
 
 
+def shard_chunks(nchunks, rank, world, per_unit=24):
+    """Chunk indices of one station this rank scans.  Units are runs of `per_unit`
+    consecutive chunks (a day of hourly chunks: they go through the kernels as one launch),
+    dealt round-robin; with fewer units than ranks the chunks are cut into `world` contiguous
+    ranges instead, so that a single day still spreads over all GPUs."""
+    nunits = (nchunks + per_unit - 1) // per_unit
+    if nunits >= world:
+        out = []
+        for u in shard_units(nunits, rank, world):
+            out.extend(range(u * per_unit, min((u + 1) * per_unit, nchunks)))
+        return out
+    b, e = shard_pairs(nchunks, rank, world)
+    return list(range(b, e))
+
+
+def gather_rows(rows):
+    """All ranks contribute a picklable object (their detection rows, histograms); every rank
+    gets the list over ranks.  Host objects, a few KB: not on the data path."""
+    import torch.distributed as dist
+    rank, world = dist_info()
+    if world == 1:
+        return [rows]
+    out = [None] * world
+    dist.all_gather_object(out, rows)
+    return out
+
+
 def shard_pairs(npairs, rank, world):
     """[begin, end) condensed-pair range of this rank; ranges tile [0, npairs)."""
     base, rem = divmod(int(npairs), int(world))

@@ -140,6 +140,64 @@ class ClusterStream(object):
 # SubSpace                                         subspace.py:715-2037
 # --------------------------------------------------------------------------
 
+class _StationUploader(object):
+    """Station data to the device ahead of its scan.  Arrays the fetcher holds in pinned
+    memory (ContinuousFetcher.pin) are copied on a second stream, under the kernels of the
+    station being scanned; pageable arrays go up synchronously as before."""
+
+    def __init__(self, fetcher, device):
+        import torch
+        self.fetcher, self.device = fetcher, device
+        self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
+        self.pending = {}
+
+    def start(self, sta):
+        import torch
+        pinned = getattr(self.fetcher, 'pinned', {}).get(sta)
+        if pinned is None or self.stream is None:
+            data = self.fetcher.data[sta][0]
+            self.pending[sta] = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+                                 .to(self.device), None)
+            return
+        main = torch.cuda.current_stream(self.device)
+        dst = torch.empty(pinned.shape, dtype=torch.float32, device=self.device)   # main stream's pool
+        ready = torch.cuda.Event()
+        self.stream.wait_stream(main)          # whatever used this block before is done
+        with torch.cuda.stream(self.stream):
+            dst.copy_(pinned, non_blocking=True)
+            ready.record(self.stream)
+        self.pending[sta] = (dst, ready)
+
+    def get(self, sta):
+        import torch
+        if sta not in self.pending:
+            self.start(sta)
+        dst, ready = self.pending.pop(sta)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
+        return dst
+
+
+def _merge_ranks(parts):
+    """Results of one station from every rank (each scanned its share of the chunks):
+    detections concatenated in time order, histogram counts added."""
+    parts = [p for p in parts if p is not None]
+    if not parts:
+        return None
+    out = {}
+    for kind in ('ss', 'sg'):
+        dfs = [p[kind] for p in parts if len(p[kind])]
+        out[kind] = (pd.concat(dfs, ignore_index=True).sort_values(['STMP', 'Name'], kind='stable')
+                     .reset_index(drop=True)) if dfs else parts[0][kind]
+    for hk in ('hist_ss', 'hist_sg'):
+        acc = {}
+        for p in parts:
+            for nm, h in p[hk].items():
+                acc[nm] = acc[nm] + h if nm in acc else np.array(h, copy=True)
+        out[hk] = acc
+    return out
+
+
 class SubSpace(object):
     """Subspaces (clusters of aligned events) and singles of every station
     (subspace.py:715-733)."""
@@ -402,6 +460,7 @@ class SubSpace(object):
               calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=True,
               classifyEvents=None, eventCorFile='EventCors', utcSaves=None, fillZeros=False,
               device=0, ctx=None):
+        # (device / ctx: the GPU and, optionally, an existing HipContext to run on)
         """subspace.py:1745-1902: run every detector over the continuous data.
 
         Returns {'ss_df': DataFrame, 'sg_df': DataFrame} with the reference's
@@ -411,20 +470,56 @@ class SubSpace(object):
         trigger (dtx_trigger_stats + detect.mags_from_stats); they are NaN with estimateMags=False as in the
         reference.  A raw ContinuousFetcher is decimated (clusters.decimate),
         detrended and band-passed (clusters.filt) chunk by chunk on the device."""
+        import torch
+        from . import parallel
         from .detect import scan_station
+        from .hip import HipContext
         if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
             _error('multiprocessing and trigcon other than 0 not supported')
         if classifyEvents is not None or utcSaves is not None:
             _error('classifyEvents / utcSaves are not supported')
         if self.cfetcher is None:
             _error('no continuous-data fetcher attached (conDatFetcher)')
-        if subspaceDB is not None and delOldCorrs and os.path.exists(subspaceDB):
+        rank, world = parallel.dist_info()
+        if subspaceDB is not None and delOldCorrs and rank == 0 and os.path.exists(subspaceDB):
             os.remove(subspaceDB)                           # subspace.py:1847-1854
+        if ctx is None:
+            # one context per device for the life of the object: its workspaces (channel
+            # planes, window statistics, block spectra: ~0.5 GB at one station-day) are
+            # allocated once, not per call
+            cache = self.__dict__.setdefault('_hip_ctx', {})
+            if device not in cache:
+                cache[device] = HipContext(device)
+            ctx = cache[device]
+        stations = [sta for sta in self.Stations if sta in self.cfetcher.data]
+        up = _StationUploader(self.cfetcher, ctx.device)
+        if stations:
+            up.start(stations[0])
         out = {'ss_df': [], 'sg_df': []}
-        for sta in self.Stations:
+        for i, sta in enumerate(stations):
+            planes = up.get(sta)
+            if i + 1 < len(stations):
+                up.start(stations[i + 1])                   # next station's H2D under this scan
+            bank = self._detector_bank(sta, useSubSpaces, useSingles)
+            chunk_sel = None
+            if world > 1 and bank[0]:
+                # one process per GPU: rank 0's basis goes to every rank (RCCL broadcast over
+                # xGMI, the only collective on the path), each rank scans its share of the chunks
+                names, kinds, U, det_off, offsets, thr = bank
+                Ut, det_off = parallel.broadcast_basis(U if rank == 0 else None,
+                                                       det_off if rank == 0 else None,
+                                                       U.shape[1], ctx.device)
+                bank = (names, kinds, Ut.cpu().numpy(), det_off, offsets, thr)
+                nchunks = len(self.cfetcher.chunk_bounds(sta, utcStart, utcEnd))
+                per = max(1, int(round(86400.0 / self.cfetcher.conDatDuration)))
+                chunk_sel = parallel.shard_chunks(nchunks, rank, world, per_unit=per)
             res = scan_station(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime,
                                calcHist, useSubSpaces, useSingles, fillZeros, device, ctx,
-                               estimateMags=estimateMags)
+                               estimateMags=estimateMags, planes_dev=planes, chunk_sel=chunk_sel,
+                               bank=bank)
+            del planes
+            if world > 1:
+                res = _merge_ranks(parallel.gather_rows(res))
             if res is None:
                 continue
             for kind in ('ss', 'sg'):
@@ -436,9 +531,14 @@ class SubSpace(object):
                 'ProEnMag']
         for k in out:
             out[k] = pd.concat(out[k], ignore_index=True) if out[k] else pd.DataFrame(columns=cols)
-        if subspaceDB is not None:
+        if subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         return out
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop('_hip_ctx', None)                             # device contexts are not picklable
+        return d
 
     def _write_db(self, path, out):
         """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /

@@ -42,6 +42,8 @@ for k in range(nplant):
     con[:, t:t + L] += 3.0 * td[e].reshape(L, NC).T / np.std(td[e])
 cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])
 cf.add('TA.M17A', con, starttime=1.5e9)
+if os.environ.get('E2E_PIN', '1') == '1':
+    cf.pin()        # page-locked host memory: the H2D copy runs at PCIe rate on a copy stream
 t0 = tick('synthetic data (host)', t0)
 
 ctx = HipContext(0)
@@ -54,8 +56,8 @@ ss.SVD(selectCriteria=4, selectValue=7, threshold=0.3, useSingles=False)
 t0 = tick('SVD', t0)
 names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
 print('detectors: %d, basis vectors: %d, n = %d' % (len(names), U.shape[0], U.shape[1]))
-for rep in range(3):
-    res = ss.detex(subspaceDB=None, ctx=ctx)
+for rep in range(4):
+    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
     t0 = tick('detex() pass %d' % rep, t0)
 print('detections: %d of %d planted' % (len(res['ss_df']), nplant))
 res = ss.detex(subspaceDB='/tmp/e2e_SubSpace.db', ctx=ctx, estimateMags=True)

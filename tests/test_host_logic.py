@@ -4,6 +4,7 @@ basis selection, chunk geometry, STA/LTA at a trigger, beta MLE.  The GPU seam
 (_makeDFcclags -> dtx_xcorr_allpairs) is stood in for by the oracle through a
 fake context -- test infrastructure only."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -14,25 +15,12 @@ from detex_amd import (ContinuousFetcher, EventFetcher, createCluster, createSub
 from detex_amd import construct, detect, fas
 from oracle import detex_oracle as orc
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-class OracleCtx(object):
-    """Stands in for HipContext.xcorr_allpairs in CPU tests."""
-    device = torch.device('cpu')
-
-    def xcorr_allpairs(self, td, Nc):
-        td = td.numpy().astype(np.float64)
-        cc, lag, ss = orc.make_cclags(list(td), Nc, form='fft')
-        iu = np.triu_indices(len(td), 1)
-        f = lambda m: torch.from_numpy(m[iu[0], iu[1] - 1])  # noqa: E731
-        return f(cc), f(lag), f(ss)
-
-    def sync(self):
-        pass
-
-    def close(self):
-        pass
+from stub_ctx import OracleCtx  # noqa: E402
 
 
 def _fetcher_from_golden(tag):
@@ -304,3 +292,155 @@ def test_est_mag_matches_reference():
     c = detect.mag_constants(ewf, np.array([-99., -99, -99, -99]), U, True)
     g = detect.mags_from_stats(c, True, n, orc.trigger_stats_row(40, Nc, MPcon, U, ewf))
     assert np.isnan(g[0]) and np.isnan(g[1]) and g[2] > 0
+
+
+def small_workflow(ctx):
+    """Ten events in two families + a loner, 400 s of data in 120 s + 20 s chunks: small
+    enough for the CPU oracle, the same calls as the GPU pipeline tests."""
+    rs = np.random.RandomState(1)
+    SR, NC, L = 20.0, 3, 80
+    env = np.exp(-np.arange(L + 20) / (0.3 * L))
+    k = np.hanning(7)
+    fams = [[np.convolve(rs.standard_normal(L + 26), k / k.sum(), 'valid') * env for _ in range(NC)]
+            for _ in range(2)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    n = 0
+    for wav in fams:
+        for _ in range(4):
+            sh = int(rs.randint(0, 15))
+            data = np.array([rs.uniform(.5, 2) * w[sh:sh + L] + rs.standard_normal(L) * np.std(w) / 8
+                             for w in wav])
+            ef.add('TA.M17A', 'ev%02d' % n, data, starttime=5000.0 + 50 * n, origintime=4990.0 + 50 * n,
+                   magnitude=1.0 + 0.25 * n)
+            n += 1
+    ef.add('TA.M17A', 'ev%02d' % n, rs.standard_normal((NC, L)), starttime=9000., origintime=8990.,
+           magnitude=2.0)
+    T = int(400 * SR)
+    con = rs.standard_normal((NC, T)) * 0.05
+    plants = [(600, 0, 1.0), (2300, 1, 0.7), (2500, 0, 0.5), (4100, 1, 0.9), (7000, 0, 1.2)]
+    for (t, f, a) in plants:
+        for c in range(NC):
+            con[c, t:t + L] += a * fams[f][c][5:5 + L]
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], conDatDuration=120, conBuff=20)
+    cf.add('TA.M17A', con.astype(np.float32), starttime=1.2e6)
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, ctx=ctx)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=0.0, defaultDuration=1.5)
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    ss.setSinglesThresholds(threshold=0.4)
+    return ss, cf, plants, (SR, NC, L)
+
+
+def oracle_scan(ss, cf, sta, SR, NC, lta_s=5, sta_s=0):
+    """The reference's per-chunk loop (detect.py:137-218) with the CPU oracle."""
+    from detex_amd.getdata import multiplex
+    names, kinds, U, off, offsets, thr = ss._detector_bank(sta)
+    want = []
+    hist = {nm: np.zeros(400, dtype=np.int64) for nm in names}
+    for chunk, t0 in cf.getConData(sta):
+        x = multiplex(list(chunk)).astype(np.float64)
+        if len(x) <= U.shape[1] or (len(x) - U.shape[1]) // NC + 1 < 10:
+            continue
+        for d, nm in enumerate(names):
+            ds = orc.mpxds_fft(x, U[off[d]:off[d + 1]].astype(np.float32), NC)
+            ds, maxds = orc.scrub_ds(ds)
+            ds = ds.astype(np.float32).astype(np.float64)
+            hist[nm] += orc.ds_histogram(ds)
+            if orc.eval_trig_con(ds.max(), np.float32(thr[nm])):
+                sl = orc.get_stalta(ds, lta_s * SR, sta_s * SR)
+                for t in orc.pick_triggers(ds, np.float32(thr[nm]), SR, t0, offsets[nm], stalta=sl):
+                    if t['DS'] <= 1.05:
+                        mg = orc.est_mag(t['index'], NC, x, ss._bank_mags[nm], U[off[d]:off[d + 1]],
+                                         ss._bank_ewf[nm], kinds[d] == 'ss')
+                        want.append((nm, t['STMP'], t['DS'], t['DS_STALTA'], t['MSTAMPmin'],
+                                     t['MSTAMPmax'], mg))
+    want.sort(key=lambda r: (r[0], r[1]))
+    return want, hist
+
+
+def check_detex(res, want, hist, ss, sta):
+    import pandas as pd
+    got = pd.concat([res['ss_df'], res['sg_df']], ignore_index=True)
+    got = got.sort_values(['Name', 'STMP']).reset_index(drop=True)
+    assert len(got) == len(want) and len(want) >= 3
+    for (_, g), w in zip(got.iterrows(), want):
+        assert g.Name == w[0] and g.STMP == w[1]
+        assert abs(g.DS - w[2]) <= 1e-6
+        assert abs(g.DS_STALTA - w[3]) <= 1e-6 * max(1, abs(w[3]))
+        assert abs(g.MSTAMPmin - w[4]) < 1e-6 and abs(g.MSTAMPmax - w[5]) < 1e-6
+        assert np.allclose([g.ProEnMag, g.Mag, g.SNR], list(w[6]), rtol=2e-5, equal_nan=True)
+    allh = dict(ss.histSubSpaces[sta])
+    allh.update(ss.histSingles[sta])
+    for nm, h in hist.items():
+        assert np.array_equal(allh[nm], h), nm
+
+
+def test_detex_host_logic_on_cpu(tmp_path):
+    """SubSpace.detex / scan_station end to end with the HIP context replaced by the oracle
+    stand-in: batching of the chunks, sparse trigger picking, STA/LTA window placement,
+    magnitude formulas, histogram bookkeeping, SQLite tables -- against the reference's
+    per-chunk loop restated with the oracle."""
+    import sqlite3
+    ctx = OracleCtx()
+    ss, cf, plants, (SR, NC, L) = small_workflow(ctx)
+    db = str(tmp_path / 'SubSpace.db')
+    res = ss.detex(subspaceDB=db, useSingles=True, ctx=ctx)            # estimateMags defaults to True
+    want, hist = oracle_scan(ss, cf, 'TA.M17A', SR, NC)
+    check_detex(res, want, hist, ss, 'TA.M17A')
+    scans = [c for c in ctx.calls if c[0] == 'scan']
+    assert [c[1] for c in scans] == [3, 1]                             # 3 full chunks in one launch + the short tail
+    found = sum(bool((np.abs(res['ss_df'].STMP - (1.2e6 + (t + 5) / SR)) < 1.0).any())
+                for (t, f, a) in plants)
+    assert found >= 3
+    con = sqlite3.connect(db)
+    n_db = con.execute('select count(*) from ss_df').fetchone()[0]
+    con.close()
+    assert n_db == len(res['ss_df'])
+    # STA > 0, and fillZeros (STA/LTA forced to 0)
+    res2 = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx, triggerSTATime=0.5, estimateMags=False)
+    want2, _ = oracle_scan(ss, cf, 'TA.M17A', SR, NC, sta_s=0.5)
+    got2 = res2['ss_df'].sort_values(['Name', 'STMP'])
+    w2 = [w for w in want2 if w[0].startswith('SS')]
+    assert np.allclose(got2.DS_STALTA.values, [w[3] for w in w2], rtol=1e-6)
+    assert got2.Mag.isna().all() and got2.SNR.isna().all()
+    res3 = ss.detex(subspaceDB=None, ctx=ctx, fillZeros=True, estimateMags=False)
+    assert (res3['ss_df'].DS_STALTA == 0).all() and len(res3['ss_df']) == len(got2)
+
+
+def test_candidate_overflow_and_failing_batch(caplog, monkeypatch):
+    """More candidates than the list holds: listed again at the counted size (no exception);
+    a batch whose scan fails is logged and skipped, the others are kept (detect.py:160-174)."""
+    import logging
+    from detex_amd import DetexHipError
+    ctx = OracleCtx()
+    ss, cf, plants, (SR, NC, L) = small_workflow(ctx)
+    ref = ss.detex(subspaceDB=None, ctx=ctx)
+
+    monkeypatch.setattr(detect, 'CAND_CAP', 3)
+    with caplog.at_level(logging.WARNING, logger='detex_amd.detect'):
+        got = ss.detex(subspaceDB=None, ctx=OracleCtx())
+    monkeypatch.setattr(detect, 'CAND_CAP', 1 << 18)
+    assert got['ss_df'].equals(ref['ss_df'])
+    assert any('above threshold' in r.message for r in caplog.records)
+
+    class FailsOnce(OracleCtx):
+        def __init__(self, which):
+            OracleCtx.__init__(self)
+            self.which, self.seen = which, 0
+
+        def subspace_scan(self, x, **kw):
+            self.seen += 1
+            if self.seen == self.which:
+                raise DetexHipError('dtx_subspace_scan failed (-2): injected fault')
+            return OracleCtx.subspace_scan(self, x, **kw)
+    for which, keep in ((2, lambda t: t < 1.2e6 + 360), (1, lambda t: t >= 1.2e6 + 360)):
+        caplog.clear()
+        with caplog.at_level(logging.WARNING, logger='detex_amd.detect'):
+            got = ss.detex(subspaceDB=None, ctx=FailsOnce(which))
+        assert any('failing to run detector' in r.message for r in caplog.records)
+        # batch 1 = the three full chunks (0 .. 380 s), batch 2 = the short tail from 360 s:
+        # the other batch's detections are all there
+        left = ref['ss_df'][[keep(t) for t in ref['ss_df'].STMP]].reset_index(drop=True)
+        assert len(got['ss_df']) == len(left)
+        assert np.allclose(got['ss_df'].STMP.values, left.STMP.values)
+    assert len(ref['ss_df']) >= 3
