@@ -225,7 +225,9 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
             'ProEnMag']
     rows = {'ss': [], 'sg': []}
     try:
-        ctx.upload_basis(U, det_off, Nc)
+        if getattr(ctx, '_basis_of', None) is not U:      # the same bank object: images are resident
+            ctx.upload_basis(U, det_off, Nc)
+            ctx._basis_of = U
         data, t0 = fetcher.data[sta]
         raw = bool(getattr(fetcher, 'raw', False))
         dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
@@ -243,6 +245,7 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
             xdev = ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
         del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
+        thr_dev = torch.from_numpy(thr_arr).to(ctx.device)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
         if chunk_sel is not None:
@@ -253,10 +256,18 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         LTA = triggerLTATime * sr
         STA = triggerSTATime * sr
         need_stats = estimateMags or not fillZeros
-        mbank = _MagBank(ss, names, kinds, U, det_off, ctx.device) if need_stats else None
+        mbank = None
+        if need_stats:
+            # the training events on the device + their constants: kept with the bank they
+            # belong to (rebuilt only when the bank is)
+            held = getattr(ctx, '_magbank', None)
+            if held is None or held[0] is not U:
+                held = (U, _MagBank(ss, names, kinds, U, det_off, ctx.device))
+                ctx._magbank = held
+            mbank = held[1]
         for (i0, i1, stride) in _chunk_batches(bounds):
             try:
-                _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bounds, i0,
+                _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, thr_dev, hist, calcHist, bounds, i0,
                             i1, stride, raw, dec, rawdev if raw else None, xdev, Nc, n, D, sr,
                             sr_raw if raw else sr, LTA, STA, fillZeros, estimateMags, mbank, rows)
             except DetexHipError as e:
@@ -274,7 +285,7 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     return out
 
 
-def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bounds, i0, i1, stride,
+def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, thr_dev, hist, calcHist, bounds, i0, i1, stride,
                 raw, dec, rawdev, xdev, Nc, n, D, sr, sr_raw, LTA, STA, fillZeros, estimateMags, bank,
                 rows):
     """One launch group of equal-length chunks: scan, trigger picking, trigger-time estimates."""
@@ -295,14 +306,14 @@ def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, hist, calcHist, bo
         cstride = stride * Nc
     cap = CAND_CAP
     ds, res = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else nb,
-                                thr=thr_arr, hist=hist if calcHist else None, cand_cap=cap)
+                                thr=thr_dev, hist=hist if calcHist else None, cand_cap=cap)
     if res['ncand'] > cap:
         # the candidate list is sized for ordinary thresholds; one that overflows is listed
         # again from the DS tensor at the size the device counted (no second scan; the
         # histogram already holds this batch)
         _warn('%d samples above threshold on %s in one batch of %d chunks: thresholds very low?'
               % (res['ncand'], sta, nb))
-        again = ctx.ds_post(ds, thr=thr_arr, want_max=False, cand_cap=int(res['ncand']) + 1024)
+        again = ctx.ds_post(ds, thr=thr_dev, want_max=False, cand_cap=int(res['ncand']) + 1024)
         res['cand'], res['ncand'] = again['cand'], again['ncand']
     P = int(ds.shape[2])
     maxds = res['maxds'].cpu().numpy()

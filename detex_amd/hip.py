@@ -116,6 +116,7 @@ class HipContext(object):
                                        D, int(Ut.shape[1]), int(Nc))
         self._ck(rc, 'dtx_basis_upload')
         self.D, self.n, self.Nc = D, int(Ut.shape[1]), int(Nc)
+        self._basis_of = None          # scan_station's residency token: any direct upload clears it
 
     def num_windows(self, M):
         return int(self.lib.dtx_num_windows(int(M), self.n, self.Nc))
@@ -157,8 +158,11 @@ class HipContext(object):
         maxds = torch.empty((nchunk, D), dtype=torch.float32, device=dev) if want_max else None
         thr_t = key = val = cnt = None
         if thr is not None:
-            thr_t = torch.as_tensor(np.broadcast_to(np.asarray(thr, dtype=np.float32), (D,)).copy(),
-                                    device=dev)
+            if isinstance(thr, torch.Tensor):      # already on the device (a scan loop keeps it there)
+                thr_t = thr
+            else:
+                thr_t = torch.as_tensor(np.broadcast_to(np.asarray(thr, dtype=np.float32), (D,)).copy(),
+                                        device=dev)
             key = torch.empty((cand_cap,), dtype=torch.int64, device=dev)
             val = torch.empty((cand_cap,), dtype=torch.float32, device=dev)
             cnt = torch.zeros((1,), dtype=torch.int32, device=dev)

@@ -143,13 +143,16 @@ class ClusterStream(object):
 class _StationUploader(object):
     """Station data to the device ahead of its scan.  Arrays the fetcher holds in pinned
     memory (ContinuousFetcher.pin) are copied on a second stream, under the kernels of the
-    station being scanned; pageable arrays go up synchronously as before."""
+    station being scanned, into one of two device buffers the uploader owns; pageable arrays
+    go up synchronously as before."""
 
     def __init__(self, fetcher, device):
         import torch
         self.fetcher, self.device = fetcher, device
         self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
         self.pending = {}
+        self.slots = [None, None]      # [buffer, event recorded when its last reader was enqueued]
+        self.turn = 0
 
     def start(self, sta):
         import torch
@@ -157,25 +160,41 @@ class _StationUploader(object):
         if pinned is None or self.stream is None:
             data = self.fetcher.data[sta][0]
             self.pending[sta] = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
-                                 .to(self.device), None)
+                                 .to(self.device), None, None)
             return
-        main = torch.cuda.current_stream(self.device)
-        dst = torch.empty(pinned.shape, dtype=torch.float32, device=self.device)   # main stream's pool
+        k = self.turn
+        self.turn ^= 1
+        slot = self.slots[k]
+        if slot is None or slot[0].numel() < pinned.numel():
+            slot = [torch.empty(pinned.numel(), dtype=torch.float32, device=self.device), None]
+            self.slots[k] = slot
+        dst = slot[0][:pinned.numel()].view(pinned.shape)
         ready = torch.cuda.Event()
-        self.stream.wait_stream(main)          # whatever used this block before is done
         with torch.cuda.stream(self.stream):
+            if slot[1] is not None and not slot[1].query():
+                self.stream.wait_event(slot[1])        # the scan that last read this buffer
             dst.copy_(pinned, non_blocking=True)
             ready.record(self.stream)
-        self.pending[sta] = (dst, ready)
+        self.pending[sta] = (dst, ready, k)
 
     def get(self, sta):
         import torch
         if sta not in self.pending:
             self.start(sta)
-        dst, ready = self.pending.pop(sta)
+        dst, ready, self.cur = self.pending.pop(sta)
         if ready is not None:
             torch.cuda.current_stream(self.device).wait_event(ready)
         return dst
+
+    def release(self):
+        """The scan of the station handed out last has been enqueued: its buffer may be
+        overwritten once the work queued so far is done."""
+        import torch
+        if getattr(self, 'cur', None) is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.slots[self.cur][1] = ev
+            self.cur = None
 
 
 def _merge_ranks(parts):
@@ -396,6 +415,35 @@ class SubSpace(object):
         singles their trimmed, normalised, NOT demeaned template
         (detect.py:357-364).  Returns (names, kinds, U [Ktot, n], det_off,
         offsets {name: array}, thresholds {name: float})."""
+        key = self._bank_key(sta, useSubSpaces, useSingles, need_thr)
+        cache = self.__dict__.setdefault('_bank_cache', {})
+        hit = cache.get((sta, useSubSpaces, useSingles, need_thr))
+        if hit is not None and hit[0] == key:
+            self._bank_ewf, self._bank_mags = hit[2], hit[3]
+            return hit[1]
+        bank = self._build_bank(sta, useSubSpaces, useSingles, need_thr)
+        cache[(sta, useSubSpaces, useSingles, need_thr)] = (key, bank, self._bank_ewf, self._bank_mags)
+        return bank
+
+    def _bank_key(self, sta, useSubSpaces, useSingles, need_thr):
+        """What the bank depends on, read cheaply: the identity of each detector's SVD / waveform
+        containers and its scalars.  SVD(), attachPickTimes() and the threshold setters replace or
+        change these, so a changed SubSpace never sees a stale bank."""
+        key = []
+        if useSubSpaces and sta in self.subspaces:
+            df = self.subspaces[sta]
+            for name, svd, nb, ok, st, th, ali in zip(df.Name, df.SVD, df.NumBasis, df.SVDdefined,
+                                                      df.SampleTrims, df.Threshold, df.AlignedTD):
+                key.append((name, id(svd), nb, bool(ok), tuple(sorted((st or {}).items())),
+                            float(th) if need_thr else None, id(ali)))
+        if useSingles and sta in self.singles:
+            df = self.singles[sta]
+            for name, st, th, mp in zip(df.Name, df.SampleTrims, df.Threshold, df.MPtd):
+                key.append((name, tuple(sorted((st or {}).items())),
+                            float(th) if need_thr else None, id(mp)))
+        return tuple(key)
+
+    def _build_bank(self, sta, useSubSpaces, useSingles, need_thr):
         names, kinds, blocks, offsets, thr = [], [], [], {}, {}
         self._bank_ewf, self._bank_mags = {}, {}
         if useSubSpaces and sta in self.subspaces:
@@ -518,6 +566,7 @@ class SubSpace(object):
                                estimateMags=estimateMags, planes_dev=planes, chunk_sel=chunk_sel,
                                bank=bank)
             del planes
+            up.release()
             if world > 1:
                 res = _merge_ranks(parallel.gather_rows(res))
             if res is None:
@@ -538,6 +587,7 @@ class SubSpace(object):
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop('_hip_ctx', None)                             # device contexts are not picklable
+        d.pop('_bank_cache', None)
         return d
 
     def _write_db(self, path, out):

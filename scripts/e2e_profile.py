@@ -1,8 +1,20 @@
-import cProfile, pstats, sys, io, os, runpy
-sys.argv=['scripts/e2e_time.py']
-src=open('scripts/e2e_time.py').read()
-# replace the three-pass loop with a profiled pass
-src=src.replace("for rep in range(3):\n    res = ss.detex(subspaceDB=None, ctx=ctx)\n    t0 = tick('detex() pass %d' % rep, t0)",
-"res = ss.detex(subspaceDB=None, ctx=ctx)\npr=cProfile.Profile(); pr.enable()\nfor rep in range(3):\n    res = ss.detex(subspaceDB=None, ctx=ctx)\n    torch.cuda.synchronize()\npr.disable()\nimport pstats; pstats.Stats(pr).sort_stats('cumulative').print_stats(28)")
-src=src.replace("res = ss.detex(subspaceDB='/tmp/e2e_SubSpace.db', ctx=ctx, estimateMags=True)","sys.exit(0)")
-exec(compile(src,'e2e','exec'))
+"""cProfile of SubSpace.detex() at config-2 size (after one warm call): where the host time of
+a station-day goes.  Usage: python scripts/e2e_profile.py"""
+import cProfile
+import os
+import pstats
+import sys
+
+sys.argv = ['scripts/e2e_time.py']
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'e2e_time.py')).read()
+head, tail = src.split("for rep in range(4):")
+exec(compile(head, 'e2e_head', 'exec'))
+res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)        # noqa: F821  (warm)
+torch.cuda.synchronize()                                             # noqa: F821
+pr = cProfile.Profile()
+pr.enable()
+for rep in range(5):
+    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=True)     # noqa: F821
+    torch.cuda.synchronize()                                         # noqa: F821
+pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)

@@ -29,10 +29,13 @@ def tick(label, t0):
 
 t0 = time.time()
 td = synth.event_families(1, NFAM, NPER, NC, L, maxshift=20, snr=8.0)
+NSTA = int(os.environ.get('E2E_STATIONS', '1'))      # > 1: the steady-state cost per station-day
+STAS = ['TA.M17A'] + ['TA.S%02dA' % i for i in range(1, NSTA)]
 ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
-for e in range(len(td)):
-    ef.add('TA.M17A', 'ev%03d' % e, td[e].reshape(L, NC).T, starttime=1000.0 + 100 * e,
-           origintime=990.0 + 100 * e, magnitude=1.0 + (e % 5) * .2)
+for sta in STAS:
+    for e in range(len(td)):
+        ef.add(sta, 'ev%03d' % e, td[e].reshape(L, NC).T, starttime=1000.0 + 100 * e,
+               origintime=990.0 + 100 * e, magnitude=1.0 + (e % 5) * .2)
 T = int(hours * 3600 * SR)
 con = rs.standard_normal((NC, T)).astype(np.float32)
 nplant = max(2, int(50 * hours / 24))
@@ -41,7 +44,8 @@ for k in range(nplant):
     t = int(rs.randint(0, T - L))
     con[:, t:t + L] += 3.0 * td[e].reshape(L, NC).T / np.std(td[e])
 cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])
-cf.add('TA.M17A', con, starttime=1.5e9)
+for sta in STAS:
+    cf.add(sta, con if sta == STAS[0] else con.copy(), starttime=1.5e9)
 if os.environ.get('E2E_PIN', '1') == '1':
     cf.pin()        # page-locked host memory: the H2D copy runs at PCIe rate on a copy stream
 t0 = tick('synthetic data (host)', t0)
@@ -58,7 +62,7 @@ names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
 print('detectors: %d, basis vectors: %d, n = %d' % (len(names), U.shape[0], U.shape[1]))
 for rep in range(4):
     res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
-    t0 = tick('detex() pass %d' % rep, t0)
+    t0 = tick('detex() pass %d (%d station-days)' % (rep, NSTA), t0)
 print('detections: %d of %d planted' % (len(res['ss_df']), nplant))
 res = ss.detex(subspaceDB='/tmp/e2e_SubSpace.db', ctx=ctx, estimateMags=True)
 t0 = tick('detex() + magnitudes + SQLite', t0)

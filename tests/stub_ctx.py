@@ -65,7 +65,7 @@ class OracleCtx(object):
                 for d in range(D):
                     hist[d] += torch.from_numpy(orc.ds_histogram(ds[b, d]).astype(np.int32))
         if thr is not None:
-            thr = np.broadcast_to(np.asarray(thr, np.float32), (D,))
+            thr = np.broadcast_to(np.asarray(thr.numpy() if isinstance(thr, torch.Tensor) else thr, np.float32), (D,))
             b, d, p = np.nonzero(ds >= thr[None, :, None])
             res['ncand'] = len(b)
             m = min(len(b), cand_cap)
