@@ -531,16 +531,10 @@ class SubSpace(object):
         rank, world = parallel.dist_info()
         if subspaceDB is not None and delOldCorrs and rank == 0 and os.path.exists(subspaceDB):
             os.remove(subspaceDB)                           # subspace.py:1847-1854
-        if ctx is None:
-            # one context per device for the life of the object: its workspaces (channel
-            # planes, window statistics, block spectra: ~0.5 GB at one station-day) are
-            # allocated once, not per call
-            cache = self.__dict__.setdefault('_hip_ctx', {})
-            if device not in cache:
-                cache[device] = HipContext(device)
-            ctx = cache[device]
+        own_ctx = ctx is None
+        dev = torch.device('cuda', int(device)) if own_ctx else ctx.device
         stations = [sta for sta in self.Stations if sta in self.cfetcher.data]
-        up = _StationUploader(self.cfetcher, ctx.device)
+        up = _StationUploader(self.cfetcher, dev)
         if stations:
             up.start(stations[0])
         out = {'ss_df': [], 'sg_df': []}
@@ -549,6 +543,8 @@ class SubSpace(object):
             if i + 1 < len(stations):
                 up.start(stations[i + 1])                   # next station's H2D under this scan
             bank = self._detector_bank(sta, useSubSpaces, useSingles)
+            if own_ctx:
+                ctx = self._station_ctx(device, sta)
             chunk_sel = None
             if world > 1 and bank[0]:
                 # one process per GPU: rank 0's basis goes to every rank (RCCL broadcast over
@@ -583,6 +579,22 @@ class SubSpace(object):
         if subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         return out
+
+    def _station_ctx(self, device, sta, keep=16):
+        """One HipContext per (device, station), kept for the life of the object (the `keep`
+        most recently used): its workspaces (channel planes, window statistics, block
+        spectra: ~0.4 GB at one station-day) are allocated once, and the station's basis
+        images, pair spectra and training events stay resident between calls."""
+        from .hip import HipContext
+        cache = self.__dict__.setdefault('_hip_ctx', {})
+        key = (device, sta)
+        if key in cache:
+            cache[key] = cache.pop(key)                     # most recently used last
+        else:
+            while len(cache) >= keep:
+                cache.pop(next(iter(cache))).close()
+            cache[key] = HipContext(device)
+        return cache[key]
 
     def __getstate__(self):
         d = dict(self.__dict__)

@@ -61,10 +61,10 @@ t0 = tick('SVD', t0)
 names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
 print('detectors: %d, basis vectors: %d, n = %d' % (len(names), U.shape[0], U.shape[1]))
 for rep in range(4):
-    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
+    res = ss.detex(subspaceDB=None, estimateMags=False)
     t0 = tick('detex() pass %d (%d station-days)' % (rep, NSTA), t0)
 print('detections: %d of %d planted' % (len(res['ss_df']), nplant))
-res = ss.detex(subspaceDB='/tmp/e2e_SubSpace.db', ctx=ctx, estimateMags=True)
+res = ss.detex(subspaceDB="/tmp/e2e_SubSpace.db", estimateMags=True)
 t0 = tick('detex() + magnitudes + SQLite', t0)
 ctx.timer_start()
 x = torch.from_numpy(np.ascontiguousarray(con.T.reshape(-1))).cuda()
