@@ -124,6 +124,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
     if eng == 'fft':
         N = 8192
         V = (N - L + 1) // 512 * 512 if L <= 5633 else 4096      # segmented templates advance by 4096
+        nseg = 1 if L <= 5633 else (L + 4095) // 4096
         nblk = (P + V - 1) // V
         npairs = D * ((K // D + 1) // 2) if K % D == 0 else (K + 1) // 2
         nfft = npairs * nblk * chunks
@@ -131,11 +132,15 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         bytes_alg = (4.0 * Nc + 4.0 * D) * P * chunks
         # what the kernel computes: one 8192-point complex transform (5 N log2 N) and Nc complex
         # MACs per frequency (8 flop each) per (pair, block)
-        nseg = 1 if L <= 5633 else (L + 4095) // 4096
         flop_fft = nfft * (5.0 * N * 13 + 8.0 * Nc * nseg * N)
         gbs = bytes_alg / (kms * 1e-3) / 1e9
-        return {'bound': 'hbm', 'kernel': 'ds_fft_kernel<%d>' % (V // 512), 'achieved': gbs, 'peak': 8000.0,
-                'unit': 'GB/s', 'frac': gbs / 8000.0, 'traffic': pmc('*_bench_pmc_ds_fft_kernel.json'),
+        # single-segment templates on 1 or 3 channels run the ping-pong kernel (two half-workgroups
+        # per CU taking turns on the transform image), everything else the one-group kernel
+        pp = Nc in (1, 3) and nseg == 1
+        kname = ('ds_fft_pp_kernel<%d>' if pp else 'ds_fft_kernel<%d>') % (V // 512)
+        return {'bound': 'hbm', 'kernel': kname, 'achieved': gbs, 'peak': 8000.0,
+                'unit': 'GB/s', 'frac': gbs / 8000.0,
+                'traffic': pmc('*_bench_pmc_ds_fft_pp_kernel.json' if pp else '*_bench_pmc_ds_fft_kernel.json'),
                 'kernel_ms': kms, 'bytes_per_launch': bytes_alg, 'engine': 'fft',
                 'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
                             'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,

@@ -33,10 +33,30 @@
 // instead of sqrt(n) (measured 2e-7 at DS = 1 against 2e-6 for the MFMA engines).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "dtx_fftcore.h"
 
 namespace {
+
+// Basis pair spectra in memory: thread (wave w, lane l) of the scan holds frequencies
+// f = 8 (l + 64 r) + w, r = 0 .. 15.  Registers r = 2 j, 2 j + 1 of one lane are adjacent, so a
+// lane fetches its 16 values of a channel with eight 16-byte loads (eight 1 KiB wave
+// instructions) instead of sixteen 8-byte ones.
+__host__ __device__ constexpr int w_slot(int f) {
+  const int w = f & 7, n2 = f >> 3, l = n2 & 63, r = n2 >> 6;
+  return w * 1024 + (r >> 1) * 128 + 2 * l + (r & 1);
+}
+// pw[r] = W_c[8 (l + 64 r) + w]; wl = 512 w + l in float4 units from the channel base
+__device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32 (&pw)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(wc);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 t = (q + 64 * j)[wl];
+    pw[2 * j] = make_float2(t.x, t.y);
+    pw[2 * j + 1] = make_float2(t.z, t.w);
+  }
+}
 
 // ---------------------------------------------------------------- the scan
 // Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when the
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     return xx;
   };
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
-  const int wlo = 1024 * wv + ln;             // basis spectra are stored wave-decimated: [w][n2]
+  const int wlo = 512 * wv + ln;              // basis spectra: see w_slot (float4 units)
   // block spectra of this block; a template longer than one segment also reads the following
   // blocks': segment s of the template meets the data of block blk + s (advance == segment length)
   const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
@@ -223,10 +243,8 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
         const c32* wca = wpa + (int64_t)vc * kN;
         const c32* wcb = wpb + (int64_t)vc * kN;
         const c32* xc = xh + ((int64_t)sg * a.Nc + c) * kXh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pa[r] = (wca + 64 * r)[wlo];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pb[r] = (wcb + 64 * r)[wlo];
+        w_load16(wca, wlo, pa);
+        w_load16(wcb, wlo, pb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
         mac16(z, pa, px);
@@ -257,8 +275,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       for (int c = 0; c < NCH; ++c) {
         c32 pw[16], px[16];
         const c32* wc = wp + (int64_t)c * kN;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pw[r] = (wc + 64 * r)[wlo];
+        w_load16(wc, wlo, pw);
 #pragma unroll
         for (int r = 0; r < 16; ++r) px[r] = fix_x(xs[c * kXh + x_slot(r)], r);
         mac16(z, pw, px);
@@ -269,9 +286,177 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   }
 }
 
+// ---------------------------------------------------------------- ping-pong variant
+// The same work with TWO half-workgroups of 512 threads in one 1024-thread workgroup (16 waves,
+// four per SIMD, 128 registers each; 112 used, no scratch).  The halves share the block spectra
+// staged in LDS and take turns on the single 64 KB transform image: while one half runs the
+// image-bound front of its pair's transform, the other runs the register-only tail of its
+// previous transform, that pair's epilogue and the MAC of its next pair (basis spectra from L2,
+// block spectra from LDS) -- a butterfly / LDS-heavy and a load-heavy instruction stream on
+// every SIMD at any time, instead of eight waves that all load, then all transform.  A unit's
+// detectors are split between the halves at a detector boundary (unit.z pairs to half 0), so
+// each half keeps its own DS accumulators and stores its own rows: no exchange between them.
+// Rounds: in round r half h is in phase q = r - h; odd q = front of the transform of its pair
+// q / 2 (scatter ... cross-wave reads), even q = tail + epilogue of pair q / 2 - 1, then MAC of
+// pair q / 2.  Every round holds exactly two workgroup barriers on both sides (the transform's
+// own two), which is all the synchronisation the shared image needs: a round's leading barrier
+// separates one half's last reads of the image from the other half's first writes.
+// Register discipline (the compiler spills 100+ registers otherwise): opaque zeros keep loop
+// invariants (LDS slots, row addresses) inside the round, the channel loop is not unrolled (the
+// scheduler would hoist the next channel's loads), mean / den are loaded next to their use.
+// Measured at configs[1] (profiles/g*): 5.6 -> 4.56 ms; with 16-byte basis-spectrum loads 3.94 ms.
+template <int VM, bool TWO, int NCH>
+__global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
+  static_assert(NCH > 0, "the ping-pong kernel keeps the block spectra in LDS");
+  __shared__ c32 lds[kLdsC + NCH * kXh];
+  const int half = threadIdx.x >> 9, tid = threadIdx.x & (kT - 1);
+  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  const int tile = logical / kTile, slot = logical - tile * kTile;
+  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
+  const int unit = tu * kTileU + slot % kTileU;
+  const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
+  if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
+  const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;
+  const int4 ui0 = a.unit[unit];
+  // this half's run of pairs
+  const int4 ui = make_int4(half ? ui0.x + ui0.z : ui0.x, half ? ui0.y - ui0.z : ui0.z, 0, 0);
+  // half h runs phases q = 0 .. 2 n_h (the last one only finishes its last pair), one round later for h = 1
+  const int rounds = max(2 * ui0.z + 1, 2 * (ui0.y - ui0.z) + 2);
+  const int64_t p0 = (int64_t)blk * a.V;
+  const LdsBases lb = lds_bases(tid);
+  float acc0[VM], acc1[TWO ? VM : 1];
+#pragma unroll
+  for (int m = 0; m < VM; ++m) {
+    acc0[m] = 0.f;
+    if (TWO) acc1[m] = 0.f;
+  }
+  const float* mean = a.mean + (int64_t)chunk * a.Ppad + p0;
+  const float* den = a.den + (int64_t)chunk * a.Ppad + p0;
+  const int wv = tid >> 6, ln = tid & 63;
+  const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
+  auto fix_x = [&](c32 xx, int r) {
+    if (r == 0 && tid == 0) xx.y = 0.f;
+    if (r == 8 && tid == 0) return make_float2(xx.y, 0.f);
+    if (r >= 8) xx.y = -xx.y;
+    return xx;
+  };
+  const int wlo = 512 * wv + ln;
+  const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
+  c32* xs = lds + kLdsC;
+  {
+    const float4* src = reinterpret_cast<const float4*>(xh);
+    float4* dst = reinterpret_cast<float4*>(xs);
+#pragma unroll
+    for (int q = 0; q < NCH * kXh / 2 / (2 * kT); ++q)
+      dst[threadIdx.x + 2 * kT * q] = src[threadIdx.x + 2 * kT * q];
+    __syncthreads();
+  }
+  c32 z[16];
+#pragma nounroll
+  for (int r = 0; r < rounds; ++r) {
+    const int q = r - half;                    // this half's phase
+    if (q & 1) {
+      // ---- front of the transform of pair q / 2 (its MAC ran in the previous round): everything
+      // that touches the image, ending with the cross-wave reads.  The register-only tail and
+      // the epilogue run at the head of this half's next round, beside the other half's transform.
+      const int pr = q >> 1;
+      if (q >= 0 && pr < ui.y) {
+        fft8192<1, true, true>(z, lds, lb, a.tab, tid);    // two workgroup barriers inside
+      } else {
+        __syncthreads();
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
+      // ---- tail of the transform of pair q / 2 - 1 and its epilogue
+      if (q >= 2 && (q >> 1) - 1 < ui.y) {
+        const int pr = (q >> 1) - 1;
+        fft8192_back<1>(z, a.tab, tid);
+        int oe;                                  // nothing below is hoisted out of the round loop
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
+        const int te = tid + oe;
+        const float4 pi = a.pinfo[ui.x + pr];
+        const int2 pd = a.pdet[ui.x + pr];
+        const bool two = TWO && pd.y >= 0;
+#pragma unroll
+        for (int m = 0; m < VM; ++m) {
+          const float mu = (mean + 512 * m)[te];
+          /* explicit fma chain: every instantiation of the kernels rounds the same way */
+          const float re = __fmaf_rn(-pi.x, mu, z[m].x), im = __fmaf_rn(-pi.y, mu, z[m].y);
+          const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
+          acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
+          if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
+        }
+        if (pd.x >= 0) {
+          float* row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;     // uniform
+          float* row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
+          const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
+#pragma unroll
+          for (int m = 0; m < VM; ++m) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (te + 512 * m < lim) {
+              const float dn = (den + 512 * m)[te];
+              float v0 = (dn > 0.f) ? __fdiv_rn(acc0[m], dn) : 0.f;
+              if (__builtin_isinf(v0)) v0 = 0.f;
+              DTX_DS_STORE(v0, &(row0 + 512 * m)[te]);
+              if (two) {
+                float v1 = (dn > 0.f) ? __fdiv_rn(acc1[m], dn) : 0.f;
+                if (__builtin_isinf(v1)) v1 = 0.f;
+                DTX_DS_STORE(v1, &(row1 + 512 * m)[te]);
+              }
+            }
+            acc0[m] = 0.f;
+            if (TWO) acc1[m] = 0.f;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MAC of pair q / 2: half-channel batches of eight loads (the register budget is 128)
+      if (q >= 0 && (q >> 1) < ui.y) {
+        const int pr = q >> 1;
+        int oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        const int xlo_ = xlo + oz, xhi_ = xhi + oz, wlo_ = wlo + oz;
+        auto x_slot = [&](int r) { return r < 8 ? xlo_ + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi_ - 64 * r); };
+        const c32* wp = a.W + (int64_t)(ui.x + pr) * NCH * kN;   // uniform
+#pragma unroll
+        for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
+#pragma nounroll
+        for (int c = 0; c < NCH; ++c) {      // (unrolled, the scheduler hoists the next channel's loads: spills)
+          const c32* wc = wp + (int64_t)c * kN;
+          __builtin_amdgcn_sched_barrier(0);
+          c32 pw[16];                        // the whole channel's basis spectrum in flight at once
+          w_load16(wc, wlo_, pw);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            c32 px[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) px[e] = fix_x(xs[c * kXh + x_slot(4 * h + e)], 4 * h + e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int m = 4 * h + e;
+              z[m].x += pw[m].x * px[e].x - pw[m].y * px[e].y;
+              z[m].y += pw[m].x * px[e].y + pw[m].y * px[e].x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();                           // the second barrier of the round
+    }
+  }
+}
+
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   const bool xl = DTX_FFT_XLDS && a.nseg == 1;   // block spectra LDS-resident: single-segment templates
+  if (ctx->fft.pingpong && xl && (a.Nc == 3 || a.Nc == 1)) {
+    if (two && a.Nc == 3) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 3>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
+    else if (two) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 1>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
+    else if (a.Nc == 3) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, false, 3>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((ds_fft_pp_kernel<VM, false, 1>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
+    return;
+  }
   if (two && a.Nc == 3 && xl) {   // some pair holds two single-vector detectors
     hipLaunchKernelGGL((ds_fft_kernel<VM, true, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   } else if (two) {
@@ -327,9 +512,9 @@ __global__ __launch_bounds__(512) void wspec64_kernel(const float* __restrict__ 
     __syncthreads();
   }
   c32* dst = W + (size_t)blockIdx.x * kN;
-  // stored wave-decimated: [w][n2] holds frequency f = 8 n2 + w (what wave w of the scan reads)
+  // stored in the order the scan reads (w_slot): wave w's frequencies f = 8 n2 + w, register pairs adjacent
   for (int q = tid; q < kN; q += 512)
-    dst[(q & 7) * (kN / 8) + (q >> 3)] = make_float2((float)(z[q].x / kN), (float)(z[q].y / kN));
+    dst[w_slot(q)] = make_float2((float)(z[q].x / kN), (float)(z[q].y / kN));
 }
 
 // pinfo[pair] = {S_ra, S_rb, 0, 0} from the row sums
@@ -381,9 +566,17 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   std::vector<int2> pdet;
   std::vector<int2> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
   int ufirst = 0;
+  int pp_rounds = 0;        // rounds the ping-pong kernel needs over all units (ideal: one per pair)
   auto close_unit = [&]() {
     const int np = (int)prow.size() - ufirst;
-    if (np > 0) units.push_back(make_int4(ufirst, np, 0, 0));
+    if (np > 0) {
+      // pairs [0, z) go to half 0 of the ping-pong kernel: the detector boundary nearest to np / 2
+      int best = np, bestd = np;
+      for (int q = 1; q <= np; ++q)
+        if (pdet[ufirst + q - 1].x >= 0 && std::abs(2 * q - np) < bestd) { best = q; bestd = std::abs(2 * q - np); }
+      pp_rounds += std::max(2 * best, 2 * (np - best) + 1);       // + one short finishing round
+      units.push_back(make_int4(ufirst, np, best, 0));
+    }
     ufirst = (int)prow.size();
   };
   for (int d = 0; d < D;) {
@@ -408,6 +601,11 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   close_unit();
   f.nunits = (int)units.size();
   f.npairs = (int)prow.size();
+  {
+    const char* e = getenv("DTX_FFT_PP");
+    // worth it when the halves are balanced: at least 0.8 pairs per round over the whole basis
+    f.pingpong = 5 * f.npairs >= 4 * pp_rounds && f.nseg == 1 && !(e && e[0] == '0');
+  }
 
   const int nvc = Nc * f.nseg;
   static const std::vector<float2> tab = [] {          // e^{+2 pi i m / kN}, once per process
@@ -476,6 +674,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {
+#ifndef DTX_FFT_ONLY_VM
     case 1: launch_fft<1>(ctx, a, (unsigned)grid, f.two); break;
     case 2: launch_fft<2>(ctx, a, (unsigned)grid, f.two); break;
     case 3: launch_fft<3>(ctx, a, (unsigned)grid, f.two); break;
@@ -485,12 +684,15 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
     case 7: launch_fft<7>(ctx, a, (unsigned)grid, f.two); break;
     case 8: launch_fft<8>(ctx, a, (unsigned)grid, f.two); break;
     case 9: launch_fft<9>(ctx, a, (unsigned)grid, f.two); break;
+#endif
     case 10: launch_fft<10>(ctx, a, (unsigned)grid, f.two); break;
+#ifndef DTX_FFT_ONLY_VM
     case 11: launch_fft<11>(ctx, a, (unsigned)grid, f.two); break;
     case 12: launch_fft<12>(ctx, a, (unsigned)grid, f.two); break;
     case 13: launch_fft<13>(ctx, a, (unsigned)grid, f.two); break;
     case 14: launch_fft<14>(ctx, a, (unsigned)grid, f.two); break;
     case 15: launch_fft<15>(ctx, a, (unsigned)grid, f.two); break;
+#endif
     default: return dtx_fail(ctx, DTX_E_STATE, "FFT engine: bad block advance %d", V);
   }
   DTX_HIP(ctx, hipGetLastError());

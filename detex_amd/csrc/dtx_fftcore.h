@@ -194,7 +194,33 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
 }
 
 // v[r] = point 8 (l + 64 r) + wave in, natural-order transform point (tid + 512 m) out in v[m]
+// LEAN: for the 128-register kernels -- each pass loads its twiddles just before it uses them
+// (L1 / L2 hits; four waves per SIMD cover the latency) and the two radix-8 butterflies of
+// phase B run strictly one after the other, so that at most one set of temporaries is live
+// the register-only tail of the transform: the two radix-8 butterflies across the waves, from
+// the values the phase-B reads left in v.  Separate so that a kernel can release the LDS image
+// (a workgroup barrier) between the reads and this arithmetic.
 template <int SG>
+__device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict__ tab, int tid) {
+  int opaque;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+  c32 p4[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    p4[e] = tab[(tid + opaque) << e];
+    if (SG < 0) p4[e].y = -p4[e].y;
+  }
+  // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
+  // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
+  c32 u[8];
+  bfly8<SG, 0>(v, u, p4[0], p4[1], p4[2]);
+  dtx::static_for<0, 8>([&](auto sc) { constexpr int s = sc; v[2 * s] = u[rev3(s)]; });
+  __builtin_amdgcn_sched_barrier(0);
+  bfly8<SG, 1>(v, u, mul_root<SG, 16, 1>(p4[0]), mul_root<SG, 8, 1>(p4[1]), muli<SG>(p4[2]));
+  dtx::static_for<0, 8>([&](auto sc) { constexpr int s = sc; v[2 * s + 1] = u[rev3(s)]; });
+}
+
+template <int SG, bool LEAN = false, bool FRONT_ONLY = false>
 __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
                                         const c32* __restrict__ tab, int tid) {
   // The ~50 swizzled LDS addresses below and the 9 twiddles are loop invariants of the
@@ -203,7 +229,21 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   int opaque;
   asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
   Twid w;
-  load_twiddles<SG>(w, tab, tid + opaque);
+  auto ldtw = [&](int idx) {
+    c32 t = tab[idx];
+    if (SG < 0) t.y = -t.y;
+    return t;
+  };
+  if constexpr (!LEAN) load_twiddles<SG>(w, tab, tid + opaque);
+  if constexpr (LEAN && FRONT_ONLY) {
+    // the front's own twiddles (passes 2 and 3), issued now: pass 1 and the first exchange
+    // cover their latency.  12 registers; phase B's three are loaded by fft8192_back
+    const int l = (tid + opaque) & 63;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w.a[e] = ldtw(((l & 15) * (kN / 256)) << e);
+    w.b[0] = ldtw(l * (kN / 1024));
+    w.b[1] = ldtw(l * (kN / 512));
+  }
   LdsBases lb;   // in bytes from here on
   lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
   lb.f = (lb0.f + opaque) << 3;
@@ -216,6 +256,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   wave_sync();
   // ---- pass 2: radix 16, sub-transforms of 16 -> 256
   {
+    if constexpr (LEAN && !FRONT_ONLY) {
+      const int l15 = ((tid + opaque) & 15) * (kN / 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w.a[e] = ldtw(l15 << e);
+    }
     const c32 w1 = w.a[0], w2 = w.a[1], w4 = w.a[2], w8 = w.a[3];
     const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
     v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
@@ -235,6 +280,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   wave_sync();
   // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
   // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
+  if constexpr (LEAN && !FRONT_ONLY) {
+    const int l = (tid + opaque) & 63;
+    w.b[0] = ldtw(l * (kN / 1024));
+    w.b[1] = ldtw(l * (kN / 512));
+  }
   dtx::static_for<0, 4>([&](auto bc) {
     constexpr int b = bc;
     const c32 w1 = mul_root<SG, 16, b>(w.b[0]), w2 = mul_root<SG, 8, b>(w.b[1]);
@@ -253,16 +303,28 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     constexpr int m = mc;
     v[m] = lds_at(lds, lb.f + 8 * (512 * (m & 1) + 1024 * (m >> 1)));
   });
+  if constexpr (FRONT_ONLY) return;
   // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
   // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
-  c32 u0[8], u1[8];
-  bfly8<SG, 0>(v, u0, w.p4[0], w.p4[1], w.p4[2]);
-  bfly8<SG, 1>(v, u1, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
-  dtx::static_for<0, 8>([&](auto sc) {
-    constexpr int s = sc;
-    v[2 * s] = u0[rev3(s)];
-    v[2 * s + 1] = u1[rev3(s)];
-  });
+  if constexpr (LEAN) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) w.p4[e] = ldtw((tid + opaque) << e);
+    c32 u[8];
+    bfly8<SG, 0>(v, u, w.p4[0], w.p4[1], w.p4[2]);
+    dtx::static_for<0, 8>([&](auto sc) { constexpr int s = sc; v[2 * s] = u[rev3(s)]; });
+    __builtin_amdgcn_sched_barrier(0);
+    bfly8<SG, 1>(v, u, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
+    dtx::static_for<0, 8>([&](auto sc) { constexpr int s = sc; v[2 * s + 1] = u[rev3(s)]; });
+  } else {
+    c32 u0[8], u1[8];
+    bfly8<SG, 0>(v, u0, w.p4[0], w.p4[1], w.p4[2]);
+    bfly8<SG, 1>(v, u1, mul_root<SG, 16, 1>(w.p4[0]), mul_root<SG, 8, 1>(w.p4[1]), muli<SG>(w.p4[2]));
+    dtx::static_for<0, 8>([&](auto sc) {
+      constexpr int s = sc;
+      v[2 * s] = u0[rev3(s)];
+      v[2 * s + 1] = u1[rev3(s)];
+    });
+  }
 }
 
 // ---------------------------------------------------------------- block spectra

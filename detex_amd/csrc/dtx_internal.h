@@ -34,6 +34,7 @@ struct DtxKTile {
 struct DtxFft {
   bool ok = false;
   bool two = false;            // some unit pairs two single-vector detectors
+  bool pingpong = false;       // every unit splits between two half-workgroups: ds_fft_pp_kernel
   int V = 0;                   // windows per block (block advance), a multiple of 512
   int nseg = 1;                // template segments (> 1: templates longer than kFftMaxL)
   int nunits = 0, npairs = 0;
