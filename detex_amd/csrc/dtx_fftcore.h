@@ -327,6 +327,25 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   }
 }
 
+// Basis pair spectra in memory: thread (wave w, lane l) of a MAC holds frequencies
+// f = 8 (l + 64 r) + w, r = 0 .. 15.  Registers r = 2 j, 2 j + 1 of one lane are adjacent, so a
+// lane fetches its 16 values of a channel with eight 16-byte loads (eight 1 KiB wave
+// instructions) instead of sixteen 8-byte ones.
+__host__ __device__ constexpr int w_slot(int f) {
+  const int w = f & 7, n2 = f >> 3, l = n2 & 63, r = n2 >> 6;
+  return w * 1024 + (r >> 1) * 128 + 2 * l + (r & 1);
+}
+// pw[r] = W_c[8 (l + 64 r) + w]; wl = 512 w + l in float4 units from the channel base
+__device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32 (&pw)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(wc);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 t = (q + 64 * j)[wl];
+    pw[2 * j] = make_float2(t.x, t.y);
+    pw[2 * j + 1] = make_float2(t.z, t.w);
+  }
+}
+
 // ---------------------------------------------------------------- block spectra
 // Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
 // slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w

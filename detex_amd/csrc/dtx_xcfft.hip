@@ -58,10 +58,10 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
     v[r] = make_float2(re, im);
   }
   fft8192<1>(v, lds, lb, tab, tid);
-  c32* dst = W + ((int64_t)pr * nvc + vc) * kN + (tid & 7) * 1024 + (tid >> 3);
+  c32* dst = W + ((int64_t)pr * nvc + vc) * kN;       // register m holds frequency tid + 512 m
   const float sc = 1.0f / (float)kN;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) dst[64 * m] = make_float2(v[m].x * sc, v[m].y * sc);
+  for (int m = 0; m < 16; ++m) dst[w_slot(tid + 512 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
 }
 
 struct XcFftArgs {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
     return xx;
   };
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
-  const int wlo = 1024 * wv + ln;
+  const int wlo = 512 * wv + ln;              // pair spectra: w_slot order, float4 units
   const int nvc = a.Nc * a.nseg;
   const c32* xh = a.xh + ((int64_t)c * a.nblkx + blk) * a.Nc * kXh;
 
@@ -170,10 +170,8 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       const c32* wca = wpa + (int64_t)vc * kN;
       const c32* wcb = wpb + (int64_t)vc * kN;
       const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pa[r] = (wca + 64 * r)[wlo];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pb[r] = (wcb + 64 * r)[wlo];
+      w_load16(wca, wlo, pa);
+      w_load16(wcb, wlo, pb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
 #pragma unroll
