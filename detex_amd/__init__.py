@@ -8,7 +8,7 @@ hand-written HIP kernels for gfx950 behind a C ABI (include/detex_hip.h).
 __version__ = '0.1.0'
 
 from ._lib import DetexHipError  # noqa: F401
-from .construct import createCluster, createSubSpace  # noqa: F401,E402
+from .construct import createCluster, createSubSpace, fast_normcorr  # noqa: F401,E402
 from .getdata import ContinuousFetcher, EventFetcher, multiplex  # noqa: F401,E402
 from .subspace import Cluster, ClusterStream, SubSpace  # noqa: F401,E402
 from .results import detResults, SSResults  # noqa: F401,E402

@@ -103,6 +103,26 @@ def _makeDFcclags(eventList, row, ctx):
     return _frames_from_condensed(N, cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy())
 
 
+def fast_normcorr(t, s, ctx=None, device=0):
+    """detex/construct.py:469-483 on the GPU (dtx_normcorr): normalised correlation of the
+    shorter array with every same-length window of the longer one; NumPy in, NumPy out
+    (float32 arithmetic inputs, float64 accumulation)."""
+    import torch
+    from .hip import HipContext
+    own = ctx is None
+    if own:
+        ctx = HipContext(device)
+    try:
+        tt = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(ctx.device)
+        st = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).to(ctx.device)
+        out = ctx.normcorr(tt, st)
+        ctx.sync()
+        return out.cpu().numpy().astype(np.float64)
+    finally:
+        if own:
+            ctx.close()
+
+
 def _flatNoNan(df):
     """construct.py:702-708."""
     ar = np.asarray(df.values, dtype=np.float64).flatten()

@@ -245,7 +245,73 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- fast_normcorr
+// detex/construct.py:469-483: Pearson correlation of the template t (n samples) with every
+// length-n window of s: out[p] = sum_j (t_j - mean t)(s_{p+j} - mean_p) / (n std t std_p),
+// population standard deviations.  One thread per window position, float64 accumulation; the
+// template's statistics come in pre-reduced (tstat = {mean t, std t}).  A window of zero
+// variance gives the reference's division by zero: +-inf / nan, reproduced by the final divide.
+__global__ __launch_bounds__(256) void normcorr_kernel(const float* __restrict__ t, int n,
+                                                       const float* __restrict__ s, int64_t nout,
+                                                       const double* __restrict__ tstat,
+                                                       float* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= nout) return;
+  const double mt = tstat[0], st = tstat[1];
+  const float* w = s + p;
+  double s1 = 0.0;
+  for (int j = 0; j < n; ++j) s1 += (double)w[j];
+  const double mw = s1 / n;
+  double num = 0.0, ssw = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double d = (double)w[j] - mw;
+    num += ((double)t[j] - mt) * d;
+    ssw += d * d;
+  }
+  out[p] = (float)(num / ((double)n * st * sqrt(ssw / n)));
+}
+
+__global__ __launch_bounds__(256) void normcorr_tstat_kernel(const float* __restrict__ t, int n,
+                                                             double* __restrict__ tstat) {
+  __shared__ double red[4];
+  auto bsum = [&](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  double a = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) a += (double)t[j];
+  const double mt = bsum(a) / n;
+  a = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double d = (double)t[j] - mt;
+    a += d * d;
+  }
+  const double var = bsum(a) / n;
+  if (threadIdx.x == 0) { tstat[0] = mt; tstat[1] = sqrt(var); }
+}
+
 }  // namespace
+
+extern "C" int dtx_normcorr(dtx_ctx* ctx, const float* t_dev, int n, const float* s_dev, int64_t m,
+                            float* out_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!t_dev || !s_dev || !out_dev || n <= 0 || m < n)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_normcorr: null pointer, n <= 0 or the series is shorter than the template");
+  DtxDeviceGuard g(ctx->device);
+  int rc;
+  if ((rc = dtx_reserve(ctx, ctx->ws_trig_doff, 64))) return rc;
+  double* tstat = (double*)ctx->ws_trig_doff.p;
+  const int64_t nout = m - n + 1;
+  hipLaunchKernelGGL(normcorr_tstat_kernel, dim3(1), dim3(256), 0, ctx->stream, t_dev, n, tstat);
+  hipLaunchKernelGGL(normcorr_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, ctx->stream,
+                     t_dev, n, s_dev, nout, (const double*)tstat, out_dev);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
 
 extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
                                  const float* ds_dev, int64_t P, int64_t ldp,

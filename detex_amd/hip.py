@@ -280,6 +280,18 @@ class HipContext(object):
         self._ck(rc, 'dtx_trigger_stats')
         return out
 
+    def normcorr(self, t, s):
+        """fast_normcorr(t, s) (construct.py:469-483) on the device: t [n], s [m >= n] float32 CUDA
+        tensors -> [m - n + 1] float32 (asynchronous)."""
+        if t.numel() > s.numel():               # construct.py:473-474: the shorter one is the template
+            t, s = s, t
+        t = t.to(torch.float32).contiguous()
+        s = s.to(torch.float32).contiguous()
+        out = torch.empty((s.numel() - t.numel() + 1,), dtype=torch.float32, device=s.device)
+        rc = self.lib.dtx_normcorr(self.h, _ptr(t), int(t.numel()), _ptr(s), int(s.numel()), _ptr(out))
+        self._ck(rc, 'dtx_normcorr')
+        return out
+
     # ------------------------------------------------------------ xcorr
     def xcorr_allpairs(self, td, Nc, pair_begin=0, pair_end=None):
         """td: [N, n] float32 CUDA tensor of multiplexed events.  Returns

@@ -234,6 +234,43 @@ class SubSpace(object):
         self.histSubSpaces = {}
         self.histSingles = {}
 
+    # ------------------------------------------------------------ validation
+    def validateClusters(self, device=0, ctx=None):
+        """subspace.py:737-783: drop events whose aligned (and trimmed) waveform no longer
+        correlates with any later event of its cluster at the cluster's ccReq (misaligned
+        events, reference issue 25).  The correlations are fast_normcorr at lag 0
+        (construct.py:469-483) on the device (dtx_normcorr).  As in the reference, without
+        trim times the last sample is left out (``[0:-1]``, subspace.py:752-753)."""
+        import torch
+        from .hip import HipContext
+        own = ctx is None
+        if own:
+            ctx = HipContext(device)
+        try:
+            for sta in list(self.subspaces.keys()):
+                subs = self.subspaces[sta]
+                ccreq = self.clusters[sta].ccReq
+                for ind, row in subs.iterrows():
+                    st = row.SampleTrims or {}
+                    start, stop = (st['Starttime'], st['Endtime']) if ('Starttime' in st and
+                                                                       'Endtime' in st) else (0, -1)
+                    dev = {e: torch.from_numpy(np.ascontiguousarray(row.AlignedTD[e][start:stop],
+                                                                    dtype=np.float32)).to(ctx.device)
+                           for e in row.Events}
+                    events = list(row.Events)
+                    cc = {}
+                    for i, ev1 in enumerate(events[:-1]):
+                        cc[ev1] = [ctx.normcorr(dev[ev1], dev[ev2]) for ev2 in events[i + 1:]]
+                    ctx.sync()
+                    for ev1 in events[:-1]:              # subspace.py:761-771
+                        ccs = [float(c.cpu().numpy()[0]) for c in cc[ev1]]
+                        if ccs and max(ccs) < ccreq:
+                            row.Events.remove(ev1)       # _removeEvent (775-783)
+                            row.AlignedTD.pop(ev1, None)
+        finally:
+            if own:
+                ctx.close()
+
     # ------------------------------------------------------------ trims
     def attachPickTimes(self, startSeconds=0.0, defaultDuration=30):
         """Window of the (aligned) waveforms the detectors use, as

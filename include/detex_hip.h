@@ -14,6 +14,7 @@
  *   detex/detect.py:275-281  MaxDS / inf scrub                    -> dtx_ds_post (maxds)
  *   detex/detect.py:410      candidates for the trigger loop      -> dtx_ds_post (cand)
  *   detex/detect.py:447-499  _estMag at every trigger (+ 501-524 STA/LTA there) -> dtx_trigger_stats
+ *   detex/construct.py:469-483 fast_normcorr(t, s)               -> dtx_normcorr
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++ / torch types.
@@ -188,6 +189,13 @@ int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
                       const float* ds_dev, int64_t P, int64_t ldp, const int32_t* trig_dev,
                       int ntrig, int sta_len, int lta_len, const float* ewf_dev,
                       const int32_t* ewf_off_dev, int emax, double* out_dev);
+
+/* fast_normcorr(t, s) (construct.py:469-483; callers detect.py:484, subspace.py:765): Pearson
+ * correlation of the n-sample template t with every length-n window of the m-sample series s
+ * (m >= n), out[p], p = 0 .. m - n; float64 accumulation, float32 in / out.  A window of zero
+ * variance divides by zero as in the reference (inf / nan).  Asynchronous. */
+int dtx_normcorr(dtx_ctx* ctx, const float* t_dev, int n, const float* s_dev, int64_t m,
+                 float* out_dev);
 
 static inline uint64_t dtx_cand_pack(uint32_t chunk, uint32_t det, uint32_t p) {
   return ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;

@@ -103,6 +103,10 @@ class OracleCtx(object):
             out[r, :len(row)] = row
         return torch.from_numpy(out)
 
+    def normcorr(self, t, s):
+        return torch.from_numpy(orc.fast_normcorr(t.numpy().astype(np.float64),
+                                                  s.numpy().astype(np.float64)).astype(np.float32))
+
     def sync(self):
         pass
 

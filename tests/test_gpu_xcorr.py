@@ -202,3 +202,25 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
                 nchecked += 1
             k += 1
     assert nchecked >= N
+
+
+def test_fast_normcorr_golden(ctx):
+    """fast_normcorr (construct.py:469-483) on the device against the reference's own outputs
+    (tests/golden/normcorr.npz), through the context method and the NumPy-facing function."""
+    from detex_amd import fast_normcorr
+    z = np.load(os.path.join(G, 'normcorr.npz'))
+    for i in range(3):
+        t, s, ref = z['n%d_t' % i], z['n%d_s' % i], z['n%d_out' % i]
+        got = ctx.normcorr(torch.from_numpy(t.astype(np.float32)).cuda(),
+                           torch.from_numpy(s.astype(np.float32)).cuda()).cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 2e-6, i
+        got2 = fast_normcorr(s, t, ctx=ctx)              # arguments in either order (473-474)
+        assert np.max(np.abs(got2 - ref)) <= 2e-6, i
+    # a long series: every window against the float64 oracle
+    rs = np.random.RandomState(9)
+    t, s = rs.standard_normal(3000), rs.standard_normal(40000) + 2.0
+    s[7000:10000] += 3 * t
+    got = fast_normcorr(t, s, ctx=ctx)
+    ref = orc.fast_normcorr(t.astype(np.float32).astype(np.float64), s.astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(got - ref)) <= 2e-6 and int(np.argmax(got)) == 7000

@@ -444,3 +444,29 @@ def test_candidate_overflow_and_failing_batch(caplog, monkeypatch):
         assert len(got['ss_df']) == len(left)
         assert np.allclose(got['ss_df'].STMP.values, left.STMP.values)
     assert len(ref['ss_df']) >= 3
+
+
+def test_validateClusters_drops_a_misaligned_event():
+    """subspace.py:737-783 with the oracle stand-in: an event whose aligned waveform was
+    replaced by an unrelated one no longer reaches ccReq against any later event and is
+    removed; the well-aligned ones stay."""
+    ctx = OracleCtx()
+    ss, cf, plants, _ = small_workflow(ctx)
+    df = ss.subspaces['TA.M17A']
+    row = df.iloc[0]
+    events = list(row.Events)
+    assert len(events) >= 4
+    rs = np.random.RandomState(3)
+    row.AlignedTD[events[0]] = rs.standard_normal(len(row.AlignedTD[events[0]]))
+    # the reference's loop (subspace.py:745-771) with the oracle, on a copy
+    st = row.SampleTrims
+    wf = {e: np.asarray(row.AlignedTD[e], dtype=np.float32).astype(np.float64)[st['Starttime']:st['Endtime']]
+          for e in events}
+    ccreq = ss.clusters['TA.M17A'].ccReq
+    keep = [e for i, e in enumerate(events)
+            if i == len(events) - 1 or
+            max(orc.fast_normcorr(wf[e], wf[e2])[0] for e2 in events[i + 1:]) >= ccreq]
+    ss.validateClusters(ctx=ctx)
+    assert list(ss.subspaces['TA.M17A'].iloc[0].Events) == keep
+    assert events[0] not in keep and events[0] not in ss.subspaces['TA.M17A'].iloc[0].AlignedTD
+    assert len(keep) >= 3
