@@ -17,7 +17,7 @@ SYMBOLS = [
     'dtx_ctx_stream', 'dtx_last_error', 'dtx_set_engine', 'dtx_basis_upload', 'dtx_num_windows',
     'dtx_subspace_ds', 'dtx_subspace_scan', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
-    'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr',
+    'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
 ]
 
 
@@ -85,6 +85,10 @@ def load():
     lib.dtx_trigger_stats.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp]
     lib.dtx_normcorr.restype = i32
     lib.dtx_normcorr.argtypes = [vp, vp, i32, vp, i64, vp]
+    lib.dtx_ingest_counts.restype = i32
+    lib.dtx_ingest_counts.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp]
+    lib.dtx_gapfree_run.restype = i32
+    lib.dtx_gapfree_run.argtypes = [vp, vp, i32, i64, i64, vp]
     lib.dtx_timer_start.restype = i32
     lib.dtx_timer_start.argtypes = [vp]
     lib.dtx_timer_stop.restype = i32

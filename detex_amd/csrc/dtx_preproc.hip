@@ -13,6 +13,8 @@
 // S_b = M S_{b-1} + f_{b-1} with M the state transition over one block (a tiny
 // sequential pass per series), (3) every block is run again from its true state
 // and written out.  Series (chunk x channel) and blocks are independent.
+#include <algorithm>
+
 #include "dtx_internal.h"
 
 namespace {
@@ -312,6 +314,80 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
   return DTX_OK;
 }
 
+// ---------------------------------------------------------------- raw-count ingest
+// The front half of _applyFilter (detex/construct.py:1005-1022): a chunk arrives as FRAGMENTS of
+// raw int32 digitiser counts (ObsPy traces of one channel each, with gaps between them).
+//   ingest_scatter_kernel   Stream.merge(fill_value=0.0) (construct.py:1038 / 1070): every
+//                           fragment converted to float32 at its place in a zeroed [Nc][T] plane
+//   ingest_run_kernel       _mergeChannels (1033-1066): the product of the channels is zero where
+//                           any channel has a gap (or an exact zero sample -- the reference's
+//                           test is on the values); the longest run of non-zero products, the
+//                           first one among equals (1059-1063), is what the chunk is trimmed to
+struct IngestFrag { int64_t chan, src, dst, len; };
+
+__global__ __launch_bounds__(256) void ingest_scatter_kernel(const int32_t* __restrict__ counts,
+                                                             const IngestFrag* __restrict__ frag,
+                                                             int64_t T, float* __restrict__ planes) {
+  const IngestFrag f = frag[blockIdx.y];
+  const int32_t* src = counts + f.src;
+  float* dst = planes + f.chan * T + f.dst;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < f.len; i += (int64_t)gridDim.x * 256)
+    dst[i] = (float)src[i];
+}
+
+// longest run of samples at which every channel is non-zero: each thread summarises a slice
+// (length, leading run, trailing run, best run and where it starts), slices are combined in order
+struct RunSeg { int64_t len, pre, suf, best, best_at; };
+__device__ inline RunSeg run_join(const RunSeg& a, const RunSeg& b, int64_t a0, int64_t b0) {
+  // a covers [a0, a0 + a.len), b the samples right behind it starting at b0
+  RunSeg r;
+  r.len = a.len + b.len;
+  r.pre = a.pre == a.len ? a.len + b.pre : a.pre;
+  r.suf = b.suf == b.len ? b.len + a.suf : b.suf;
+  r.best = a.best; r.best_at = a.best_at;
+  const int64_t mid = a.suf + b.pre, mid_at = b0 - a.suf;
+  if (mid > r.best) { r.best = mid; r.best_at = mid_at; }          // strictly longer: the first one wins ties
+  if (b.best > r.best) { r.best = b.best; r.best_at = b.best_at; }
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void ingest_run_kernel(const float* __restrict__ planes, int Nc,
+                                                          int64_t T, int64_t stride,
+                                                          int64_t* __restrict__ run) {
+  __shared__ RunSeg seg[1024];
+  __shared__ int64_t seg0[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (T + 1023) / 1024;
+  const int64_t t0 = min((int64_t)tid * per, T), t1 = min(t0 + per, T);
+  RunSeg s{t1 - t0, 0, 0, 0, t0};
+  int64_t cur = 0;
+  bool lead = true;
+  for (int64_t t = t0; t < t1; ++t) {
+    bool nz = true;
+    for (int c = 0; c < Nc; ++c) nz = nz && planes[(int64_t)c * stride + t] != 0.f;
+    if (nz) {
+      ++cur;
+      if (cur > s.best) { s.best = cur; s.best_at = t - cur + 1; }
+    } else {
+      if (lead) { s.pre = cur; lead = false; }
+      cur = 0;
+    }
+  }
+  if (lead) s.pre = cur;
+  s.suf = cur;
+  seg[tid] = s;
+  seg0[tid] = t0;
+  __syncthreads();
+  for (int stride = 1; stride < 1024; stride <<= 1) {
+    if ((tid & (2 * stride - 1)) == 0) seg[tid] = run_join(seg[tid], seg[tid + stride], seg0[tid], seg0[tid + stride]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    run[0] = seg[0].best > 0 ? seg[0].best_at : -1;
+    run[1] = seg[0].best;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -404,6 +480,54 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
                      out_dev, 1, out_stride, factor);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
+
+int dtx_ingest_counts(dtx_ctx* ctx, const int32_t* counts_dev, const int64_t* frag_host, int nfrag,
+                      int Nc, int64_t T, float* planes_dev, int64_t* run_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!counts_dev || !frag_host || !planes_dev || nfrag < 0 || Nc <= 0 || T <= 0)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_ingest_counts: null pointer or non-positive size");
+  for (int i = 0; i < nfrag; ++i) {
+    const int64_t* f = frag_host + 4 * (int64_t)i;
+    if (f[0] < 0 || f[0] >= Nc || f[1] < 0 || f[2] < 0 || f[3] < 0 || f[2] + f[3] > T)
+      return dtx_fail(ctx, DTX_E_ARG, "dtx_ingest_counts: fragment %d lies outside the %lld-sample chunk",
+                      i, (long long)T);
+  }
+  DtxDeviceGuard g(ctx->device);
+  int rc;
+  DTX_HIP(ctx, hipMemsetAsync(planes_dev, 0, (size_t)Nc * T * sizeof(float), ctx->stream));
+  if (nfrag > 0) {
+    if ((rc = dtx_reserve(ctx, ctx->ws_misc2, (size_t)nfrag * sizeof(IngestFrag)))) return rc;
+    // a few dozen bytes per fragment; the descriptors are host data of the caller
+    DTX_HIP(ctx, hipMemcpyAsync(ctx->ws_misc2.p, frag_host, (size_t)nfrag * sizeof(IngestFrag),
+                                hipMemcpyHostToDevice, ctx->stream));
+    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frag_host may be reused by the caller
+    int64_t longest = 1;
+    for (int i = 0; i < nfrag; ++i) longest = std::max(longest, frag_host[4 * (int64_t)i + 3]);
+    const unsigned gx = (unsigned)std::min<int64_t>((longest + 255) / 256, 1024);
+    hipLaunchKernelGGL(ingest_scatter_kernel, dim3(gx, (unsigned)nfrag), dim3(256), 0, ctx->stream,
+                       counts_dev, (const IngestFrag*)ctx->ws_misc2.p, T, planes_dev);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  if (run_dev) {
+    hipLaunchKernelGGL(ingest_run_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const float*)planes_dev,
+                       Nc, T, T, run_dev);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  return DTX_OK;
+}
+
+int dtx_gapfree_run(dtx_ctx* ctx, const float* planes_dev, int Nc, int64_t T, int64_t plane_stride,
+                    int64_t* run_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!planes_dev || !run_dev || Nc <= 0 || T <= 0 || plane_stride < T)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_gapfree_run: null pointer or bad size");
+  DtxDeviceGuard g(ctx->device);
+  hipLaunchKernelGGL(ingest_run_kernel, dim3(1), dim3(1024), 0, ctx->stream, planes_dev, Nc, T,
+                     plane_stride, run_dev);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

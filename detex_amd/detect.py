@@ -231,7 +231,12 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         data, t0 = fetcher.data[sta]
         raw = bool(getattr(fetcher, 'raw', False))
         dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
-        if planes_dev is None:
+        counts = getattr(fetcher, 'counts', {}).get(sta)
+        if counts is not None:
+            # raw int32 counts in fragments: merged with zero fill on the device
+            # (construct.py:1038 / 1070); the per-chunk trimming follows below
+            planes_dev = _ingest_station(ctx, counts, Nc, data.shape[1])
+        elif planes_dev is None:
             planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
         if raw:
             # unfiltered planes stay on the device; each chunk is decimated, detrended and
@@ -250,6 +255,8 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
         if chunk_sel is not None:
             bounds = [bounds[i] for i in chunk_sel if i < len(bounds)]
+        if counts is not None and not fillZeros:
+            bounds = _trim_to_gapfree(ctx, rawdev, counts, bounds, fetcher.sampling_rate, sta)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
         bounds = [b for b in bounds
                   if _dec_len(b[1], dec) * Nc > n and (_dec_len(b[1], dec) * Nc - n) // Nc + 1 >= 10]
@@ -282,6 +289,49 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     out = {k: pd.DataFrame(v, columns=cols) for k, v in rows.items()}
     out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
     out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
+    return out
+
+
+def _ingest_station(ctx, counts, Nc, T):
+    """All fragments of a station in one dtx_ingest_counts call -> zero-filled [Nc, T] planes."""
+    import torch
+    off, frs = 0, []
+    for (c, t0, x) in counts:
+        frs.append((c, off, t0, len(x)))
+        off += len(x)
+    flat = np.concatenate([x for (_, _, x) in counts]) if counts else np.zeros(0, np.int32)
+    cdev = torch.from_numpy(flat).to(ctx.device)
+    planes, _ = ctx.ingest_counts(cdev, frs, Nc, T, want_run=False)
+    return planes
+
+
+def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
+    """_mergeChannels per chunk (construct.py:1033-1066): each chunk is cut to its longest
+    stretch without a gap (a zero) in any channel; chunks that are then still in several
+    pieces on some channel are dropped like the reference's 'Stream is too fractured'
+    (construct.py:1011-1018).  One device pass per chunk, one copy back for all of them."""
+    import torch
+    if not bounds:
+        return bounds
+    runs = torch.zeros((len(bounds), 2), dtype=torch.int64, device=planes.device)
+    for k, (s0, cnt, _) in enumerate(bounds):
+        ctx.gapfree_run(planes[:, s0:s0 + cnt], out=runs[k])
+    runs = runs.cpu().numpy()
+    out = []
+    for (s0, cnt, ts), (r0, rl) in zip(bounds, runs):
+        if rl <= 0:
+            _warn('no gap-free data on %s from %s' % (sta, ts))
+            continue
+        if (r0, rl) != (0, cnt):
+            a, b = s0 + int(r0), s0 + int(r0) + int(rl)
+            per = {}
+            for (c, t0, x) in counts:                  # traces that reach into the kept window
+                if t0 < b and t0 + len(x) > a:
+                    per[c] = per.get(c, 0) + 1
+            if any(v > 1 for v in per.values()):       # len(st) != len(nc)
+                _warn('Stream is too fractured around %s on %s' % (ts, sta))
+                continue
+        out.append((s0 + int(r0), int(rl), ts + int(r0) / sr))
     return out
 
 

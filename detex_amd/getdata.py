@@ -81,6 +81,25 @@ class ContinuousFetcher(object):
         self.data[station] = (data, float(starttime))
         return self
 
+    def add_counts(self, station, fragments, nsamples, starttime):
+        """Continuous data of a station as it comes off the digitiser: ``fragments`` is a list
+        of (channel index, first sample, int32 counts) -- one entry per ObsPy trace --, with
+        gaps between them; ``nsamples`` the extent of the record.  Marks the fetcher raw: the
+        scan merges (zero fill), finds each chunk's longest gap-free stretch, decimates,
+        detrends and band-passes on the device (construct.py:990-1030, _applyFilter)."""
+        self.raw = True
+        self.counts = getattr(self, 'counts', {})
+        frs = sorted(((int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments),
+                     key=lambda f: (f[0], f[1]))
+        for c, t0, x in frs:
+            if not (0 <= c < len(self.channels)) or t0 < 0 or t0 + len(x) > nsamples:
+                raise ValueError('fragment of channel %d at sample %d does not fit the record' % (c, t0))
+        self.counts[station] = frs
+        # chunk geometry only needs the extent: a zero-stride placeholder, no memory
+        self.data[station] = (np.broadcast_to(np.float32(0), (len(self.channels), int(nsamples))),
+                              float(starttime))
+        return self
+
     def pin(self):
         """Move every station's array into page-locked host memory (as float32): the scan then
         uploads it at PCIe rate on a copy stream, under the previous station's kernels
@@ -88,7 +107,7 @@ class ContinuousFetcher(object):
         import torch
         self.pinned = getattr(self, 'pinned', {})
         for sta, (data, t0) in list(self.data.items()):
-            if sta in self.pinned:
+            if sta in self.pinned or sta in getattr(self, 'counts', {}):
                 continue
             t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).pin_memory()
             self.pinned[sta] = t

@@ -334,6 +334,37 @@ class HipContext(object):
         self._ck(rc, 'dtx_preprocess')
         return out
 
+    def ingest_counts(self, counts, frags, Nc, T, want_run=True):
+        """dtx_ingest_counts: fragments of raw int32 counts -> zero-filled [Nc, T] float32
+        planes (+ the longest run without a zero in any channel, construct.py:1033-1066).
+
+        counts: int32 CUDA tensor, the fragments' samples concatenated; frags: [(channel,
+        offset into counts, first sample in the chunk, length), ...].  Returns (planes, run)
+        with run a 2-element int64 CUDA tensor (start, length) or None; asynchronous."""
+        if counts.dtype != torch.int32 or not counts.is_cuda:
+            raise ValueError('counts must be an int32 CUDA tensor')
+        fr = np.ascontiguousarray(np.asarray(frags, dtype=np.int64).reshape(-1, 4))
+        planes = torch.empty((int(Nc), int(T)), dtype=torch.float32, device=counts.device)
+        run = torch.zeros((2,), dtype=torch.int64, device=counts.device) if want_run else None
+        rc = self.lib.dtx_ingest_counts(self.h, _ptr(counts), fr.ctypes.data_as(C.c_void_p), len(fr),
+                                        int(Nc), int(T), _ptr(planes), _ptr(run))
+        self._ck(rc, 'dtx_ingest_counts')
+        return planes, run
+
+    def gapfree_run(self, planes, out=None):
+        """dtx_gapfree_run on a [Nc, T] float32 CUDA view (columns of a larger plane buffer are
+        fine: stride(1) == 1): (start, length) of the longest run without a zero in any channel,
+        as a 2-element int64 CUDA tensor (asynchronous)."""
+        if planes.dtype != torch.float32 or not planes.is_cuda or planes.dim() != 2 or planes.stride(1) != 1:
+            raise ValueError('planes must be a [Nc, T] float32 CUDA tensor with unit sample stride')
+        if out is None:
+            out = torch.zeros((2,), dtype=torch.int64, device=planes.device)
+        rc = self.lib.dtx_gapfree_run(self.h, _ptr(planes), int(planes.shape[0]), int(planes.shape[1]),
+                                      int(planes.stride(0)) if planes.shape[0] > 1 else int(planes.shape[1]),
+                                      _ptr(out))
+        self._ck(rc, 'dtx_gapfree_run')
+        return out
+
     def decimate(self, raw, factor, sampling_rate):
         """Trace.decimate(factor) on the device (construct.py:1016-1017): causal
         Chebyshev-II low-pass, then every factor-th sample.

@@ -157,6 +157,9 @@ class _StationUploader(object):
     def start(self, sta):
         import torch
         pinned = getattr(self.fetcher, 'pinned', {}).get(sta)
+        if sta in getattr(self.fetcher, 'counts', {}):
+            self.pending[sta] = (None, None, None)     # raw counts: scan_station ingests the fragments
+            return
         if pinned is None or self.stream is None:
             data = self.fetcher.data[sta][0]
             self.pending[sta] = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))

@@ -15,6 +15,7 @@
  *   detex/detect.py:410      candidates for the trigger loop      -> dtx_ds_post (cand)
  *   detex/detect.py:447-499  _estMag at every trigger (+ 501-524 STA/LTA there) -> dtx_trigger_stats
  *   detex/construct.py:469-483 fast_normcorr(t, s)               -> dtx_normcorr
+ *   detex/construct.py:1005-1022, 1033-1071 _applyFilter merge / longest gap-free run -> dtx_ingest_counts
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++ / torch types.
@@ -259,6 +260,27 @@ int dtx_xcorr_allpairs_host(dtx_ctx* ctx, const float* td_host, int N, int n,
 int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc,
                    int64_t T, int64_t ser_stride, const double* sos, int nsec,
                    int zerophase, int detrend, float* mp_dev, int64_t mp_stride);
+
+/* The front half of _applyFilter (construct.py:1005-1022) for one chunk that arrives as
+ * fragments of raw int32 digitiser counts (one ObsPy trace each):
+ *   - Stream.merge(fill_value=0.0) (construct.py:1038, 1070): the fragments are converted to
+ *     float32 at their place in planes_dev [Nc][T], gaps are zero (fillZeros=True stops here);
+ *   - _mergeChannels (1033-1066): run_dev[0], run_dev[1] = first sample and length of the longest
+ *     run in which no channel is zero -- the product test of construct.py:1047-1050, so an exact
+ *     zero sample counts as a gap, as there; the first run among equals (1062); (-1, 0) if
+ *     none.  The caller trims the chunk to it before dtx_decimate / dtx_preprocess.
+ * counts_dev: the fragments' samples, concatenated; frag_host: [nfrag][4] int64 host array of
+ * (channel, offset into counts_dev, first sample in the chunk, length); fragments must not
+ * overlap (ObsPy resolves overlaps by its merge method; not restated).  run_dev may be NULL.
+ * Asynchronous apart from staging the descriptors. */
+int dtx_ingest_counts(dtx_ctx* ctx, const int32_t* counts_dev, const int64_t* frag_host, int nfrag,
+                      int Nc, int64_t T, float* planes_dev, int64_t* run_dev);
+
+/* The _mergeChannels step alone (construct.py:1033-1066) on zero-filled planes that are already
+ * on the device, e.g. one chunk's columns of a whole day: channel c at planes_dev + c*plane_stride,
+ * T samples each; run_dev[0..1] as for dtx_ingest_counts.  Asynchronous. */
+int dtx_gapfree_run(dtx_ctx* ctx, const float* planes_dev, int Nc, int64_t T, int64_t plane_stride,
+                    int64_t* run_dev);
 
 /* Trace.decimate(factor) of _applyFilter (construct.py:1016-1017), which runs
  * BEFORE the detrend / band-pass above: ObsPy (third-party, not vendored)

@@ -584,6 +584,31 @@ def trigger_stats_row(trigIndex, Nc, MPcon, U, ewf, ds=None, sta_lo=-1, sta_len=
 # pre-processing                                   construct.py:990-1030
 # --------------------------------------------------------------------------
 
+def merge_fill(frags, Nc, T):
+    """Stream.merge(fill_value=0.0) of construct.py:1038 / 1070 on arrays: fragments
+    (channel, first sample, samples) placed in zeroed [Nc, T] planes (third-party ObsPy
+    behaviour, restated for non-overlapping fragments)."""
+    planes = np.zeros((Nc, T))
+    for (c, t0, x) in frags:
+        planes[c, t0:t0 + len(x)] = np.asarray(x, dtype=np.float64)
+    return planes
+
+
+def merge_channels_run(planes):
+    """_mergeChannels (construct.py:1033-1066) on the merged planes: the product of the channels
+    (1047-1049) masked where it is zero (1050), split into its contiguous unmasked pieces (1056),
+    the longest kept, the first among equals (1059-1063).  Returns (first sample, length),
+    (-1, 0) if everything is masked."""
+    ar = np.prod(np.asarray(planes, dtype=np.float64), axis=0)
+    ok = np.concatenate([[False], ar != 0.0, [False]])
+    edges = np.flatnonzero(ok[1:] != ok[:-1])
+    starts, stops = edges[0::2], edges[1::2]
+    if len(starts) == 0:
+        return -1, 0
+    k = int(np.argmax(stops - starts))                # argmax: first of the longest
+    return int(starts[k]), int(stops[k] - starts[k])
+
+
 def bandpass_sos(freqmin, freqmax, df, corners):
     """obspy.signal.filter.bandpass design (ObsPy 1.0.2, third-party, absent here;
     restated from its published algorithm): Butterworth band-pass as zpk ->

@@ -145,3 +145,144 @@ def test_decimate_matches_scipy(ctx, T, factor, sr, shape):
 def test_decimate_rejects_large_factor(ctx):
     with pytest.raises(ValueError):
         ctx.decimate(torch.zeros((1, 100), device='cuda'), 17, 100.0)
+
+
+def _random_fragments(rs, Nc, T, holes, dead_channel=False):
+    """Non-overlapping fragments of int32 counts per channel with `holes` gaps each."""
+    frags = []
+    for c in range(Nc):
+        if dead_channel and c == Nc - 1:
+            continue
+        cuts = np.sort(rs.choice(np.arange(20, T - 20), size=2 * holes, replace=False))
+        edges = [0] + list(cuts) + [T]
+        for k in range(0, len(edges), 2):
+            a, b = int(edges[k]), int(edges[k + 1])
+            if b > a:
+                x = rs.randint(-2000, 2000, size=b - a).astype(np.int32)
+                x[x == 0] = 7                      # zeros only where planted below
+                frags.append((c, a, x))
+    return frags
+
+
+@pytest.mark.parametrize('Nc,T,holes,seed', [(3, 5000, 0, 0), (3, 5000, 2, 1), (1, 777, 3, 2),
+                                             (6, 20000, 4, 3), (3, 372000, 1, 4), (2, 1500, 0, 5)])
+def test_ingest_counts_matches_merge_restatement(ctx, Nc, T, holes, seed):
+    """dtx_ingest_counts / dtx_gapfree_run against the NumPy restatement of the merge with zero
+    fill (construct.py:1038 / 1070) and of _mergeChannels' longest-run rule (construct.py:1033-1066),
+    incl. an exact zero sample acting as a gap, ties between equal runs (the first wins), a
+    run on a column slice of a larger buffer.  ObsPy itself is not installable here: parity vs
+    ObsPy's Stream.merge / Trace.split unpinned."""
+    rs = np.random.RandomState(seed)
+    frags = _random_fragments(rs, Nc, T, holes)
+    if seed == 5:                                  # two equal runs: sample 500 and 1001 are zero
+        frags = [(c, 0, np.where(np.isin(np.arange(T), [500, 1001]), 0, 9).astype(np.int32)) for c in range(Nc)]
+        frags[1] = (1, 0, np.full(T, 5, np.int32))
+    if seed == 0:                                  # a genuine zero count in one channel
+        c, a, x = frags[1]
+        x[T // 3] = 0
+    flat = np.concatenate([x for (_, _, x) in frags])
+    off, desc = 0, []
+    for (c, a, x) in frags:
+        desc.append((c, off, a, len(x)))
+        off += len(x)
+    planes, run = ctx.ingest_counts(torch.from_numpy(flat).cuda(), desc, Nc, T)
+    ctx.sync()
+    want = orc.merge_fill(frags, Nc, T)
+    assert np.array_equal(planes.cpu().numpy(), want.astype(np.float32))
+    r0, rl = (int(v) for v in run.cpu().numpy())
+    assert (r0, rl) == orc.merge_channels_run(want)
+    if seed == 5:
+        assert (r0, rl) == (0, 500)                # 0..499 and 501..1000 tie: the first is kept
+    # the run of a chunk = columns [a, b) of the day buffer
+    a, b = T // 5, T - T // 7
+    sub = ctx.gapfree_run(planes[:, a:b])
+    ctx.sync()
+    assert tuple(int(v) for v in sub.cpu().numpy()) == orc.merge_channels_run(want[:, a:b])
+    # a channel without any data: nothing survives
+    frags2 = _random_fragments(rs, max(Nc, 2), T, 1, dead_channel=True)
+    flat2 = np.concatenate([x for (_, _, x) in frags2])
+    off, desc2 = 0, []
+    for (c, a_, x) in frags2:
+        desc2.append((c, off, a_, len(x)))
+        off += len(x)
+    _, run2 = ctx.ingest_counts(torch.from_numpy(flat2).cuda(), desc2, max(Nc, 2), T)
+    assert tuple(int(v) for v in run2.cpu().numpy()) == (-1, 0)
+
+
+def test_detex_on_raw_counts_with_gaps(ctx):
+    """SubSpace.detex on a fetcher that holds raw int32 counts in fragments (add_counts): merge
+    with zero fill, per-chunk longest gap-free stretch, detrend + band-pass, scan -- against the
+    oracle's merge -> trim -> filter -> DS chain; a chunk whose kept stretch is still in two
+    pieces on one channel is dropped ('too fractured', construct.py:1011-1018); fillZeros=True
+    scans the zero-filled chunks whole."""
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
+    from detex_amd.getdata import multiplex
+    rs = np.random.RandomState(21)
+    sr, Nc, L = 20.0, 3, 160
+    filt = [1, 8, 2, True]
+    wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
+           for _ in range(Nc)]
+    wavf = orc.apply_filter([w.astype(np.float32) for w in wav], filt, sr)
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    for i in range(4):
+        ef.add('XX.STA', 'ev%d' % i, np.array([rs.uniform(.5, 2) * w + 0.02 * rs.standard_normal(L)
+                                                for w in wavf]), starttime=100. * i)
+    T = int(1500 * sr)                                   # chunks of 600 s + 60 s: 0, 12000, 24000
+    con = rs.standard_normal((Nc, T)) * 300 + 5000.0
+    for t in (4000, 9000, 16000, 22000, 27000):
+        for c in range(Nc):
+            con[c, t:t + L] += 3000.0 * wav[c]
+    cnt = np.rint(con).astype(np.int32)
+    cnt[cnt == 0] = 1
+    # channel 1 loses samples 6000..6999 (inside chunk 0); channel 2 is delivered in two abutting
+    # traces that meet at 20000 (inside chunk 1) and has a hole at 13000..13099 as well
+    frags = [(0, 0, cnt[0]), (1, 0, cnt[1, :6000]), (1, 7000, cnt[1, 7000:]),
+             (2, 0, cnt[2, :13000]), (2, 13100, cnt[2, 13100:20000]), (2, 20000, cnt[2, 20000:])]
+    cf = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=60)
+    cf.add_counts('XX.STA', frags, T, starttime=6.0e5)
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, ctx=ctx)
+    ss = createSubSpace(clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(0.0, 6.0)
+    ss.SVD(selectCriteria=4, selectValue=0, threshold=0.35, useSingles=False)
+    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('XX.STA', useSingles=False)
+    merged = orc.merge_fill(frags, Nc, T)
+    want = []
+    kept = []
+    for (s0, n, ts) in cf.chunk_bounds('XX.STA'):
+        r0, rl = orc.merge_channels_run(merged[:, s0:s0 + n])
+        a, b = s0 + r0, s0 + r0 + rl
+        pieces = {}
+        for (c, t0, x) in frags:
+            if t0 < b and t0 + len(x) > a:
+                pieces[c] = pieces.get(c, 0) + 1
+        if rl <= 0 or ((r0, rl) != (0, n) and max(pieces.values()) > 1):
+            continue
+        kept.append((a, rl))
+        x = multiplex(orc.apply_filter([m.astype(np.float32) for m in merged[:, a:b]], filt, sr))
+        if len(x) <= U.shape[1]:
+            continue
+        ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
+            want += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, ts + r0 / sr)]
+    # chunk 0 (0..13199) has two holes that leave equal stretches 0..5999 and 7000..12999: the
+    # first is kept; chunk 1 (12000..25199) is cut to 13100..25199, which holds the seam at 20000
+    # on channel 2 -> dropped; chunk 2 is whole
+    assert kept == [(0, 6000), (24000, 6000)]
+    got = res['ss_df'].sort_values('STMP')
+    assert len(got) == len(want) >= 2
+    for (_, g), w in zip(got.iterrows(), sorted(want)):
+        assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5
+    # fillZeros: the merged chunks are scanned whole (construct.py:1007-1008)
+    resz = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False, fillZeros=True)
+    wz = []
+    for (s0, n, ts) in cf.chunk_bounds('XX.STA'):
+        x = multiplex(orc.apply_filter([m.astype(np.float32) for m in merged[:, s0:s0 + n]], filt, sr))
+        ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
+            wz += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, ts)
+                   if t['DS'] <= 1.05]
+    gz = resz['ss_df'].sort_values('STMP')
+    assert len(gz) == len(wz) >= len(want)
+    for (_, g), w in zip(gz.iterrows(), sorted(wz)):
+        assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and g.DS_STALTA == 0.0
