@@ -42,7 +42,7 @@ namespace {
 // it), pass 1 repeats the mean over the non-zero samples within 3 sigma of the pass-0
 // mean, so that a spike of any size cannot move it either.
 // csum[b] = {sum, sumsq, count, sum', count'}
-constexpr int kMeanSlices = 32;
+constexpr int kMeanSlices = 128;
 constexpr int kCsum = 5;
 template <int PASS>
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ x, int64_t M,
