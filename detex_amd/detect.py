@@ -201,30 +201,56 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     caller, e.g. from pinned memory on a copy stream); chunk_sel: indices into the station's
     chunk list this call scans (multi-GPU sharding); bank: the station's detector bank if the
     caller already built (or received) it; a failing batch is logged and skipped like a
-    failing chunk of the reference (detect.py:160-174)."""
-    import pandas as pd
-    import torch
-    from ._lib import DetexHipError
-    from .hip import HipContext
-    if bank is None:
-        bank = ss._detector_bank(sta, useSubSpaces, useSingles)
-    names, kinds, U, det_off, offsets, thr = bank
-    if not names:
-        return None
-    fetcher = ss.cfetcher
-    if sta not in fetcher.data:
-        return None
-    sr = fetcher.sampling_rate
-    Nc = len(fetcher.channels)
-    n = U.shape[1]
-    D = len(names)
-    own = ctx is None
-    if own:
-        ctx = HipContext(device)
-    cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
-            'ProEnMag']
-    rows = {'ss': [], 'sg': []}
+    failing chunk of the reference (detect.py:160-174).  (StationScan.start / .finish are
+    the two halves: SubSpace.detex starts the next station before it finishes this one.)"""
+    job = StationScan(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
+                      useSingles, fillZeros, device, ctx, estimateMags, planes_dev, chunk_sel, bank)
     try:
+        job.start()
+        return job.finish()
+    finally:
+        job.close()
+
+
+class StationScan(object):
+    """One station's scan in two halves: start() enqueues everything the GPU does for the
+    detection statistic (basis upload if needed, interleaving / filtering, one dtx_subspace_scan
+    per batch of chunks, the small results on their way to pinned host memory); finish() picks
+    the triggers from the candidate lists, runs dtx_trigger_stats and builds the rows."""
+
+    COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
+
+    def __init__(self, ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
+                 useSingles, fillZeros, device=0, ctx=None, estimateMags=True, planes_dev=None,
+                 chunk_sel=None, bank=None):
+        from .hip import HipContext
+        self.ss, self.sta = ss, sta
+        self.args = (utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags)
+        self.bank = bank if bank is not None else ss._detector_bank(sta, useSubSpaces, useSingles)
+        self.planes_dev, self.chunk_sel = planes_dev, chunk_sel
+        self.empty = (not self.bank[0]) or sta not in ss.cfetcher.data
+        self.own = ctx is None and not self.empty
+        self.ctx = HipContext(device) if self.own else ctx
+        self.batches = []
+
+    def close(self):
+        if self.own and self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    def start(self):
+        import torch
+        from ._lib import DetexHipError
+        if self.empty:
+            return
+        ss, sta, ctx = self.ss, self.sta, self.ctx
+        utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags = self.args
+        names, kinds, U, det_off, offsets, thr = self.bank
+        fetcher = ss.cfetcher
+        sr = fetcher.sampling_rate
+        Nc = len(fetcher.channels)
+        n = U.shape[1]
+        D = len(names)
         if getattr(ctx, '_basis_of', None) is not U:      # the same bank object: images are resident
             ctx.upload_basis(U, det_off, Nc)
             ctx._basis_of = U
@@ -232,36 +258,37 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
         raw = bool(getattr(fetcher, 'raw', False))
         dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
         counts = getattr(fetcher, 'counts', {}).get(sta)
+        planes_dev = self.planes_dev
+        self.planes_dev = None
         if counts is not None:
             # raw int32 counts in fragments: merged with zero fill on the device
             # (construct.py:1038 / 1070); the per-chunk trimming follows below
             planes_dev = _ingest_station(ctx, counts, Nc, data.shape[1])
         elif planes_dev is None:
             planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
+        sr_raw = sr
         if raw:
             # unfiltered planes stay on the device; each chunk is decimated, detrended and
             # band-passed separately, like the reference's per-chunk _applyFilter
             # (detect.py:231); after decimation everything runs at sr / decimate (detect.py:239)
             rawdev, xdev = planes_dev, None
-            sr_raw, sr = sr, sr / dec
+            sr = sr / dec
         else:
             # channel planes are interleaved on the device
             # (construct.py:977-978; dtx_preprocess without filter or detrend)
-            xdev = ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
+            rawdev, xdev = None, ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
         del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         thr_dev = torch.from_numpy(thr_arr).to(ctx.device)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
-        if chunk_sel is not None:
-            bounds = [bounds[i] for i in chunk_sel if i < len(bounds)]
+        if self.chunk_sel is not None:
+            bounds = [bounds[i] for i in self.chunk_sel if i < len(bounds)]
         if counts is not None and not fillZeros:
             bounds = _trim_to_gapfree(ctx, rawdev, counts, bounds, fetcher.sampling_rate, sta)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
         bounds = [b for b in bounds
                   if _dec_len(b[1], dec) * Nc > n and (_dec_len(b[1], dec) * Nc - n) // Nc + 1 >= 10]
-        LTA = triggerLTATime * sr
-        STA = triggerSTATime * sr
         need_stats = estimateMags or not fillZeros
         mbank = None
         if need_stats:
@@ -272,24 +299,56 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
                 held = (U, _MagBank(ss, names, kinds, U, det_off, ctx.device))
                 ctx._magbank = held
             mbank = held[1]
+        self.st = dict(names=names, kinds=kinds, offsets=offsets, thr_arr=thr_arr, thr_dev=thr_dev, hist=hist,
+                       bounds=bounds, Nc=Nc, n=n, D=D, sr=sr, LTA=triggerLTATime * sr, STA=triggerSTATime * sr,
+                       mbank=mbank)
         for (i0, i1, stride) in _chunk_batches(bounds):
             try:
-                _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, thr_dev, hist, calcHist, bounds, i0,
-                            i1, stride, raw, dec, rawdev if raw else None, xdev, Nc, n, D, sr,
-                            sr_raw if raw else sr, LTA, STA, fillZeros, estimateMags, mbank, rows)
+                s0, cnt = bounds[i0][0], bounds[i0][1]
+                M = _dec_len(cnt, dec) * Nc
+                if raw:
+                    planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt] for k in range(i0, i1)])
+                    if dec > 1:                                      # construct.py:1016-1017
+                        planes = ctx.decimate(planes, dec, sr_raw)
+                    xb = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
+                    xarg, xM, xstride, cstride = xb, None, None, int(xb.stride(0))
+                else:
+                    xb = xdev[s0 * Nc:]
+                    xarg, xM, xstride, cstride = xb, M, stride * Nc, stride * Nc
+                ds, fetch = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else i1 - i0,
+                                              thr=thr_dev, hist=hist if calcHist else None, cand_cap=CAND_CAP,
+                                              lazy=True)
+                self.batches.append((i0, i1, xb, M, cstride, ds, fetch))
             except DetexHipError as e:
-                # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
-                _warn('failing to run detector on %s from %s to %s: %s'
-                      % (sta, bounds[i0][2], bounds[i1 - 1][2] + bounds[i1 - 1][1] / sr, e))
-        ctx.sync()
-        h = hist.cpu().numpy()
-    finally:
-        if own:
-            ctx.close()
-    out = {k: pd.DataFrame(v, columns=cols) for k, v in rows.items()}
-    out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
-    out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
-    return out
+                self._skip(i0, i1, e)
+
+    def _skip(self, i0, i1, e):
+        # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
+        b = self.st['bounds']
+        _warn('failing to run detector on %s from %s to %s: %s'
+              % (self.sta, b[i0][2], b[i1 - 1][2] + b[i1 - 1][1] / self.st['sr'], e))
+
+    def finish(self):
+        import pandas as pd
+        from ._lib import DetexHipError
+        if self.empty:
+            return None
+        st = self.st
+        rows = {'ss': [], 'sg': []}
+        for (i0, i1, xb, M, cstride, ds, fetch) in self.batches:
+            try:
+                _finish_batch(self.ctx, self.sta, st, self.args[5], self.args[6], i0, i1, xb, M, cstride, ds,
+                              fetch, rows)
+            except DetexHipError as e:
+                self._skip(i0, i1, e)
+        self.batches = []
+        self.ctx.sync()
+        h = st['hist'].cpu().numpy()
+        names, kinds = st['names'], st['kinds']
+        out = {k: pd.DataFrame(v, columns=self.COLS) for k, v in rows.items()}
+        out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
+        out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
+        return out
 
 
 def _ingest_station(ctx, counts, Nc, T):
@@ -335,29 +394,15 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
     return out
 
 
-def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, thr_dev, hist, calcHist, bounds, i0, i1, stride,
-                raw, dec, rawdev, xdev, Nc, n, D, sr, sr_raw, LTA, STA, fillZeros, estimateMags, bank,
-                rows):
-    """One launch group of equal-length chunks: scan, trigger picking, trigger-time estimates."""
-    import torch
-    s0, cnt = bounds[i0][0], bounds[i0][1]
-    M = _dec_len(cnt, dec) * Nc
+def _finish_batch(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, rows):
+    """The host half of one launch group of equal-length chunks: candidates -> triggers ->
+    trigger-time estimates -> rows."""
+    names, kinds, offsets, thr_arr, thr_dev = st['names'], st['kinds'], st['offsets'], st['thr_arr'], st['thr_dev']
+    bounds, Nc, n, D, sr, LTA, STA, bank = (st['bounds'], st['Nc'], st['n'], st['D'], st['sr'], st['LTA'],
+                                            st['STA'], st['mbank'])
     nb = i1 - i0
-    if raw:
-        planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt] for k in range(i0, i1)])
-        if dec > 1:                                      # construct.py:1016-1017
-            planes = ctx.decimate(planes, dec, sr_raw)
-        xb = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
-        xarg, xM, xstride = xb, None, None
-        cstride = int(xb.stride(0))
-    else:
-        xb = xdev[s0 * Nc:]
-        xarg, xM, xstride = xb, M, stride * Nc
-        cstride = stride * Nc
-    cap = CAND_CAP
-    ds, res = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else nb,
-                                thr=thr_dev, hist=hist if calcHist else None, cand_cap=cap)
-    if res['ncand'] > cap:
+    res = fetch()
+    if res['ncand'] > CAND_CAP:
         # the candidate list is sized for ordinary thresholds; one that overflows is listed
         # again from the DS tensor at the size the device counted (no second scan; the
         # histogram already holds this batch)
@@ -366,7 +411,7 @@ def _scan_batch(ctx, ss, sta, names, kinds, offsets, thr_arr, thr_dev, hist, cal
         again = ctx.ds_post(ds, thr=thr_dev, want_max=False, cand_cap=int(res['ncand']) + 1024)
         res['cand'], res['ncand'] = again['cand'], again['ncand']
     P = int(ds.shape[2])
-    maxds = res['maxds'].cpu().numpy()
+    maxds = res['maxds'].cpu().numpy() if res['maxds'].is_cuda else res['maxds'].numpy()
     cb, cd, cp, cv = res['cand']
     # candidates grouped by (chunk, detector); pairs without one cannot trigger
     key = cb.astype(np.int64) * D + cd

@@ -118,6 +118,17 @@ class HipContext(object):
         self.D, self.n, self.Nc = D, int(Ut.shape[1]), int(Nc)
         self._basis_of = None          # scan_station's residency token: any direct upload clears it
 
+    def _check_out(self, out, nchunk, P):
+        """A caller-supplied DS tensor is addressed as ds[(chunk * D + det) * ldp + p]: it must be a
+        float32 CUDA tensor [nchunk, D, >= P] with unit window stride and rows packed per chunk."""
+        if (out.dtype != torch.float32 or not out.is_cuda or out.dim() != 3 or
+                int(out.shape[0]) != int(nchunk) or int(out.shape[1]) != self.D or
+                int(out.shape[2]) < max(int(P), 0) or out.stride(2) != 1 or
+                (out.shape[0] > 1 and out.stride(0) != self.D * out.stride(1)) or out.stride(1) < P):
+            raise ValueError('out must be a float32 CUDA tensor [nchunk=%d, D=%d, >= P=%d] with unit window '
+                             'stride and stride(0) == D * stride(1); got shape %s, strides %s, %s'
+                             % (nchunk, self.D, P, tuple(out.shape), tuple(out.stride()), out.dtype))
+
     def num_windows(self, M):
         return int(self.lib.dtx_num_windows(int(M), self.n, self.Nc))
 
@@ -147,6 +158,8 @@ class HipContext(object):
             ldp = (max(P, 1) + 63) // 64 * 64
             out = torch.empty((nchunk, self.D, ldp), dtype=torch.float32,
                               device=x.device)[:, :, :max(P, 0)]
+        else:
+            self._check_out(out, nchunk, P)
         rc = self.lib.dtx_subspace_ds(self.h, _ptr(x), int(M), int(chunk_stride),
                                       int(nchunk), _ptr(out), int(out.stride(1)))
         self._ck(rc, 'dtx_subspace_ds')
@@ -155,6 +168,9 @@ class HipContext(object):
     def _post_buffers(self, nchunk, D, dev, thr, hist, want_max, cand_cap):
         if hist is None:
             hist = torch.zeros((D, HIST_BINS), dtype=torch.int32, device=dev)
+        elif (hist.dtype != torch.int32 or not hist.is_cuda or tuple(hist.shape) != (D, HIST_BINS) or
+              not hist.is_contiguous()):
+            raise ValueError('hist must be a contiguous int32 CUDA tensor [D=%d, %d]' % (D, HIST_BINS))
         maxds = torch.empty((nchunk, D), dtype=torch.float32, device=dev) if want_max else None
         thr_t = key = val = cnt = None
         if thr is not None:
@@ -192,6 +208,8 @@ class HipContext(object):
             ldp = (max(P, 1) + 63) // 64 * 64
             out = torch.empty((nchunk, self.D, ldp), dtype=torch.float32,
                               device=x.device)[:, :, :max(P, 0)]
+        else:
+            self._check_out(out, nchunk, P)
         hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, self.D, x.device, thr, hist,
                                                                want_max, cand_cap)
         rc = self.lib.dtx_subspace_scan(self.h, _ptr(x), int(M), int(chunk_stride), int(nchunk),
@@ -199,11 +217,57 @@ class HipContext(object):
                                         _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
-            def fetch():
-                self.sync()          # the context's stream, whatever torch's current stream is now
-                return self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
-            return out, fetch
+            return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap)
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
+
+    def _lazy_fetch(self, hist, maxds, thr, key, val, cnt, cand_cap, fast=1 << 14):
+        """The small results of an enqueued scan copied to pinned host memory on a side stream
+        as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
+        whatever was enqueued on the context's stream after the scan (the next station's scan)."""
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
+        ev = torch.cuda.Event()
+        ev.record(main)
+        host = {}
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            if maxds is not None:
+                host['maxds'] = torch.empty(maxds.shape, dtype=maxds.dtype, pin_memory=True)
+                host['maxds'].copy_(maxds, non_blocking=True)
+                maxds.record_stream(side)
+            if thr is not None:
+                nf = min(int(cand_cap), int(fast))
+                host['cnt'] = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                host['key'] = torch.empty((nf,), dtype=torch.int64, pin_memory=True)
+                host['val'] = torch.empty((nf,), dtype=torch.float32, pin_memory=True)
+                host['cnt'].copy_(cnt, non_blocking=True)
+                host['key'].copy_(key[:nf], non_blocking=True)
+                host['val'].copy_(val[:nf], non_blocking=True)
+                for t in (cnt, key, val):
+                    t.record_stream(side)
+            done = torch.cuda.Event()
+            done.record(side)
+
+        def fetch():
+            done.synchronize()
+            res = dict(hist=hist, maxds=host.get('maxds', maxds), cand=None, ncand=0)
+            if thr is not None:
+                n = int(host['cnt'][0])
+                if n > len(host['key']):          # more candidates than the fast path copies: the plain way
+                    self.sync()
+                    return self._post_result(hist, host.get('maxds', maxds), thr, key, val, cnt, cand_cap)
+                res['ncand'] = n
+                k = host['key'][:n].numpy().astype(np.uint64)
+                v = host['val'][:n].numpy().copy()
+                order = np.argsort(k, kind='stable')
+                k, v = k[order], v[order]
+                res['cand'] = ((k >> np.uint64(48)).astype(np.int64),
+                               ((k >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64),
+                               (k & np.uint64(0xFFFFFFFF)).astype(np.int64), v)
+            return res
+        return fetch
 
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
         """Histogram / max / threshold candidates of a DS tensor [nchunk, D, P].
@@ -243,8 +307,14 @@ class HipContext(object):
         nchunk, D, P = (int(s) for s in ds.shape)
         if hist is None:
             hist = torch.zeros((D, nbins), dtype=torch.int32, device=ds.device)
+        elif (hist.dtype != torch.int32 or not hist.is_cuda or tuple(hist.shape) != (D, nbins) or
+              not hist.is_contiguous()):
+            raise ValueError('hist must be a contiguous int32 CUDA tensor [D=%d, nbins=%d]' % (D, nbins))
         if sums is None:
             sums = torch.zeros((D, 5), dtype=torch.float64, device=ds.device)
+        elif (sums.dtype != torch.float64 or not sums.is_cuda or tuple(sums.shape) != (D, 5) or
+              not sums.is_contiguous()):
+            raise ValueError('sums must be a contiguous float64 CUDA tensor [D=%d, 5]' % D)
         rc = self.lib.dtx_ds_moments(self.h, _ptr(ds), P, int(ds.stride(1)), nchunk, D,
                                      float(lo), float(hi), int(nbins), _ptr(hist), _ptr(sums))
         self._ck(rc, 'dtx_ds_moments')

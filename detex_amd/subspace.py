@@ -560,8 +560,7 @@ class SubSpace(object):
         detrended and band-passed (clusters.filt) chunk by chunk on the device."""
         import torch
         from . import parallel
-        from .detect import scan_station
-        from .hip import HipContext
+        from .detect import StationScan
         if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
             _error('multiprocessing and trigcon other than 0 not supported')
         if classifyEvents is not None or utcSaves is not None:
@@ -578,6 +577,28 @@ class SubSpace(object):
         if stations:
             up.start(stations[0])
         out = {'ss_df': [], 'sg_df': []}
+
+        def collect(job):
+            """Second half of a station: triggers, trigger-time estimates, rows; gathered over
+            the ranks in a multi-process run."""
+            try:
+                res = job.finish()
+            finally:
+                job.close()
+            if world > 1:
+                res = _merge_ranks(parallel.gather_rows(res))
+            if res is None:
+                return
+            for kind in ('ss', 'sg'):
+                if len(res[kind]):
+                    out[kind + '_df'].append(res[kind])
+            self.histSubSpaces[job.sta] = res['hist_ss']
+            self.histSingles[job.sta] = res['hist_sg']
+
+        # Two stations are in flight: station i + 1's scan is enqueued (and its data on the way up)
+        # before station i's candidates are fetched, so the GPU works through the next scan while the
+        # host picks triggers and builds rows for this one.
+        pending = None
         for i, sta in enumerate(stations):
             planes = up.get(sta)
             if i + 1 < len(stations):
@@ -597,21 +618,22 @@ class SubSpace(object):
                 nchunks = len(self.cfetcher.chunk_bounds(sta, utcStart, utcEnd))
                 per = max(1, int(round(86400.0 / self.cfetcher.conDatDuration)))
                 chunk_sel = parallel.shard_chunks(nchunks, rank, world, per_unit=per)
-            res = scan_station(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime,
-                               calcHist, useSubSpaces, useSingles, fillZeros, device, ctx,
-                               estimateMags=estimateMags, planes_dev=planes, chunk_sel=chunk_sel,
-                               bank=bank)
+            job = StationScan(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
+                              useSubSpaces, useSingles, fillZeros, device, ctx, estimateMags,
+                              planes_dev=planes, chunk_sel=chunk_sel, bank=bank)
             del planes
+            job.start()
             up.release()
-            if world > 1:
-                res = _merge_ranks(parallel.gather_rows(res))
-            if res is None:
-                continue
-            for kind in ('ss', 'sg'):
-                if len(res[kind]):
-                    out[kind + '_df'].append(res[kind])
-            self.histSubSpaces[sta] = res['hist_ss']
-            self.histSingles[sta] = res['hist_sg']
+            if pending is not None:
+                collect(pending)
+            pending = job
+            if not own_ctx:
+                # a context handed in by the caller serves every station in turn: its basis and
+                # training events are replaced by the next start(), so this station is finished first
+                collect(pending)
+                pending = None
+        if pending is not None:
+            collect(pending)
         cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
                 'ProEnMag']
         for k in out:

@@ -83,7 +83,8 @@ class OracleCtx(object):
         self.calls.append(('scan', len(chunks), M))
         if hist is None:
             hist = torch.zeros((self.D, 400), dtype=torch.int32)
-        return torch.from_numpy(ds), self._post(ds, thr, hist, cand_cap)
+        res = self._post(ds, thr, hist, cand_cap)
+        return torch.from_numpy(ds), ((lambda: res) if lazy else res)
 
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
         if hist is None:

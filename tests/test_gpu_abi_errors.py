@@ -93,3 +93,34 @@ def test_host_entry_points(raw):
     iu = np.triu_indices(5, 1)
     assert np.max(np.abs(cc - rcc[iu[0], iu[1] - 1])) <= 1e-5
     assert np.array_equal(lag, rlag[iu[0], iu[1] - 1].astype(np.int32))
+
+
+def test_wrapper_rejects_misshapen_outputs():
+    """A caller-supplied DS / histogram / sums tensor of the wrong shape, dtype or pitch is refused
+    before the kernels would write through it."""
+    import numpy as np
+    import torch
+    from detex_amd.hip import HipContext
+    ctx = HipContext(0)
+    U = np.random.RandomState(0).standard_normal((3, 90)).astype(np.float32)
+    ctx.upload_basis(U, [0, 2, 3], 3)
+    x = torch.randn(2, 3000, device='cuda')
+    P = ctx.num_windows(3000)
+    good = torch.empty((2, 2, P + 5), device='cuda')[:, :, :P]
+    ctx.subspace_ds(x, out=good)
+    for bad in (torch.empty((2, 3, P), device='cuda'), torch.empty((2, 2, P - 1), device='cuda'),
+                torch.empty((2, 2, P), device='cuda', dtype=torch.float64),
+                torch.empty((2, 2, 2 * P), device='cuda')[:, :, ::2],
+                torch.empty((1, 2, P), device='cuda'), torch.empty((2, 2, P))):
+        with pytest.raises(ValueError):
+            ctx.subspace_ds(x, out=bad)
+        with pytest.raises(ValueError):
+            ctx.subspace_scan(x, out=bad, thr=np.float32(0.5))
+    with pytest.raises(ValueError):
+        ctx.subspace_scan(x, thr=np.float32(0.5), hist=torch.zeros((2, 399), dtype=torch.int32, device='cuda'))
+    ds = ctx.subspace_ds(x)
+    with pytest.raises(ValueError):
+        ctx.ds_moments(ds, sums=torch.zeros((2, 5), dtype=torch.float32, device='cuda'))
+    with pytest.raises(ValueError):
+        ctx.ds_moments(ds, hist=torch.zeros((3, 400), dtype=torch.int32, device='cuda'))
+    ctx.close()
