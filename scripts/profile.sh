@@ -9,8 +9,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"
-# 1. kernel trace + stats (no counters)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# 1. kernel trace + stats (no counters), on the step / warm-up counts the driver's bench run uses, so that the
+#    per-kernel average is over warm launches like the live HIP-event figure in the bench line
+BENCH_T="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH_T > $OUT/trace.log 2>&1
 # 2..4 counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
