@@ -147,7 +147,7 @@ def _checkClusterInputs(filt, dtype, trim, decimate):
 
 
 def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=None,
-                  templateKey=None, trim=[10, 120], saveclust=False, fileName='clust.pkl',
+                  templateKey=None, trim=[10, 120], saveclust=True, fileName='clust.pkl',
                   decimate=None, dtype='double', eventsOnAllStations=False,
                   enforceOrigin=False, fillZeros=False, phases=None, device=0, ctx=None):
     """Create a ClusterStream (detex/construct.py:25-171).
@@ -199,7 +199,9 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
     clust._mptd = {r.Station: r.MPtd for _, r in TRDF.iterrows()}
     clust._channels = {r.Station: r.Channels for _, r in TRDF.iterrows()}
     if saveclust:
-        clust.write()
+        from . import parallel
+        if parallel.dist_info()[0] == 0:       # one process per GPU: rank 0 writes the pickle
+            clust.write()
     return clust
 
 
