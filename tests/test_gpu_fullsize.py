@@ -333,3 +333,24 @@ def test_config1_full_workflow(tmp_path):
     for nm in names:
         h = ss.histSubSpaces['TA.M17A'][nm]
         assert h.sum() == hist[nm].sum() and np.abs(h - hist[nm]).sum() <= 8
+
+
+def test_bench_config4_mode_on_one_gpu():
+    """bench.py --config 4 (BASELINE configs[3]: stations x days dealt round-robin, per-station
+    bases broadcast and resident, strong scaling) at a reduced count on the one GPU of this box:
+    the unit dealing, per-station contexts, device-side noise + planted events (every plant must
+    come back as a candidate of its detector: asserted inside the bench) and the JSON contract."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', '4', '--stations', '2',
+                        '--days', '2', '--chunks', '3', '--steps', '1', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['unit'] == 'windows/s' and d['scaling'] == 'strong' and d['n_gpus'] == 1
+    assert d['config']['workload'].startswith('configs[3]: 2 stations x 2 days = 4 station-days')
+    P = (int(round(3720.0 * 100.0)) * 3 - 9000) // 3 + 1
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 4 * 3 * P) <= 1e-6 * 4 * 3 * P
