@@ -267,6 +267,10 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   }
 }
 
+#ifndef DTX_PP_TILE
+#define DTX_PP_TILE 24           // blocks per L2 tile of the ping-pong kernel (measured: 8 .. 32 within 1 %)
+#endif
+constexpr int kPPTileB = DTX_PP_TILE;
 // ---------------------------------------------------------------- ping-pong variant
 // The same work with TWO half-workgroups of 512 threads in one 1024-thread workgroup (16 waves,
 // four per SIMD, 128 registers each; 112 used, no scratch).  The halves share the block spectra
@@ -291,12 +295,17 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   static_assert(NCH > 0, "the ping-pong kernel keeps the block spectra in LDS");
   __shared__ c32 lds[kLdsC + NCH * kXh];
   const int half = threadIdx.x >> 9, tid = threadIdx.x & (kT - 1);
+  // Work order (workgroups are dealt to the XCDs round-robin, each XCD runs a contiguous piece of
+  // this list): tiles of kPPTileB blocks; consecutive tiles are the SAME blocks under the next
+  // unit, so an XCD keeps a tile's block spectra (kPPTileB x 96 KB) in its 4 MB L2 while the units'
+  // basis spectra (16 pairs x 192 KB = 3 MB) stream through -- with the units outermost every
+  // unit re-fetched all block spectra from beyond L2 (13 x 172 MB per station-day: most of the
+  // 4.2 GB of fabric-side reads) and the kernel ran 8 % longer.
   const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
-  const int tile = logical / kTile, slot = logical - tile * kTile;
-  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
-  const int unit = tu * kTileU + slot % kTileU;
-  const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
-  if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
+  const int tile = logical / kPPTileB, slot = logical - tile * kPPTileB;
+  const int tb = tile / a.nunits, unit = tile - tb * a.nunits;
+  const int cb = tb * kPPTileB + slot;                 // chunk * nblk + blk
+  if (cb >= a.nchunk * a.nblk) return;
   const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;
   const int4 ui0 = a.unit[unit];
   // this half's run of pairs
@@ -542,7 +551,9 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
   // closed once they hold kUnitPairs = 8 (a detector with more pairs is a unit of its own) -- the
   // block spectra a workgroup stages in LDS serve all its pairs
-  constexpr int kUnitPairs = DTX_FFT_UNIT;
+  // 16 pairs where the ping-pong kernel can run (its fill / drain rounds amortise over more pairs and
+  // its L2 tiles are block-major), 8 for the one-group kernel (tuned in round 1)
+  const int kUnitPairs = (f.nseg == 1 && (Nc == 1 || Nc == 3)) ? 2 * DTX_FFT_UNIT : DTX_FFT_UNIT;
   std::vector<int4> units;
   std::vector<int2> pdet;
   std::vector<int2> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
@@ -629,9 +640,12 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
   const int Nc = ctx->Nc, V = f.V;
   const int nblk = (int)((P + V - 1) / V);
+  const bool pp = f.pingpong && DTX_FFT_XLDS && f.nseg == 1 && (Nc == 3 || Nc == 1);   // launch_fft's choice
   const int ntile_u = (f.nunits + kTileU - 1) / kTileU;
-  const int ntile_b = (int)(((int64_t)nchunk * nblk + kTileB - 1) / kTileB);
-  const int64_t per_xcd = ((int64_t)ntile_u * ntile_b * kTile + 7) / 8;
+  const int ntile_b = pp ? (int)(((int64_t)nchunk * nblk + kPPTileB - 1) / kPPTileB)
+                         : (int)(((int64_t)nchunk * nblk + kTileB - 1) / kTileB);
+  const int64_t per_xcd = pp ? ((int64_t)f.nunits * ntile_b * kPPTileB + 7) / 8
+                             : ((int64_t)ntile_u * ntile_b * kTile + 7) / 8;
   const int64_t grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;
