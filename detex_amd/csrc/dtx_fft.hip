@@ -147,12 +147,18 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   const int tid = threadIdx.x;
   // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
   // every XCD a contiguous run of the logical work list, and order that list in tiles of
-  // kTileU units x kTileB blocks (1 x 32): the ~32 workgroups an XCD runs at a time then read
-  // the same unit's basis spectra (pairs * Nc * 64 KB = 1.5 MB for eight pairs) and 32 blocks'
-  // spectra (Nc * 32 KB each, 3 MB) instead of unrelated ones.
+  // kTileU units x kTileB blocks (1 x 16): the workgroups an XCD runs at a time then read the same
+  // unit's basis spectra and the same few blocks' spectra instead of unrelated ones; consecutive
+  // tiles are the same blocks under the next unit, so the block spectra are fetched into the
+  // L2 once per tile, not once per unit.
   const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
   const int tile = logical / kTile, slot = logical - tile * kTile;
+#if DTX_FFT_BLOCK_MAJOR
+  const int ntu = (a.nunits + kTileU - 1) / kTileU;
+  const int tb = tile / ntu, tu = tile - tb * ntu;     // consecutive tiles: the same blocks under the next unit
+#else
   const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
+#endif
   const int unit = tu * kTileU + slot % kTileU;
   const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
   if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;

@@ -26,7 +26,10 @@ constexpr int kXlMax = 3;            // channels whose block spectra fit in LDS 
 #define DTX_FFT_TILEU 1                 // measured (200 basis vectors): 2 x 16 tiles 6.21 ms, 1 x 32 5.85 ms
 #endif
 #ifndef DTX_FFT_TILE
-#define DTX_FFT_TILE 32
+#define DTX_FFT_TILE 16                  // blocks per L2 tile of the one-group kernel (block-major order: 16 measured best)
+#endif
+#ifndef DTX_FFT_BLOCK_MAJOR
+#define DTX_FFT_BLOCK_MAJOR 1            // consecutive tiles = the same blocks under the next unit (long templates: 15.6 -> 14.3 ms)
 #endif
 constexpr int kTileU = DTX_FFT_TILEU, kTileB = DTX_FFT_TILE / DTX_FFT_TILEU, kTile = kTileU * kTileB;
 #ifndef DTX_FFT_WAVES
