@@ -65,6 +65,8 @@ int dtx_ctx_create(int device, void* stream, int own_stream, dtx_ctx** out) {
   DtxDeviceGuard g(device);
   dtx_ctx* c = new dtx_ctx();
   c->device = device;
+  if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->ncu <= 0)
+    c->ncu = 256;
   if (!own_stream) {
     c->stream = (hipStream_t)stream;   // NULL = the default stream
   } else {

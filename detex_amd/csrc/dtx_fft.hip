@@ -33,7 +33,9 @@
 // instead of sqrt(n) (measured 2e-7 at DS = 1 against 2e-6 for the MFMA engines).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "dtx_fftcore.h"
 
@@ -77,6 +79,14 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
   }
 }
 
+#ifndef DTX_PP_P1_IN_MAC
+#define DTX_PP_P1_IN_MAC 1     // the transform's first pass: 0 in the front, 1 at the end of the MAC round, 2 staggered
+#endif
+#ifndef DTX_PP_ABLATE
+#define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong): 1 no basis-spectrum loads, 2 no transform fronts
+#endif
+constexpr int kMaxGroups = 32;
+[[maybe_unused]] constexpr int kStampRounds = 24, kStampWgs = 56, kStampEvery = 29;   // -DDTX_PP_STAMPS builds
 struct FftArgs {
   const c32* xh;        // [nchunk][nblkx][Nc][kXh] half spectra, nblkx = nblk + nseg - 1
   const c32* W;         // [npairs][Nc][kN]
@@ -90,6 +100,15 @@ struct FftArgs {
   int64_t Ppad, ldp, P;
   int Nc, D, V, nblk, nchunk;
   int nunits, ntile_b, per_xcd;   // tiling of the grid (launch_fft)
+  // ping-pong kernel: the pairs are stored half 0's first (every unit's share, in unit order), then
+  // half 1's; upre[u] = {pairs of half 0, pairs of half 1} in the units before u.  The first nfull
+  // blocks get one workgroup each that runs ALL units; each of the other nrem blocks is split over
+  // ngroups workgroups, group g running units gb[g] .. gb[g + 1] - 1 (dtx_fft_scan sizes this so
+  // that the last wave of workgroups is short)
+  const int2* upre;     // [nunits + 1]
+  int nfull, nrem, ngroups;
+  short gb[kMaxGroups + 1];
+  long long* stamps;    // diagnostic builds (-DDTX_PP_STAMPS): [56 workgroups][2 halves][kStampRounds][16] s_memtime
   int nseg, nblkx;      // template segments (virtual channels per real channel), block spectra stored per chunk
 };
 
@@ -273,10 +292,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   }
 }
 
-#ifndef DTX_PP_TILE
-#define DTX_PP_TILE 24           // blocks per L2 tile of the ping-pong kernel (measured: 8 .. 32 within 1 %)
-#endif
-constexpr int kPPTileB = DTX_PP_TILE;
 // ---------------------------------------------------------------- ping-pong variant
 // The same work with TWO half-workgroups of 512 threads in one 1024-thread workgroup (16 waves,
 // four per SIMD, 128 registers each; 112 used, no scratch).  The halves share the block spectra
@@ -300,24 +315,25 @@ template <int VM, bool TWO, int NCH>
 __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   static_assert(NCH > 0, "the ping-pong kernel keeps the block spectra in LDS");
   __shared__ c32 lds[kLdsC + NCH * kXh];
-  const int half = threadIdx.x >> 9, tid = threadIdx.x & (kT - 1);
-  // Work order (workgroups are dealt to the XCDs round-robin, each XCD runs a contiguous piece of
-  // this list): tiles of kPPTileB blocks; consecutive tiles are the SAME blocks under the next
-  // unit, so an XCD keeps a tile's block spectra (kPPTileB x 96 KB) in its 4 MB L2 while the units'
-  // basis spectra (16 pairs x 192 KB = 3 MB) stream through -- with the units outermost every
-  // unit re-fetched all block spectra from beyond L2 (13 x 172 MB per station-day: most of the
-  // 4.2 GB of fabric-side reads) and the kernel ran 8 % longer.
-  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
-  const int tile = logical / kPPTileB, slot = logical - tile * kPPTileB;
-  const int tb = tile / a.nunits, unit = tile - tb * a.nunits;
-  const int cb = tb * kPPTileB + slot;                 // chunk * nblk + blk
-  if (cb >= a.nchunk * a.nblk) return;
-  const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;
-  const int4 ui0 = a.unit[unit];
-  // this half's run of pairs
-  const int4 ui = make_int4(half ? ui0.x + ui0.z : ui0.x, half ? ui0.y - ui0.z : ui0.z, 0, 0);
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 9), tid = threadIdx.x & (kT - 1);   // (uniform per wave)
+  // Work order: the first nfull workgroups each take one whole block (all units: the block spectra
+  // are staged once and the round pipeline fills and drains once); the rest take (group of units,
+  // block), group-major.  Workgroups that run at the same time walk through the same basis
+  // spectra, which therefore stay in the XCDs' L2s whatever blocks they are paired with.
+  int cb, u0, u1;
+  if ((int)blockIdx.x < a.nfull) {
+    cb = blockIdx.x; u0 = 0; u1 = a.nunits;
+  } else {
+    const int j = (int)blockIdx.x - a.nfull, grp = j / a.nrem;
+    cb = a.nfull + j - grp * a.nrem; u0 = a.gb[grp]; u1 = a.gb[grp + 1];
+  }
+  const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;   // cb = chunk * nblk + blk
+  // this half's pairs: its share of every unit of the group -- whole detectors, contiguous in memory
+  const int2 g0 = a.upre[u0], g1 = a.upre[u1];
+  const int pbase = half ? a.upre[a.nunits].x + g0.y : g0.x;
+  const int nmine = half ? g1.y - g0.y : g1.x - g0.x;
   // half h runs phases q = 0 .. 2 n_h (the last one only finishes its last pair), one round later for h = 1
-  const int rounds = max(2 * ui0.z + 1, 2 * (ui0.y - ui0.z) + 2);
+  const int rounds = max(2 * (g1.x - g0.x) + 1, 2 * (g1.y - g0.y) + 2);
   const int64_t p0 = (int64_t)blk * a.V;
   const LdsBases lb = lds_bases(tid);
   float acc0[VM], acc1[TWO ? VM : 1];
@@ -347,98 +363,180 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       dst[threadIdx.x + 2 * kT * q] = src[threadIdx.x + 2 * kT * q];
     __syncthreads();
   }
+  // Where the transform's register-only first pass runs.  Waves 0-3 of a half: at the end of their
+  // MAC round; waves 4-7 (their partners on the four SIMDs): after the first barrier of the front.
+  // The partners then run half a pass apart: one's LDS exchange overlaps the other's arithmetic
+  // instead of all eight waves queueing at the LDS write path and then at the vector ALUs.
+#if DTX_PP_P1_IN_MAC == 2
+  const int p1_mode = __builtin_amdgcn_readfirstlane((tid >> 8) & 1) ? 2 : 1;
+#else
+  const int p1_mode = DTX_PP_P1_IN_MAC;
+#endif
   c32 z[16];
+#ifdef DTX_PP_STAMPS
+  Stamp stamp{nullptr, 0};
+  Stamp* const st = &stamp;
+  const bool stamped = a.stamps && tid == 0 && blockIdx.x % kStampEvery == 0 && (int)(blockIdx.x / kStampEvery) < kStampWgs;
+#else
+  Stamp* const st = nullptr;
+#endif
 #pragma nounroll
   for (int r = 0; r < rounds; ++r) {
     const int q = r - half;                    // this half's phase
+#ifdef DTX_PP_STAMPS
+    stamp.p = (stamped && r < kStampRounds) ? a.stamps + ((((int64_t)(blockIdx.x / kStampEvery) * 2 + half) * kStampRounds + r) * 16) : nullptr;
+    stamp.n = 0;
+    DTX_STAMP(st);     // 0: round start
+#endif
     if (q & 1) {
       // ---- front of the transform of pair q / 2 (its MAC ran in the previous round): everything
       // that touches the image, ending with the cross-wave reads.  The register-only tail and
       // the epilogue run at the head of this half's next round, beside the other half's transform.
       const int pr = q >> 1;
-      if (q >= 0 && pr < ui.y) {
-        fft8192<1, true, true>(z, lds, lb, a.tab, tid);    // two workgroup barriers inside
+      if (q >= 0 && pr < nmine && DTX_PP_ABLATE != 2) {       // (2: timing only, no transform fronts)
+        fft8192<1, true, true>(z, lds, lb, a.tab, tid, st, p1_mode);    // two workgroup barriers inside
       } else {
         __syncthreads();
         __syncthreads();
       }
     } else {
+      const bool fin = q >= 2 && (q >> 1) - 1 < nmine;   // a pair's transform to finish
+      const bool mac = q >= 0 && (q >> 1) < nmine;       // a pair's products to form
+      int oe;                                  // nothing below is hoisted out of the round loop
+      asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
+      const int te = tid + oe;
+      // ---- issued before the barrier, landing while this half waits for the image to change
+      // hands: the tail's twiddles, the window means, (when the pair closes its detector) the
+      // window norms
+      float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+      int2 pd = make_int2(-1, -1);
+      c32 p4[3];
+      float mu[VM], dn[VM];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) p4[e] = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < VM; ++m) mu[m] = dn[m] = 0.f;
+      if (fin) {
+        const int pr = pbase + (q >> 1) - 1;         // global pair index
+        pi = a.pinfo[pr];
+        pd = a.pdet[pr];
+        fft8192_back_twiddles<1>(p4, a.tab, te);
+#pragma unroll
+        for (int m = 0; m < VM; ++m) mu[m] = (mean + 512 * m)[te];
+        if (pd.x >= 0) {
+#pragma unroll
+          for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
+      DTX_STAMP(st);         // 1: barrier 1 passed
       // ---- tail of the transform of pair q / 2 - 1 and its epilogue
-      if (q >= 2 && (q >> 1) - 1 < ui.y) {
-        const int pr = (q >> 1) - 1;
-        fft8192_back<1>(z, a.tab, tid);
-        int oe;                                  // nothing below is hoisted out of the round loop
-        asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
-        const int te = tid + oe;
-        const float4 pi = a.pinfo[ui.x + pr];
-        const int2 pd = a.pdet[ui.x + pr];
-        const bool two = TWO && pd.y >= 0;
+      const bool two = TWO && pd.y >= 0;
+      const bool closes = fin && pd.x >= 0;
+      if (fin) {
+        fft8192_back_compute<1>(z, p4);
+        DTX_STAMP(st);                             // 2: transform tail done
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
-          const float mu = (mean + 512 * m)[te];
           /* explicit fma chain: every instantiation of the kernels rounds the same way */
-          const float re = __fmaf_rn(-pi.x, mu, z[m].x), im = __fmaf_rn(-pi.y, mu, z[m].y);
+          const float re = __fmaf_rn(-pi.x, mu[m], z[m].x), im = __fmaf_rn(-pi.y, mu[m], z[m].y);
           const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
           acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
           if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
         }
-        if (pd.x >= 0) {
-          float* row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;     // uniform
-          float* row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
-          const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
+        DTX_STAMP(st);                             // 3: accumulated
+      }
+      // the detector's statistic, stored below once the next pair's first loads are on their way
+      // (loads queued behind stores would wait for the stores' acknowledgements)
+      float* row0 = nullptr;
+      float* row1 = nullptr;
+      const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
+      if (closes) {
+        row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;         // uniform
+        row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
+#pragma unroll
+        for (int m = 0; m < VM; ++m) {
+          float v0 = (dn[m] > 0.f) ? __fdiv_rn(acc0[m], dn[m]) : 0.f;
+          if (__builtin_isinf(v0)) v0 = 0.f;
+          acc0[m] = v0;
+          if (TWO) {
+            float v1 = (dn[m] > 0.f) ? __fdiv_rn(acc1[m], dn[m]) : 0.f;
+            if (__builtin_isinf(v1)) v1 = 0.f;
+            acc1[m] = v1;
+          }
+        }
+      }
+      auto store_ds = [&]() {
+        if (closes) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
             if (te + 512 * m < lim) {
-              const float dn = (den + 512 * m)[te];
-              float v0 = (dn > 0.f) ? __fdiv_rn(acc0[m], dn) : 0.f;
-              if (__builtin_isinf(v0)) v0 = 0.f;
-              DTX_DS_STORE(v0, &(row0 + 512 * m)[te]);
-              if (two) {
-                float v1 = (dn > 0.f) ? __fdiv_rn(acc1[m], dn) : 0.f;
-                if (__builtin_isinf(v1)) v1 = 0.f;
-                DTX_DS_STORE(v1, &(row1 + 512 * m)[te]);
-              }
+              DTX_DS_STORE(acc0[m], &(row0 + 512 * m)[te]);
+              if (two) DTX_DS_STORE(acc1[m], &(row1 + 512 * m)[te]);
             }
             acc0[m] = 0.f;
             if (TWO) acc1[m] = 0.f;
           }
         }
-      }
+      };
+      DTX_STAMP(st);                               // 4: statistic formed
       __builtin_amdgcn_sched_barrier(0);
-      // ---- MAC of pair q / 2: half-channel batches of eight loads (the register budget is 128)
-      if (q >= 0 && (q >> 1) < ui.y) {
-        const int pr = q >> 1;
+      // ---- MAC of pair q / 2: half-channel batches of four 16-byte loads, three batches in flight
+      if (mac) {
+        const int pr = pbase + (q >> 1);
         int oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
         const int xlo_ = xlo + oz, xhi_ = xhi + oz, wlo_ = wlo + oz;
         auto x_slot = [&](int r) { return r < 8 ? xlo_ + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi_ - 64 * r); };
-        const c32* wp = a.W + (int64_t)(ui.x + pr) * NCH * kN;   // uniform
+        const float4* wq = reinterpret_cast<const float4*>(a.W + (int64_t)pr * NCH * kN) + wlo_;   // + lane
+        constexpr int kBatches = 2 * NCH, kDepth = kBatches < 3 ? kBatches : 3;
+        float4 pw[kDepth][4];
+        auto issue = [&](auto bc) {
+          constexpr int b = bc, c = b >> 1, h2 = b & 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#if DTX_PP_ABLATE == 1     // timing only: no basis-spectrum loads
+            pw[b % kDepth][j] = make_float4(1.f, 0.f, 1.f, 0.f);
+#else
+            pw[b % kDepth][j] = (wq + c * (kN / 2) + 64 * (4 * h2 + j))[0];
+#endif
+        };
+        dtx::static_for<0, kDepth>([&](auto bc) { issue(bc); });
+        __builtin_amdgcn_sched_barrier(0);
+        store_ds();
 #pragma unroll
         for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-#pragma nounroll
-        for (int c = 0; c < NCH; ++c) {      // (unrolled, the scheduler hoists the next channel's loads: spills)
-          const c32* wc = wp + (int64_t)c * kN;
-          __builtin_amdgcn_sched_barrier(0);
-          c32 pw[16];                        // the whole channel's basis spectrum in flight at once
-          w_load16(wc, wlo_, pw);
+        __builtin_amdgcn_sched_barrier(0);
+        dtx::static_for<0, kBatches>([&](auto bc) {
+          constexpr int b = bc, c = b >> 1, h2 = b & 1;
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
+          for (int hh = 0; hh < 2; ++hh) {
             c32 px[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) px[e] = fix_x(xs[c * kXh + x_slot(4 * h + e)], 4 * h + e);
+            for (int e = 0; e < 4; ++e) px[e] = fix_x(xs[c * kXh + x_slot(8 * h2 + 4 * hh + e)], 8 * h2 + 4 * hh + e);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int m = 4 * h + e;
-              z[m].x += pw[m].x * px[e].x - pw[m].y * px[e].y;
-              z[m].y += pw[m].x * px[e].y + pw[m].y * px[e].x;
+              const int m = 8 * h2 + 4 * hh + e;
+              const float4 t = pw[b % kDepth][2 * hh + (e >> 1)];
+              const c32 w = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+              z[m].x += w.x * px[e].x - w.y * px[e].y;
+              z[m].y += w.x * px[e].y + w.y * px[e].x;
             }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (b + kDepth < kBatches) {
+            issue(std::integral_constant<int, b + kDepth>{});
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        });
+        DTX_STAMP(st);                             // 5: products done
+        if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
+      } else {
+        store_ds();
       }
       __syncthreads();                           // the second barrier of the round
+      DTX_STAMP(st);                               // 6: barrier 2 passed
     }
   }
 }
@@ -446,7 +544,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   const bool xl = DTX_FFT_XLDS && a.nseg == 1;   // block spectra LDS-resident: single-segment templates
-  if (ctx->fft.pingpong && xl && (a.Nc == 3 || a.Nc == 1)) {
+  if (ctx->fft.pingpong) {
     if (two && a.Nc == 3) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 3>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
     else if (two) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 1>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
     else if (a.Nc == 3) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, false, 3>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
@@ -532,6 +630,7 @@ void dtx_fft_free(dtx_ctx* ctx) {
   if (f.pinfo_dev) (void)hipFree(f.pinfo_dev);
   if (f.pdet_dev) (void)hipFree(f.pdet_dev);
   if (f.prow_dev) (void)hipFree(f.prow_dev);
+  if (f.upre_dev) (void)hipFree(f.upre_dev);
   f = DtxFft();
 }
 
@@ -557,22 +656,24 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
   // closed once they hold kUnitPairs = 8 (a detector with more pairs is a unit of its own) -- the
   // block spectra a workgroup stages in LDS serve all its pairs
-  // 16 pairs where the ping-pong kernel can run (its fill / drain rounds amortise over more pairs and
-  // its L2 tiles are block-major), 8 for the one-group kernel (tuned in round 1)
-  const int kUnitPairs = (f.nseg == 1 && (Nc == 1 || Nc == 3)) ? 2 * DTX_FFT_UNIT : DTX_FFT_UNIT;
+  const int kUnitPairs = DTX_FFT_UNIT;
   std::vector<int4> units;
   std::vector<int2> pdet;
   std::vector<int2> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
   int ufirst = 0;
-  int pp_rounds = 0;        // rounds the ping-pong kernel needs over all units (ideal: one per pair)
+  int cum0 = 0, cum1 = 0;   // pairs given to half 0 / half 1 of the ping-pong kernel so far
   auto close_unit = [&]() {
     const int np = (int)prow.size() - ufirst;
     if (np > 0) {
-      // pairs [0, z) go to half 0 of the ping-pong kernel: the detector boundary nearest to np / 2
-      int best = np, bestd = np;
-      for (int q = 1; q <= np; ++q)
-        if (pdet[ufirst + q - 1].x >= 0 && std::abs(2 * q - np) < bestd) { best = q; bestd = std::abs(2 * q - np); }
-      pp_rounds += std::max(2 * best, 2 * (np - best) + 1);       // + one short finishing round
+      // pairs [0, z) go to half 0 of the ping-pong kernel: the detector boundary that leaves the two
+      // halves' running totals closest (any run of units is then balanced to within a detector or two)
+      int best = np, bestd = 1 << 30;
+      for (int q = 0; q <= np; ++q) {
+        if (q > 0 && pdet[ufirst + q - 1].x < 0) continue;        // inside a detector
+        const int dd = std::abs((cum0 + q) - (cum1 + np - q));
+        if (dd < bestd) { best = q; bestd = dd; }
+      }
+      cum0 += best; cum1 += np - best;
       units.push_back(make_int4(ufirst, np, best, 0));
     }
     ufirst = (int)prow.size();
@@ -599,10 +700,30 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   close_unit();
   f.nunits = (int)units.size();
   f.npairs = (int)prow.size();
+  std::vector<int2> upre(units.size() + 1);
+  for (size_t u = 0; u < units.size(); ++u)
+    upre[u + 1] = make_int2(upre[u].x + units[u].z, upre[u].y + units[u].y - units[u].z);
   {
     const char* e = getenv("DTX_FFT_PP");
-    // worth it when the halves are balanced: at least 0.8 pairs per round over the whole basis
-    f.pingpong = 5 * f.npairs >= 4 * pp_rounds && f.nseg == 1 && !(e && e[0] == '0');
+    // the ping-pong kernel keeps the block spectra in LDS (single-segment templates, one or three
+    // channels) and is worth it when the halves are balanced: at least 0.8 pairs per round
+    const int pp_rounds = std::max(2 * cum0 + 1, 2 * cum1 + 2);
+    f.pingpong = DTX_FFT_XLDS && f.nseg == 1 && (Nc == 1 || Nc == 3) && 5 * f.npairs >= 4 * pp_rounds &&
+                 !(e && e[0] == '0');
+  }
+  if (f.pingpong) {
+    // store the pairs half 0's first: each half-workgroup then walks a contiguous run of pairs
+    std::vector<int2> pdet2, prow2;
+    for (int h = 0; h < 2; ++h)
+      for (const int4& un : units)
+        for (int q = h ? un.z : 0; q < (h ? un.y : un.z); ++q) {
+          pdet2.push_back(pdet[un.x + q]);
+          prow2.push_back(prow[un.x + q]);
+        }
+    pdet.swap(pdet2);
+    prow.swap(prow2);
+    f.unit_pairs.resize(units.size());
+    for (size_t u = 0; u < units.size(); ++u) f.unit_pairs[u] = units[u].y;
   }
 
   const int nvc = Nc * f.nseg;
@@ -619,11 +740,13 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   DTX_HIP(ctx, hipMalloc(&f.pinfo_dev, (size_t)f.npairs * sizeof(float4)));
   DTX_HIP(ctx, hipMalloc(&f.pdet_dev, pdet.size() * sizeof(int2)));
   DTX_HIP(ctx, hipMalloc(&f.prow_dev, prow.size() * sizeof(int2)));
+  DTX_HIP(ctx, hipMalloc(&f.upre_dev, upre.size() * sizeof(int2)));
   // small synchronous copies into fresh buffers
   hipError_t e = hipMemcpy(f.prow_dev, prow.data(), prow.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.pdet_dev, pdet.data(), pdet.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.tab_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.unit_dev, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f.upre_dev, upre.data(), upre.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(pinfo_kernel, dim3((unsigned)((f.npairs + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const int2*)f.prow_dev, (const float*)ctx->srow_all.p, f.npairs,
@@ -646,13 +769,41 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
   const int Nc = ctx->Nc, V = f.V;
   const int nblk = (int)((P + V - 1) / V);
-  const bool pp = f.pingpong && DTX_FFT_XLDS && f.nseg == 1 && (Nc == 3 || Nc == 1);   // launch_fft's choice
+  const bool pp = f.pingpong;
   const int ntile_u = (f.nunits + kTileU - 1) / kTileU;
-  const int ntile_b = pp ? (int)(((int64_t)nchunk * nblk + kPPTileB - 1) / kPPTileB)
-                         : (int)(((int64_t)nchunk * nblk + kTileB - 1) / kTileB);
-  const int64_t per_xcd = pp ? ((int64_t)f.nunits * ntile_b * kPPTileB + 7) / 8
-                             : ((int64_t)ntile_u * ntile_b * kTile + 7) / 8;
-  const int64_t grid = per_xcd * 8;
+  const int ntile_b = (int)(((int64_t)nchunk * nblk + kTileB - 1) / kTileB);
+  const int64_t per_xcd = ((int64_t)ntile_u * ntile_b * kTile + 7) / 8;
+  int64_t grid = per_xcd * 8;
+  // ping-pong kernel: one workgroup per block runs every unit (the block spectra are staged once,
+  // the pipeline fills and drains once) for as many blocks as fill the CUs a whole number of
+  // times; the remaining nrem < ncu blocks are split over ng groups of units each, ng chosen so
+  // that nrem * ng short workgroups again fill the CUs evenly.
+  int nfull = 0, nrem = 0, ng = 1;
+  short gb[kMaxGroups + 1] = {0};
+  if (pp) {
+    const char* e = getenv("DTX_PP_GROUPS");     // experiments: this many groups for every block
+    const int force = e ? atoi(e) : 0;
+    const int64_t nb = (int64_t)nchunk * nblk;
+    const int ncu = std::max(1, ctx->ncu);
+    nfull = force > 0 ? 0 : (int)(nb / ncu * ncu);
+    nrem = (int)(nb - nfull);
+    double best = 1e300;
+    for (int g = 1; g <= std::min(f.nunits, kMaxGroups) && nrem > 0; ++g) {
+      if (force > 0 && g != std::min(std::min(force, f.nunits), kMaxGroups)) continue;
+      // unit borders nearest to k / g of the pairs
+      short b[kMaxGroups + 1];
+      int u = 0, acc = 0, maxp = 0, last = 0, n = 0;
+      b[0] = 0;
+      for (int k = 1; k <= g; ++k) {
+        const int target = (int)((int64_t)f.npairs * k / g);
+        while (u < f.nunits && (k == g || acc + f.unit_pairs[u] - target <= target - acc)) acc += f.unit_pairs[u++];
+        if (u > b[n]) { b[++n] = (short)u; maxp = std::max(maxp, acc - last); last = acc; }
+      }
+      const double cost = (double)(((int64_t)nrem * n + ncu - 1) / ncu) * (maxp + 3.0);
+      if (cost < best) { best = cost; ng = n; std::copy(b, b + n + 1, gb); }
+    }
+    grid = (int64_t)nfull + (int64_t)nrem * ng;
+  }
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;
   const int nblkx = nblk + f.nseg - 1;   // a segmented template also reads the blocks behind its own
@@ -670,6 +821,16 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
   a.nseg = f.nseg; a.nblkx = nblkx;
+  a.stamps = nullptr;
+#ifdef DTX_PP_STAMPS
+  const size_t stamp_n = (size_t)kStampWgs * 2 * kStampRounds * 16;
+  if (getenv("DTX_PP_STAMP_FILE") && pp) {
+    DTX_HIP(ctx, hipMalloc(&a.stamps, stamp_n * sizeof(long long)));
+    DTX_HIP(ctx, hipMemsetAsync(a.stamps, 0, stamp_n * sizeof(long long), ctx->stream));
+  }
+#endif
+  a.upre = (const int2*)f.upre_dev; a.nfull = nfull; a.nrem = std::max(nrem, 1); a.ngroups = ng;
+  std::copy(gb, gb + kMaxGroups + 1, a.gb);
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->stream, den,
                      Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list);
   DTX_HIP(ctx, hipGetLastError());
@@ -699,5 +860,17 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
+#ifdef DTX_PP_STAMPS
+  if (a.stamps) {       // dump the last launch's stamps: [workgroup][half][round][16], zeros = not taken
+    std::vector<long long> h(stamp_n);
+    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DTX_HIP(ctx, hipMemcpy(h.data(), a.stamps, stamp_n * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(a.stamps);
+    if (FILE* fp = fopen(getenv("DTX_PP_STAMP_FILE"), "wb")) {
+      fwrite(h.data(), sizeof(long long), stamp_n, fp);
+      fclose(fp);
+    }
+  }
+#endif
   return DTX_OK;
 }

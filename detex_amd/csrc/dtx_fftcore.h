@@ -196,6 +196,25 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
   dft_bitrev<SG, 8>(u);
 }
 
+// Diagnostic builds only (-DDTX_PP_STAMPS): a wave appends s_memtime (after draining its memory
+// counters) to its row of a stamp buffer.  Compiled out otherwise.
+#ifdef DTX_PP_STAMPS
+struct Stamp {
+  long long* p;
+  int n;
+  __device__ __forceinline__ void operator()() {
+    if (p) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      p[n++] = (long long)__builtin_amdgcn_s_memtime();
+    }
+  }
+};
+#define DTX_STAMP(st) do { if (st) (*(st))(); } while (0)
+#else
+struct Stamp {};
+#define DTX_STAMP(st) ((void)0)
+#endif
+
 // v[r] = point 8 (l + 64 r) + wave in, natural-order transform point (tid + 512 m) out in v[m]
 // LEAN: for the 128-register kernels -- each pass loads its twiddles just before it uses them
 // (L1 / L2 hits; four waves per SIMD cover the latency) and the two radix-8 butterflies of
@@ -204,15 +223,15 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
 // the values the phase-B reads left in v.  Separate so that a kernel can release the LDS image
 // (a workgroup barrier) between the reads and this arithmetic.
 template <int SG>
-__device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict__ tab, int tid) {
-  int opaque;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
-  c32 p4[3];
+__device__ __forceinline__ void fft8192_back_twiddles(c32 (&p4)[3], const c32* __restrict__ tab, int tid) {
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    p4[e] = tab[(tid + opaque) << e];
+    p4[e] = tab[tid << e];
     if (SG < 0) p4[e].y = -p4[e].y;
   }
+}
+template <int SG>
+__device__ __forceinline__ void fft8192_back_compute(c32 (&v)[16], const c32 (&p4)[3]) {
   // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
   // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
   c32 u[8];
@@ -222,10 +241,23 @@ __device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict
   bfly8<SG, 1>(v, u, mul_root<SG, 16, 1>(p4[0]), mul_root<SG, 8, 1>(p4[1]), muli<SG>(p4[2]));
   dtx::static_for<0, 8>([&](auto sc) { constexpr int s = sc; v[2 * s + 1] = u[rev3(s)]; });
 }
+template <int SG>
+__device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict__ tab, int tid) {
+  int opaque;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+  c32 p4[3];
+  fft8192_back_twiddles<SG>(p4, tab, tid + opaque);
+  fft8192_back_compute<SG>(v, p4);
+}
 
+template <int SG>
+__device__ __forceinline__ void fft8192_pass1(c32 (&v)[16]) { dft_bitrev<SG, 16>(v); }
+// p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1);
+// 2 here, after the barrier (wave-uniform: staggers a wave against its SIMD partner, whose LDS
+// exchanges then overlap this wave's arithmetic instead of colliding with its own)
 template <int SG, bool LEAN = false, bool FRONT_ONLY = false>
 __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
-                                        const c32* __restrict__ tab, int tid) {
+                                        const c32* __restrict__ tab, int tid, Stamp* st = nullptr, int p1 = 0) {
   // The ~50 swizzled LDS addresses below and the 9 twiddles are loop invariants of the
   // caller's pair loop; hoisted there they cost 70 registers and the kernel spills.  An opaque
   // zero keeps them inside (the twiddle loads are L1 / L2 hits, 9 per transform).
@@ -251,12 +283,16 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
   lb.f = (lb0.f + opaque) << 3;
   // ---- phase A, pass 1: radix 16 over r, no twiddles
-  dft_bitrev<SG, 16>(v);
+  if (p1 == 0) dft_bitrev<SG, 16>(v);
+  DTX_STAMP(st);     // pass 1 done
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
+  DTX_STAMP(st);     // barrier 1 passed
+  if (p1 == 2) dft_bitrev<SG, 16>(v);
   dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
   wave_sync();
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
+  DTX_STAMP(st);     // first exchange done
   // ---- pass 2: radix 16, sub-transforms of 16 -> 256
   {
     if constexpr (LEAN && !FRONT_ONLY) {
@@ -278,9 +314,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     constexpr int s = sc;
     lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ (s >> 1)))) = v[rev4(s)];
   });
+  DTX_STAMP(st);     // pass 2 computed and written
   wave_sync();
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
+  DTX_STAMP(st);     // second exchange done
   // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
   // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
   if constexpr (LEAN && !FRONT_ONLY) {
@@ -301,11 +339,14 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   });
   // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
+  DTX_STAMP(st);     // pass 3 computed and written
   __syncthreads();
+  DTX_STAMP(st);     // barrier 2 passed
   dtx::static_for<0, 16>([&](auto mc) {
     constexpr int m = mc;
     v[m] = lds_at(lds, lb.f + 8 * (512 * (m & 1) + 1024 * (m >> 1)));
   });
+  DTX_STAMP(st);     // cross-wave reads in
   if constexpr (FRONT_ONLY) return;
   // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
   // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}

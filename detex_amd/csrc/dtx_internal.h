@@ -44,6 +44,8 @@ struct DtxFft {
   void* pinfo_dev = nullptr;   // [npairs] float4
   void* pdet_dev = nullptr;    // [npairs] int2
   void* prow_dev = nullptr;    // [npairs] int2: basis rows of the real / imaginary part
+  void* upre_dev = nullptr;    // [nunits + 1] int2: pairs of half 0 / half 1 before each unit (ping-pong kernel)
+  std::vector<int> unit_pairs; // pairs per unit (host copy: dtx_fft_scan groups units per launch)
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
@@ -66,6 +68,7 @@ struct DtxBuf {
 
 struct dtx_ctx {
   int device = 0;
+  int ncu = 256;                // compute units (grid shaping)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
