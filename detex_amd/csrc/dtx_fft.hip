@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 #ifndef DTX_PP_P1_IN_MAC
 #define DTX_PP_P1_IN_MAC 1     // the transform's first pass: 0 in the front, 1 at the end of the MAC round, 2 staggered
 #endif
+#ifndef DTX_PP_MU_RES
+#define DTX_PP_MU_RES 1
+#endif
 #ifndef DTX_PP_ABLATE
 #define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong): 1 no basis-spectrum loads, 2 no transform fronts
 #endif
@@ -380,15 +383,27 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #else
   Stamp* const st = nullptr;
 #endif
-#pragma nounroll
-  for (int r = 0; r < rounds; ++r) {
-    const int q = r - half;                    // this half's phase
+  // One lambda per role; each half runs them alternately (half 0 starts with the MAC role, half 1
+  // one round later), written out as a two-phase loop body so that z flows from one role to the
+  // next in place (one loop with a branch on the phase's parity cost 64 register moves per pair
+  // where the branches met).
+  // the block's window means: the same ten for every pair -- resident while the register budget allows
+  constexpr bool kMuRes = DTX_PP_MU_RES && VM <= 10 && !TWO;
+  float mures[kMuRes ? VM : 1];
+  if constexpr (kMuRes) {
+#pragma unroll
+    for (int m = 0; m < VM; ++m) mures[m] = (mean + 512 * m)[tid];
+  }
+  auto stamp_round = [&](int r) {
 #ifdef DTX_PP_STAMPS
     stamp.p = (stamped && r < kStampRounds) ? a.stamps + ((((int64_t)(blockIdx.x / kStampEvery) * 2 + half) * kStampRounds + r) * 16) : nullptr;
     stamp.n = 0;
     DTX_STAMP(st);     // 0: round start
+#else
+    (void)r;
 #endif
-    if (q & 1) {
+  };
+  auto front_role = [&](int q) {
       // ---- front of the transform of pair q / 2 (its MAC ran in the previous round): everything
       // that touches the image, ending with the cross-wave reads.  The register-only tail and
       // the epilogue run at the head of this half's next round, beside the other half's transform.
@@ -399,7 +414,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         __syncthreads();
         __syncthreads();
       }
-    } else {
+  };
+  auto mac_role = [&](int q) {
       const bool fin = q >= 2 && (q >> 1) - 1 < nmine;   // a pair's transform to finish
       const bool mac = q >= 0 && (q >> 1) < nmine;       // a pair's products to form
       int oe;                                  // nothing below is hoisted out of the round loop
@@ -411,18 +427,24 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
       int2 pd = make_int2(-1, -1);
       c32 p4[3];
-      float mu[VM], dn[VM];
+      float mu[kMuRes ? 1 : VM], dn[VM];
 #pragma unroll
       for (int e = 0; e < 3; ++e) p4[e] = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int m = 0; m < VM; ++m) mu[m] = dn[m] = 0.f;
+      for (int m = 0; m < VM; ++m) dn[m] = 0.f;
+      if constexpr (!kMuRes) {
+#pragma unroll
+        for (int m = 0; m < VM; ++m) mu[m] = 0.f;
+      }
       if (fin) {
         const int pr = pbase + (q >> 1) - 1;         // global pair index
         pi = a.pinfo[pr];
         pd = a.pdet[pr];
         fft8192_back_twiddles<1>(p4, a.tab, te);
+        if constexpr (!kMuRes) {
 #pragma unroll
-        for (int m = 0; m < VM; ++m) mu[m] = (mean + 512 * m)[te];
+          for (int m = 0; m < VM; ++m) mu[m] = (mean + 512 * m)[te];
+        }
         if (pd.x >= 0) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
@@ -440,7 +462,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
           /* explicit fma chain: every instantiation of the kernels rounds the same way */
-          const float re = __fmaf_rn(-pi.x, mu[m], z[m].x), im = __fmaf_rn(-pi.y, mu[m], z[m].y);
+          const float mum = kMuRes ? mures[m] : mu[kMuRes ? 0 : m];
+          const float re = __fmaf_rn(-pi.x, mum, z[m].x), im = __fmaf_rn(-pi.y, mum, z[m].y);
           const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
           acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
           if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
@@ -457,13 +480,17 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
-          float v0 = (dn[m] > 0.f) ? __fdiv_rn(acc0[m], dn[m]) : 0.f;
-          if (__builtin_isinf(v0)) v0 = 0.f;
-          acc0[m] = v0;
+          // DS = acc / den by reciprocal (v_rcp_f32, 1 ulp) and one Newton step on the quotient:
+          // within 1 ulp of the correctly rounded quotient in 5 instructions instead of 12
+          const float rc = __builtin_amdgcn_rcpf(dn[m]);
+          const bool live = dn[m] > 0.f && !__builtin_isinf(rc);
+          float v0 = acc0[m] * rc;
+          v0 = __fmaf_rn(__fmaf_rn(-v0, dn[m], acc0[m]), rc, v0);
+          acc0[m] = (live && !__builtin_isinf(v0)) ? v0 : 0.f;
           if (TWO) {
-            float v1 = (dn[m] > 0.f) ? __fdiv_rn(acc1[m], dn[m]) : 0.f;
-            if (__builtin_isinf(v1)) v1 = 0.f;
-            acc1[m] = v1;
+            float v1 = acc1[m] * rc;
+            v1 = __fmaf_rn(__fmaf_rn(-v1, dn[m], acc1[m]), rc, v1);
+            acc1[m] = (live && !__builtin_isinf(v1)) ? v1 : 0.f;
           }
         }
       }
@@ -505,9 +532,6 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         dtx::static_for<0, kDepth>([&](auto bc) { issue(bc); });
         __builtin_amdgcn_sched_barrier(0);
         store_ds();
-#pragma unroll
-        for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
-        __builtin_amdgcn_sched_barrier(0);
         dtx::static_for<0, kBatches>([&](auto bc) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;
 #pragma unroll
@@ -520,8 +544,13 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
               const int m = 8 * h2 + 4 * hh + e;
               const float4 t = pw[b % kDepth][2 * hh + (e >> 1)];
               const c32 w = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
-              z[m].x += w.x * px[e].x - w.y * px[e].y;
-              z[m].y += w.x * px[e].y + w.y * px[e].x;
+              if constexpr (c == 0) {             // first channel: z starts here (no zero fill)
+                z[m].x = __fmaf_rn(-w.y, px[e].y, w.x * px[e].x);
+                z[m].y = __fmaf_rn(w.y, px[e].x, w.x * px[e].y);
+              } else {                            // two fused multiply-adds per component
+                z[m].x = __fmaf_rn(-w.y, px[e].y, __fmaf_rn(w.x, px[e].x, z[m].x));
+                z[m].y = __fmaf_rn(w.y, px[e].x, __fmaf_rn(w.x, px[e].y, z[m].y));
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -537,6 +566,23 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       }
       __syncthreads();                           // the second barrier of the round
       DTX_STAMP(st);                               // 6: barrier 2 passed
+  };
+  const int rounds2 = (rounds + 1) >> 1;       // (an odd count is padded with a round of bare barriers)
+  if (half == 0) {
+#pragma nounroll
+    for (int i = 0; i < rounds2; ++i) {
+      stamp_round(2 * i);
+      mac_role(2 * i);
+      stamp_round(2 * i + 1);
+      front_role(2 * i + 1);
+    }
+  } else {
+#pragma nounroll
+    for (int i = 0; i < rounds2; ++i) {
+      stamp_round(2 * i);
+      front_role(2 * i - 1);
+      stamp_round(2 * i + 1);
+      mac_role(2 * i);
     }
   }
 }
