@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 }
 
 #ifndef DTX_PP_P1_IN_MAC
-#define DTX_PP_P1_IN_MAC 1     // the transform's first pass: 0 in the front, 1 at the end of the MAC round, 2 staggered
+#define DTX_PP_P1_IN_MAC 0     // the transform's first pass: 0 in the front, 1 at the end of the MAC round, 2 staggered
 #endif
 #ifndef DTX_PP_MU_RES
 #define DTX_PP_MU_RES 1
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   auto mac16 = [&](c32 (&z)[16], const c32 (&ww)[16], const c32 (&xx)[16]) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      z[m].x += ww[m].x * xx[m].x - ww[m].y * xx[m].y;
-      z[m].y += ww[m].x * xx[m].y + ww[m].y * xx[m].x;
+      // (two fused multiply-adds per component; a sum of products compiles to mul + fma + add)
+      z[m].x = __fmaf_rn(-ww[m].y, xx[m].y, __fmaf_rn(ww[m].x, xx[m].x, z[m].x));
+      z[m].y = __fmaf_rn(ww[m].y, xx[m].x, __fmaf_rn(ww[m].x, xx[m].y, z[m].y));
     }
   };
   c32 z[16];
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         });
         DTX_STAMP(st);                             // 5: products done
         if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
+        if (p1_mode == 3) fft8192_pass1_head<1>(z);
       } else {
         store_ds();
       }

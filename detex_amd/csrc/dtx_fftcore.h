@@ -252,7 +252,11 @@ __device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict
 
 template <int SG>
 __device__ __forceinline__ void fft8192_pass1(c32 (&v)[16]) { dft_bitrev<SG, 16>(v); }
+// its first radix-2 stage alone (p1 = 3: the caller runs this, fft8192 the other three stages)
+template <int SG>
+__device__ __forceinline__ void fft8192_pass1_head(c32 (&v)[16]) { dif_stage<SG, 16, 16>(v); }
 // p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1);
+// 3 the caller has run its first radix-2 stage (fft8192_pass1_head), the rest here;
 // 2 here, after the barrier (wave-uniform: staggers a wave against its SIMD partner, whose LDS
 // exchanges then overlap this wave's arithmetic instead of colliding with its own)
 template <int SG, bool LEAN = false, bool FRONT_ONLY = false>
@@ -284,6 +288,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   lb.f = (lb0.f + opaque) << 3;
   // ---- phase A, pass 1: radix 16 over r, no twiddles
   if (p1 == 0) dft_bitrev<SG, 16>(v);
+  if (p1 == 3) {
+    dif_stage<SG, 16, 8>(v);
+    dif_stage<SG, 16, 4>(v);
+    dif_stage<SG, 16, 2>(v);
+  }
   DTX_STAMP(st);     // pass 1 done
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
   DTX_STAMP(st);     // barrier 1 passed

@@ -176,10 +176,12 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        z[m].x += pa[m].x * px[m].x - pa[m].y * px[m].y;
-        z[m].y += pa[m].x * px[m].y + pa[m].y * px[m].x;
-        zb[m].x += pb[m].x * px[m].x - pb[m].y * px[m].y;
-        zb[m].y += pb[m].x * px[m].y + pb[m].y * px[m].x;
+        // two fused multiply-adds per component (written as a sum of products the compiler
+        // emits mul + fma + add: the kernel is bound by vector-ALU issue)
+        z[m].x = __fmaf_rn(-pa[m].y, px[m].y, __fmaf_rn(pa[m].x, px[m].x, z[m].x));
+        z[m].y = __fmaf_rn(pa[m].y, px[m].x, __fmaf_rn(pa[m].x, px[m].y, z[m].y));
+        zb[m].x = __fmaf_rn(-pb[m].y, px[m].y, __fmaf_rn(pb[m].x, px[m].x, zb[m].x));
+        zb[m].y = __fmaf_rn(pb[m].y, px[m].x, __fmaf_rn(pb[m].x, px[m].y, zb[m].y));
       }
     }
     fft8192<1>(z, lds, lb, a.tab, tid);
