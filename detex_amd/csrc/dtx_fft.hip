@@ -390,6 +390,10 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   // where the branches met).
   // the block's window means: the same ten for every pair -- resident while the register budget allows
   constexpr bool kMuRes = DTX_PP_MU_RES && VM <= 10 && !TWO;
+  // the window norms a closing pair divides by: loaded before the barrier (latency hidden) where the
+  // registers allow, else at their use (the kernel must stay within 128 registers, no scratch)
+  constexpr bool kDnEarly = NCH == 1 ? (TWO ? VM <= 12 : true) : (TWO ? VM <= 5 : VM <= 11);
+  constexpr bool kMuEarly = kDnEarly;       // likewise the window means, where they are not resident
   float mures[kMuRes ? VM : 1];
   if constexpr (kMuRes) {
 #pragma unroll
@@ -442,11 +446,11 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         pi = a.pinfo[pr];
         pd = a.pdet[pr];
         fft8192_back_twiddles<1>(p4, a.tab, te);
-        if constexpr (!kMuRes) {
+        if constexpr (!kMuRes && kMuEarly) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) mu[m] = (mean + 512 * m)[te];
         }
-        if (pd.x >= 0) {
+        if (kDnEarly && pd.x >= 0) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
         }
@@ -463,6 +467,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
           /* explicit fma chain: every instantiation of the kernels rounds the same way */
+          if constexpr (!kMuRes && !kMuEarly) mu[m] = (mean + 512 * m)[te];
           const float mum = kMuRes ? mures[m] : mu[kMuRes ? 0 : m];
           const float re = __fmaf_rn(-pi.x, mum, z[m].x), im = __fmaf_rn(-pi.y, mum, z[m].y);
           const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
@@ -479,6 +484,10 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       if (closes) {
         row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;         // uniform
         row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
+        if constexpr (!kDnEarly) {
+#pragma unroll
+          for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
+        }
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
           // DS = acc / den by reciprocal (v_rcp_f32, 1 ulp) and one Newton step on the quotient:
@@ -518,7 +527,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         const int xlo_ = xlo + oz, xhi_ = xhi + oz, wlo_ = wlo + oz;
         auto x_slot = [&](int r) { return r < 8 ? xlo_ + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi_ - 64 * r); };
         const float4* wq = reinterpret_cast<const float4*>(a.W + (int64_t)pr * NCH * kN) + wlo_;   // + lane
-        constexpr int kBatches = 2 * NCH, kDepth = kBatches < 3 ? kBatches : 3;
+        // batches in flight: three, two where the accumulators leave no room (no scratch)
+        constexpr int kBatches = 2 * NCH, kDepth = (NCH == 1 || !kDnEarly) ? 2 : 3;
         float4 pw[kDepth][4];
         auto issue = [&](auto bc) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;

@@ -8,7 +8,10 @@
 namespace {
 
 constexpr int kPostThreads = 256;
-constexpr int kPostItems = 16;   // float4 loads per thread -> 16 KiB of DS per block
+#ifndef DTX_POST_ITEMS
+#define DTX_POST_ITEMS 64
+#endif
+constexpr int kPostItems = DTX_POST_ITEMS;   // values per thread -> kPostItems KiB of DS per block
 
 __device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
 
