@@ -328,6 +328,14 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
   DTX_STAMP(st);     // second exchange done
+#ifdef DTX_DUMMY_VALU   // diagnostic: what DTX_DUMMY_VALU more vector instructions per transform cost
+  {
+    float d = v[0].x;
+#pragma unroll
+    for (int i = 0; i < DTX_DUMMY_VALU; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
+    if (d == 12345.678f) v[0].x = d;
+  }
+#endif
   // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
   // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
   if constexpr (LEAN && !FRONT_ONLY) {
