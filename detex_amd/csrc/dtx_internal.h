@@ -78,6 +78,7 @@ struct dtx_ctx {
   std::vector<DtxKTile> tiles;
   DtxBuf U_buf;                 // device copy of the stacked basis [Ktot][n] (images are built from it on the device)
   DtxBuf srow_all;              // [Ktot] row sums S_k (float64 sums, stored float32)
+  DtxBuf doff_all;              // [D+1] int32 copy of hdoff on the device
   std::vector<int32_t> hdoff;   // [D+1]
   DtxFft fft;
 

@@ -463,6 +463,11 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
 
   ctx->D = D; ctx->n = n; ctx->Nc = Nc; ctx->L = L; ctx->Lp = Lp; ctx->Ktot = Ktot;
   ctx->hdoff.assign(det_off, det_off + D + 1);
+  {   // detector row offsets on the device (dtx_trigger_stats; the tiles hold them tile-local)
+    int rc2;
+    if ((rc2 = dtx_reserve(ctx, ctx->doff_all, (size_t)(D + 1) * sizeof(int32_t)))) return rc2;
+    DTX_HIP(ctx, hipMemcpy(ctx->doff_all.p, ctx->hdoff.data(), (size_t)(D + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   hipLaunchKernelGGL(basis_rowsum_kernel, dim3((unsigned)Ktot), dim3(256), 0, ctx->stream,
                      (const float*)Ud, n, srow_all);
   DTX_HIP(ctx, hipGetLastError());

@@ -30,7 +30,7 @@ struct TrigArgs {
   float* scratch;        // [gridDim.x][scap] rolling standard deviations of one trigger
   int64_t scap;
   int D, n, Nc, emax;
-
+  int full;              // 0: STA / LTA only (no magnitude ingredients asked for)
 };
 
 __device__ inline double wave_sum(double v) {
@@ -84,6 +84,95 @@ __device__ inline float select_rank(const float* __restrict__ v, int count, int 
   return __uint_as_float(prefix);
 }
 
+// pre-event noise of one trigger (every thread of the workgroup calls it; thread 0's return value is stored)
+__device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t a0, float* scr, double* red,
+                                    double* seg1, double* seg2, unsigned* hist, unsigned* sh) {
+  const int tid = threadIdx.x, n = a.n;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  double s;
+  // median of the rolling std (ddof = 1) of 5 n samples before the
+  // trigger, or of up to 7 n samples from it when there is not enough data before
+  // (detect.py:466-472)
+  int64_t pe0;
+  int npe;
+  if (a0 > 5 * (int64_t)n) { pe0 = a0 - 5 * (int64_t)n; npe = 5 * n; }
+  else { pe0 = a0; npe = (int)min((int64_t)7 * n, a.M - a0); }
+  const float* pe = xc + pe0;
+  const int count = npe - n + 1;
+  double noise = nan;
+  if (count >= 1 && count <= a.scap) {
+    s = 0.0;
+    for (int q = tid; q < npe; q += kTT) s += (double)pe[q];
+    const double shift = block_sum(s, red) / npe;       // std is shift-invariant: kills the cancellation
+    // prefix sums of y = pe - shift and y^2: per-thread segment sums, scanned by thread 0 .. 511
+    const int seglen = (npe + kTT - 1) / kTT;
+    const int q0 = min(tid * seglen, npe), q1 = min(q0 + seglen, npe);
+    double t1 = 0.0, t2 = 0.0;
+    for (int q = q0; q < q1; ++q) {
+      const double y = (double)pe[q] - shift;
+      t1 += y;
+      t2 += y * y;
+    }
+    __syncthreads();
+    seg1[tid] = t1;
+    seg2[tid] = t2;
+    __syncthreads();
+    if (tid < 64) {          // exclusive scan of 512 segment sums by one wave, 8 per lane
+      double l1[8], l2[8], c1 = 0.0, c2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        l1[j] = c1; l2[j] = c2;
+        c1 += seg1[8 * tid + j]; c2 += seg2[8 * tid + j];
+      }
+      double p1 = c1, p2 = c2;     // inclusive scan over lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double o1 = __shfl_up(p1, off, 64), o2 = __shfl_up(p2, off, 64);
+        if (tid >= off) { p1 += o1; p2 += o2; }
+      }
+      p1 -= c1; p2 -= c2;          // exclusive
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { seg1[8 * tid + j] = p1 + l1[j]; seg2[8 * tid + j] = p2 + l2[j]; }
+    }
+    __syncthreads();
+    auto prefix = [&](int j, double& o1, double& o2) {      // sums of y, y^2 over [0, j)
+      int sg = j / seglen;
+      if (sg >= kTT) sg = kTT - 1;
+      double b1 = seg1[sg], b2 = seg2[sg];
+      for (int q = sg * seglen; q < j; ++q) {
+        const double y = (double)pe[q] - shift;
+        b1 += y;
+        b2 += y * y;
+      }
+      o1 = b1; o2 = b2;
+    };
+    const int wper = (count + kTT - 1) / kTT;
+    const int i0 = min(tid * wper, count), i1 = min(i0 + wper, count);
+    if (i0 < i1) {
+      double A1, A2, B1, B2;
+      prefix(i0, A1, A2);
+      prefix(i0 + n, B1, B2);
+      for (int i = i0; i < i1; ++i) {
+        const double S1 = B1 - A1, S2 = B2 - A2;
+        const double var = (S2 - S1 * S1 / n) / (n - 1.0);
+        scr[i] = (float)sqrt(var > 0.0 ? var : 0.0);
+        const double ya = (double)pe[i] - shift;
+        A1 += ya; A2 += ya * ya;
+        if (i + n < npe) {
+          const double yb = (double)pe[i + n] - shift;
+          B1 += yb; B2 += yb * yb;
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const float hi = select_rank(scr, count, count / 2, hist, sh);
+    noise = (double)hi;
+    if ((count & 1) == 0) noise = 0.5 * (noise + (double)select_rank(scr, count, count / 2 - 1, hist, sh));
+  }
+  return noise;
+}
+
 __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
   __shared__ double red[kTT / 64];
   __shared__ double csh[256];            // projections c_k of the detector's rows (<= 208)
@@ -94,10 +183,35 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
   const int n = a.n;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
   float* scr = a.scratch + (int64_t)blockIdx.x * a.scap;
+  // blockIdx.y = task: 0 STA / LTA + the window's statistics and projection, 1 the dot products with
+  // the training events, 2 the pre-event noise -- three workgroups per trigger instead of one (a
+  // station-day has tens of triggers: one workgroup each left most of the chip idle for 0.5 ms)
+  const int task = blockIdx.y;
   for (int t = blockIdx.x; t < a.ntrig; t += gridDim.x) {
     const int32_t* tr = a.trig + 5 * (int64_t)t;
     const int chunk = tr[0], det = tr[1], p = tr[2], sta_lo = tr[3], lta_lo = tr[4];
     double* out = a.out + (int64_t)t * (kTrigHead + a.emax);
+    const float* xc = a.x + (int64_t)chunk * a.stride;
+    const int64_t a0 = (int64_t)p * a.Nc;
+    const float* w = xc + a0;
+    if (task == 1) {
+      // ---- dot products with the training events (fast_normcorr(x, ConDat)[0], d1 of 494)
+      const int e0 = a.eoff[det], ne = a.eoff[det + 1] - e0;
+      for (int e = wv; e < ne; e += kTT / 64) {
+        const float* ev = a.ewf + (int64_t)(e0 + e) * n;
+        double d = 0.0;
+        for (int q = ln; q < n; q += 64) d += (double)ev[q] * (double)w[q];
+        d = wave_sum(d);
+        if (ln == 0) out[kTrigHead + e] = d;
+      }
+      continue;
+    }
+    if (task == 2) {
+      const double noise = trig_noise(a, xc, a0, scr, red, seg1, seg2, hist, sh);
+      if (tid == 0) out[5] = noise;
+      __syncthreads();
+      continue;
+    }
     // ---- STA / LTA: means of |DS| over the (edge-adjusted) centred windows
     const float* row = a.ds + ((int64_t)chunk * a.D + det) * a.ldp;
     double st = nan, lt = nan;
@@ -111,10 +225,11 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
       for (int i = tid; i < a.lta_len; i += kTT) s += fabs((double)row[lta_lo + i]);
       lt = block_sum(s, red) / (double)a.lta_len;
     }
+    if (!a.full) {
+      if (tid == 0) { out[0] = st; out[1] = lt; }
+      continue;
+    }
     // ---- the triggering window ConDat = MPcon[p Nc : p Nc + n]           (detect.py:456-457)
-    const float* xc = a.x + (int64_t)chunk * a.stride;
-    const int64_t a0 = (int64_t)p * a.Nc;
-    const float* w = xc + a0;
     double s = 0.0;
     for (int q = tid; q < n; q += kTT) s += (double)w[q];
     const double mean_c = block_sum(s, red) / n;
@@ -149,97 +264,8 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
       s2 += v * v;
     }
     const double var_s = block_sum(s2, red) / n;                         // np.var: ddof = 0
-    // ---- dot products with the training events (fast_normcorr(x, ConDat)[0], d1 of 494)
-    const int e0 = a.eoff[det], ne = a.eoff[det + 1] - e0;
-    for (int e = wv; e < ne; e += kTT / 64) {
-      const float* ev = a.ewf + (int64_t)(e0 + e) * n;
-      double d = 0.0;
-      for (int q = ln; q < n; q += 64) d += (double)ev[q] * (double)w[q];
-      d = wave_sum(d);
-      if (ln == 0) out[kTrigHead + e] = d;
-    }
-    // ---- pre-event noise: median of the rolling std (ddof = 1) of 5 n samples before the
-    // trigger, or of up to 7 n samples from it when there is not enough data before
-    // (detect.py:466-472)
-    int64_t pe0;
-    int npe;
-    if (a0 > 5 * (int64_t)n) { pe0 = a0 - 5 * (int64_t)n; npe = 5 * n; }
-    else { pe0 = a0; npe = (int)min((int64_t)7 * n, a.M - a0); }
-    const float* pe = xc + pe0;
-    const int count = npe - n + 1;
-    double noise = nan;
-    if (count >= 1 && count <= a.scap) {
-      s = 0.0;
-      for (int q = tid; q < npe; q += kTT) s += (double)pe[q];
-      const double shift = block_sum(s, red) / npe;       // std is shift-invariant: kills the cancellation
-      // prefix sums of y = pe - shift and y^2: per-thread segment sums, scanned by thread 0 .. 511
-      const int seglen = (npe + kTT - 1) / kTT;
-      const int q0 = min(tid * seglen, npe), q1 = min(q0 + seglen, npe);
-      double t1 = 0.0, t2 = 0.0;
-      for (int q = q0; q < q1; ++q) {
-        const double y = (double)pe[q] - shift;
-        t1 += y;
-        t2 += y * y;
-      }
-      __syncthreads();
-      seg1[tid] = t1;
-      seg2[tid] = t2;
-      __syncthreads();
-      if (tid < 64) {          // exclusive scan of 512 segment sums by one wave, 8 per lane
-        double l1[8], l2[8], c1 = 0.0, c2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          l1[j] = c1; l2[j] = c2;
-          c1 += seg1[8 * tid + j]; c2 += seg2[8 * tid + j];
-        }
-        double p1 = c1, p2 = c2;     // inclusive scan over lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const double o1 = __shfl_up(p1, off, 64), o2 = __shfl_up(p2, off, 64);
-          if (tid >= off) { p1 += o1; p2 += o2; }
-        }
-        p1 -= c1; p2 -= c2;          // exclusive
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { seg1[8 * tid + j] = p1 + l1[j]; seg2[8 * tid + j] = p2 + l2[j]; }
-      }
-      __syncthreads();
-      auto prefix = [&](int j, double& o1, double& o2) {      // sums of y, y^2 over [0, j)
-        int sg = j / seglen;
-        if (sg >= kTT) sg = kTT - 1;
-        double b1 = seg1[sg], b2 = seg2[sg];
-        for (int q = sg * seglen; q < j; ++q) {
-          const double y = (double)pe[q] - shift;
-          b1 += y;
-          b2 += y * y;
-        }
-        o1 = b1; o2 = b2;
-      };
-      const int wper = (count + kTT - 1) / kTT;
-      const int i0 = min(tid * wper, count), i1 = min(i0 + wper, count);
-      if (i0 < i1) {
-        double A1, A2, B1, B2;
-        prefix(i0, A1, A2);
-        prefix(i0 + n, B1, B2);
-        for (int i = i0; i < i1; ++i) {
-          const double S1 = B1 - A1, S2 = B2 - A2;
-          const double var = (S2 - S1 * S1 / n) / (n - 1.0);
-          scr[i] = (float)sqrt(var > 0.0 ? var : 0.0);
-          const double ya = (double)pe[i] - shift;
-          A1 += ya; A2 += ya * ya;
-          if (i + n < npe) {
-            const double yb = (double)pe[i + n] - shift;
-            B1 += yb; B2 += yb * yb;
-          }
-        }
-      }
-      __threadfence_block();
-      __syncthreads();
-      const float hi = select_rank(scr, count, count / 2, hist, sh);
-      noise = (double)hi;
-      if ((count & 1) == 0) noise = 0.5 * (noise + (double)select_rank(scr, count, count / 2 - 1, hist, sh));
-    }
     if (tid == 0) {
-      out[0] = st; out[1] = lt; out[2] = mean_c; out[3] = std_c; out[4] = var_s; out[5] = noise;
+      out[0] = st; out[1] = lt; out[2] = mean_c; out[3] = std_c; out[4] = var_s;
     }
     __syncthreads();
   }
@@ -321,28 +347,25 @@ extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, in
   if (!ctx) return DTX_E_ARG;
   if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "dtx_trigger_stats: no basis uploaded");
   if (ntrig == 0) return DTX_OK;
-  if (!x_dev || !ds_dev || !trig_dev || !ewf_dev || !ewf_off_dev || !out_dev || ntrig < 0 || emax < 0 ||
+  if (!x_dev || !ds_dev || !trig_dev || (ewf_dev && !ewf_off_dev) || !out_dev || ntrig < 0 || emax < 0 ||
       sta_len < 0 || lta_len < 0)
     return dtx_fail(ctx, DTX_E_ARG, "dtx_trigger_stats: null pointer or negative size");
   if (M < ctx->n || P != dtx_num_windows(M, ctx->n, ctx->Nc))
     return dtx_fail(ctx, DTX_E_ARG, "dtx_trigger_stats: P does not belong to blocks of M samples");
   DtxDeviceGuard g(ctx->device);
   int rc;
-  // detector row offsets on the device (the tiles hold them tile-local)
-  if ((rc = dtx_reserve(ctx, ctx->ws_trig_doff, (size_t)(ctx->D + 1) * sizeof(int32_t)))) return rc;
-  DTX_HIP(ctx, hipMemcpyAsync(ctx->ws_trig_doff.p, ctx->hdoff.data(), (size_t)(ctx->D + 1) * sizeof(int32_t),
-                              hipMemcpyHostToDevice, ctx->stream));
   const unsigned grid = (unsigned)std::min(ntrig, 1024);
   const int64_t scap = 6 * (int64_t)ctx->n + 1;
   if ((rc = dtx_reserve(ctx, ctx->ws_trig, (size_t)grid * scap * sizeof(float)))) return rc;
   TrigArgs a;
   a.x = x_dev; a.M = M; a.stride = chunk_stride; a.ds = ds_dev; a.P = P; a.ldp = ldp;
   a.trig = trig_dev; a.ntrig = ntrig; a.sta_len = sta_len; a.lta_len = lta_len;
-  a.U = (const float*)ctx->U_buf.p; a.doff = (const int32_t*)ctx->ws_trig_doff.p;
+  a.U = (const float*)ctx->U_buf.p; a.doff = (const int32_t*)ctx->doff_all.p;
   a.ewf = ewf_dev; a.eoff = ewf_off_dev; a.out = out_dev;
   a.scratch = (float*)ctx->ws_trig.p; a.scap = scap;
   a.D = ctx->D; a.n = ctx->n; a.Nc = ctx->Nc; a.emax = emax;
-  hipLaunchKernelGGL(trig_stats_kernel, dim3(grid), dim3(kTT), 0, ctx->stream, a);
+  a.full = ewf_dev != nullptr;
+  hipLaunchKernelGGL(trig_stats_kernel, dim3(grid, a.full ? 3u : 1u), dim3(kTT), 0, ctx->stream, a);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

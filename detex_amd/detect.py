@@ -232,6 +232,7 @@ class StationScan(object):
         self.own = ctx is None and not self.empty
         self.ctx = HipContext(device) if self.own else ctx
         self.batches = []
+        self.picked = None
 
     def close(self):
         if self.own and self.ctx is not None:
@@ -279,7 +280,8 @@ class StationScan(object):
             rawdev, xdev = None, ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
         del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
-        thr_dev = torch.from_numpy(thr_arr).to(ctx.device)
+        from .hip import h2d_async
+        thr_dev = h2d_async(thr_arr, ctx.device)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
         if self.chunk_sel is not None:
@@ -321,6 +323,15 @@ class StationScan(object):
                 self.batches.append((i0, i1, xb, M, cstride, ds, fetch))
             except DetexHipError as e:
                 self._skip(i0, i1, e)
+        # the histograms follow the last scan to pinned host memory; finish() waits for this event
+        # only (a stream-wide synchronisation there would also wait for the NEXT stations' scans,
+        # which are queued behind: it drained the queue once per station-day)
+        self.hist_host = self.hist_ev = None
+        if hist.is_cuda:
+            self.hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+            self.hist_host.copy_(hist, non_blocking=True)
+            self.hist_ev = torch.cuda.Event()
+            self.hist_ev.record(torch.cuda.current_stream(hist.device))
 
     def _skip(self, i0, i1, e):
         # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
@@ -328,22 +339,37 @@ class StationScan(object):
         _warn('failing to run detector on %s from %s to %s: %s'
               % (self.sta, b[i0][2], b[i1 - 1][2] + b[i1 - 1][1] / self.st['sr'], e))
 
-    def finish(self):
-        import pandas as pd
+    def pick(self):
+        """First host half, once the scans' candidate lists are back: trigger picking, and the
+        trigger-time kernel enqueued (its results are not waited for)."""
         from ._lib import DetexHipError
-        if self.empty:
-            return None
+        if self.empty or self.picked is not None:
+            return
         st = self.st
-        rows = {'ss': [], 'sg': []}
+        self.picked = []
         for (i0, i1, xb, M, cstride, ds, fetch) in self.batches:
             try:
-                _finish_batch(self.ctx, self.sta, st, self.args[5], self.args[6], i0, i1, xb, M, cstride, ds,
-                              fetch, rows)
+                self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
+                                                           i0, i1, xb, M, cstride, ds, fetch))
             except DetexHipError as e:
                 self._skip(i0, i1, e)
-        self.batches = []
-        self.ctx.sync()
-        h = st['hist'].cpu().numpy()
+
+    def finish(self):
+        """Second host half: trigger-time estimates back from the device -> rows."""
+        import pandas as pd
+        if self.empty:
+            return None
+        self.pick()
+        st = self.st
+        rows = {'ss': [], 'sg': []}
+        for (i0, trigs, bad, stats) in self.picked:
+            _batch_rows(self.sta, st, self.args[5], self.args[6], i0, trigs, bad, stats, rows)
+        self.batches, self.picked = [], None
+        if self.hist_ev is not None:
+            self.hist_ev.synchronize()
+            h = self.hist_host.numpy()
+        else:
+            h = st['hist'].cpu().numpy()
         names, kinds = st['names'], st['kinds']
         out = {k: pd.DataFrame(v, columns=self.COLS) for k, v in rows.items()}
         out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
@@ -394,9 +420,11 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
     return out
 
 
-def _finish_batch(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, rows):
-    """The host half of one launch group of equal-length chunks: candidates -> triggers ->
-    trigger-time estimates -> rows."""
+def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch):
+    """One launch group of equal-length chunks, first host half: candidates -> triggers; the
+    trigger-time kernel is enqueued and its (device) result returned with them:
+    (trigs, bad, stats)."""
+    import torch
     names, kinds, offsets, thr_arr, thr_dev = st['names'], st['kinds'], st['offsets'], st['thr_arr'], st['thr_dev']
     bounds, Nc, n, D, sr, LTA, STA, bank = (st['bounds'], st['Nc'], st['n'], st['D'], st['sr'], st['LTA'],
                                             st['STA'], st['mbank'])
@@ -427,12 +455,10 @@ def _finish_batch(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride,
             if coef > 1.05:                              # detect.py:199-204
                 continue
             trigs.append((b, d, ti, coef))
-    if not trigs:
-        return
+    bad = np.zeros(len(trigs), dtype=bool)               # IndexError of the reference's indexing -> 0.0
     stats = None
-    if bank is not None:
+    if trigs and bank is not None:
         tab = np.full((len(trigs), 5), -1, dtype=np.int32)
-        bad = np.zeros(len(trigs), dtype=bool)           # IndexError of the reference's indexing -> 0.0
         for r, (b, d, ti, _) in enumerate(trigs):
             tab[r, :3] = (b, d, ti)
             if not fillZeros:
@@ -442,7 +468,28 @@ def _finish_batch(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride,
                 except IndexError:
                     bad[r] = True
         stats = ctx.trigger_stats(xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
-                                  bank.ewf, bank.eoff, bank.emax).cpu().numpy()
+                                  bank.ewf if estimateMags else None, bank.eoff, bank.emax)
+        if stats.is_cuda:
+            # on its way to pinned host memory behind the kernel; _batch_rows waits for the event
+            host = torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True)
+            host.copy_(stats, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(stats.device))
+            stats = (host, ev, stats)
+    return trigs, bad, stats
+
+
+def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows):
+    """Second host half: the trigger-time estimates -> rows of the detection tables."""
+    names, kinds, offsets = st['names'], st['kinds'], st['offsets']
+    bounds, n, sr, bank = st['bounds'], st['n'], st['sr'], st['mbank']
+    if not trigs:
+        return
+    if isinstance(stats, tuple):
+        stats[1].synchronize()
+        stats = stats[0].numpy()
+    elif stats is not None:
+        stats = stats.cpu().numpy()
     for r, (b, d, ti, coef) in enumerate(trigs):
         name = names[d]
         start = bounds[i0 + b][2]

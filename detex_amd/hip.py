@@ -51,6 +51,17 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def h2d_async(arr, device):
+    """A small host array to the device without blocking the host: staged in pinned memory and
+    copied on the current stream.  (A pageable torch.from_numpy(...).to(device) waits for
+    everything already queued on that stream -- inside SubSpace.detex that is the next stations'
+    scans.)"""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class HipContext(object):
     """One HIP device + stream.  All tensors passed in must live on it."""
 
@@ -335,18 +346,20 @@ class HipContext(object):
 
         x, M, chunk_stride, ds: the buffers of the subspace_scan call the triggers come from;
         trig: int32 array [ntrig, 5] (chunk, detector, window, STA start or -1, LTA start or -1);
-        ewf: [Etot, n] float32 CUDA tensor, eoff: [D+1] int32 CUDA tensor.
+        ewf: [Etot, n] float32 CUDA tensor, eoff: [D+1] int32 CUDA tensor; ewf=None: STA / LTA
+        only (columns 0, 1; the rest stays NaN).
         Returns a float64 CUDA tensor [ntrig, 6 + emax] (asynchronous)."""
         trig = np.ascontiguousarray(trig, dtype=np.int32).reshape(-1, 5)
         nt = len(trig)
         out = torch.full((nt, 6 + int(emax)), float('nan'), dtype=torch.float64, device=ds.device)
         if nt == 0:
             return out
-        tdev = torch.from_numpy(trig).to(ds.device)
+        tdev = h2d_async(trig, ds.device)
         nchunk, D, P = (int(v) for v in ds.shape)
         rc = self.lib.dtx_trigger_stats(self.h, _ptr(x), int(M), int(chunk_stride), _ptr(ds), P,
                                         int(ds.stride(1)), _ptr(tdev), nt, int(sta_len), int(lta_len),
-                                        _ptr(ewf), _ptr(eoff), int(emax), _ptr(out))
+                                        _ptr(ewf) if ewf is not None else None,
+                                        _ptr(eoff) if ewf is not None else None, int(emax), _ptr(out))
         self._ck(rc, 'dtx_trigger_stats')
         return out
 

@@ -171,7 +171,7 @@ int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
 
 /* For each of `ntrig` triggers (rows of trig_dev: chunk, detector, window index p, first DS
  * sample of the STA window or -1, first DS sample of the LTA window or -1 -- int32 x 5), in
- * float64, one workgroup per trigger:
+ * float64, three workgroups per trigger (window statistics, event dot products, noise):
  *   out[0] mean(|DS[sta_lo : sta_lo + sta_len]|)  (NaN if sta_lo < 0)   detect.py:505-511
  *   out[1] mean(|DS[lta_lo : lta_lo + lta_len]|)  (NaN if lta_lo < 0)
  *   out[2], out[3]  mean and std (ddof 0) of ConDat = x_chunk[p*Nc : p*Nc + n]   detect.py:456
@@ -184,6 +184,8 @@ int dtx_ds_moments(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
  * x_dev / M / chunk_stride / ds_dev / P / ldp as in dtx_subspace_scan (the same buffers);
  * ewf_dev [Etot][n] float32 training events, ewf_off_dev [D+1] int32 (device), emax = the
  * largest event count of a detector; out_dev [ntrig][DTX_TRIG_HEAD + emax] float64.
+ * ewf_dev == NULL: only out[0], out[1] are computed (STA / LTA without magnitude estimates,
+ * detect.py:289-295 with estimateMags=False); the other entries keep what the caller put there.
  * Uses the basis of the last dtx_basis_upload.  Asynchronous. */
 #define DTX_TRIG_HEAD 6
 int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,

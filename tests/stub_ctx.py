@@ -98,9 +98,12 @@ class OracleCtx(object):
         eoff = eoff.numpy()
         for r, (b, d, p, slo, llo) in enumerate(trig):
             xc = (x[b] if x.dim() == 2 else x[b * chunk_stride: b * chunk_stride + M]).numpy()
+            ev = ewf[eoff[d]:eoff[d + 1]].numpy() if ewf is not None else np.zeros((0, self.U.shape[1]))
             row = orc.trigger_stats_row(int(p), self.Nc, xc, self.U[self.off[d]:self.off[d + 1]],
-                                        ewf[eoff[d]:eoff[d + 1]].numpy(), ds=ds[b, d].numpy().astype(np.float64),
+                                        ev, ds=ds[b, d].numpy().astype(np.float64),
                                         sta_lo=int(slo), sta_len=sta_len, lta_lo=int(llo), lta_len=lta_len)
+            if ewf is None:                       # STA / LTA only, like the device call
+                row = row[:2]
             out[r, :len(row)] = row
         return torch.from_numpy(out)
 

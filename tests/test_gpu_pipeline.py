@@ -215,6 +215,9 @@ def test_trigger_stats_kernel():
             ne = 4 if t[1] == 0 else 1
             assert np.allclose(g[:6], w[:6], rtol=2e-6, atol=1e-12), (M, t, g[:6], w[:6])
             assert np.allclose(g[6:6 + ne], w[6:], rtol=1e-6, atol=1e-9), (M, t)
+        # without training events (estimateMags=False): STA / LTA only, the rest untouched (NaN)
+        lite = ctx.trigger_stats(x, M, M, ds, np.array(tab, np.int32), 7, 60, None, None, 4).cpu().numpy()
+        assert np.array_equal(lite[:, :2], got[:, :2], equal_nan=True) and np.isnan(lite[:, 2:]).all()
         if M == len(x32):
             # the reference's own magnitudes (float64 inputs there, float32 here)
             for tag, trig in zip(['early', 'late'], z['trigs']):
