@@ -101,6 +101,54 @@ __device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
   dif_stage<SG, R, 4>(u);
   dif_stage<SG, R, 2>(u);
 }
+#ifndef DTX_FFT_FOLD
+#define DTX_FFT_FOLD 1      // inter-pass twiddles folded into the butterflies (dft_tw_bitrev)
+#endif
+// (x, y) -> (x + T y, x - T y) in six fused multiply-adds (the difference as 2 x - (x + T y))
+__device__ __forceinline__ void bfly_tw(c32& x, c32& y, c32 T) {
+  const float px = __fmaf_rn(T.x, y.x, __fmaf_rn(-T.y, y.y, x.x));
+  const float py = __fmaf_rn(T.x, y.y, __fmaf_rn(T.y, y.x, x.y));
+  y = make_float2(__fmaf_rn(2.f, x.x, -px), __fmaf_rn(2.f, x.y, -py));
+  x = make_float2(px, py);
+}
+// t * e^{SG 2 pi i E / R}, 0 <= E < R / 2: first-quadrant roots by mul_root, the second quadrant as
+// i times those (a register swap and a sign the consumer's fma absorbs)
+template <int SG, int R, int E>
+__device__ __forceinline__ c32 rot_root(c32 t) {
+  if constexpr (4 * E >= R) return muli<SG>(rot_root<SG, R, E - R / 4>(t));
+  else return mul_root<SG, R, E>(t);
+}
+// Twiddled radix-R DFT: X[q] = sum_s (u[s] w^s) e^{SG 2 pi i s q / R}, left bit-reversed
+// (X[q] = u[rev(q)]) like dft_bitrev.  wp[j] = w^(R >> (j + 1)): w^(R/2), .., w^2, w -- the only
+// powers needed.  Same data flow as the decimation-in-frequency stages of dft_bitrev, but the
+// inter-pass twiddles w^s are folded into the butterflies: stage LEN, block j multiplies the lower
+// input by T = w^(LEN/2) e^{SG 2 pi i a LEN / (2 R)} (a = the block's path, bit-reversed j) and
+// forms x +- T y in six fused multiply-adds; nothing is multiplied afterwards.  Against
+// "multiply the inputs by w^s, then dft_bitrev": 208 instead of 272 instructions for R = 16
+// (60 twiddle products + 44 to derive w^3 .. w^15 + 168 butterfly), 76 instead of ~115 for R = 8.
+template <int SG, int R, int LEN, int STAGE, int LG>
+__device__ __forceinline__ void tw_stage(c32 (&u)[R], const c32 (&wp)[LG]) {
+  constexpr int H = LEN / 2, NB = R / LEN;
+  dtx::static_for<0, NB>([&](auto jc) {
+    constexpr int j = jc;
+    // a = sum_t j_t R / (2 LEN 2^t): the odd branches taken on the way down, most recent first
+    constexpr int a = [] { int s = 0; for (int t = 0; (1 << t) < NB; ++t) s += ((j >> t) & 1) * (R / (2 * LEN) >> t); return s; }();
+    constexpr int e = (a * H) % R;
+    const c32 T = rot_root<SG, R, e>(wp[STAGE]);
+    dtx::static_for<0, H>([&](auto qc) {
+      constexpr int q = qc;
+      bfly_tw(u[j * LEN + q], u[j * LEN + q + H], T);
+    });
+  });
+}
+template <int SG, int R, int LG>
+__device__ __forceinline__ void dft_tw_bitrev(c32 (&u)[R], const c32 (&wp)[LG]) {
+  static_assert((1 << LG) == R, "wp holds log2 R powers");
+  if constexpr (R >= 16) tw_stage<SG, R, 16, LG - 4, LG>(u, wp);
+  if constexpr (R >= 8) tw_stage<SG, R, 8, LG - 3, LG>(u, wp);
+  tw_stage<SG, R, 4, LG - 2, LG>(u, wp);
+  tw_stage<SG, R, 2, LG - 1, LG>(u, wp);
+}
 __host__ __device__ constexpr int rev2(int q) { return ((q & 1) << 1) | (q >> 1); }
 __host__ __device__ constexpr int rev3(int q) { return ((q & 1) << 2) | (q & 2) | ((q >> 2) & 1); }
 __host__ __device__ constexpr int rev4(int q) {
@@ -184,6 +232,12 @@ __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ t
 // transform is left bit-reversed in u
 template <int SG, int H>
 __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c32 w2, c32 w4) {
+#if DTX_FFT_FOLD
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) u[sidx] = v[2 * sidx + H];
+  const c32 wp[3] = {w4, w2, w1};
+  dft_tw_bitrev<SG, 8>(u, wp);
+#else
   u[0] = v[H];
   u[1] = cmul(v[2 + H], w1);
   u[2] = cmul(v[4 + H], w2);
@@ -194,6 +248,7 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
   u[5] = cmul(v[10 + H], cmul(w1, w4));
   u[6] = cmul(v[12 + H], cmul(w2, w4));
   dft_bitrev<SG, 8>(u);
+#endif
 }
 
 // Diagnostic builds only (-DDTX_PP_STAMPS): a wave appends s_memtime (after draining its memory
@@ -309,6 +364,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) w.a[e] = ldtw(l15 << e);
     }
+#if DTX_FFT_FOLD
+    const c32 wp[4] = {w.a[3], w.a[2], w.a[1], w.a[0]};
+    dft_tw_bitrev<SG, 16>(v, wp);
+  }
+#else
     const c32 w1 = w.a[0], w2 = w.a[1], w4 = w.a[2], w8 = w.a[3];
     const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
     v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
@@ -319,6 +379,7 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     v[15] = cmul(v[15], cmul(w7, w8));
   }
   dft_bitrev<SG, 16>(v);
+#endif
   dtx::static_for<0, 16>([&](auto sc) {
     constexpr int s = sc;
     lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ (s >> 1)))) = v[rev4(s)];
@@ -347,11 +408,17 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     constexpr int b = bc;
     const c32 w1 = mul_root<SG, 16, b>(w.b[0]), w2 = mul_root<SG, 8, b>(w.b[1]);
     c32 u[4];
+#if DTX_FFT_FOLD
+    u[0] = v[b]; u[1] = v[b + 4]; u[2] = v[b + 8]; u[3] = v[b + 12];
+    const c32 wp[2] = {w2, w1};
+    dft_tw_bitrev<SG, 4>(u, wp);
+#else
     u[0] = v[b];
     u[1] = cmul(v[b + 4], w1);
     u[2] = cmul(v[b + 8], w2);
     u[3] = cmul(v[b + 12], cmul(w1, w2));
     dft_bitrev<SG, 4>(u);
+#endif
     dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
   });
   // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
