@@ -104,6 +104,9 @@ __device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
 #ifndef DTX_FFT_FOLD
 #define DTX_FFT_FOLD 1      // inter-pass twiddles folded into the butterflies (dft_tw_bitrev)
 #endif
+#ifndef DTX_FFT_CONST1
+#define DTX_FFT_CONST1 DTX_FFT_FOLD   // the untwiddled pass by constant-root butterflies (dft_const_bitrev)
+#endif
 // (x, y) -> (x + T y, x - T y) in six fused multiply-adds (the difference as 2 x - (x + T y))
 __device__ __forceinline__ void bfly_tw(c32& x, c32& y, c32 T) {
   const float px = __fmaf_rn(T.x, y.x, __fmaf_rn(-T.y, y.y, x.x));
@@ -207,9 +210,6 @@ __device__ __forceinline__ void dft_const_bitrev(c32 (&u)[R]) {
 // the untwiddled 16-point pass
 template <int SG>
 __device__ __forceinline__ void dft16_plain(c32 (&v)[16]) {
-#ifndef DTX_FFT_CONST1
-#define DTX_FFT_CONST1 DTX_FFT_FOLD
-#endif
 #if DTX_FFT_CONST1
   dft_const_bitrev<SG, 16>(v);
 #else
@@ -376,7 +376,13 @@ template <int SG>
 __device__ __forceinline__ void fft8192_pass1(c32 (&v)[16]) { dft16_plain<SG>(v); }
 // its first radix-2 stage alone (p1 = 3: the caller runs this, fft8192 the other three stages)
 template <int SG>
-__device__ __forceinline__ void fft8192_pass1_head(c32 (&v)[16]) { dif_stage<SG, 16, 16>(v); }
+__device__ __forceinline__ void fft8192_pass1_head(c32 (&v)[16]) {
+#if DTX_FFT_CONST1
+  const_stage<SG, 16, 16>(v);
+#else
+  dif_stage<SG, 16, 16>(v);
+#endif
+}
 // p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1);
 // 3 the caller has run its first radix-2 stage (fft8192_pass1_head), the rest here;
 // 2 here, after the barrier (wave-uniform: staggers a wave against its SIMD partner, whose LDS
@@ -411,9 +417,15 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   // ---- phase A, pass 1: radix 16 over r, no twiddles
   if (p1 == 0) dft16_plain<SG>(v);
   if (p1 == 3) {
+#if DTX_FFT_CONST1
+    const_stage<SG, 16, 8>(v);
+    const_stage<SG, 16, 4>(v);
+    const_stage<SG, 16, 2>(v);
+#else
     dif_stage<SG, 16, 8>(v);
     dif_stage<SG, 16, 4>(v);
     dif_stage<SG, 16, 2>(v);
+#endif
   }
   DTX_STAMP(st);     // pass 1 done
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
