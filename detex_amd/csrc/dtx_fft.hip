@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 #define DTX_PP_MU_RES 1
 #endif
 #ifndef DTX_PP_ABLATE
-#define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong): 1 no basis-spectrum loads, 2 no transform fronts
+#define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong), bit flags: 1 no basis-spectrum loads, 2 no transform fronts,
+                                // 4 no transform tail / epilogue, 8 no MAC
 #endif
 constexpr int kMaxGroups = 32;
 [[maybe_unused]] constexpr int kStampRounds = 24, kStampWgs = 56, kStampEvery = 29;   // -DDTX_PP_STAMPS builds
@@ -298,23 +299,27 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
 
 // ---------------------------------------------------------------- ping-pong variant
 // The same work with TWO half-workgroups of 512 threads in one 1024-thread workgroup (16 waves,
-// four per SIMD, 128 registers each; 112 used, no scratch).  The halves share the block spectra
-// staged in LDS and take turns on the single 64 KB transform image: while one half runs the
-// image-bound front of its pair's transform, the other runs the register-only tail of its
-// previous transform, that pair's epilogue and the MAC of its next pair (basis spectra from L2,
-// block spectra from LDS) -- a butterfly / LDS-heavy and a load-heavy instruction stream on
-// every SIMD at any time, instead of eight waves that all load, then all transform.  A unit's
-// detectors are split between the halves at a detector boundary (unit.z pairs to half 0), so
-// each half keeps its own DS accumulators and stores its own rows: no exchange between them.
-// Rounds: in round r half h is in phase q = r - h; odd q = front of the transform of its pair
-// q / 2 (scatter ... cross-wave reads), even q = tail + epilogue of pair q / 2 - 1, then MAC of
-// pair q / 2.  Every round holds exactly two workgroup barriers on both sides (the transform's
-// own two), which is all the synchronisation the shared image needs: a round's leading barrier
-// separates one half's last reads of the image from the other half's first writes.
+// four per SIMD, <= 128 registers, no scratch).  The halves share the block spectra staged in
+// LDS and take turns on the single 64 KB transform image.  In round r half h is in phase
+// q = r - h:
+//   even q  MAC role: the products of pair q / 2 (basis spectra from L2 in half-channel batches,
+//           three in flight; block spectra from LDS) between the round's two barriers;
+//   odd q   FRONT role: the whole transform of that pair -- first pass in registers, the
+//           image-bound passes between the two barriers, the cross-wave reads, then (in the gap
+//           to the next round's first barrier, where the other half runs ITS first pass) the
+//           register-only last pass, the accumulation (Y - S mu)^2 and, when the pair closes its
+//           detector, the statistic and its stores.
+// Every round holds exactly two workgroup barriers on both sides (the transform's own two), which
+// is all the synchronisation the shared image needs: a round's leading barrier separates one
+// half's last reads of the image from the other half's first writes.  A workgroup runs every unit
+// of its block (or a group of units, for the blocks of the last partial wave of workgroups); the
+// detectors are dealt to the halves whole, so each half keeps its own DS accumulators and stores
+// its own rows: no exchange between them.
 // Register discipline (the compiler spills 100+ registers otherwise): opaque zeros keep loop
-// invariants (LDS slots, row addresses) inside the round, the channel loop is not unrolled (the
-// scheduler would hoist the next channel's loads), mean / den are loaded next to their use.
-// Measured at configs[1] (profiles/g*): 5.6 -> 4.56 ms; with 16-byte basis-spectrum loads 3.94 ms.
+// invariants (LDS slots, row addresses) inside the round, scheduling barriers pin the load
+// batches, each role is a straight-line stretch of a two-phase loop body.
+// What bounds it is vector-ALU issue and the latency of the few waves, not memory: DESIGN.md 4.1
+// has the ladder (5.6 ms for the round-1 kernel -> 2.9 ms) and the ablations behind each step.
 template <int VM, bool TWO, int NCH>
 __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   static_assert(NCH > 0, "the ping-pong kernel keeps the block spectra in LDS");
@@ -336,8 +341,9 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   const int2 g0 = a.upre[u0], g1 = a.upre[u1];
   const int pbase = half ? a.upre[a.nunits].x + g0.y : g0.x;
   const int nmine = half ? g1.y - g0.y : g1.x - g0.x;
-  // half h runs phases q = 0 .. 2 n_h (the last one only finishes its last pair), one round later for h = 1
-  const int rounds = max(2 * (g1.x - g0.x) + 1, 2 * (g1.y - g0.y) + 2);
+  // half h runs phases q = 0 .. 2 n_h - 1 (products of pair i in phase 2 i, its transform in 2 i + 1), one
+  // round later for h = 1
+  const int rounds = max(2 * (g1.x - g0.x), 2 * (g1.y - g0.y) + 1);
   const int64_t p0 = (int64_t)blk * a.V;
   const LdsBases lb = lds_bases(tid);
   float acc0[VM], acc1[TWO ? VM : 1];
@@ -380,7 +386,9 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #ifdef DTX_PP_STAMPS
   Stamp stamp{nullptr, 0};
   Stamp* const st = &stamp;
-  const bool stamped = a.stamps && tid == 0 && blockIdx.x % kStampEvery == 0 && (int)(blockIdx.x / kStampEvery) < kStampWgs;
+  // (wave-uniform: every lane of wave 0 of each half stores the same stamp -- a per-lane condition costs the kernel its registers)
+  const bool stamped = a.stamps && __builtin_amdgcn_readfirstlane(tid >> 6) == 0 && blockIdx.x % kStampEvery == 0 &&
+                       (int)(blockIdx.x / kStampEvery) < kStampWgs;
 #else
   Stamp* const st = nullptr;
 #endif
@@ -408,62 +416,34 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
     (void)r;
 #endif
   };
-  auto front_role = [&](int q) {
-      // ---- front of the transform of pair q / 2 (its MAC ran in the previous round): everything
-      // that touches the image, ending with the cross-wave reads.  The register-only tail and
-      // the epilogue run at the head of this half's next round, beside the other half's transform.
-      const int pr = q >> 1;
-      if (q >= 0 && pr < nmine && DTX_PP_ABLATE != 2) {       // (2: timing only, no transform fronts)
-        fft8192<1, true, true>(z, lds, lb, a.tab, tid, st, p1_mode);    // two workgroup barriers inside
-      } else {
-        __syncthreads();
-        __syncthreads();
-      }
-  };
-  auto mac_role = [&](int q) {
-      const bool fin = q >= 2 && (q >> 1) - 1 < nmine;   // a pair's transform to finish
-      const bool mac = q >= 0 && (q >> 1) < nmine;       // a pair's products to form
-      int oe;                                  // nothing below is hoisted out of the round loop
-      asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
-      const int te = tid + oe;
-      // ---- issued before the barrier, landing while this half waits for the image to change
-      // hands: the tail's twiddles, the window means, (when the pair closes its detector) the
-      // window norms
-      float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-      int2 pd = make_int2(-1, -1);
-      c32 p4[3];
-      float mu[kMuRes ? 1 : VM], dn[VM];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) p4[e] = make_float2(0.f, 0.f);
-#pragma unroll
-      for (int m = 0; m < VM; ++m) dn[m] = 0.f;
-      if constexpr (!kMuRes) {
-#pragma unroll
-        for (int m = 0; m < VM; ++m) mu[m] = 0.f;
-      }
-      if (fin) {
-        const int pr = pbase + (q >> 1) - 1;         // global pair index
+  // Roles.  FRONT: the whole transform of the pair whose products this half formed in its previous
+  // round -- first pass, the image-bound passes between the round's two barriers, and, after the
+  // cross-wave reads, the register-only tail, the accumulation and (closing pair) the statistic and
+  // its stores; those run while the OTHER half does the first pass of its next transform, between
+  // this round's second barrier and the next round's first.  MAC: nothing but the products of the
+  // next pair between the two barriers.  (With the tail and the epilogue at the head of the MAC round
+  // the interval between the barriers held 2.2 ms-equivalents of MAC-role work against 1.4 of
+  // transform passes: timing-only ablations, profiles/g9_ablations.txt.)
+  // accumulation of a finished transform (z) and, when the pair closes its detector, the statistic
+  // and its stores
+  // (the loads it waits for are issued by fetch_pair, ahead of whatever hides their latency)
+  auto fetch_pair = [&](int pr, int te, float4& pi, int2& pd, float (&mu)[kMuRes ? 1 : VM], float (&dn)[VM]) {
         pi = a.pinfo[pr];
         pd = a.pdet[pr];
-        fft8192_back_twiddles<1>(p4, a.tab, te);
         if constexpr (!kMuRes && kMuEarly) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) mu[m] = (mean + 512 * m)[te];
         }
+#pragma unroll
+        for (int m = 0; m < VM; ++m) dn[m] = 0.f;
         if (kDnEarly && pd.x >= 0) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
-      DTX_STAMP(st);         // 1: barrier 1 passed
-      // ---- tail of the transform of pair q / 2 - 1 and its epilogue
-      const bool two = TWO && pd.y >= 0;
-      const bool closes = fin && pd.x >= 0;
-      if (fin) {
-        fft8192_back_compute<1>(z, p4);
-        DTX_STAMP(st);                             // 2: transform tail done
+  };
+  auto finish_pair = [&](int te, const float4 pi, const int2 pd, float (&mu)[kMuRes ? 1 : VM], float (&dn)[VM]) {
+        const bool two = TWO && pd.y >= 0;
+        const bool closes = pd.x >= 0;
 #pragma unroll
         for (int m = 0; m < VM; ++m) {
           /* explicit fma chain: every instantiation of the kernels rounds the same way */
@@ -474,51 +454,64 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
           acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
           if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
         }
-        DTX_STAMP(st);                             // 3: accumulated
-      }
-      // the detector's statistic, stored below once the next pair's first loads are on their way
-      // (loads queued behind stores would wait for the stores' acknowledgements)
-      float* row0 = nullptr;
-      float* row1 = nullptr;
-      const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
-      if (closes) {
-        row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;         // uniform
-        row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
-        if constexpr (!kDnEarly) {
-#pragma unroll
-          for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
-        }
-#pragma unroll
-        for (int m = 0; m < VM; ++m) {
-          // DS = acc / den by reciprocal (v_rcp_f32, 1 ulp) and one Newton step on the quotient:
-          // within 1 ulp of the correctly rounded quotient in 5 instructions instead of 12
-          const float rc = __builtin_amdgcn_rcpf(dn[m]);
-          const bool live = dn[m] > 0.f && !__builtin_isinf(rc);
-          float v0 = acc0[m] * rc;
-          v0 = __fmaf_rn(__fmaf_rn(-v0, dn[m], acc0[m]), rc, v0);
-          acc0[m] = (live && !__builtin_isinf(v0)) ? v0 : 0.f;
-          if (TWO) {
-            float v1 = acc1[m] * rc;
-            v1 = __fmaf_rn(__fmaf_rn(-v1, dn[m], acc1[m]), rc, v1);
-            acc1[m] = (live && !__builtin_isinf(v1)) ? v1 : 0.f;
-          }
-        }
-      }
-      auto store_ds = [&]() {
         if (closes) {
+          float* row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;         // uniform
+          float* row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
+          const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
+          if constexpr (!kDnEarly) {
+#pragma unroll
+            for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
+          }
 #pragma unroll
           for (int m = 0; m < VM; ++m) {
-            if (te + 512 * m < lim) {
-              DTX_DS_STORE(acc0[m], &(row0 + 512 * m)[te]);
-              if (two) DTX_DS_STORE(acc1[m], &(row1 + 512 * m)[te]);
-            }
+            // DS = acc / den by reciprocal (v_rcp_f32, 1 ulp) and one Newton step on the quotient:
+            // within 1 ulp of the correctly rounded quotient in 5 instructions instead of 12
+            const float rc = __builtin_amdgcn_rcpf(dn[m]);
+            const bool live = dn[m] > 0.f && !__builtin_isinf(rc);
+            float v0 = acc0[m] * rc;
+            v0 = __fmaf_rn(__fmaf_rn(-v0, dn[m], acc0[m]), rc, v0);
+            v0 = (live && !__builtin_isinf(v0)) ? v0 : 0.f;
+            if (te + 512 * m < lim) DTX_DS_STORE(v0, &(row0 + 512 * m)[te]);
             acc0[m] = 0.f;
-            if (TWO) acc1[m] = 0.f;
+            if (TWO) {
+              float v1 = acc1[m] * rc;
+              v1 = __fmaf_rn(__fmaf_rn(-v1, dn[m], acc1[m]), rc, v1);
+              v1 = (live && !__builtin_isinf(v1)) ? v1 : 0.f;
+              if (two && te + 512 * m < lim) DTX_DS_STORE(v1, &(row1 + 512 * m)[te]);
+              acc1[m] = 0.f;
+            }
           }
         }
-      };
-      DTX_STAMP(st);                               // 4: statistic formed
-      __builtin_amdgcn_sched_barrier(0);
+  };
+  auto front_role = [&](int q) {
+      const int pi_ = q >> 1;
+      if (q >= 0 && pi_ < nmine && !(DTX_PP_ABLATE & 2)) {     // (timing only: no transform fronts)
+        int oe;                                  // nothing below is hoisted out of the round loop
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
+        const int te = tid + oe;
+        const int pr = pbase + pi_;              // global pair index
+        // issued now, landing under the transform: the tail's twiddles, the pair's constants, the
+        // window means and norms
+        c32 p4[3];
+        float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+        int2 pd = make_int2(-1, -1);
+        float mu[kMuRes ? 1 : VM], dn[VM];
+        fft8192_back_twiddles<1>(p4, a.tab, te);
+        fetch_pair(pr, te, pi, pd, mu, dn);
+        __builtin_amdgcn_sched_barrier(0);
+        fft8192<1, true, true>(z, lds, lb, a.tab, tid, st, p1_mode);    // two workgroup barriers inside
+        if constexpr (!(DTX_PP_ABLATE & 4)) {
+          fft8192_back_compute<1>(z, p4);
+          finish_pair(te, pi, pd, mu, dn);
+        }
+      } else {
+        __syncthreads();
+        __syncthreads();
+      }
+  };
+  auto mac_role = [&](int q) {
+      const bool mac = q >= 0 && (q >> 1) < nmine && !(DTX_PP_ABLATE & 8);       // a pair's products to form
+      __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
       // ---- MAC of pair q / 2: half-channel batches of four 16-byte loads, three batches in flight
       if (mac) {
         const int pr = pbase + (q >> 1);
@@ -534,7 +527,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-#if DTX_PP_ABLATE == 1     // timing only: no basis-spectrum loads
+#if DTX_PP_ABLATE & 1      // timing only: no basis-spectrum loads
             pw[b % kDepth][j] = make_float4(1.f, 0.f, 1.f, 0.f);
 #else
             pw[b % kDepth][j] = (wq + c * (kN / 2) + 64 * (4 * h2 + j))[0];
@@ -542,7 +535,6 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         };
         dtx::static_for<0, kDepth>([&](auto bc) { issue(bc); });
         __builtin_amdgcn_sched_barrier(0);
-        store_ds();
         dtx::static_for<0, kBatches>([&](auto bc) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;
 #pragma unroll
@@ -573,11 +565,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         DTX_STAMP(st);                             // 5: products done
         if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
         if (p1_mode == 3) fft8192_pass1_head<1>(z);
-      } else {
-        store_ds();
       }
       __syncthreads();                           // the second barrier of the round
-      DTX_STAMP(st);                               // 6: barrier 2 passed
   };
   const int rounds2 = (rounds + 1) >> 1;       // (an odd count is padded with a round of bare barriers)
   if (half == 0) {

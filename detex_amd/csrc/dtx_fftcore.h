@@ -326,7 +326,9 @@ struct Stamp {
   int n;
   __device__ __forceinline__ void operator()() {
     if (p) {
+#if DTX_PP_STAMPS == 1      // (2: light stamps -- memory operations in flight are not waited for)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
       p[n++] = (long long)__builtin_amdgcn_s_memtime();
     }
   }
