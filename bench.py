@@ -146,20 +146,21 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
                             'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
                             'frac': flop_fft / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                             'contraction_equivalent': flops / (kms * 1e-3) / 1e12},
-                # what actually bounds the ping-pong kernel (profiles/g7_ablations.txt):
-                # vector-ALU issue.  1000 instructions per pair and wave in the <10,false,3> binary
-                # (scripts/valu_count.py), two waves per role on each SIMD, 2 cycles per instruction
+                # the vector ALUs' share of a round of the ping-pong kernel (one pair per CU and round; DESIGN.md
+                # 4.1, profiles/g9_ablations.txt): 1000 instructions per pair and wave in the <10,false,3>
+                # binary (scripts/valu_count.py = SQ_INSTS_VALU), four waves of ~500 per SIMD and round,
+                # 2 cycles per instruction
                 'valu_issue': ({'instructions_per_pair_and_wave': 1000,
-                                'issue_cycles_per_pair_and_simd': 4000,
-                                'cycles_per_pair_and_cu_at_2.4GHz': kms * 2.4e6 * 256 / nfft,
+                                'issue_cycles_per_round_and_simd': 4000,
+                                'cycles_per_round_at_2.4GHz': kms * 2.4e6 * 256 / nfft,
                                 'frac': 4000.0 / (kms * 2.4e6 * 256 / nfft)}
                                if pp and V == 5120 and Nc == 3 else None),
                 'note': 'overlap-save engine: %d transforms of 8192 complex points per launch in LDS; '
                         'neither HBM- nor MFMA-bound -- the algorithmic HBM bytes (112 B/window) are '
                         'what the schema asks for, `compute` prices the transforms against the f32 '
                         'vector peak, `contraction_equivalent` is the direct contraction it replaces '
-                        '(2*K*n flop per window); the kernel is bound by vector-ALU issue (`valu_issue`; '
-                        'DESIGN.md 4.1 has the ablations)' % nfft}
+                        '(2*K*n flop per window); no unit is saturated (`valu_issue`: the vector ALUs\' share) -- the '
+                        'bound is the dependent instruction chains of the four waves per SIMD, DESIGN.md 4.1' % nfft}
     if eng == 'fp32':
         ach = flops / (kms * 1e-3) / 1e12
         return {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8)),
