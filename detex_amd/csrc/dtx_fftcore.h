@@ -318,6 +318,23 @@ __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c
 #endif
 }
 
+#ifndef DTX_FFT_PERMLANE
+#define DTX_FFT_PERMLANE 1     // the transform's second in-wave exchange: lane swaps instead of LDS
+#endif
+// a <-> b transposed over (which of the two registers, lane bit 4 / lane bit 5)
+__device__ __forceinline__ void lane_swap16(c32& a, c32& b) {
+  auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = make_float2(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+  b = make_float2(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+__device__ __forceinline__ void lane_swap32(c32& a, c32& b) {
+  auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = make_float2(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+  b = make_float2(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+
 // Diagnostic builds only (-DDTX_PP_STAMPS): a wave appends s_memtime (after draining its memory
 // counters) to its row of a stamp buffer.  Compiled out otherwise.
 #ifdef DTX_PP_STAMPS
@@ -461,6 +478,28 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   }
   dft_bitrev<SG, 16>(v);
 #endif
+#if DTX_FFT_PERMLANE
+  // Second exchange without LDS.  Output k2 = s of pass 2 sits in v[rev4(s)] of lane
+  // l = k1 + 16 x3; pass 3 wants point j = k1 + 16 k2 of sub-sequence x3 in lane j & 63, register
+  // (j >> 6) + 4 x3: the low two bits of k2 trade places with lane bits 4 and 5.  gfx950's
+  // v_permlane16_swap / v_permlane32_swap transpose exactly (one register bit, lane bit 4 / 5).
+  {
+    c32 y[16];
+    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; y[s] = v[rev4(s)]; });
+    dtx::static_for<0, 16>([&](auto sc) {
+      constexpr int s = sc;
+      if constexpr ((s & 1) == 0) lane_swap16(y[s], y[s + 1]);
+    });
+    dtx::static_for<0, 16>([&](auto sc) {
+      constexpr int s = sc;
+      if constexpr ((s & 2) == 0) lane_swap32(y[s], y[s + 2]);
+    });
+    // y index: bits 1:0 = x3, bits 3:2 = k2 >> 2 = b
+    dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = y[(r >> 2) + 4 * (r & 3)]; });
+  }
+  DTX_STAMP(st);     // pass 2 computed
+  DTX_STAMP(st);     // second exchange done
+#else
   dtx::static_for<0, 16>([&](auto sc) {
     constexpr int s = sc;
     lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ (s >> 1)))) = v[rev4(s)];
@@ -470,6 +509,7 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
   DTX_STAMP(st);     // second exchange done
+#endif
 #ifdef DTX_DUMMY_VALU   // diagnostic: what DTX_DUMMY_VALU more vector instructions per transform cost
   {
     float d = v[0].x;
