@@ -11,6 +11,13 @@ constexpr int kPostThreads = 256;
 #ifndef DTX_POST_ITEMS
 #define DTX_POST_ITEMS 64
 #endif
+#ifndef DTX_POST_NT
+#define DTX_POST_NT 0
+#endif
+#ifndef DTX_POST_BATCH
+#define DTX_POST_BATCH 4
+#endif
+typedef float fvec4 __attribute__((ext_vector_type(4)));
 constexpr int kPostItems = DTX_POST_ITEMS;   // values per thread -> kPostItems KiB of DS per block
 
 __device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
@@ -36,17 +43,30 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
   // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
   const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
-  for (int it = 0; it < kPostItems / 4; ++it) {
-    const int64_t p4 = base + ((int64_t)it * kPostThreads + tid) * 4;
-    float vv[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int kBatch = DTX_POST_BATCH;      // 16-byte loads in flight per thread
+  static_assert(kPostItems / 4 % kBatch == 0, "whole batches");
+  for (int it0 = 0; it0 < kPostItems / 4; it0 += kBatch) {
+  float vb[kBatch][4];
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const int64_t p4 = base + ((int64_t)(it0 + u) * kPostThreads + tid) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[u][j] = 0.f;
     if (vec && p4 + 3 < P) {
-      const float4 q = *reinterpret_cast<const float4*>(row + p4);
-      vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
+      const fvec4 q = DTX_POST_NT ? __builtin_nontemporal_load(reinterpret_cast<const fvec4*>(row + p4))
+                                  : *reinterpret_cast<const fvec4*>(row + p4);
+      vb[u][0] = q.x; vb[u][1] = q.y; vb[u][2] = q.z; vb[u][3] = q.w;
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (p4 + j < P) vv[j] = row[p4 + j];
+        if (p4 + j < P) vb[u][j] = row[p4 + j];
     }
+  }
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const int it = it0 + u;
+    const int64_t p4 = base + ((int64_t)it * kPostThreads + tid) * 4;
+    const float (&vv)[4] = vb[u];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t p = p4 + j;
@@ -70,6 +90,7 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
         }
       }
     }
+  }
   }
   if (hist) {
 #pragma unroll

@@ -35,10 +35,16 @@ __device__ inline int dtx_hist_bin(float vf) {
 // the same bin; nearly every window is noise in the first four bins: settle those with three
 // compares against the same float64 edges i * (1/400) the general search uses -- no loop, no
 // divergence inside a wave
+// (in float32: for a float v and a float64 edge e, (double)v < e  <=>  v < up(e), up(e) the
+// smallest float32 >= e -- the four edges below, each checked against its neighbour)
 __device__ inline int dtx_hist_bin_fast(float vf) {
-  const double vd = (double)vf, step = 1.0 / 400.0;
-  if (vd >= 0.0 && vd < 4.0 * step)
-    return vd < 2.0 * step ? (vd < 1.0 * step ? 0 : 1) : (vd < 3.0 * step ? 2 : 3);
+  constexpr double step = 1.0 / 400.0;
+  constexpr float t1 = 0x1.47ae16p-9f, t2 = 0x1.47ae16p-8f, t3 = 0x1.eb852p-8f, t4 = 0x1.47ae16p-7f;
+  static_assert((double)t1 >= 1.0 * step && (double)0x1.47ae14p-9f < 1.0 * step, "edge 1");
+  static_assert((double)t2 >= 2.0 * step && (double)0x1.47ae14p-8f < 2.0 * step, "edge 2");
+  static_assert((double)t3 >= 3.0 * step && (double)0x1.eb851ep-8f < 3.0 * step, "edge 3");
+  static_assert((double)t4 >= 4.0 * step && (double)0x1.47ae14p-7f < 4.0 * step, "edge 4");
+  if (vf >= 0.f && vf < t4) return vf < t2 ? (vf < t1 ? 0 : 1) : (vf < t3 ? 2 : 3);
   return dtx_hist_bin(vf);
 }
 
