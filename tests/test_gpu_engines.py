@@ -217,3 +217,51 @@ def test_fused_scan_equals_two_calls(ctx, burst):
     for a_, b_ in zip(r1['cand'], r2['cand']):
         assert np.array_equal(a_, b_)
     assert int(r2['hist'].sum()) == nchunk * D * ds2.shape[2]
+
+
+
+@pytest.mark.parametrize('nchunk,T', [(1, 9000), (3, 40000), (3, 700000)])
+def test_scan_grid_shapes_agree(nchunk, T):
+    """The ping-pong scan kernel deals its work as one workgroup per block over all units, plus
+    groups of units for the blocks of the last partial wave (dtx_fft_scan): however the units
+    are grouped, every (block, detector) is computed by the same instruction sequence, so DS is
+    bit-identical.  DTX_PP_GROUPS forces a group count (read at every scan); unset = the product's
+    choice.  Block counts below / around / far above the CU count, detectors of 1 .. 9 vectors
+    (odd counts pair with a zero row, single-vector detectors share a pair)."""
+    from detex_amd import synth
+    from detex_amd.hip import HipContext
+    Nc, L, ks = 3, 1200, [8, 1, 1, 3, 9, 2, 8, 8, 5, 1, 4, 8, 7]
+    n = Nc * L
+    rs = np.random.RandomState(5)
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+    U = np.concatenate([synth.orthonormal_basis(rs, n, k) for k in ks]).astype(np.float32)
+    x = rs.standard_normal((nchunk, Nc * T)).astype(np.float32)
+    x[0, 3000 * Nc:3000 * Nc + n] += (5 * np.sqrt(n) * U[off[4]]).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    c = HipContext(0)
+    c.set_engine('fft')
+    c.upload_basis(U, off, Nc)
+    old = os.environ.pop('DTX_PP_GROUPS', None)
+    try:
+        ref = c.subspace_ds(xt).clone()
+        c.sync()
+        assert float(ref[0, 4, 3000]) > 0.9
+        for g in ('1', '2', '5', '32'):
+            os.environ['DTX_PP_GROUPS'] = g
+            ds = c.subspace_ds(xt)
+            c.sync()
+            assert torch.equal(ds, ref), g
+    finally:
+        os.environ.pop('DTX_PP_GROUPS', None)
+        if old is not None:
+            os.environ['DTX_PP_GROUPS'] = old
+        c.close()
+    # and against the float64 oracle at a few windows of the first chunk
+    dsh = ref[0].cpu().numpy()
+    for d in (0, 1, 4, 9):
+        for p in (0, 3000, T - L - 1):
+            w = x[0, p * Nc:p * Nc + n].astype(np.float64)
+            mu = w.mean()
+            Ud = U[off[d]:off[d + 1]].astype(np.float64)
+            want = np.sum((Ud @ w - Ud.sum(axis=1) * mu) ** 2) / (n / (n - 1.0) * np.sum((w - mu) ** 2))
+            assert abs(dsh[d, p] - want) <= 1e-5, (d, p)
