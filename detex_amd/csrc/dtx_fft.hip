@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 }
 
 #ifndef DTX_PP_P1_IN_MAC
-#define DTX_PP_P1_IN_MAC 0     // the transform's first pass: 0 in the front, 1 at the end of the MAC round, 2 staggered
+#define DTX_PP_P1_IN_MAC 0     // the transform's first pass: 0 in the FRONT role, 1 at the end of the MAC round
 #endif
 #ifndef DTX_PP_MU_RES
 #define DTX_PP_MU_RES 1
@@ -373,15 +373,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       dst[threadIdx.x + 2 * kT * q] = src[threadIdx.x + 2 * kT * q];
     __syncthreads();
   }
-  // Where the transform's register-only first pass runs.  Waves 0-3 of a half: at the end of their
-  // MAC round; waves 4-7 (their partners on the four SIMDs): after the first barrier of the front.
-  // The partners then run half a pass apart: one's LDS exchange overlaps the other's arithmetic
-  // instead of all eight waves queueing at the LDS write path and then at the vector ALUs.
-#if DTX_PP_P1_IN_MAC == 2
-  const int p1_mode = __builtin_amdgcn_readfirstlane((tid >> 8) & 1) ? 2 : 1;
-#else
-  const int p1_mode = DTX_PP_P1_IN_MAC;
-#endif
+  const int p1_mode = DTX_PP_P1_IN_MAC;   // where the transform's register-only first pass runs (measured equal)
   c32 z[16];
 #ifdef DTX_PP_STAMPS
   Stamp stamp{nullptr, 0};
@@ -564,7 +556,6 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         });
         DTX_STAMP(st);                             // 5: products done
         if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
-        if (p1_mode == 3) fft8192_pass1_head<1>(z);
       }
       __syncthreads();                           // the second barrier of the round
   };

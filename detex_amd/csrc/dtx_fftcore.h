@@ -393,19 +393,7 @@ __device__ __forceinline__ void fft8192_back(c32 (&v)[16], const c32* __restrict
 
 template <int SG>
 __device__ __forceinline__ void fft8192_pass1(c32 (&v)[16]) { dft16_plain<SG>(v); }
-// its first radix-2 stage alone (p1 = 3: the caller runs this, fft8192 the other three stages)
-template <int SG>
-__device__ __forceinline__ void fft8192_pass1_head(c32 (&v)[16]) {
-#if DTX_FFT_CONST1
-  const_stage<SG, 16, 16>(v);
-#else
-  dif_stage<SG, 16, 16>(v);
-#endif
-}
-// p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1);
-// 3 the caller has run its first radix-2 stage (fft8192_pass1_head), the rest here;
-// 2 here, after the barrier (wave-uniform: staggers a wave against its SIMD partner, whose LDS
-// exchanges then overlap this wave's arithmetic instead of colliding with its own)
+// p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1)
 template <int SG, bool LEAN = false, bool FRONT_ONLY = false>
 __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
                                         const c32* __restrict__ tab, int tid, Stamp* st = nullptr, int p1 = 0) {
@@ -435,21 +423,9 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   lb.f = (lb0.f + opaque) << 3;
   // ---- phase A, pass 1: radix 16 over r, no twiddles
   if (p1 == 0) dft16_plain<SG>(v);
-  if (p1 == 3) {
-#if DTX_FFT_CONST1
-    const_stage<SG, 16, 8>(v);
-    const_stage<SG, 16, 4>(v);
-    const_stage<SG, 16, 2>(v);
-#else
-    dif_stage<SG, 16, 8>(v);
-    dif_stage<SG, 16, 4>(v);
-    dif_stage<SG, 16, 2>(v);
-#endif
-  }
   DTX_STAMP(st);     // pass 1 done
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
   DTX_STAMP(st);     // barrier 1 passed
-  if (p1 == 2) dft16_plain<SG>(v);
   dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
   wave_sync();
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
