@@ -310,6 +310,9 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
 // a block-wide scan (pandas rolling_mean / rolling_var, detect.py:566-568 and
 // construct.py:446-447).  planes: [batch][Nc][plane_stride].
 // ---------------------------------------------------------------------------
+#ifndef DTX_STATS_BATCHED
+#define DTX_STATS_BATCHED 1
+#endif
 constexpr int kStatsPB = 2048;  // windows per block
 
 // variance below float64 round-off relative to the window power counts as 0
@@ -375,8 +378,43 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   }
   __syncthreads();
 
-  // local element e turns window (p0 + E*tid + e) into the next one
+  // local element e turns window (p0 + E*tid + e) into the next one: per channel the thread's E
+  // steps touch E + 1 consecutive samples at the head and E + 1 at the tail of its windows -- all
+  // loaded first (independent loads in flight), each once
   double l1[E], l2[E], l3[E];
+  double r1_ = 0.0, r2_ = 0.0, r3_ = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) l1[e] = l2[e] = l3[e] = 0.0;
+  const int64_t pt = p0 + (int64_t)E * tid;
+  // (the batched loads read up to sample pt + L + E - 1 of the plane whatever P is: only where that
+  // stays inside the plane -- the last threads of a chunk's last block take the guarded loop)
+  if (DTX_STATS_BATCHED && pt + L + E <= plane_stride) {
+  for (int c = 0; c < Nc; ++c) {
+    const float* o = xb + (int64_t)c * plane_stride + pt;
+    float ha[E + 1], tb[E + 1];                                // ha[j] = o[j], tb[j] = o[L - 1 + j]
+#pragma unroll
+    for (int j = 0; j <= E; ++j) ha[j] = o[j];
+#pragma unroll
+    for (int j = 0; j <= E; ++j) tb[j] = o[L - 1 + j];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double vo = (double)ha[e], vn = (double)tb[e + 1];
+      l1[e] += vn - vo;
+      l2[e] += vn * vn - vo * vo;
+      // changes entering (between samples L-1 and L) and leaving (between 0 and 1)
+      if (L > 1) l3[e] += ((tb[e + 1] != tb[e]) ? 1.0 : 0.0) - ((ha[e + 1] != ha[e]) ? 1.0 : 0.0);
+    }
+  }
+  double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (pt + e + 1 < P) { r1 += l1[e]; r2 += l2[e]; r3 += l3[e]; }
+    l1[e] = r1;
+    l2[e] = r2;
+    l3[e] = r3;
+  }
+  r1_ = r1; r2_ = r2; r3_ = r3;
+  } else {
   double r1 = 0.0, r2 = 0.0, r3 = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -395,6 +433,9 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     l2[e] = r2;
     l3[e] = r3;
   }
+  r1_ = r1; r2_ = r2; r3_ = r3;
+  }
+  const double r1 = r1_, r2 = r2_, r3 = r3_;
   const double i1 = wave_incl_scan(r1, lane), i2 = wave_incl_scan(r2, lane),
                i3 = wave_incl_scan(r3, lane);
   __syncthreads();
