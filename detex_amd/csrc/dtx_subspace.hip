@@ -62,15 +62,20 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict_
     band = 3.0 * sqrt(fmax(cs[1] / cnt - m1 * m1, 0.0));
   }
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int64_t i = i0 + tid; i < i1; i += 256) {
-    const float vf = xb[i];
+  auto take = [&](float vf) {
     const double v = (double)vf;
     if (PASS == 0) {
       if (vf != 0.f) { s0 += v; s1 += v * v; s2 += 1.0; }
     } else {
       if (vf != 0.f && fabs(v - m1) <= band) { s0 += v; s2 += 1.0; }
     }
+  };
+  int64_t i = i0 + tid;
+  for (; i + 3 * 256 < i1; i += 4 * 256) {       // four loads in flight
+    const float v0 = xb[i], v1 = xb[i + 256], v2 = xb[i + 512], v3 = xb[i + 768];
+    take(v0); take(v1); take(v2); take(v3);
   }
+  for (; i < i1; i += 256) take(xb[i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s0 += __shfl_down(s0, off, 64);
@@ -106,10 +111,24 @@ __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x,
   const float* xb = x + (int64_t)b * chunk_stride;
   float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
   const float m0 = block_offset(csum + (int64_t)b * kCsum);
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tpad;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t src = t * Nc + c;
-    dst[t] = (t < Tvalid && src < M) ? xb[src] - m0 : 0.f;
+  // four consecutive samples per thread: four gathers in flight, one 16-byte store where the plane
+  // allows it
+  const bool vec = ((Tpad & 3) == 0) && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0);
+  for (int64_t t = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); t < Tpad;
+       t += 4 * (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t src = (t + k) * Nc + c;
+      v[k] = (t + k < Tvalid && src < M) ? xb[src] : m0;
+    }
+    if (vec && t + 3 < Tpad) {
+      *reinterpret_cast<float4*>(dst + t) = make_float4(v[0] - m0, v[1] - m0, v[2] - m0, v[3] - m0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t + k < Tpad) dst[t + k] = v[k] - m0;
+    }
   }
 }
 
@@ -539,7 +558,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
 
   {
     const int64_t Tvalid = P + ctx->L - 1;
-    dim3 grid((unsigned)std::min<int64_t>((Tpad + 255) / 256, 4096), (unsigned)Nc,
+    dim3 grid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), (unsigned)Nc,
               (unsigned)nchunk);
     const size_t cbytes = (size_t)nchunk * kCsum * sizeof(double);
     if ((rc = dtx_reserve(ctx, ctx->ws_csum, cbytes))) return rc;
