@@ -232,3 +232,51 @@ def test_trigger_stats_kernel():
                     else:       # the golden singleton ran the reference's non-subspace branch on ewf[0]
                         assert np.allclose(m, ref, rtol=2e-5), (kind, tag, m, ref)
     ctx.close()
+
+
+def test_stations_in_flight_equal_one_at_a_time():
+    """SubSpace.detex keeps three stations in flight on per-station contexts (scans enqueued ahead,
+    trigger picking and the trigger-time kernel of one station under the scan of the next, results
+    waited for by event); with a caller's context every station is finished before the next starts.
+    Same tables, same histograms -- five stations with different data and different plant times,
+    magnitudes on (the trigger-time kernel reads DS and the stream of ITS station)."""
+    from detex_amd.hip import HipContext
+    rs = np.random.RandomState(3)
+    fams = _wavelets(rs, 2)
+    stas = ['TA.S%02dA' % i for i in range(5)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], conDatDuration=600, conBuff=60)
+    T = int(2000 * SR)
+    for si, sta in enumerate(stas):
+        n = 0
+        for f, wav in enumerate(fams):
+            for _ in range(5):
+                sh = int(rs.randint(0, 30))
+                data = np.array([rs.uniform(.5, 2) * w[sh:sh + L] + rs.standard_normal(L) * np.std(w) / 8
+                                 for w in wav])
+                ef.add(sta, 'ev%02d' % n, data, starttime=5000.0 + 50 * n, origintime=4990.0 + 50 * n,
+                       magnitude=1.0 + 0.1 * n)
+                n += 1
+        con = rs.standard_normal((NC, T)) * 0.05
+        for k in range(4 + si):
+            t = int(rs.randint(100, T - L - 100))
+            f = int(rs.randint(2))
+            for c in range(NC):
+                con[c, t:t + L] += rs.uniform(.5, 1.2) * fams[f][c][10:10 + L]
+        cf.add(sta, con.astype(np.float32), starttime=1.2e6 + 1e4 * si)
+    cf.pin()
+    cl = createCluster(CCreq=0.55, fetch_arg=ef, device=0)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=0.0, defaultDuration=6.0)
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    piped = ss.detex(subspaceDB=None, triggerLTATime=5, triggerSTATime=0, estimateMags=True)
+    hist_p = {s: {k: v.copy() for k, v in ss.histSubSpaces[s].items()} for s in stas}
+    ctx = HipContext(0)
+    serial = ss.detex(subspaceDB=None, triggerLTATime=5, triggerSTATime=0, estimateMags=True, ctx=ctx)
+    ctx.close()
+    assert len(piped['ss_df']) >= 12 and set(piped['ss_df'].Sta) == set(stas)
+    pd.testing.assert_frame_equal(piped['ss_df'], serial['ss_df'])
+    pd.testing.assert_frame_equal(piped['sg_df'], serial['sg_df'])
+    for s in stas:
+        for k, v in ss.histSubSpaces[s].items():
+            assert np.array_equal(v, hist_p[s][k]), (s, k)
