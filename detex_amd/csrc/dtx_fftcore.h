@@ -572,6 +572,9 @@ __device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32
 }
 
 // ---------------------------------------------------------------- block spectra
+#ifndef DTX_XHAT_ROWSTORE
+#define DTX_XHAT_ROWSTORE 1
+#endif
 // Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
 // slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w
 // takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0.
@@ -596,10 +599,30 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
   }
   fft8192<-1>(v, lds, lb, tab, tid);
+#if DTX_XHAT_ROWSTORE
+  // Thread tid holds X[tid + 512 m] in v[m]; slot (f & 7) * 512 + (f >> 3) puts a wave's eight
+  // values of one m into eight 64-byte pieces 4 KB apart.  Through the (free) image instead: wave w
+  // stores row f & 7 = w, 64 consecutive slots (512 bytes) per instruction.  Image layout
+  // [m][tid + (tid >> 3)]: the reads (lane stride 9 elements) are conflict-free.
+  c32* row = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid >> 6) * 512 + (tid & 63);   // nblk: blocks STORED per chunk
+  __syncthreads();                                     // every wave's reads of the image are done
+#pragma unroll
+  for (int m = 0; m < 8; ++m) lds[m * 576 + tid + (tid >> 3)] = v[m];
+  if (tid == 0) lds[8 * 576] = v[8];                   // X[kN / 2]
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t2 = 8 * (tid & 63) + (tid >> 6);        // the thread that held f = 512 j + 8 lane + wave
+    c32 o = lds[j * 576 + t2 + (t2 >> 3)];
+    if (tid == 0 && j == 0) o.y = lds[8 * 576].x;
+    row[64 * j] = o;
+  }
+#else
   c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);   // nblk: blocks STORED per chunk
   if (tid == 0) v[0].y = v[8].x;
 #pragma unroll
   for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
+#endif
 }
 
 }  // namespace
