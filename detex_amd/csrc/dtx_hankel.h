@@ -310,6 +310,9 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
 // a block-wide scan (pandas rolling_mean / rolling_var, detect.py:566-568 and
 // construct.py:446-447).  planes: [batch][Nc][plane_stride].
 // ---------------------------------------------------------------------------
+#ifndef DTX_STATS_ROWSTORE
+#define DTX_STATS_ROWSTORE 1
+#endif
 #ifndef DTX_STATS_BATCHED
 #define DTX_STATS_BATCHED 1
 #endif
@@ -460,6 +463,35 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     mo[p0] = (float)(a1 / dn);
     so[p0] = constant(p0, a3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(a2, a1, dn));
   }
+#if DTX_STATS_ROWSTORE
+  // a thread's eight results are eight consecutive windows: stored directly, a wave instruction
+  // writes 64 four-byte pieces 32 bytes apart.  Through LDS (slot q + (q >> 5): the strided writes are
+  // conflict-free) each instruction stores 256 consecutive bytes.
+  __shared__ float stm[kStatsPB + kStatsPB / 32], sts[kStatsPB + kStatsPB / 32];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int64_t pw = p0 + (int64_t)E * tid + e + 1;
+    float m = 0.f, sd = 0.f;
+    if (pw < P && pw < p0 + kStatsPB) {
+      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
+      m = (float)(S1 / dn);
+      sd = constant(pw, S3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
+    }
+    const int q = E * tid + e;                           // window p0 + 1 + q
+    stm[q + (q >> 5)] = m;
+    sts[q + (q >> 5)] = sd;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int q = 256 * e + tid;
+    const int64_t pw = p0 + 1 + q;
+    if (pw < P && pw < p0 + kStatsPB) {
+      mo[pw] = stm[q + (q >> 5)];
+      so[pw] = sts[q + (q >> 5)];
+    }
+  }
+#else
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int64_t pw = p0 + (int64_t)E * tid + e + 1;
@@ -469,6 +501,7 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
       so[pw] = constant(pw, S3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
     }
   }
+#endif
 }
 
 }  // namespace dtx
