@@ -201,8 +201,8 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     caller, e.g. from pinned memory on a copy stream); chunk_sel: indices into the station's
     chunk list this call scans (multi-GPU sharding); bank: the station's detector bank if the
     caller already built (or received) it; a failing batch is logged and skipped like a
-    failing chunk of the reference (detect.py:160-174).  (StationScan.start / .finish are
-    the two halves: SubSpace.detex starts the next station before it finishes this one.)"""
+    failing chunk of the reference (detect.py:160-174).  (StationScan.start / .pick / .finish are
+    the three stages: SubSpace.detex keeps three stations in flight, one in each.)"""
     job = StationScan(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
                       useSingles, fillZeros, device, ctx, estimateMags, planes_dev, chunk_sel, bank)
     try:
@@ -213,10 +213,12 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
 
 
 class StationScan(object):
-    """One station's scan in two halves: start() enqueues everything the GPU does for the
+    """One station's scan in three stages: start() enqueues everything the GPU does for the
     detection statistic (basis upload if needed, interleaving / filtering, one dtx_subspace_scan
-    per batch of chunks, the small results on their way to pinned host memory); finish() picks
-    the triggers from the candidate lists, runs dtx_trigger_stats and builds the rows."""
+    per batch of chunks, the small results on their way to pinned host memory); pick() takes the
+    triggers from the candidate lists and enqueues dtx_trigger_stats; finish() waits for its rows
+    (by event: nothing here synchronises the stream, which holds the next stations' scans) and
+    builds the tables."""
 
     COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
 
