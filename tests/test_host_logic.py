@@ -470,3 +470,27 @@ def test_validateClusters_drops_a_misaligned_event():
     assert list(ss.subspaces['TA.M17A'].iloc[0].Events) == keep
     assert events[0] not in keep and events[0] not in ss.subspaces['TA.M17A'].iloc[0].AlignedTD
     assert len(keep) >= 3
+
+
+def test_mags_from_stats_many_equals_row_by_row():
+    """The vectorised magnitude formulas (all triggers of a detector at once) against the scalar
+    ones the golden estmag vectors pin, on random trigger rows incl. unusable magnitudes and NaNs."""
+    from detex_amd import detect
+    rs = np.random.RandomState(4)
+    n, ne = 600, 5
+    ewf = rs.standard_normal((ne, n))
+    U = np.linalg.qr(rs.standard_normal((n, 3)))[0].T
+    for issub in (True, False):
+        for mags in ([1.0, 2.0, -20.0, 0.5, 3.0], [-99.0] * 5, [np.nan, 1, 1, 1, 1]):
+            c = detect.mag_constants(ewf, mags, U, issub)
+            O = rs.standard_normal((9, 6 + ne)) * 3
+            O[:, 3] = np.abs(O[:, 3]) + .1
+            O[:, 4] = np.abs(O[:, 4]) + .1
+            O[:, 5] = np.abs(O[:, 5]) + .1
+            O[2, 5] = 0.0                                # zero noise -> inf SNR like the reference
+            O[4, 6:] = np.nan
+            got = detect.mags_from_stats_many(c, issub, n, O)
+            for r in range(len(O)):
+                want = detect.mags_from_stats(c, issub, n, O[r])
+                for g, w in zip(got, want):
+                    assert (np.isnan(g[r]) and np.isnan(w)) or g[r] == w or abs(g[r] - w) <= 1e-12 * abs(w), (issub, mags, r)
