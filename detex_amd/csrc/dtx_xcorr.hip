@@ -249,6 +249,9 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
   xc_epilogue<RM, TN>(acc, a, c, kt, p0);
 }
 
+#ifndef DTX_XCFIN_BATCH
+#define DTX_XCFIN_BATCH 4
+#endif
 // One wave per pair: float64 re-evaluation of the winning lag and its two
 // neighbours, reference scrub, cosine sub-sample fit, outputs.
 __global__ __launch_bounds__(256) void xc_finish_kernel(
@@ -328,8 +331,28 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
       __syncthreads();
       if (live) {
         const int jend = min(J0 + kCh, n + Nc);
-#pragma unroll 2
         for (int jb = J0; jb < jend; jb += 64) {        // jb: the iteration's first index (uniform)
+          constexpr int kB = DTX_XCFIN_BATCH;           // interior iterations taken together
+          if (kB > 1 && jb + 64 * kB <= jend && jb - Nc >= 0 && jb + 64 * kB - 1 + Nc < n && jb + sh1 >= 0 &&
+              jb + 64 * kB - 1 + sh1 < n) {
+            // kB interior iterations: their loads of x_c first (all in flight), then the same sums in
+            // the same order
+            float vb[kB];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) vb[k] = x2[jb + 64 * k + lane + sh1];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) {
+              const int i = jb + 64 * k + lane - J0 + Nc;
+              const double v = (double)vb[k];
+              dot[0] += (double)x1s[i + Nc] * v;
+              dot[1] += (double)x1s[i] * v;
+              dot[2] += (double)x1s[i - Nc] * v;
+              swc += v;
+              sqc += v * v;
+            }
+            jb += 64 * (kB - 1);
+            continue;
+          }
           const int jm = jb + lane, t = jm + sh1;
           const int i = jm - J0 + Nc;                   // x1s index of x_b[jm]
           if (jb - Nc >= 0 && jb + 63 + Nc < n && jb + sh1 >= 0 && jb + 63 + sh1 < n) {
