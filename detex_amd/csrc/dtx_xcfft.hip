@@ -64,6 +64,12 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
   for (int m = 0; m < 16; ++m) dst[w_slot(tid + 512 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
 }
 
+#ifndef DTX_XC_XLDS
+#define DTX_XC_XLDS 1         // block spectra of the MAC staged through LDS (four 16-byte loads per thread and channel)
+#endif
+#ifndef DTX_XC_ABLATE
+#define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads
+#endif
 struct XcFftArgs {
   const c32* xh;        // [N][nblkx][Nc][kXh] block spectra of the padded planes of every event
   const c32* W;         // [ceil(N/2)][Nc*nseg][kN] pair spectra
@@ -83,6 +89,9 @@ struct XcFftArgs {
 template <int VM>
 __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftArgs a) {
   __shared__ c32 lds[kLdsC];
+#if DTX_XC_XLDS
+  __shared__ c32 xst[2][kXh];     // the block spectrum of the current / next virtual channel (see the MAC loop)
+#endif
   const int tid = threadIdx.x;
   // workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of the
   // (unit-major) work list so that the workgroups sharing an L2 share a unit's pair spectra
@@ -163,17 +172,58 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
     c32 z[16], zb[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
+#if DTX_XC_XLDS
+    // The block spectrum of a virtual channel (32 KB) is the same for every thread's 16 mirrored
+    // 8-byte reads: fetched from L2 they are 16 load instructions per thread and channel and cost as
+    // much as the 1.5 MB of pair spectra (timing-only ablation: 290 ms -> 184 without them).  Staged
+    // through LDS instead -- four 16-byte loads per thread, double-buffered a channel ahead; the
+    // kernel's 198 registers hold it to one workgroup per CU, so 64 KB of LDS beside the image are free.
+    auto xsrc = [&](int vc) {
+      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
+      return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + ch) * kXh);
+    };
+    float4 xn[4];
+    {
+      const float4* src = xsrc(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xn[k] = src[tid + 512 * k];
+      float4* dst = reinterpret_cast<float4*>(xst[0]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[tid + 512 * k] = xn[k];
+    }
+    __syncthreads();
+#endif
 #pragma nounroll
     for (int vc = 0; vc < nvc; ++vc) {
       const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
       c32 pa[16], pb[16], px[16];
       const c32* wca = wpa + (int64_t)vc * kN;
       const c32* wcb = wpb + (int64_t)vc * kN;
+#if DTX_XC_XLDS
+      if (vc + 1 < nvc) {
+        const float4* src = xsrc(vc + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = src[tid + 512 * k];
+      }
+      const c32* xc = xst[vc & 1];
+      (void)ch; (void)sg;
+#else
       const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
+#endif
+#if DTX_XC_ABLATE & 1     // timing only: no pair-spectrum loads
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = pb[r] = make_float2(1.f, 0.5f);
+#else
       w_load16(wca, wlo, pa);
       w_load16(wcb, wlo, pb);
+#endif
+#if DTX_XC_ABLATE & 2     // timing only: no block-spectrum loads
+#pragma unroll
+      for (int r = 0; r < 16; ++r) px[r] = make_float2(0.25f, 1.f);
+#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
+#endif
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         // two fused multiply-adds per component (written as a sum of products the compiler
@@ -183,6 +233,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
         zb[m].x = __fmaf_rn(-pb[m].y, px[m].y, __fmaf_rn(pb[m].x, px[m].x, zb[m].x));
         zb[m].y = __fmaf_rn(pb[m].y, px[m].x, __fmaf_rn(pb[m].x, px[m].y, zb[m].y));
       }
+#if DTX_XC_XLDS
+      if (vc + 1 < nvc) {
+        float4* dst = reinterpret_cast<float4*>(xst[(vc + 1) & 1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[tid + 512 * k] = xn[k];
+      }
+      __syncthreads();
+#endif
     }
     fft8192<1>(z, lds, lb, a.tab, tid);
     reduce_rows(z, pr);
