@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   // blocks': segment s of the template meets the data of block blk + s (advance == segment length)
   const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
+  __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];   // NCH == 0: the current / next virtual channel's block spectrum
   if constexpr (NCH > 0) {
     const float4* src = reinterpret_cast<const float4*>(xh);
     float4* dst = reinterpret_cast<float4*>(xs);
@@ -247,19 +248,47 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       c32 zb[16];
 #pragma unroll
       for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
+      // The block spectrum of a virtual channel is staged through LDS, a channel ahead: four 16-byte
+      // loads per thread instead of sixteen mirrored 8-byte ones (as in xc_fft_kernel, where the
+      // sixteen cost as much as all the pair spectra; this kernel too runs one workgroup per CU, so
+      // the LDS beside the image is free).
+      auto xsrc = [&](int vc) {
+        const int c = vc / a.nseg, sg = vc - c * a.nseg;   // (channel, template segment)
+        return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + c) * kXh);
+      };
+      float4 xn[4];
+      {
+        const float4* src = xsrc(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = src[tid + kT * k];
+        float4* dst = reinterpret_cast<float4*>(xst);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[tid + kT * k] = xn[k];
+      }
+      __syncthreads();
 #pragma nounroll
       for (int vc = 0; vc < nvc; ++vc) {
-        const int c = vc / a.nseg, sg = vc - c * a.nseg;   // (channel, template segment)
         c32 pa[16], pb[16], px[16];
         const c32* wca = wpa + (int64_t)vc * kN;
         const c32* wcb = wpb + (int64_t)vc * kN;
-        const c32* xc = xh + ((int64_t)sg * a.Nc + c) * kXh;
+        if (vc + 1 < nvc) {
+          const float4* src = xsrc(vc + 1);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xn[k] = src[tid + kT * k];
+        }
+        const c32* xc = xst + (vc & 1) * kXh;
         w_load16(wca, wlo, pa);
         w_load16(wcb, wlo, pb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
         mac16(z, pa, px);
         mac16(zb, pb, px);
+        if (vc + 1 < nvc) {
+          float4* dst = reinterpret_cast<float4*>(xst + ((vc + 1) & 1) * kXh);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[tid + kT * k] = xn[k];
+        }
+        __syncthreads();
       }
       {
         const int pr = pr0;
