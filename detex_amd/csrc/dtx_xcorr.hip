@@ -249,6 +249,9 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
   xc_epilogue<RM, TN>(acc, a, c, kt, p0);
 }
 
+#ifndef DTX_XCFIN_ABLATE
+#define DTX_XCFIN_ABLATE 0   // timing only: 1 no x_c loads, 2 no LDS reads of x_b (interior iterations)
+#endif
 #ifndef DTX_XCFIN_BATCH
 #define DTX_XCFIN_BATCH 4
 #endif
@@ -339,14 +342,22 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
             // the same order
             float vb[kB];
 #pragma unroll
+#if DTX_XCFIN_ABLATE & 1
+            for (int k = 0; k < kB; ++k) vb[k] = 0.5f;
+#else
             for (int k = 0; k < kB; ++k) vb[k] = x2[jb + 64 * k + lane + sh1];
+#endif
 #pragma unroll
             for (int k = 0; k < kB; ++k) {
               const int i = jb + 64 * k + lane - J0 + Nc;
               const double v = (double)vb[k];
+#if DTX_XCFIN_ABLATE & 2
+              dot[0] += 0.25 * v; dot[1] += 0.5 * v; dot[2] += 0.75 * v;
+#else
               dot[0] += (double)x1s[i + Nc] * v;
               dot[1] += (double)x1s[i] * v;
               dot[2] += (double)x1s[i - Nc] * v;
+#endif
               swc += v;
               sqc += v * v;
             }
