@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
     }
   }
   if (!stage && !live) return;
+  // a block whose four pairs are all dead (below the diagonal of a diagonal tile, past the last event,
+  // outside the rank's pair range) would still stage the earlier event through LDS ten times over
+  if (stage && !__syncthreads_or(live)) return;
   const int p = live ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
   const float* x1 = td + (b < N ? b : 0) * (int64_t)n;
   const float* x2 = td + (c < N ? c : 0) * (int64_t)n;
