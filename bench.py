@@ -116,11 +116,14 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         # --pmc passes, gfx950 FETCH_SIZE x2 correction) for the default configuration only
         if not default_cfg:
             return None
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), key=os.path.getmtime)
         if not pm:
             return None
         with open(pm[-1]) as f:
-            return json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
+            b = json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
+        # NOT a live counter: read from the committed rocprofv3 --pmc summary of the same command
+        # (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+        return {'bytes': b, 'source': 'profiles/' + os.path.basename(pm[-1]), 'live': False}
     if eng == 'fft':
         N = 8192
         V = (N - L + 1) // 512 * 512 if L <= 5633 else 4096      # segmented templates advance by 4096
@@ -222,11 +225,12 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
                     % (x.nbytes / 1e6)}
 
 
-def xcorr_full(ctx, synth, Nc):
+def xcorr_full(ctx, synth, Nc, cpu=True):
     """BASELINE configs[2] at full size: 2000 events x (3 x 13000) samples, 1 999 000 pairs."""
     N, L = 2000, 13000
     n = Nc * L
-    td = torch.from_numpy(synth.event_families(2, 100, 20, Nc, L)).cuda()
+    td_host = synth.event_families(2, 100, 20, Nc, L)
+    td = torch.from_numpy(td_host).cuda()
     npairs = N * (N - 1) // 2
     S = L - L // 2
     flop_pair = 2.0 * Nc * ((2 * S + 1) * L - S * (S + 1))        # SURVEY 8d: 0.7605 GFLOP
@@ -250,13 +254,43 @@ def xcorr_full(ctx, synth, Nc):
     flop_fft = nfft * (5.0 * 8192 * 13 + 8.0 * Nc * nseg * 8192)
     l2_bytes = nfft * Nc * nseg * (8192 * 8 + 4096 * 8 / 2.0)      # pair spectrum + half of a shared block spectrum
     bytes_alg = 4.0 * N * n + 12.0 * npairs                        # events once + 12 B per pair
+    # counters of the committed rocprofv3 --pmc passes of scripts/bench_xcorr.py (scripts/profile_xc.sh), newest tag
+    import glob
+    pmc, pmc_src = {}, None
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_xcorr_pmc.json')), key=os.path.getmtime)[-1:]:
+        with open(fn) as f:
+            pmc, pmc_src = json.load(f).get('kernels', {}), 'profiles/' + os.path.basename(fn)
+
+    def cnt(kern, name):
+        v = pmc.get(kern, {}).get(name)
+        return v['mean_per_launch'] if isinstance(v, dict) else v
+    hbm = cnt('xc_fft_kernel', 'hbm_bytes_per_launch_corrected')
+    l2req = cnt('xc_fft_kernel', 'TCC_REQ_sum')
+    cpu_leg = None
+    if cpu:
+        # the reference's _CCX2 (construct.py:425-466) on this host: one core (the reference is
+        # single-threaded) and all physical cores; a bounded sample of the same events
+        from oracle import cpu_bench
+        try:
+            cpu_leg = cpu_bench.xcorr_onecore(td_host, Nc, npairs=400)
+            cpu_leg['all_cores'] = cpu_bench.xcorr_allcores(td_host, Nc, pairs_per_worker=200)
+        except Exception as e:                          # noqa: BLE001 -- a bounded leg never takes the line down
+            cpu_leg = dict(value=None, unit='pairs/s', error=repr(e))
     return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,
             'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs),
-            'cc_mean': ccm,
+            'cc_mean': ccm, 'cpu_baseline': cpu_leg,
             'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
                          'achieved': bytes_alg / (kms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                         'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0,
+                         'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False} if hbm else None),
                          'bytes_per_launch': bytes_alg,
+                         'bound_actual': 'L2 -> CU stream of the pair spectra (counters: %s) -- the algorithmic HBM '
+                                         'bytes the schema prices are 3 orders of magnitude below what the '
+                                         'frequency-domain search moves on chip' % pmc_src,
+                         'l2_counters': ({'TCC_REQ_sum': l2req, 'bytes_at_128B': 128.0 * l2req,
+                                          'TBps': 128.0 * l2req / (kms * 1e-3) / 1e12,
+                                          'hit_rate': cnt('xc_fft_kernel', 'TCC_HIT_sum') / l2req,
+                                          'source': pmc_src, 'live': False} if l2req else None),
                          'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
                                      'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
                                      'frac': flop_fft / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -309,6 +343,69 @@ def config5(ctx, synth):
                                  'roofline': {'bound': 'mfma', 'achieved': flops / (res['fp32'][1] * 1e-3) / 1e12,
                                               'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                               'frac': flops / (res['fp32'][1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}}
+
+
+def e2e_detex(local):
+    """The configs[1] workload through the reference's API (subspace.py:1745-1902, detect.py:137-218):
+    createCluster -> createSubSpace -> SVD on 25 families x 8 events (25 detectors x 8 basis vectors of
+    30 s), then SubSpace.detex(estimateMags=True) over 8 stations x 1 day (24 chunks of 3720 s each) held
+    by a pinned ContinuousFetcher: uploads, scans, trigger picking, STA/LTA, magnitudes and the result
+    tables are all inside the timed region; once without and once with the SQLite file."""
+    import tempfile
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace, synth
+    SR, NC, L, NFAM, NPER, NSTA = 100.0, 3, 3300, 25, 8, 8
+    rs = np.random.RandomState(0)
+    td = synth.event_families(1, NFAM, NPER, NC, L, maxshift=20, snr=8.0)
+    stas = ['TA.S%02dA' % i for i in range(NSTA)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    for sta in stas:
+        for e in range(len(td)):
+            ef.add(sta, 'ev%03d' % e, td[e].reshape(L, NC).T, starttime=1000.0 + 100 * e,
+                   origintime=990.0 + 100 * e, magnitude=1.0 + (e % 5) * .2)
+    T = int(24 * 3600 * SR)
+    con = rs.standard_normal((NC, T)).astype(np.float32)
+    nplant = 50
+    for k in range(nplant):
+        e = int(rs.randint(len(td)))
+        t = int(rs.randint(0, T - L))
+        con[:, t:t + L] += 3.0 * td[e].reshape(L, NC).T / np.std(td[e])
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    for i, sta in enumerate(stas):
+        cf.add(sta, con if i == 0 else con.copy(), starttime=1.5e9)
+    cf.pin()
+    t0 = time.perf_counter()
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, device=local)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
+    ss.SVD(selectCriteria=4, selectValue=7, threshold=0.3, useSingles=False)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    names, kinds, U, off, _, _ = ss._detector_bank(stas[0], useSingles=False)
+    n = U.shape[1]
+    P = (int(round(3720.0 * SR)) * NC - n) // NC + 1
+    windows = NSTA * 24 * P
+    out = {'workload': '%d stations x 1 day (24 chunks of 3720 s, 3-ch 100 Hz) through createCluster / createSubSpace / '
+                       'SVD / SubSpace.detex(estimateMags=True); %d detectors, %d basis vectors, n = %d; pinned fetcher'
+                       % (NSTA, len(names), U.shape[0], n),
+           'setup_s': t_setup, 'unit': 'windows/s'}
+    with tempfile.TemporaryDirectory() as tmp:
+        for key, db in (('no_db', None), ('sqlite', os.path.join(tmp, 'SubSpace.db'))):
+            res = ss.detex(subspaceDB=db, estimateMags=True, device=local)       # warm: contexts, basis images
+            torch.cuda.synchronize()
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = ss.detex(subspaceDB=db, estimateMags=True, device=local)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[key] = {'value': windows / dt, 'ms_per_call': 1e3 * dt, 'ms_per_station_day': 1e3 * dt / NSTA,
+                        'detections': int(len(res['ss_df']))}
+    got = res['ss_df']
+    out['planted'] = nplant * NSTA
+    out['detections_with_magnitude'] = int(got.Mag.notna().sum())
+    assert len(got) >= nplant * NSTA * 0.9, 'e2e_detex: %d detections for %d planted events' % (len(got), nplant * NSTA)
+    out['value'] = out['no_db']['value']
+    return out
 
 
 def run_config4(a, rank, world, local, use_dist):
@@ -367,6 +464,8 @@ def run_config4(a, rank, world, local, use_dist):
     thr = np.full(D, 0.3, dtype=np.float32)
     hists = {s: torch.zeros((D, 400), dtype=torch.int32, device=dev) for s in ctxs}
 
+    found = [0, 0]
+
     def step(check=False):
         fetches = []
         for (s, d) in mine:
@@ -375,6 +474,8 @@ def run_config4(a, rank, world, local, use_dist):
                 cb, cd, cp, cv = f()['cand']
                 for (b, p, dd) in plants[(s, d)]:
                     assert ((cb == b) & (cd == dd) & (np.abs(cp - p) <= 2)).any(), (s, d, b, p, dd)
+                    found[0] += 1
+                found[1] += len(plants[(s, d)])
             else:
                 fetches.append(f)
         return [f() for f in fetches[-1:]]        # the last fetch synchronises the stream
@@ -398,6 +499,12 @@ def run_config4(a, rank, world, local, use_dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     windows = len(units) * a.chunks * P * a.steps
+    if use_dist:
+        t = torch.tensor(found, dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        found = [int(v) for v in t.tolist()]
+    for c in ctxs.values():
+        c.close()
     return {'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)', 'value': windows / dt,
             'unit': 'windows/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'strong',
@@ -407,6 +514,8 @@ def run_config4(a, rank, world, local, use_dist):
                                    % (a.stations, a.days, len(units), D * k, D, k, a.chunks, a.chunk_seconds,
                                       Nc, a.sr, world),
                        'engine': a.engine, 'station_days_per_gpu_max': -(-len(units) // world),
+                       'planted_found': '%d/%d' % tuple(found),
+                       'resident_stream_gb_per_gpu': sum(v.numel() for v in data.values()) * 4 / 1e9,
                        'basis_broadcast_and_upload_s': t_up}}
 
 
@@ -553,9 +662,28 @@ def main():
                         'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
         ctx.set_engine(a.engine)
         out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, min(a.steps, 50))
-        out['xcorr_full'] = xcorr_full(ctx, synth, Nc)
+        out['xcorr_full'] = xcorr_full(ctx, synth, Nc, cpu=not a.no_cpu_baseline)
         out['config5'] = config5(ctx, synth)
         ctx.upload_basis(Ut, det_off, Nc)
+        # BASELINE configs[3] at its real size on this one GPU: the N = 1 anchor of the strong-scaling curve
+        # (the driver measures N = 2, 4, 8 with --config 4 --gpus N)
+        try:
+            import copy
+            a4 = copy.copy(a)
+            a4.config, a4.steps, a4.warmup, a4.stations, a4.days = 4, 2, 1, 8, 30
+            del ds
+            torch.cuda.empty_cache()
+            c4 = run_config4(a4, 0, 1, local, False)
+            out['config4_n1'] = {'value': c4['value'], 'unit': c4['unit'], 'ms_per_step': c4['ms_per_step'],
+                                 'steps': a4.steps, 'scaling': 'strong', 'n_gpus': 1,
+                                 'ms_per_station_day': c4['ms_per_step'] / 240.0, 'config': c4['config']}
+        except Exception as e:                         # noqa: BLE001 -- a secondary field never takes the line down
+            out['config4_n1'] = {'value': None, 'error': repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            out['e2e_detex'] = e2e_detex(local)
+        except Exception as e:                         # noqa: BLE001
+            out['e2e_detex'] = {'value': None, 'error': repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
         if default_cfg and not a.no_extras:

@@ -1,7 +1,16 @@
 """Host side of the detection scan: the reference's trigger-picking loop
 (detex/detect.py:390-445, 526-557) run on the sparse list of above-threshold
 samples the GPU returns instead of on the full detection-statistic vector."""
+import contextlib
+
 import numpy as np
+
+
+def _stream_of(ctx, device):
+    """The stream a context's kernels run on (events that order against them are recorded there)."""
+    import torch
+    st = getattr(ctx, 'stream', None)
+    return st if st is not None else torch.cuda.current_stream(device)
 
 
 def pick_triggers_sparse(idx, val, P, threshold, sr, maxds, buff=20, maxcount=4000):
@@ -201,9 +210,10 @@ class _MagBank(object):
     """The training events of every detector of a station on the device (for
     dtx_trigger_stats) and their host-side constants."""
 
-    def __init__(self, ss, names, kinds, U, det_off, device):
+    def __init__(self, ss, sta, names, kinds, U, det_off, device):
         import torch
-        self.consts = [mag_constants(ss._bank_ewf[nm], ss._bank_mags[nm],
+        ewf, mags = ss._bank_aux[sta]
+        self.consts = [mag_constants(ewf[nm], mags[nm],
                                      U[det_off[d]:det_off[d + 1]], kinds[d] == 'ss')
                        for d, nm in enumerate(names)]
         eoff = np.concatenate([[0], np.cumsum([len(c['mags']) for c in self.consts])])
@@ -221,7 +231,7 @@ class _MagBank(object):
 
 def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
                  useSubSpaces, useSingles, fillZeros, device=0, ctx=None, estimateMags=True,
-                 planes_dev=None, chunk_sel=None, bank=None):
+                 shard=None, bank=None):
     """_SSDetex._corDat (detect.py:137-218) for one station with all its
     detectors in one GPU basis: per batch of chunks the detection statistic
     (dtx_subspace_scan: detection statistic + histogram / max / candidates), the
@@ -229,14 +239,15 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     for the STA/LTA and magnitude ingredients of all the batch's triggers.  Returns
     dict(ss=DataFrame, sg=DataFrame, hist_ss={name: counts}, hist_sg={...}) or None.
 
-    planes_dev: the station's [Nc, T] data already on the device (uploaded ahead by the
-    caller, e.g. from pinned memory on a copy stream); chunk_sel: indices into the station's
-    chunk list this call scans (multi-GPU sharding); bank: the station's detector bank if the
+    shard: what SubSpace.detex's uploader prepared -- dict(planes=[Nc, T] device tensor or None,
+    bounds=[(first sample in planes, samples, start time, chunk index)], T, counts=fragments in the
+    same coordinates or None): the whole station, or in a multi-process run only the rank's own
+    chunks, packed; bank: the station's detector bank if the
     caller already built (or received) it; a failing batch is logged and skipped like a
     failing chunk of the reference (detect.py:160-174).  (StationScan.start / .pick / .finish are
     the three stages: SubSpace.detex keeps three stations in flight, one in each.)"""
     job = StationScan(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
-                      useSingles, fillZeros, device, ctx, estimateMags, planes_dev, chunk_sel, bank)
+                      useSingles, fillZeros, device, ctx, estimateMags, shard, bank)
     try:
         job.start()
         return job.finish()
@@ -255,13 +266,12 @@ class StationScan(object):
     COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
 
     def __init__(self, ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
-                 useSingles, fillZeros, device=0, ctx=None, estimateMags=True, planes_dev=None,
-                 chunk_sel=None, bank=None):
+                 useSingles, fillZeros, device=0, ctx=None, estimateMags=True, shard=None, bank=None):
         from .hip import HipContext
         self.ss, self.sta = ss, sta
         self.args = (utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags)
         self.bank = bank if bank is not None else ss._detector_bank(sta, useSubSpaces, useSingles)
-        self.planes_dev, self.chunk_sel = planes_dev, chunk_sel
+        self.shard = shard
         self.empty = (not self.bank[0]) or sta not in ss.cfetcher.data
         self.own = ctx is None and not self.empty
         self.ctx = HipContext(device) if self.own else ctx
@@ -273,11 +283,21 @@ class StationScan(object):
             self.ctx.close()
             self.ctx = None
 
+    def _guard(self):
+        """The context's stream made current (HipContext.on_stream): buffers, events and kernels of
+        this scan agree on the stream whatever stream the caller works on."""
+        g = getattr(self.ctx, 'on_stream', None)
+        return g() if g is not None else contextlib.nullcontext()
+
     def start(self):
-        import torch
-        from ._lib import DetexHipError
         if self.empty:
             return
+        with self._guard():
+            self._start()
+
+    def _start(self):
+        import torch
+        from ._lib import DetexHipError
         ss, sta, ctx = self.ss, self.sta, self.ctx
         utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags = self.args
         names, kinds, U, det_off, offsets, thr = self.bank
@@ -292,13 +312,20 @@ class StationScan(object):
         data, t0 = fetcher.data[sta]
         raw = bool(getattr(fetcher, 'raw', False))
         dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
-        counts = getattr(fetcher, 'counts', {}).get(sta)
-        planes_dev = self.planes_dev
-        self.planes_dev = None
+        shard = self.shard
+        self.shard = None
+        if shard is None:                                 # the whole station, uploaded here
+            counts = getattr(fetcher, 'counts', {}).get(sta)
+            bounds = [(int(b[0]), int(b[1]), b[2], i)
+                      for i, b in enumerate(fetcher.chunk_bounds(sta, utcStart, utcEnd))]
+            planes_dev, T = None, data.shape[1]
+        else:
+            counts, bounds, planes_dev, T = shard['counts'], list(shard['bounds']), shard['planes'], shard['T']
+        del shard
         if counts is not None:
             # raw int32 counts in fragments: merged with zero fill on the device
             # (construct.py:1038 / 1070); the per-chunk trimming follows below
-            planes_dev = _ingest_station(ctx, counts, Nc, data.shape[1])
+            planes_dev = _ingest_station(ctx, counts, Nc, T)
         elif planes_dev is None:
             planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
         sr_raw = sr
@@ -317,9 +344,6 @@ class StationScan(object):
         from .hip import h2d_async
         thr_dev = h2d_async(thr_arr, ctx.device)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
-        bounds = fetcher.chunk_bounds(sta, utcStart, utcEnd)
-        if self.chunk_sel is not None:
-            bounds = [bounds[i] for i in self.chunk_sel if i < len(bounds)]
         if counts is not None and not fillZeros:
             bounds = _trim_to_gapfree(ctx, rawdev, counts, bounds, fetcher.sampling_rate, sta)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
@@ -332,7 +356,7 @@ class StationScan(object):
             # belong to (rebuilt only when the bank is)
             held = getattr(ctx, '_magbank', None)
             if held is None or held[0] is not U:
-                held = (U, _MagBank(ss, names, kinds, U, det_off, ctx.device))
+                held = (U, _MagBank(ss, sta, names, kinds, U, det_off, ctx.device))
                 ctx._magbank = held
             mbank = held[1]
         self.st = dict(names=names, kinds=kinds, offsets=offsets, thr_arr=thr_arr, thr_dev=thr_dev, hist=hist,
@@ -365,7 +389,7 @@ class StationScan(object):
             self.hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
             self.hist_host.copy_(hist, non_blocking=True)
             self.hist_ev = torch.cuda.Event()
-            self.hist_ev.record(torch.cuda.current_stream(hist.device))
+            self.hist_ev.record(_stream_of(ctx, hist.device))
 
     def _skip(self, i0, i1, e):
         # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
@@ -381,12 +405,13 @@ class StationScan(object):
             return
         st = self.st
         self.picked = []
-        for (i0, i1, xb, M, cstride, ds, fetch) in self.batches:
-            try:
-                self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
-                                                           i0, i1, xb, M, cstride, ds, fetch))
-            except DetexHipError as e:
-                self._skip(i0, i1, e)
+        with self._guard():
+            for (i0, i1, xb, M, cstride, ds, fetch) in self.batches:
+                try:
+                    self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
+                                                               i0, i1, xb, M, cstride, ds, fetch))
+                except DetexHipError as e:
+                    self._skip(i0, i1, e)
 
     def finish(self):
         """Second host half: trigger-time estimates back from the device -> rows."""
@@ -396,8 +421,9 @@ class StationScan(object):
         self.pick()
         st = self.st
         rows = {'ss': [], 'sg': []}
+        keys = {'ss': [], 'sg': []}
         for (i0, trigs, bad, stats) in self.picked:
-            _batch_rows(self.sta, st, self.args[5], self.args[6], i0, trigs, bad, stats, rows)
+            _batch_rows(self.sta, st, self.args[5], self.args[6], i0, trigs, bad, stats, rows, keys)
         self.batches, self.picked = [], None
         if self.hist_ev is not None:
             self.hist_ev.synchronize()
@@ -406,6 +432,10 @@ class StationScan(object):
             h = st['hist'].cpu().numpy()
         names, kinds = st['names'], st['kinds']
         out = {k: pd.DataFrame(v, columns=self.COLS) for k, v in rows.items()}
+        # (chunk index in the station's chunk list, detector, order found) per row: a multi-process
+        # run merges the ranks' tables by it into the single-process order
+        for k, v in keys.items():
+            out['key_' + k] = np.asarray(v, dtype=np.int64).reshape(-1, 3)
         out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
         out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
         return out
@@ -424,33 +454,71 @@ def _ingest_station(ctx, counts, Nc, T):
     return planes
 
 
+def chunk_traces(counts, s0, cnt):
+    """The traces a chunk [s0, s0 + cnt) of a fragmented record consists of, per channel: the
+    fragments that reach into it, clipped to it -- what the reference's fetcher hands to
+    _applyFilter as ``st`` (one ObsPy trace per fragment).  {channel: [(first, end), ...]}"""
+    per = {}
+    for (c, t0, x) in counts:
+        lo, hi = max(int(t0), s0), min(int(t0) + len(x), s0 + cnt)
+        if hi > lo:
+            per.setdefault(c, []).append((lo, hi))
+    return per
+
+
 def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
-    """_mergeChannels per chunk (construct.py:1033-1066): each chunk is cut to its longest
-    stretch without a gap (a zero) in any channel; chunks that are then still in several
-    pieces on some channel are dropped like the reference's 'Stream is too fractured'
-    (construct.py:1011-1018).  One device pass per chunk, one copy back for all of them."""
+    """The front half of _applyFilter per chunk (construct.py:1003-1022).
+
+    A chunk with ONE trace per channel (``len(st) == len(nc)``, construct.py:1005) is not merged at
+    all: it is only trimmed to the span all its traces cover (1019-1023) -- exact zero counts in it
+    are ordinary samples.  Only a chunk in which some channel arrives in several traces goes
+    through _mergeChannels (1033-1066): cut to its longest stretch without a gap or a zero in any
+    channel (one device pass, dtx_gapfree_run); if the kept stretch is still in several traces on
+    some channel it is dropped like the reference's 'Stream is too fractured' (1011-1018).  A chunk
+    in which a channel has no data at all is dropped with a warning (the reference would go on
+    with fewer channels than the templates have; deliberate deviation)."""
     import torch
     if not bounds:
         return bounds
-    runs = torch.zeros((len(bounds), 2), dtype=torch.int64, device=planes.device)
-    for k, (s0, cnt, _) in enumerate(bounds):
-        ctx.gapfree_run(planes[:, s0:s0 + cnt], out=runs[k])
-    runs = runs.cpu().numpy()
-    out = []
-    for (s0, cnt, ts), (r0, rl) in zip(bounds, runs):
-        if rl <= 0:
-            _warn('no gap-free data on %s from %s' % (sta, ts))
+    Nc = int(planes.shape[0])
+    plan, fractured = [], []
+    for k, (s0, cnt, ts, gi) in enumerate(bounds):
+        per = chunk_traces(counts, s0, cnt)
+        if len(per) < Nc:
+            _warn('no data on %d of %d channels of %s from %s' % (Nc - len(per), Nc, sta, ts))
+            plan.append(None)
+        elif all(len(v) == 1 for v in per.values()):
+            a = max(v[0][0] for v in per.values())            # startTrim / endTrim, construct.py:1019-1023
+            b = min(v[0][1] for v in per.values())
+            plan.append((a - s0, b - a) if b > a else None)
+        else:
+            plan.append('merge')
+            fractured.append(k)
+    runs = None
+    if fractured:
+        runs = torch.zeros((len(fractured), 2), dtype=torch.int64, device=planes.device)
+        for j, k in enumerate(fractured):
+            s0, cnt = bounds[k][0], bounds[k][1]
+            ctx.gapfree_run(planes[:, s0:s0 + cnt], out=runs[j])
+        runs = runs.cpu().numpy()
+    out, j = [], 0
+    for (s0, cnt, ts, gi), pl in zip(bounds, plan):
+        if pl is None:
             continue
-        if (r0, rl) != (0, cnt):
-            a, b = s0 + int(r0), s0 + int(r0) + int(rl)
-            per = {}
-            for (c, t0, x) in counts:                  # traces that reach into the kept window
-                if t0 < b and t0 + len(x) > a:
-                    per[c] = per.get(c, 0) + 1
-            if any(v > 1 for v in per.values()):       # len(st) != len(nc)
-                _warn('Stream is too fractured around %s on %s' % (ts, sta))
+        if pl == 'merge':
+            r0, rl = (int(v) for v in runs[j])
+            j += 1
+            if rl <= 0:
+                _warn('no gap-free data on %s from %s' % (sta, ts))
                 continue
-        out.append((s0 + int(r0), int(rl), ts + int(r0) / sr))
+            if (r0, rl) != (0, cnt):
+                per = chunk_traces(counts, s0 + r0, rl)       # traces that reach into the kept window
+                if any(len(v) > 1 for v in per.values()):     # len(st) != len(nc)
+                    _warn('Stream is too fractured around %s on %s' % (ts, sta))
+                    continue
+        else:
+            r0, rl = pl
+        out.append((s0 + int(r0), int(rl), ts + int(r0) / sr, gi))
     return out
 
 
@@ -508,12 +576,12 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
             host = torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True)
             host.copy_(stats, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(stats.device))
+            ev.record(_stream_of(ctx, stats.device))
             stats = (host, ev, stats)
     return trigs, bad, stats
 
 
-def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows):
+def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows, keys=None):
     """Second host half: the trigger-time estimates -> rows of the detection tables."""
     names, kinds, offsets = st['names'], st['kinds'], st['offsets']
     bounds, n, sr, bank = st['bounds'], st['n'], st['sr'], st['mbank']
@@ -543,3 +611,5 @@ def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows):
         of = offsets[name]
         rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
                                times - np.min(of), float(stm_a[r]), float(snr_a[r]), float(pem_a[r])])
+        if keys is not None:
+            keys[kinds[d]].append((bounds[i0 + b][3], d, r))

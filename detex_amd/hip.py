@@ -4,7 +4,9 @@ torch is used for device memory, streams and (elsewhere) torch.distributed --
 plumbing only; all arithmetic happens in the hand-written HIP kernels of
 libdetexhip.so.
 """
+import contextlib
 import ctypes as C
+import functools
 import os
 
 import numpy as np
@@ -62,8 +64,27 @@ def h2d_async(arr, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def _on_ctx_stream(fn):
+    """Run a HipContext method with the context's stream as torch's current stream (see
+    HipContext.on_stream)."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with self.on_stream():
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class HipContext(object):
-    """One HIP device + stream.  All tensors passed in must live on it."""
+    """One HIP device + stream.  All tensors passed in must live on it.
+
+    Stream contract: the kernels run on the stream that was torch's current stream when the
+    context was created (``ctx.stream``).  Every method enters that stream before it allocates,
+    records or waits for anything, so tensors, events and kernels always agree on the stream --
+    also when the caller has since made another stream current (``with torch.cuda.stream(s)``).
+    In that case the context's stream first waits for the caller's (inputs produced there are
+    complete) and the caller's stream waits for the context's afterwards (results are ordered
+    for whatever the caller enqueues next): a call behaves as if it had been enqueued on the
+    caller's stream."""
 
     def __init__(self, device=0):
         self.lib = _lib.load()
@@ -84,6 +105,24 @@ class HipContext(object):
         env = os.environ.get('DETEX_AMD_ENGINE')
         if env:
             self.set_engine(env)
+
+    @property
+    def stream(self):
+        """The torch stream the context enqueues on (the one handed to dtx_ctx_create)."""
+        return self._stream
+
+    @contextlib.contextmanager
+    def on_stream(self):
+        """Make the context's stream current for the body; order it against the caller's current
+        stream on the way in and out if the two differ (class docstring)."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur == self._stream:
+            yield
+            return
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            yield
+        cur.wait_stream(self._stream)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -112,6 +151,7 @@ class HipContext(object):
         self._ck(self.lib.dtx_ctx_sync(self.h), 'dtx_ctx_sync')
 
     # ------------------------------------------------------------ subspace
+    @_on_ctx_stream
     def upload_basis(self, U, det_off, Nc):
         """U: [Ktot, n] float32 (numpy or torch, host or device);
         det_off: D+1 ints (detector d owns rows det_off[d]:det_off[d+1])."""
@@ -143,6 +183,7 @@ class HipContext(object):
     def num_windows(self, M):
         return int(self.lib.dtx_num_windows(int(M), self.n, self.Nc))
 
+    @_on_ctx_stream
     def subspace_ds(self, x, M=None, chunk_stride=None, nchunk=None, out=None):
         """Detection statistic of every uploaded detector.
 
@@ -195,6 +236,7 @@ class HipContext(object):
             cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
         return hist, maxds, thr_t, key, val, cnt
 
+    @_on_ctx_stream
     def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None,
                       hist=None, want_max=True, cand_cap=1 << 20, lazy=False):
         """subspace_ds + ds_post in one call (dtx_subspace_scan).
@@ -235,7 +277,7 @@ class HipContext(object):
         """The small results of an enqueued scan copied to pinned host memory on a side stream
         as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
         whatever was enqueued on the context's stream after the scan (the next station's scan)."""
-        main = torch.cuda.current_stream(self.device)
+        main = self._stream
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(self.device)
         side = self._side
@@ -280,6 +322,7 @@ class HipContext(object):
             return res
         return fetch
 
+    @_on_ctx_stream
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
         """Histogram / max / threshold candidates of a DS tensor [nchunk, D, P].
 
@@ -311,6 +354,7 @@ class HipContext(object):
                            (k & np.uint64(0xFFFFFFFF)).astype(np.int64), v)
         return res
 
+    @_on_ctx_stream
     def ds_moments(self, ds, lo=-.01, hi=1.0, nbins=400, hist=None, sums=None):
         """FAS pass over a DS tensor [nchunk, D, P]: histogram on
         np.linspace(lo, hi, nbins+1) and the beta-MLE sufficient statistics
@@ -331,6 +375,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_ds_moments')
         return hist, sums
 
+    @_on_ctx_stream
     def subspace_ds_host(self, x):
         """numpy in, numpy out (one block); includes the PCIe transfers."""
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -341,6 +386,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_ds_host')
         return out
 
+    @_on_ctx_stream
     def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax):
         """dtx_trigger_stats: STA / LTA means and the magnitude / SNR ingredients at triggers.
 
@@ -363,6 +409,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_trigger_stats')
         return out
 
+    @_on_ctx_stream
     def normcorr(self, t, s):
         """fast_normcorr(t, s) (construct.py:469-483) on the device: t [n], s [m >= n] float32 CUDA
         tensors -> [m - n + 1] float32 (asynchronous)."""
@@ -376,6 +423,7 @@ class HipContext(object):
         return out
 
     # ------------------------------------------------------------ xcorr
+    @_on_ctx_stream
     def xcorr_allpairs(self, td, Nc, pair_begin=0, pair_end=None):
         """td: [N, n] float32 CUDA tensor of multiplexed events.  Returns
         (cc, lag, subsamp) condensed CUDA tensors of length N(N-1)/2."""
@@ -395,6 +443,7 @@ class HipContext(object):
         return cc, lag, ss
 
     # ------------------------------------------------------------ pre-processing
+    @_on_ctx_stream
     def preprocess(self, raw, filt=None, sampling_rate=None, detrend=True, out=None):
         """Detrend + band-pass + multiplex on the device (construct.py:990-1030).
 
@@ -417,6 +466,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_preprocess')
         return out
 
+    @_on_ctx_stream
     def ingest_counts(self, counts, frags, Nc, T, want_run=True):
         """dtx_ingest_counts: fragments of raw int32 counts -> zero-filled [Nc, T] float32
         planes (+ the longest run without a zero in any channel, construct.py:1033-1066).
@@ -434,6 +484,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_ingest_counts')
         return planes, run
 
+    @_on_ctx_stream
     def gapfree_run(self, planes, out=None):
         """dtx_gapfree_run on a [Nc, T] float32 CUDA view (columns of a larger plane buffer are
         fine: stride(1) == 1): (start, length) of the longest run without a zero in any channel,
@@ -448,6 +499,7 @@ class HipContext(object):
         self._ck(rc, 'dtx_gapfree_run')
         return out
 
+    @_on_ctx_stream
     def decimate(self, raw, factor, sampling_rate):
         """Trace.decimate(factor) on the device (construct.py:1016-1017): causal
         Chebyshev-II low-pass, then every factor-th sample.
@@ -468,9 +520,11 @@ class HipContext(object):
         return out
 
     # ------------------------------------------------------------ timing
+    @_on_ctx_stream
     def timer_start(self):
         self._ck(self.lib.dtx_timer_start(self.h), 'dtx_timer_start')
 
+    @_on_ctx_stream
     def timer_stop(self):
         ms = C.c_float()
         self._ck(self.lib.dtx_timer_stop(self.h, C.byref(ms)), 'dtx_timer_stop')

@@ -11,6 +11,10 @@ Units of work:
 import numpy as np
 import torch
 
+# collectives issued through this module since import (tests assert that a SubSpace.detex call
+# costs a fixed number of them, whatever the number of stations)
+COLLECTIVES = {'broadcast': 0, 'all_gather': 0, 'all_gather_object': 0, 'broadcast_object': 0}
+
 
 def dist_info():
     """(rank, world) of the default process group, (0, 1) if not initialised."""
@@ -41,6 +45,72 @@ def shard_chunks(nchunks, rank, world, per_unit=24):
     return list(range(b, e))
 
 
+def deal_station_chunks(nchunks, per_unit, rank, world):
+    """Chunk indices this rank scans, per station: nchunks[s] chunks on station s, cut into
+    (station, day) units of `per_unit` consecutive chunks (a day of hourly chunks goes through
+    the kernels as one launch).  The units of ALL stations form one list that is dealt
+    round-robin (shard_units) -- what bench.py --config 4 does: with 30 days on 8 ranks every
+    rank gets 30 of the 240 station-days, where a per-station deal would hand ranks 0..5 the
+    extra day of every station.  With fewer units than ranks the chunks of all stations are cut
+    into `world` contiguous ranges instead, so that a single day still spreads over the GPUs.
+    Returns one list of chunk indices per station (empty: nothing of that station here)."""
+    per_unit = max(1, int(per_unit))
+    units = [(s, u) for s, nc in enumerate(nchunks) for u in range((nc + per_unit - 1) // per_unit)]
+    out = [[] for _ in nchunks]
+    if len(units) >= world:
+        for i in shard_units(len(units), rank, world):
+            s, u = units[i]
+            out[s].extend(range(u * per_unit, min((u + 1) * per_unit, nchunks[s])))
+        return out
+    flat = [(s, c) for s, nc in enumerate(nchunks) for c in range(nc)]
+    b, e = shard_pairs(len(flat), rank, world)
+    for s, c in flat[b:e]:
+        out[s].append(c)
+    return out
+
+
+def plan_shard(bounds, sel):
+    """The sample ranges a rank needs of one station, packed: bounds = the station's chunks
+    [(first sample, samples, start time), ...], sel = the chunk indices scanned here.
+    Overlapping / abutting chunks (consecutive hours share the 120 s buffer) merge into runs;
+    the runs are laid end to end in a compact buffer.  Returns (runs, local, T):
+    runs = [(first sample, end sample, offset in the compact buffer)], local = [(first sample in
+    the compact buffer, samples, start time, chunk index)] for the selected chunks, T = compact
+    length.  Only these T samples per channel are uploaded -- the host link is the one resource
+    the ranks share."""
+    sel = sorted(int(i) for i in sel if 0 <= int(i) < len(bounds))
+    runs = []
+    for i in sel:
+        a, b = int(bounds[i][0]), int(bounds[i][0]) + int(bounds[i][1])
+        if runs and a <= runs[-1][1]:
+            runs[-1][1] = max(runs[-1][1], b)
+        else:
+            runs.append([a, b])
+    off, packed = 0, []
+    for a, b in runs:
+        packed.append((a, b, off))
+        off += b - a
+    local = []
+    for i in sel:
+        a = int(bounds[i][0])
+        r = next(r for r in packed if r[0] <= a < r[1])
+        local.append((r[2] + a - r[0], int(bounds[i][1]), bounds[i][2], i))
+    return packed, local, off
+
+
+def rebase_fragments(frags, runs):
+    """Fragments (channel, first sample, samples) of a station clipped to the runs of
+    plan_shard and moved to compact-buffer coordinates."""
+    out = []
+    for (c, t0, x) in frags:
+        for (a, b, off) in runs:
+            lo, hi = max(t0, a), min(t0 + len(x), b)
+            if hi > lo:
+                out.append((c, off + lo - a, x[lo - t0:hi - t0]))
+    out.sort(key=lambda f: (f[0], f[1]))
+    return out
+
+
 def gather_rows(rows):
     """All ranks contribute a picklable object (their detection rows, histograms); every rank
     gets the list over ranks.  Host objects, a few KB: not on the data path."""
@@ -49,7 +119,50 @@ def gather_rows(rows):
     if world == 1:
         return [rows]
     out = [None] * world
+    COLLECTIVES['all_gather_object'] += 1
     dist.all_gather_object(out, rows)
+    return out
+
+
+def broadcast_banks(banks, device, src=0):
+    """The detector bases of ALL stations from rank `src` in one go: banks = [(U [Ktot, n]
+    float array or None, det_off, thresholds float array), ...] per station (None entries on
+    the other ranks are fine: only `src`'s are read).  One object broadcast for the shapes,
+    offsets and thresholds (host, a few hundred bytes), one tensor broadcast for every basis
+    concatenated (7.2 MB per station at configs[1]; RCCL over xGMI under backend 'nccl').
+    Returns [(U float32 ndarray, det_off int32, thresholds float64)] on every rank."""
+    import torch.distributed as dist
+    rank, world = dist_info()
+    if world == 1:
+        return [(None if U is None else np.asarray(U, dtype=np.float32),
+                 None if U is None else np.asarray(off, np.int32), thr) for (U, off, thr) in banks]
+    meta = [None]
+    if rank == src:
+        meta[0] = [None if U is None else (tuple(np.shape(U)), [int(v) for v in off],
+                                           [float(v) for v in thr]) for (U, off, thr) in banks]
+    COLLECTIVES['broadcast_object'] += 1
+    dist.broadcast_object_list(meta, src=src)
+    meta = meta[0]
+    total = sum(m[0][0] * m[0][1] for m in meta if m is not None)
+    if rank == src:
+        flat = np.concatenate([np.asarray(U, dtype=np.float32).ravel() for (U, _, _) in banks
+                               if U is not None]) if total else np.zeros(0, np.float32)
+        buf = torch.from_numpy(flat).to(device)
+    else:
+        buf = torch.empty(total, dtype=torch.float32, device=device)
+    if total:
+        COLLECTIVES['broadcast'] += 1
+        dist.broadcast(buf, src=src)
+    host = buf.cpu().numpy()
+    out, pos = [], 0
+    for m in meta:
+        if m is None:
+            out.append((None, None, None))
+            continue
+        (K, n), off, thr = m
+        out.append((host[pos:pos + K * n].reshape(K, n), np.asarray(off, np.int32),
+                    np.asarray(thr, np.float64)))
+        pos += K * n
     return out
 
 
@@ -73,6 +186,7 @@ def broadcast_basis(U, det_off, n, device, src=0):
         meta = torch.tensor([off.numel(), int(n)], dtype=torch.int64, device=device)
     else:
         meta = torch.zeros(2, dtype=torch.int64, device=device)
+    COLLECTIVES['broadcast'] += 3
     dist.broadcast(meta, src=src)
     if rank != src:
         off = torch.zeros(int(meta[0]), dtype=torch.int64, device=device)
@@ -100,6 +214,7 @@ def gather_condensed(parts, ranges, npairs, device):
     b, e = ranges[rank]
     buf[:e - b] = parts[b:e]
     out = [torch.zeros_like(buf) for _ in range(world)]
+    COLLECTIVES['all_gather'] += 1
     dist.all_gather(out, buf)
     full = torch.zeros(npairs, dtype=parts.dtype, device=device)
     for r, (b, e) in enumerate(ranges):

@@ -144,73 +144,124 @@ class _StationUploader(object):
     """Station data to the device ahead of its scan.  Arrays the fetcher holds in pinned
     memory (ContinuousFetcher.pin) are copied on a second stream, under the kernels of the
     station being scanned, into one of three device buffers the uploader owns (detex keeps three
-    stations in flight); pageable arrays go up synchronously as before."""
+    stations in flight); pageable arrays go up synchronously.  In a multi-process run only the
+    sample ranges of the rank's own chunks are uploaded, packed end to end
+    (parallel.plan_shard): the host link is the one resource the ranks share.  The uploader and
+    its buffers live as long as the SubSpace (one per device)."""
 
-    def __init__(self, fetcher, device):
+    def __init__(self, device):
         import torch
-        self.fetcher, self.device = fetcher, device
+        self.device = device
         self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
         self.pending = {}
         self.slots = [None, None, None]   # [buffer, event recorded when its last reader was enqueued]
         self.turn = 0
+        self.cur = None
+        self.bytes_uploaded = 0           # host -> device bytes of station data since reset()
 
-    def start(self, sta):
+    def reset(self):
+        self.pending = {}
+        self.cur = None
+        self.bytes_uploaded = 0
+
+    def _slot(self, numel):
+        """The next of the three device buffers, grown if needed.  Buffers are allocated with the
+        copy stream current: their memory comes from that stream's pool, so a block a kernel queued
+        on another stream still reads is never handed out; a buffer that is replaced is freed only
+        behind its last reader."""
         import torch
-        pinned = getattr(self.fetcher, 'pinned', {}).get(sta)
-        if sta in getattr(self.fetcher, 'counts', {}):
-            self.pending[sta] = (None, None, None)     # raw counts: scan_station ingests the fragments
-            return
-        if pinned is None or self.stream is None:
-            data = self.fetcher.data[sta][0]
-            self.pending[sta] = (torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
-                                 .to(self.device), None, None)
-            return
         k = self.turn
         self.turn = (k + 1) % len(self.slots)
         slot = self.slots[k]
-        if slot is None or slot[0].numel() < pinned.numel():
-            slot = [torch.empty(pinned.numel(), dtype=torch.float32, device=self.device), None]
+        if slot is None or slot[0].numel() < numel:
+            with torch.cuda.stream(self.stream):
+                if slot is not None and slot[1] is not None:
+                    self.stream.wait_event(slot[1])
+                self.slots[k] = slot = None
+                slot = [torch.empty(numel, dtype=torch.float32, device=self.device), None]
             self.slots[k] = slot
-        dst = slot[0][:pinned.numel()].view(pinned.shape)
+        return k, slot
+
+    def start(self, fetcher, sta, bounds, sel=None):
+        """bounds: the station's chunks (ContinuousFetcher.chunk_bounds); sel: the chunk indices
+        scanned here (None: all, the whole record is uploaded).  The chunks are handed to the scan
+        as (first sample in the uploaded buffer, samples, start time, chunk index)."""
+        import torch
+        from . import parallel
+        data = fetcher.data[sta][0]
+        Nc = data.shape[0]
+        counts = getattr(fetcher, 'counts', {}).get(sta)
+        if sel is None:
+            runs = [(0, data.shape[1], 0)]
+            local = [(int(b[0]), int(b[1]), b[2], i) for i, b in enumerate(bounds)]
+            T = data.shape[1]
+        else:
+            runs, local, T = parallel.plan_shard(bounds, sel)
+            if counts is not None:
+                counts = parallel.rebase_fragments(counts, runs)
+        job = dict(planes=None, ready=None, slot=None, bounds=local, T=T, counts=counts)
+        self.pending[sta] = job
+        if counts is not None or T == 0:
+            # raw counts: scan_station ingests the fragments (their upload is counted here)
+            self.bytes_uploaded += sum(4 * len(x) for (_, _, x) in (counts or []))
+            return
+        pinned = getattr(fetcher, 'pinned', {}).get(sta)
+        self.bytes_uploaded += 4 * Nc * T
+        if pinned is None or self.stream is None:
+            host = data if sel is None else np.concatenate([data[:, a:b] for (a, b, _) in runs], axis=1)
+            job['planes'] = torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32)).to(self.device)
+            return
+        k, slot = self._slot(Nc * T)
+        dst = slot[0][:Nc * T].view(Nc, T)
         ready = torch.cuda.Event()
         with torch.cuda.stream(self.stream):
             if slot[1] is not None and not slot[1].query():
                 self.stream.wait_event(slot[1])        # the scan that last read this buffer
-            dst.copy_(pinned, non_blocking=True)
+            if sel is None:
+                dst.copy_(pinned, non_blocking=True)
+            else:
+                for (a, b, off) in runs:               # contiguous rows: plain asynchronous copies
+                    for c in range(Nc):
+                        dst[c, off:off + b - a].copy_(pinned[c, a:b], non_blocking=True)
             ready.record(self.stream)
-        self.pending[sta] = (dst, ready, k)
+        job.update(planes=dst, ready=ready, slot=k)
 
-    def get(self, sta):
-        import torch
-        if sta not in self.pending:
-            self.start(sta)
-        dst, ready, self.cur = self.pending.pop(sta)
-        if ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(ready)
-        return dst
+    def get(self, sta, stream=None):
+        """The station's upload job; `stream` (the scanning context's) waits for the copy."""
+        job = self.pending.pop(sta)
+        self.cur = job['slot']
+        if job['ready'] is not None and stream is not None:
+            stream.wait_event(job['ready'])
+        return job
 
-    def release(self):
-        """The scan of the station handed out last has been enqueued: its buffer may be
-        overwritten once the work queued so far is done."""
+    def release(self, stream=None):
+        """The scan of the station handed out last has been enqueued on `stream`: its buffer may
+        be overwritten once the work queued there so far is done."""
         import torch
-        if getattr(self, 'cur', None) is not None:
+        if self.cur is not None and stream is not None:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            ev.record(stream)
             self.slots[self.cur][1] = ev
-            self.cur = None
+        self.cur = None
 
 
-def _merge_ranks(parts):
-    """Results of one station from every rank (each scanned its share of the chunks):
-    detections concatenated in time order, histogram counts added."""
+def _merge_ranks(parts, names_order=None):
+    """Results of one station from every rank (each scanned its share of the chunks): detection
+    rows in the order a single process produces them -- by (chunk, detector, order found), the
+    key StationScan.finish returns next to the tables --, histogram counts added."""
     parts = [p for p in parts if p is not None]
     if not parts:
         return None
     out = {}
     for kind in ('ss', 'sg'):
         dfs = [p[kind] for p in parts if len(p[kind])]
-        out[kind] = (pd.concat(dfs, ignore_index=True).sort_values(['STMP', 'Name'], kind='stable')
-                     .reset_index(drop=True)) if dfs else parts[0][kind]
+        if not dfs:
+            out[kind] = parts[0][kind]
+            continue
+        keys = np.concatenate([np.asarray(p['key_' + kind], dtype=np.int64).reshape(-1, 3)
+                               for p in parts if len(p[kind])])
+        order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+        out[kind] = pd.concat(dfs, ignore_index=True).iloc[order].reset_index(drop=True)
     for hk in ('hist_ss', 'hist_sg'):
         acc = {}
         for p in parts:
@@ -455,33 +506,46 @@ class SubSpace(object):
         singles their trimmed, normalised, NOT demeaned template
         (detect.py:357-364).  Returns (names, kinds, U [Ktot, n], det_off,
         offsets {name: array}, thresholds {name: float})."""
-        key = self._bank_key(sta, useSubSpaces, useSingles, need_thr)
+        key, held = self._bank_key(sta, useSubSpaces, useSingles, need_thr)
         cache = self.__dict__.setdefault('_bank_cache', {})
+        aux = self.__dict__.setdefault('_bank_aux', {})     # {station: (training events, magnitudes)}
         hit = cache.get((sta, useSubSpaces, useSingles, need_thr))
-        if hit is not None and hit[0] == key:
-            self._bank_ewf, self._bank_mags = hit[2], hit[3]
+        if (hit is not None and hit[0] == key and len(hit[4]) == len(held) and
+                all(a is b for a, b in zip(hit[4], held))):
+            self._bank_ewf, self._bank_mags = aux[sta] = (hit[2], hit[3])
             return hit[1]
         bank = self._build_bank(sta, useSubSpaces, useSingles, need_thr)
-        cache[(sta, useSubSpaces, useSingles, need_thr)] = (key, bank, self._bank_ewf, self._bank_mags)
+        aux[sta] = (self._bank_ewf, self._bank_mags)
+        cache[(sta, useSubSpaces, useSingles, need_thr)] = (key, bank, self._bank_ewf, self._bank_mags, held)
         return bank
 
     def _bank_key(self, sta, useSubSpaces, useSingles, need_thr):
-        """What the bank depends on, read cheaply: the identity of each detector's SVD / waveform
-        containers and its scalars.  SVD(), attachPickTimes() and the threshold setters replace or
-        change these, so a changed SubSpace never sees a stale bank."""
-        key = []
+        """What the bank depends on, read cheaply: (scalars, containers).  The scalars -- names, basis
+        counts, trims, thresholds, the event lists, their magnitudes and offsets -- are compared by
+        value; the SVD / waveform containers by identity, and the cache entry keeps them alive, so
+        that a freed container's address can never be mistaken for a new one's.  SVD(),
+        attachPickTimes(), validateClusters() and the threshold setters replace or change these:
+        a changed SubSpace never sees a stale bank."""
+        key, held = [], []
         if useSubSpaces and sta in self.subspaces:
             df = self.subspaces[sta]
-            for name, svd, nb, ok, st, th, ali in zip(df.Name, df.SVD, df.NumBasis, df.SVDdefined,
-                                                      df.SampleTrims, df.Threshold, df.AlignedTD):
-                key.append((name, id(svd), nb, bool(ok), tuple(sorted((st or {}).items())),
-                            float(th) if need_thr else None, id(ali)))
+            for _, r in df.iterrows():
+                ev = tuple(r.Events)
+                key.append((r.Name, r.NumBasis, bool(r.SVDdefined), tuple(sorted((r.SampleTrims or {}).items())),
+                            float(r.Threshold) if need_thr else None, ev,
+                            tuple(float(r.Stats[e]['magnitude']) for e in ev),
+                            tuple(np.asarray(r.Offsets, dtype=np.float64).ravel().tolist())))
+                held += [r.SVD, r.AlignedTD]
         if useSingles and sta in self.singles:
             df = self.singles[sta]
-            for name, st, th, mp in zip(df.Name, df.SampleTrims, df.Threshold, df.MPtd):
-                key.append((name, tuple(sorted((st or {}).items())),
-                            float(th) if need_thr else None, id(mp)))
-        return tuple(key)
+            for _, r in df.iterrows():
+                ev = tuple(r.Events)
+                key.append((r.Name, tuple(sorted((r.SampleTrims or {}).items())),
+                            float(r.Threshold) if need_thr else None, ev,
+                            tuple(float(r.Stats[e]['magnitude']) for e in ev),
+                            tuple(np.asarray(r.Offsets, dtype=np.float64).ravel().tolist())))
+                held.append(r.MPtd)
+        return repr(key), held
 
     def _build_bank(self, sta, useSubSpaces, useSingles, need_thr):
         names, kinds, blocks, offsets, thr = [], [], [], {}, {}
@@ -571,29 +635,52 @@ class SubSpace(object):
         if subspaceDB is not None and delOldCorrs and rank == 0 and os.path.exists(subspaceDB):
             os.remove(subspaceDB)                           # subspace.py:1847-1854
         own_ctx = ctx is None
+        if device is None:
+            # one process per GPU: the launcher's LOCAL_RANK names this process's device
+            device = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
         dev = torch.device('cuda', int(device)) if own_ctx else ctx.device
-        stations = [sta for sta in self.Stations if sta in self.cfetcher.data]
-        up = _StationUploader(self.cfetcher, dev)
-        if stations:
-            up.start(stations[0])
-        out = {'ss_df': [], 'sg_df': []}
+        fetcher = self.cfetcher
+        stations = [sta for sta in self.Stations if sta in fetcher.data]
+        bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
+        banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
+        sel = {sta: None for sta in stations}
+        if world > 1:
+            # One process per GPU.  (station, day) units of ALL stations are dealt round-robin
+            # (parallel.deal_station_chunks, as bench.py --config 4 deals them); rank 0's bases and
+            # thresholds go to every rank in ONE broadcast (RCCL over xGMI, the only collective on
+            # the data path); the rows come back in ONE gather after the last station.
+            per = max(1, int(round(86400.0 / fetcher.conDatDuration)))
+            dealt = parallel.deal_station_chunks([len(bounds[s]) for s in stations], per, rank, world)
+            sel = dict(zip(stations, dealt))
+            sent = parallel.broadcast_banks(
+                [(banks[s][2], banks[s][3], [banks[s][5][nm] for nm in banks[s][0]]) if banks[s][0]
+                 else (None, None, None) for s in stations], dev)
+            for sta, (Ub, offb, thrb) in zip(stations, sent):
+                if Ub is None:
+                    continue
+                names, kinds, U, det_off, offsets, thr = banks[sta]
+                # every rank (rank 0 too) scans with the numbers that were sent; the bank object is kept
+                # while they are the ones already resident (its basis images stay on the device)
+                held = self.__dict__.setdefault('_rank_banks', {}).get(sta)
+                if (held is not None and held[0][0] == names and np.array_equal(held[1], Ub) and
+                        np.array_equal(held[2], thrb)):
+                    banks[sta] = held[0]
+                else:
+                    banks[sta] = (names, kinds, Ub, offb, offsets, dict(zip(names, thrb)))
+                    self._rank_banks[sta] = (banks[sta], Ub, thrb)
+        todo = [sta for sta in stations if sel[sta] is None or len(sel[sta])]
+        up = self._uploader(dev)
+        up.reset()
+        results, failure = {}, None
 
         def collect(job):
-            """Second half of a station: triggers, trigger-time estimates, rows; gathered over
-            the ranks in a multi-process run."""
+            """Second half of a station: triggers, trigger-time estimates, rows."""
             try:
                 res = job.finish()
             finally:
                 job.close()
-            if world > 1:
-                res = _merge_ranks(parallel.gather_rows(res))
-            if res is None:
-                return
-            for kind in ('ss', 'sg'):
-                if len(res[kind]):
-                    out[kind + '_df'].append(res[kind])
-            self.histSubSpaces[job.sta] = res['hist_ss']
-            self.histSingles[job.sta] = res['hist_sg']
+            if res is not None:
+                results[job.sta] = res
 
         # Three stations are in flight on the one stream, in the order S0 S1 T0 S2 T1 S3 ... (S: a
         # station's scans, T: its trigger-time kernel).  The host picks station i's triggers and
@@ -602,43 +689,61 @@ class SubSpace(object):
         # the wait for T_i -- queued behind S_{i+1} -- drained the queue: 2.5 ms of idle GPU per
         # station-day.)
         queue = []                                          # jobs started, oldest first
-        for i, sta in enumerate(stations):
-            planes = up.get(sta)
-            if i + 1 < len(stations):
-                up.start(stations[i + 1])                   # next station's H2D under this scan
-            bank = self._detector_bank(sta, useSubSpaces, useSingles)
-            if own_ctx:
-                ctx = self._station_ctx(device, sta)
-            chunk_sel = None
-            if world > 1 and bank[0]:
-                # one process per GPU: rank 0's basis goes to every rank (RCCL broadcast over
-                # xGMI, the only collective on the path), each rank scans its share of the chunks
-                names, kinds, U, det_off, offsets, thr = bank
-                Ut, det_off = parallel.broadcast_basis(U if rank == 0 else None,
-                                                       det_off if rank == 0 else None,
-                                                       U.shape[1], ctx.device)
-                bank = (names, kinds, Ut.cpu().numpy(), det_off, offsets, thr)
-                nchunks = len(self.cfetcher.chunk_bounds(sta, utcStart, utcEnd))
-                per = max(1, int(round(86400.0 / self.cfetcher.conDatDuration)))
-                chunk_sel = parallel.shard_chunks(nchunks, rank, world, per_unit=per)
-            job = StationScan(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
-                              useSubSpaces, useSingles, fillZeros, device, ctx, estimateMags,
-                              planes_dev=planes, chunk_sel=chunk_sel, bank=bank)
-            del planes
-            job.start()
-            up.release()
-            queue.append(job)
-            if not own_ctx:
-                # a context handed in by the caller serves every station in turn: its basis and
-                # training events are replaced by the next start(), so this station is finished first
+        try:
+            if todo:
+                up.start(fetcher, todo[0], bounds[todo[0]], sel[todo[0]])
+            for i, sta in enumerate(todo):
+                if own_ctx:
+                    ctx = self._station_ctx(device, sta)
+                stream = getattr(ctx, 'stream', None)
+                shard = up.get(sta, stream)
+                if i + 1 < len(todo):                       # next station's H2D under this scan
+                    up.start(fetcher, todo[i + 1], bounds[todo[i + 1]], sel[todo[i + 1]])
+                job = StationScan(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
+                                  useSubSpaces, useSingles, fillZeros, device, ctx, estimateMags,
+                                  shard=shard, bank=banks[sta])
+                del shard
+                job.start()
+                up.release(stream)
+                queue.append(job)
+                if not own_ctx:
+                    # a context handed in by the caller serves every station in turn: its basis and
+                    # training events are replaced by the next start(), so this station is finished first
+                    collect(queue.pop(0))
+                    continue
+                if len(queue) >= 2:
+                    queue[-2].pick()                        # T_{i-1} goes in behind S_i
+                if len(queue) >= 3:
+                    collect(queue.pop(0))                   # rows of station i - 2, S_i still queued
+            while queue:
                 collect(queue.pop(0))
+        except Exception as e:                              # noqa: BLE001
+            if world == 1:
+                raise
+            # the other ranks are (or will be) waiting in the gather below: take part in it with an
+            # error marker instead of leaving them hung, then fail on every rank
+            for job in queue:
+                job.close()
+            failure = '%s: %s' % (type(e).__name__, e)
+        self.last_run = dict(rank=rank, world=world, uploaded_bytes=up.bytes_uploaded,
+                             chunks={sta: (len(bounds[sta]) if sel[sta] is None else len(sel[sta]))
+                                     for sta in stations})
+        if world > 1:
+            parts = parallel.gather_rows((results, failure))
+            bad = [(r, p[1]) for r, p in enumerate(parts) if p[1] is not None]
+            if bad:
+                _error('SubSpace.detex failed on rank(s) %s' % '; '.join('%d (%s)' % b for b in bad))
+            results = {sta: _merge_ranks([p[0].get(sta) for p in parts]) for sta in stations}
+        out = {'ss_df': [], 'sg_df': []}
+        for sta in stations:
+            res = results.get(sta)
+            if res is None:
                 continue
-            if len(queue) >= 2:
-                queue[-2].pick()                            # T_{i-1} goes in behind S_i
-            if len(queue) >= 3:
-                collect(queue.pop(0))                       # rows of station i - 2, S_i still queued
-        while queue:
-            collect(queue.pop(0))
+            for kind in ('ss', 'sg'):
+                if len(res[kind]):
+                    out[kind + '_df'].append(res[kind])
+            self.histSubSpaces[sta] = res['hist_ss']
+            self.histSingles[sta] = res['hist_sg']
         cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
                 'ProEnMag']
         for k in out:
@@ -646,6 +751,15 @@ class SubSpace(object):
         if subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         return out
+
+    def _uploader(self, dev):
+        """One _StationUploader (copy stream + three device buffers) per device, kept for the life
+        of the object."""
+        cache = self.__dict__.setdefault('_uploaders', {})
+        key = str(dev)
+        if key not in cache:
+            cache[key] = _StationUploader(dev)
+        return cache[key]
 
     def _station_ctx(self, device, sta, keep=16):
         """One HipContext per (device, station), kept for the life of the object (the `keep`
@@ -665,8 +779,8 @@ class SubSpace(object):
 
     def __getstate__(self):
         d = dict(self.__dict__)
-        d.pop('_hip_ctx', None)                             # device contexts are not picklable
-        d.pop('_bank_cache', None)
+        for k in ('_hip_ctx', '_bank_cache', '_bank_aux', '_uploaders', '_rank_banks'):
+            d.pop(k, None)                                  # device contexts / buffers are not picklable
         return d
 
     def _write_db(self, path, out):

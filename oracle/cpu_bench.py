@@ -148,5 +148,94 @@ def allcores_baseline(U, det_off, x_chunks, Nc, nvec_per_worker=40, max_workers=
                                           max(r['seconds'] for r in res), K))
 
 
+def xcorr_onecore(td, Nc, npairs=24):
+    """pairs/s of the reference's _CCX2 (detex/construct.py:425-466, oracle restatement ccx2_fft,
+    float64) on one core: `npairs` pairs drawn from the events td [>= 2][n]; the events' spectra
+    are precomputed as in the reference (_getFreqDomain once per event, construct.py:669-676)."""
+    sys.path.insert(0, ROOT)
+    from oracle import detex_oracle as orc
+    ne = min(len(td), 8)
+    ev = [np.asarray(td[i], dtype=np.float64) for i in range(ne)]
+    fds = [orc.get_freq_domain(e) for e in ev]
+    pairs = [(b, c) for b in range(ne) for c in range(b + 1, ne)]
+    t0 = time.perf_counter()
+    for k in range(npairs):
+        b, c = pairs[k % len(pairs)]
+        orc.ccx2_fft(ev[b], ev[c], Nc, fds[b], fds[c])
+    dt = time.perf_counter() - t0
+    model, ncores, logical = cpu_info()
+    return dict(value=npairs / dt, unit='pairs/s', cores=1, kind='port', cpu_model=model,
+                physical_cores=ncores, os_cpu_count=logical,
+                sample='%d pairs of n = %d (float64 FFT path of _CCX2, spectra precomputed), %.1f s'
+                       % (npairs, len(ev[0]), dt))
+
+
+def _xc_worker(workdir, i):
+    """One worker of the all-cores cross-correlation leg: `npairs` pairs of its own events."""
+    sys.path.insert(0, ROOT)
+    from oracle import detex_oracle as orc
+    z = np.load(os.path.join(workdir, 'xtask%d.npz' % i))
+    ev = [e.astype(np.float64) for e in z['td']]
+    Nc, npairs = int(z['Nc']), int(z['npairs'])
+    fds = [orc.get_freq_domain(e) for e in ev]
+    pairs = [(b, c) for b in range(len(ev)) for c in range(b + 1, len(ev))]
+    open(os.path.join(workdir, 'ready%d' % i), 'w').close()
+    deadline = time.time() + 600
+    while not os.path.exists(os.path.join(workdir, 'go')):
+        if time.time() > deadline:
+            sys.exit(2)
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    for k in range(npairs):
+        b, c = pairs[k % len(pairs)]
+        orc.ccx2_fft(ev[b], ev[c], Nc, fds[b], fds[c])
+    with open(os.path.join(workdir, 'done%d.json' % i), 'w') as f:
+        json.dump(dict(npairs=npairs, seconds=time.perf_counter() - t0), f)
+
+
+def xcorr_allcores(td, Nc, pairs_per_worker=24, max_workers=None, timeout=300.0):
+    """pairs/s of the same restatement with one worker process per physical core."""
+    model, ncores, logical = cpu_info()
+    workers = max(1, min(ncores, int(_mem_available_gb() / 0.25)))
+    if max_workers:
+        workers = min(workers, int(max_workers))
+    procs = []
+    with tempfile.TemporaryDirectory(prefix='dtx_cpux_') as wd:
+        for w in range(workers):
+            np.savez(os.path.join(wd, 'xtask%d.npz' % w), td=np.asarray(td[(4 * w) % max(1, len(td) - 4):][:4]),
+                     Nc=Nc, npairs=pairs_per_worker)
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        try:
+            for w in range(workers):
+                procs.append(subprocess.Popen([sys.executable, '-m', 'oracle.cpu_bench', wd, str(w), 'xc'],
+                                              cwd=ROOT, env=env))
+            t_end = time.time() + timeout
+            while not all(os.path.exists(os.path.join(wd, 'ready%d' % w)) for w in range(workers)):
+                if time.time() > t_end or any(p.poll() not in (None, 0) for p in procs):
+                    raise RuntimeError('cpu_bench workers failed to start')
+                time.sleep(0.01)
+            t0 = time.perf_counter()
+            open(os.path.join(wd, 'go'), 'w').close()
+            for p in procs:
+                p.wait(timeout=max(1.0, t_end - time.time()))
+            wall = time.perf_counter() - t0
+            res = []
+            for w in range(workers):
+                with open(os.path.join(wd, 'done%d.json' % w)) as f:
+                    res.append(json.load(f))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    total = sum(r['npairs'] for r in res)
+    return dict(value=total / wall, unit='pairs/s', cores=workers, kind='port', cpu_model=model,
+                physical_cores=ncores, os_cpu_count=logical,
+                sample='%d worker processes x %d pairs of n = %d each, %.1f s wall (slowest worker %.1f s)'
+                       % (workers, pairs_per_worker, int(np.shape(td)[1]), wall, max(r['seconds'] for r in res)))
+
+
 if __name__ == '__main__':
-    _worker(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == 'xc':
+        _xc_worker(sys.argv[1], int(sys.argv[2]))
+    else:
+        _worker(sys.argv[1], int(sys.argv[2]))

@@ -609,6 +609,46 @@ def merge_channels_run(planes):
     return int(starts[k]), int(stops[k] - starts[k])
 
 
+def chunk_span(frags, Nc, s0, cnt):
+    """Front half of _applyFilter (construct.py:1003-1023) for the chunk [s0, s0 + cnt) of a record
+    that arrives as fragments (channel, first sample, samples), one ObsPy trace each: returns
+    (first sample, length) of what is filtered and scanned, or None if the chunk is dropped.
+
+    * ``len(st) > len(nc)`` (1005) -- some channel has several traces in the chunk: _mergeChannels
+      (1033-1066) on the zero-filled merge, longest run without a zero in any channel; if the kept
+      stretch still holds several traces of a channel: 'too fractured' (1009-1014) -> None.
+    * otherwise the traces are NOT merged and zeros are ordinary samples: only the trim to
+      [max start, min end] of 1019-1023.
+    * a channel without any trace in the chunk: None (the build drops it; the reference would
+      continue with fewer channels)."""
+    per = {}
+    for (c, t0, x) in frags:
+        lo, hi = max(int(t0), s0), min(int(t0) + len(x), s0 + cnt)
+        if hi > lo:
+            per.setdefault(c, []).append((lo, hi))
+    if len(per) < Nc:
+        return None
+    if all(len(v) == 1 for v in per.values()):
+        a = max(v[0][0] for v in per.values())
+        b = min(v[0][1] for v in per.values())
+        return (a, b - a) if b > a else None
+    merged = merge_fill([(c, t0 - s0, x) for (c, t0, x) in
+                         [(c, max(t0, s0), np.asarray(x)[max(t0, s0) - t0:min(t0 + len(x), s0 + cnt) - t0])
+                          for (c, t0, x) in frags if min(t0 + len(x), s0 + cnt) > max(t0, s0)]], Nc, cnt)
+    r0, rl = merge_channels_run(merged)
+    if rl <= 0:
+        return None
+    if (r0, rl) != (0, cnt):
+        a, b = s0 + r0, s0 + r0 + rl
+        pieces = {}
+        for (c, t0, x) in frags:
+            if t0 < b and t0 + len(x) > a:
+                pieces[c] = pieces.get(c, 0) + 1
+        if max(pieces.values()) > 1:
+            return None
+    return s0 + r0, rl
+
+
 def bandpass_sos(freqmin, freqmax, df, corners):
     """obspy.signal.filter.bandpass design (ObsPy 1.0.2, third-party, absent here;
     restated from its published algorithm): Butterworth band-pass as zpk ->

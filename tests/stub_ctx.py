@@ -44,9 +44,26 @@ class OracleCtx(object):
         self.D = len(self.off) - 1
 
     def preprocess(self, raw, filt=None, sampling_rate=None, detrend=True, out=None):
-        assert filt is None and not detrend, 'stub: multiplexing only'
-        return torch.stack([torch.from_numpy(orc.multiplex(list(p.numpy())).astype(np.float32))
+        if filt is None and not detrend:
+            return torch.stack([torch.from_numpy(orc.multiplex(list(p.numpy())).astype(np.float32))
+                                for p in raw])
+        return torch.stack([torch.from_numpy(orc.multiplex(orc.apply_filter(list(p.numpy()), filt, sampling_rate,
+                                                                            detrend)).astype(np.float32))
                             for p in raw])
+
+    def ingest_counts(self, counts, frags, Nc, T, want_run=True):
+        cnt = counts.numpy()
+        planes = orc.merge_fill([(c, t0, cnt[off:off + m]) for (c, off, t0, m) in frags], Nc, T)
+        run = torch.tensor(orc.merge_channels_run(planes), dtype=torch.int64) if want_run else None
+        return torch.from_numpy(planes.astype(np.float32)), run
+
+    def gapfree_run(self, planes, out=None):
+        self.calls.append(('gapfree', int(planes.shape[1])))
+        r = torch.tensor(orc.merge_channels_run(planes.numpy().astype(np.float64)), dtype=torch.int64)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
 
     def num_windows(self, M):
         return (int(M) - self.n) // self.Nc + 1

@@ -325,7 +325,12 @@ def test_config1_full_workflow(tmp_path):
     for (_, g), w in zip(got.iterrows(), want):
         assert g.Name == w[0] and g.STMP == w[1]                   # trigger index bit-exact
         assert abs(g.DS - w[2]) <= 1e-5
-        assert abs(g.DS_STALTA - w[3]) <= 1e-3 * max(1, abs(w[3]))
+        # DS_STALTA = DS[i] / mean(|DS|) (detect.py:501-514).  Both come from the device's float32 DS, held
+        # to 1e-5 ABSOLUTE of the float64 oracle: at a trigger DS[i] >= threshold ~ 0.3 (<= 3e-5 relative),
+        # the LTA mean of a noise-level DS ~ 1e-3 is an average of ~500 values whose float32 errors are
+        # ~1e-9 each (<= 1e-5 relative; the window means themselves are held to 2e-6 by
+        # test_trigger_stats_kernel).  1e-4 relative is that budget with a factor of two
+        assert abs(g.DS_STALTA - w[3]) <= 1e-4 * max(1, abs(w[3]))
         assert np.allclose([g.ProEnMag, g.Mag, g.SNR], list(w[4]), rtol=1e-5, equal_nan=True)
     for (t, f, a) in plants:
         hit = got[np.abs(got.STMP - (1.2e6 + (t + 50) / SR)) < 2.0]
@@ -354,3 +359,68 @@ def test_bench_config4_mode_on_one_gpu():
     assert d['config']['workload'].startswith('configs[3]: 2 stations x 2 days = 4 station-days')
     P = (int(round(3720.0 * 100.0)) * 3 - 9000) // 3 + 1
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 4 * 3 * P) <= 1e-6 * 4 * 3 * P
+
+
+def test_bench_config4_full_size_on_one_gpu():
+    """BASELINE configs[3] at its REAL size on the one GPU of this box: 8 stations x 30 days = 240
+    station-days (25.7 GB of stream resident in HBM), eight per-station bases broadcast and resident,
+    one step = all 240 scans.  Every planted event (5 per station-day, 1200 in all) must come back as
+    a candidate of its detector -- asserted inside bench.py's checked first step; this is the N = 1
+    anchor of the strong-scaling curve the driver measures at 2 / 4 / 8 GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', '4', '--stations', '8',
+                        '--days', '30', '--steps', '1', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 1
+    assert d['config']['workload'].startswith('configs[3]: 8 stations x 30 days = 240 station-days')
+    assert d['config']['planted_found'] == '1200/1200'
+    P = (int(round(3720.0 * 100.0)) * 3 - 9000) // 3 + 1
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 240 * 24 * P) <= 1e-6 * 240 * 24 * P
+    assert d['ms_per_step'] < 3000.0            # 240 x ~3.5 ms
+
+
+def test_scan_config2_production_grid(ctx):
+    """configs[1] exactly as bench.py runs it -- 25 detectors x 8 vectors, 24 chunks of 3720 s: the
+    production grid of the ping-pong kernel (1752 blocks = 6 full waves of 256 workgroups + 216 blocks
+    split over groups of units) -- against the float64 closed form at windows spread over the first /
+    last blocks of the first / last chunks, a block of the split remainder, block borders, and detectors
+    of both halves of the ping-pong pair order; all 50 plants found at their exact index."""
+    Nc, L, D, k, T, nchunk = 3, 3000, 25, 8, 372000, 24
+    n, M = Nc * L, Nc * T
+    U, off = synth.detector_bank(1, D, k, n)
+    x, plants = synth.continuous_day(1001, nchunk, M, Nc, U, off, nplant=50)
+    xt = torch.from_numpy(x).cuda()
+    ctx.set_engine('auto')
+    ctx.upload_basis(U, off, Nc)
+    ds, res = ctx.subspace_scan(xt, thr=np.full(D, 0.3, np.float32))
+    ctx.sync()
+    P = T - L + 1
+    V = (8192 - L + 1) // 512 * 512
+    nblk = (P + V - 1) // V
+    assert tuple(ds.shape) == (nchunk, D, P) and nchunk * nblk == 1752
+    cb, cd, cp, cv = res['cand']
+    for (b, p, d) in plants:
+        assert ((cb == b) & (cd == d) & (cp == p)).any(), (b, p, d)
+    assert int(res['hist'].sum()) == nchunk * D * P
+    rs = np.random.RandomState(3)
+    pts = []
+    for b in (0, 1, 11, 22, 23):                       # chunks 22, 23 hold the 216 split blocks (1536 ..)
+        for blk in (0, 1, nblk // 2, nblk - 2, nblk - 1):
+            lo, hi = blk * V, min((blk + 1) * V, P)
+            for p in (lo, hi - 1, int(rs.randint(lo, hi))):
+                pts.append((b, p, int(rs.randint(D))))
+    pts += [(b, p, d) for (b, p, d) in plants[:10]]
+    # detectors 0 .. 24 are dealt whole to the two halves: make sure both ends of the order are hit
+    pts += [(23, P - 1, 0), (23, P - 1, D - 1), (0, 0, 0), (0, 0, D - 1), (12, V, 12), (12, V - 1, 13)]
+    assert len(pts) >= 50
+    idx = torch.tensor(pts, device='cuda')
+    got = ds[idx[:, 0], idx[:, 2], idx[:, 1]].cpu().numpy()
+    for (b, p, d), g in zip(pts, got):
+        ref = _spot_ds(x[b], U[off[d]:off[d + 1]], Nc, p)
+        assert abs(g - ref) <= 1e-5, (b, p, d, g, ref)

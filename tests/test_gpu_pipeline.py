@@ -108,7 +108,12 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
     for (_, g), w in zip(got.iterrows(), want):
         assert g.Name == w[0] and g.STMP == w[1]                   # trigger index bit-exact
         assert abs(g.DS - w[2]) <= 1e-5
-        assert abs(g.DS_STALTA - w[3]) <= 1e-3 * max(1, abs(w[3]))
+        # DS_STALTA = DS[i] / mean(|DS|) (detect.py:501-514).  Both come from the device's float32 DS, held
+        # to 1e-5 ABSOLUTE of the float64 oracle: at a trigger DS[i] >= threshold ~ 0.3 (<= 3e-5 relative),
+        # the LTA mean of a noise-level DS ~ 1e-3 is an average of ~500 values whose float32 errors are
+        # ~1e-9 each (<= 1e-5 relative; the window means themselves are held to 2e-6 by
+        # test_trigger_stats_kernel).  1e-4 relative is that budget with a factor of two
+        assert abs(g.DS_STALTA - w[3]) <= 1e-4 * max(1, abs(w[3]))
         assert abs(g.MSTAMPmin - w[4]) < 1e-6 and abs(g.MSTAMPmax - w[5]) < 1e-6
         assert g.Sta == 'TA.M17A'
         pem, stm, snr = w[6]
@@ -280,3 +285,47 @@ def test_stations_in_flight_equal_one_at_a_time():
     for s in stas:
         for k, v in ss.histSubSpaces[s].items():
             assert np.array_equal(v, hist_p[s][k]), (s, k)
+
+
+def test_stream_contract_non_default_current_stream(workflow):
+    """A context enqueues on the stream that was current when it was created.  Calls made later under
+    ANOTHER current stream (``with torch.cuda.stream(s)``) must still order their buffers, events and
+    results against the context's stream: subspace_scan(lazy=True) and SubSpace.detex give the same
+    answers as on the creation stream (HipContext.on_stream; VERDICT r2 / ADVICE r2)."""
+    from detex_amd.hip import HipContext
+    from detex_amd import synth
+    Nc, L, D, k, T = 3, 1200, 6, 4, 120000
+    n = Nc * L
+    U, off = synth.detector_bank(3, D, k, n)
+    x, plants = synth.continuous_day(5, 6, Nc * T, Nc, U, off, nplant=12)
+    thr = np.full(D, 0.3, np.float32)
+    ctx = HipContext(0)                                  # created on the default stream
+    ctx.upload_basis(U, off, Nc)
+    xt = torch.from_numpy(x).cuda()
+    ds0, f0 = ctx.subspace_scan(xt, thr=thr, lazy=True)
+    r0 = f0()
+    ctx.sync()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        # the input is produced on the side stream right before the call: the scan must wait for it
+        xs = torch.from_numpy(x).cuda() * 1.0
+        for _ in range(3):                               # keep the side stream busy behind the scan too
+            ds1, f1 = ctx.subspace_scan(xs, thr=thr, lazy=True)
+        r1 = f1()
+        # results used on the side stream without any synchronisation by the caller
+        diff = (ds1 - ds0).abs().max()
+    assert float(diff) == 0.0
+    assert r1['ncand'] == r0['ncand'] > 0
+    for a, b in zip(r0['cand'], r1['cand']):
+        assert np.array_equal(a, b)
+    assert np.array_equal(r0['maxds'].numpy(), r1['maxds'].numpy())
+    ctx.close()
+    # the product path: detex() on the default stream, then again under a side stream (the per-station
+    # contexts cached on the SubSpace were created under the first)
+    ss = workflow['ss']
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    ss.setSinglesThresholds(threshold=0.4)
+    ref = ss.detex(subspaceDB=None, useSingles=True)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        got = ss.detex(subspaceDB=None, useSingles=True)
+    assert len(ref['ss_df']) >= 3 and got['ss_df'].equals(ref['ss_df']) and got['sg_df'].equals(ref['sg_df'])

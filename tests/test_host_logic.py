@@ -331,6 +331,46 @@ def small_workflow(ctx):
     return ss, cf, plants, (SR, NC, L)
 
 
+def multi_station_workflow(ctx, nsta=3, pin=False):
+    """Three stations x two days of 1 Hz data in 12 h + 120 s chunks (two chunks = one day = one
+    sharding unit, six units in all): the shape of BASELINE configs[3] at a size the CPU oracle
+    scans in seconds."""
+    rs = np.random.RandomState(7)
+    SR, NC, L = 1.0, 3, 80
+    env = np.exp(-np.arange(L + 20) / (0.3 * L))
+    k = np.hanning(7)
+    stas = ['TA.S%02d' % i for i in range(nsta)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], conDatDuration=43200, conBuff=120)
+    T = 2 * 86400 + 120
+    for si, sta in enumerate(stas):
+        fams = [[np.convolve(rs.standard_normal(L + 26), k / k.sum(), 'valid') * env for _ in range(NC)]
+                for _ in range(2)]
+        n = 0
+        for wav in fams:
+            for _ in range(4):
+                sh = int(rs.randint(0, 15))
+                data = np.array([rs.uniform(.5, 2) * w[sh:sh + L] + rs.standard_normal(L) * np.std(w) / 8
+                                 for w in wav])
+                ef.add(sta, 'ev%02d' % n, data, starttime=5000.0 + 500 * n, origintime=4990.0 + 500 * n,
+                       magnitude=1.0 + 0.25 * n)
+                n += 1
+        con = rs.standard_normal((NC, T)) * 0.05
+        for j in range(14):
+            t = int(rs.randint(100, T - 200))
+            f, a = int(rs.randint(2)), rs.uniform(.5, 1.2)
+            for c in range(NC):
+                con[c, t:t + L] += a * fams[f][c][5:5 + L]
+        cf.add(sta, con.astype(np.float32), starttime=86400.0 * 10)
+    if pin:
+        cf.pin()
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, ctx=ctx)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=0.0, defaultDuration=30)
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    return ss, cf, stas, (SR, NC, L)
+
+
 def oracle_scan(ss, cf, sta, SR, NC, lta_s=5, sta_s=0):
     """The reference's per-chunk loop (detect.py:137-218) with the CPU oracle."""
     from detex_amd.getdata import multiplex
@@ -494,3 +534,71 @@ def test_mags_from_stats_many_equals_row_by_row():
                 want = detect.mags_from_stats(c, issub, n, O[r])
                 for g, w in zip(got, want):
                     assert (np.isnan(g[r]) and np.isnan(w)) or g[r] == w or abs(g[r] - w) <= 1e-12 * abs(w), (issub, mags, r)
+
+
+def test_raw_counts_trimming_is_gated_like_applyFilter():
+    """construct.py:1003-1023 on a record that arrives as int32 fragments (ContinuousFetcher.add_counts):
+    a chunk with ONE trace per channel is never merged -- genuine zero counts in it are ordinary samples
+    and it is only trimmed to the span all channels cover; only a chunk with several traces on some channel
+    goes through _mergeChannels' longest-run rule (where a zero is a gap); a chunk a channel is missing
+    from is dropped.  Against the oracle's chunk_span -> filter -> DS chain, on the CPU stand-in."""
+    from detex_amd.getdata import multiplex
+    rs = np.random.RandomState(33)
+    sr, Nc, L = 20.0, 3, 160
+    filt = [1, 8, 2, True]
+    wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
+           for _ in range(Nc)]
+    wavf = orc.apply_filter([w.astype(np.float32) for w in wav], filt, sr)
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    for i in range(4):
+        ef.add('XX.STA', 'ev%d' % i, np.array([rs.uniform(.5, 2) * w + 0.02 * rs.standard_normal(L)
+                                                for w in wavf]), starttime=100. * i)
+    T = int(2700 * sr)                                   # chunks of 600 s + 60 s: 0, 12000, 24000, 36000, 48000
+    con = rs.standard_normal((Nc, T)) * 300
+    for t in (4000, 9000, 16000, 22000, 27000, 40000, 50000):
+        for c in range(Nc):
+            con[c, t:t + L] += 3000.0 * wav[c]
+    cnt = np.rint(con).astype(np.int32)
+    assert (cnt[:, :11800] == 0).sum() >= 3              # zero-mean counts: exact zeros are routine
+    # chunk 0 (0..13199): one trace per channel, WITH zero counts; channel 1 ends early (at 11800).
+    # chunk 1 (12000..25199): channel 1 starts late (at 13500), still one trace per channel.  chunk 2 (24000..37199): channel 2 in two traces with a hole ->
+    # _mergeChannels.  chunk 3 (36000..49199): channel 0 has no data at all.  chunk 4 (48000..53999): whole.
+    cnt[2, 30000:30100] = 5                              # (what is under the hole does not matter)
+    seg = cnt[:, 24000:37200]
+    seg[seg == 0] = 1                                    # in the merged chunk a zero would be a gap (construct.py:1047-1050)
+    frags = [(0, 0, cnt[0, :36000]), (0, 49200, cnt[0, 49200:]),
+             (1, 0, cnt[1, :11800]), (1, 13500, cnt[1, 13500:]),
+             (2, 0, cnt[2, :30000]), (2, 30100, cnt[2, 30100:])]
+    cf = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=60)
+    cf.add_counts('XX.STA', frags, T, starttime=6.0e5)
+    ctx = OracleCtx()
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, ctx=ctx)
+    ss = createSubSpace(clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(0.0, 6.0)
+    ss.SVD(selectCriteria=4, selectValue=0, threshold=0.35, useSingles=False)
+    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('XX.STA', useSingles=False)
+    merged = orc.merge_fill(frags, Nc, T)
+    spans, want = [], []
+    for (s0, n, ts) in cf.chunk_bounds('XX.STA'):
+        sp = orc.chunk_span(frags, Nc, s0, n)
+        spans.append(sp)
+        if sp is None:
+            continue
+        a, m = sp
+        x = multiplex(orc.apply_filter([p.astype(np.float32) for p in merged[:, a:a + m]], filt, sr))
+        if len(x) <= U.shape[1]:
+            continue
+        ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
+            want += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, ts + (a - s0) / sr)]
+    assert spans[0] == (0, 11800)                        # zeros inside: untouched; common span of single traces
+    assert spans[1] == (13500, 11700)
+    assert spans[2] == (24000, 6000)                     # channel 0 ends at 36000: 24000..29999 beats 30100..35999
+    assert spans[3] is None and spans[4] == (49200, T - 49200)
+    # the device pass ran for the fractured chunk only
+    assert [c for c in ctx.calls if c[0] == 'gapfree'] == [('gapfree', 13200)]
+    got = res['ss_df'].sort_values('STMP')
+    assert len(got) == len(want) >= 4
+    for (_, g), w in zip(got.iterrows(), sorted(want)):
+        assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5

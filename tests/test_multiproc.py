@@ -145,3 +145,95 @@ def test_product_entry_points_world2():
             assert hist[nm] == h.tolist()
     # the four chunks were split two and two: each rank scanned only its share
     assert [c[1] for c in res[0][2]] == [2] and [c[1] for c in res[1][2]] == [1, 1]
+
+
+def _expected_upload(cf, stas, rank, world):
+    """Bytes of station data rank `rank` has to upload: its own chunks' sample ranges, merged."""
+    from detex_amd import parallel
+    bounds = [cf.chunk_bounds(s) for s in stas]
+    per = max(1, int(round(86400.0 / cf.conDatDuration)))
+    dealt = parallel.deal_station_chunks([len(b) for b in bounds], per, rank, world)
+    return sum(4 * len(cf.channels) * parallel.plan_shard(b, d)[2] for b, d in zip(bounds, dealt)), dealt
+
+
+def _configs3_worker(rank, world, port, q):
+    """SubSpace.detex over three stations x two days with one process per 'GPU' (gloo + the
+    oracle stand-in): what each rank uploads, how many collectives the call costs, the tables."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from detex_amd import parallel
+    from stub_ctx import OracleCtx
+    from test_host_logic import multi_station_workflow
+    ctx = OracleCtx()
+    ss, cf, stas, _ = multi_station_workflow(ctx)
+    before = dict(parallel.COLLECTIVES)
+    res = ss.detex(subspaceDB=None, ctx=ctx)
+    coll = {k: parallel.COLLECTIVES[k] - before[k] for k in before}
+    scans = [c[1] for c in ctx.calls if c[0] == 'scan']
+    hist = {sta: {k: v.tolist() for k, v in ss.histSubSpaces[sta].items()} for sta in stas}
+    last = dict(ss.last_run)
+    # a failure on ONE rank must not leave the others hung in the gather: both raise
+    class Boom(OracleCtx):
+        def subspace_scan(self, *a, **kw):
+            if rank == 1:
+                raise RuntimeError('injected fault on rank 1')
+            return OracleCtx.subspace_scan(self, *a, **kw)
+    try:
+        ss.detex(subspaceDB=None, ctx=Boom())
+        failed = None
+    except Exception as e:
+        failed = str(e)
+    q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_sharding_world2():
+    """(station, day) units dealt globally, only the rank's own sample ranges uploaded, one
+    basis broadcast + one gather per call whatever the number of stations, rows and histograms
+    identical to the single-process run (row order included), a failing rank fails every rank."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from stub_ctx import OracleCtx
+    from test_host_logic import multi_station_workflow
+    c1 = OracleCtx()
+    ss1, cf, stas, _ = multi_station_workflow(c1)
+    ref = ss1.detex(subspaceDB=None, ctx=c1)
+    assert len(ref['ss_df']) >= 10
+    total = sum(4 * 3 * cf.data[s][0].shape[1] for s in stas)
+    assert ss1.last_run['uploaded_bytes'] == total and ss1.last_run['world'] == 1
+    world = 2
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_configs3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    up = []
+    for rank, coll, last, scans, rows, hist, failed in res:
+        # three collectives per call: shapes / thresholds (object), the bases (tensor), the rows
+        assert coll == {'broadcast': 1, 'broadcast_object': 1, 'all_gather_object': 1, 'all_gather': 0}, coll
+        want_bytes, dealt = _expected_upload(cf, stas, rank, world)
+        assert last['uploaded_bytes'] == want_bytes and last['rank'] == rank and last['world'] == world
+        # five chunks per station = two days + a 120 s tail = three units; the nine units of the three
+        # stations are dealt round-robin as ONE list (a per-station deal would give rank 0 the extra unit thrice)
+        assert dealt == ([[0, 1, 4], [2, 3], [0, 1, 4]] if rank == 0 else [[2, 3], [0, 1, 4], [2, 3]])
+        assert last['chunks'] == {s: len(d) for s, d in zip(stas, dealt)}
+        up.append(last['uploaded_bytes'])
+        # identical tables on every rank, in the single-process row order
+        assert len(rows) == len(ref['ss_df'])
+        for got, (_, want) in zip(rows, ref['ss_df'].iterrows()):
+            assert got[3] == want.Name and got[4] == want.Sta and got[2] == want.STMP
+            assert np.allclose([got[0], got[1]] + got[5:], [want.DS, want.DS_STALTA] + list(want.values[5:]),
+                               rtol=1e-6, equal_nan=True)
+        for sta in stas:
+            for nm, h in ss1.histSubSpaces[sta].items():
+                assert hist[sta][nm] == h.tolist()
+        assert failed is not None and 'rank' in failed and 'injected fault' in failed
+    # each rank moved about half of the data over the host link (plus the 120 s chunk overlap)
+    assert max(up) < 0.52 * total and sum(up) < 1.01 * total
