@@ -273,7 +273,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
         from oracle import cpu_bench
         try:
             cpu_leg = cpu_bench.xcorr_onecore(td_host, Nc, npairs=400)
-            cpu_leg['all_cores'] = cpu_bench.xcorr_allcores(td_host, Nc, pairs_per_worker=200)
+            cpu_leg['all_cores'] = cpu_bench.xcorr_allcores(td_host, Nc, pairs_per_worker=60)
         except Exception as e:                          # noqa: BLE001 -- a bounded leg never takes the line down
             cpu_leg = dict(value=None, unit='pairs/s', error=repr(e))
     return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,

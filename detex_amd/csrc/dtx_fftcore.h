@@ -582,16 +582,19 @@ __device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32
 // template: window p < V reads samples p .. p + L - 1); the rest of the 8192 are transformed as
 // zeros -- exact, and it keeps a burst that lies only in that tail out of this block's float32
 // rounding (the dynamic-range guard looks at the block's own windows).  kN: no masking.
+// nsub > 1 (the cross-correlation's lag search): stored block j = blk * nsub + s starts at sample
+// blk V + s sub_stride -- the data that segment s of a template cut into segments of sub_stride
+// samples meets in lag block blk (advance V != segment length: every (block, segment) has its own spectrum).
 __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, int64_t Tpad,
                                                   int Nc, int V, int nblk, int keep,
                                                   const c32* __restrict__ tab,
-                                                  c32* __restrict__ xh) {
+                                                  c32* __restrict__ xh, int nsub = 1, int sub_stride = 0) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
   const LdsBases lb = lds_bases(tid);
   const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
   const int tb = 8 * (tid & 63) + (tid >> 6);          // sample within the block
-  const int64_t t0 = (int64_t)blk * V + tb;
+  const int64_t t0 = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride + tb;
   c32 v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {

@@ -18,7 +18,6 @@
 namespace {
 
 constexpr float kScrubTolF = 1e-5f;   // dtx_xcorr.hip: kScrubTol
-constexpr int kSegX = kN / 2;
 constexpr int kUnitX = 8;             // event pairs per workgroup (they share the window statistics; 4: 402 ms, 8: 392, 16: 390)
 
 __device__ inline int64_t condensed_index_x(int64_t N, int64_t b, int64_t c) {
@@ -64,14 +63,11 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
   for (int m = 0; m < 16; ++m) dst[w_slot(tid + 512 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
 }
 
-#ifndef DTX_XC_XLDS
-#define DTX_XC_XLDS 1         // block spectra of the MAC staged through LDS (four 16-byte loads per thread and channel)
-#endif
 #ifndef DTX_XC_ABLATE
 #define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads
 #endif
 struct XcFftArgs {
-  const c32* xh;        // [N][nblkx][Nc][kXh] block spectra of the padded planes of every event
+  const c32* xh;        // [N][nblk][nseg][Nc][kXh] block spectra of the padded planes of every event
   const c32* W;         // [ceil(N/2)][Nc*nseg][kN] pair spectra
   const c32* tab;
   const int2* items;    // (c, first pair of the unit)
@@ -81,7 +77,8 @@ struct XcFftArgs {
   const float* rsw;     // [N][Ppad]
   unsigned long long* keys;
   int64_t Ppad, pair_begin, pair_end;
-  int N, Nc, nseg, nblk, nblkx, V, Pz;
+  int N, Nc, nseg, nblk, V, Pz;
+  int seglen, zend;     // template segment length; first sample of the padded planes behind the data (S + L)
   int64_t per_xcd, nwork;
 };
 
@@ -89,9 +86,7 @@ struct XcFftArgs {
 template <int VM>
 __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftArgs a) {
   __shared__ c32 lds[kLdsC];
-#if DTX_XC_XLDS
   __shared__ c32 xst[2][kXh];     // the block spectrum of the current / next virtual channel (see the MAC loop)
-#endif
   const int tid = threadIdx.x;
   // workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of the
   // (unit-major) work list so that the workgroups sharing an L2 share a unit's pair spectra
@@ -124,7 +119,21 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
   const int wlo = 512 * wv + ln;              // pair spectra: w_slot order, float4 units
   const int nvc = a.Nc * a.nseg;
-  const c32* xh = a.xh + ((int64_t)c * a.nblkx + blk) * a.Nc * kXh;
+  // Segment s of the earlier events meets the later event's padded planes at samples blk V + s seglen ..:
+  // a (block, segment) whose 8192 samples lie wholly in the zero padding behind the data contributes
+  // nothing and is skipped (3 of 16 products at L = 13 000 with segments of 4096; 1 of 12 with the
+  // 3 x 4 layout the host picks).  nse: segments of this lag block that see data.
+  const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+  const int nsteps = a.Nc * nse;
+  const c32* xh = a.xh + ((int64_t)c * a.nblk + blk) * a.nseg * a.Nc * kXh;
+  auto xsrc = [&](int i) {                    // block spectrum of step i = (channel, segment): uniform
+    const int ch = i / nse, sg = i - ch * nse;
+    return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + ch) * kXh) + tid;
+  };
+  auto woff = [&](int i) {                    // its pair spectrum inside a pair's [nvc][kN]
+    const int ch = i / nse, sg = i - ch * nse;
+    return (int64_t)(ch * a.nseg + sg) * (kN / 2) + wlo;      // float4 units
+  };
 
   // rows 2 pr (real part) and 2 pr + 1 (imaginary part) of a finished transform: normalise,
   // scrub, max / first argmax over the block's lags, one atomicMax per row and wave
@@ -161,86 +170,98 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       }
     }
   };
-  // Pairs are taken two at a time: the block spectra (the operand both share) are loaded once
-  // per virtual channel for two MACs -- the MAC streams 1.2 MB per transform from L2 and is what
-  // bounds this kernel.
+  // Pairs are taken two at a time: the block spectra (the operand both share) are staged once
+  // per step for two MACs -- the MAC streams ~1 MB per transform from L2 and is what bounds this kernel.
+  //
+  // One step = one (channel, segment): z += W_a X, zb += W_b X at the thread's 16 frequencies.
+  //   * X (32 KB, the same for every thread's mirrored reads) goes through LDS, double-buffered a step
+  //     ahead: four 16-byte loads per thread at the top of the step, four 16-byte LDS stores at its end.
+  //     (They are held in four NAMED registers: as an array the compiler moved them to LDS itself --
+  //     global load, wait, LDS store, LDS load, LDS store -- and the wait sat right behind the loads.)
+  //   * W (2 x 64 KB) comes in half-step batches of eight 16-byte loads, the batch of the NEXT step issued as
+  //     soon as its registers are free: a load has a whole step to land instead of being waited for at once.
   for (int q = 0; q < npr; q += 2) {
     const int pr = pr0 + q;
     const bool has2 = q + 1 < npr;
-    const c32* wpa = a.W + (int64_t)pr * nvc * kN;
-    const c32* wpb = wpa + (has2 ? (int64_t)nvc * kN : 0);
+    const float4* wqa = reinterpret_cast<const float4*>(a.W + (int64_t)pr * nvc * kN);
+    const float4* wqb = wqa + (has2 ? (int64_t)nvc * (kN / 2) : 0);
     c32 z[16], zb[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
-#if DTX_XC_XLDS
-    // The block spectrum of a virtual channel (32 KB) is the same for every thread's 16 mirrored
-    // 8-byte reads: fetched from L2 they are 16 load instructions per thread and channel and cost as
-    // much as the 1.5 MB of pair spectra (timing-only ablation: 290 ms -> 184 without them).  Staged
-    // through LDS instead -- four 16-byte loads per thread, double-buffered a channel ahead; the
-    // kernel's 198 registers hold it to one workgroup per CU, so 64 KB of LDS beside the image are free.
-    auto xsrc = [&](int vc) {
-      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
-      return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + ch) * kXh);
+    float4 wa[2][4], wb[2][4];
+    auto issue_w = [&](int i, auto hc) {
+      constexpr int h = hc;
+      const int64_t o = woff(i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#if DTX_XC_ABLATE & 1     // timing only: no pair-spectrum loads
+        wa[h][j] = wb[h][j] = make_float4(1.f, 0.5f, 1.f, 0.5f);
+#else
+        wa[h][j] = (wqa + o + 64 * (4 * h + j))[0];
+        wb[h][j] = (wqb + o + 64 * (4 * h + j))[0];
+#endif
+      }
     };
-    float4 xn[4];
+    auto mac_half = [&](const c32* xc, auto hc) {
+      constexpr int h = hc;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {             // four frequencies at a time: eight live X registers
+        c32 px[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          constexpr int dummy = 0; (void)dummy;
+          const int r = 8 * h + 4 * g + e;
+#if DTX_XC_ABLATE & 2     // timing only: no block-spectrum loads
+          px[e] = make_float2(0.25f, 1.f);
+#else
+          px[e] = fix_x(xc[x_slot(r)], r);
+#endif
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = 8 * h + 4 * g + e;
+          const float4 ta = wa[h][2 * g + (e >> 1)], tb = wb[h][2 * g + (e >> 1)];
+          const c32 pa = (e & 1) ? make_float2(ta.z, ta.w) : make_float2(ta.x, ta.y);
+          const c32 pb = (e & 1) ? make_float2(tb.z, tb.w) : make_float2(tb.x, tb.y);
+          // two fused multiply-adds per component (written as a sum of products the compiler
+          // emits mul + fma + add)
+          z[m].x = __fmaf_rn(-pa.y, px[e].y, __fmaf_rn(pa.x, px[e].x, z[m].x));
+          z[m].y = __fmaf_rn(pa.y, px[e].x, __fmaf_rn(pa.x, px[e].y, z[m].y));
+          zb[m].x = __fmaf_rn(-pb.y, px[e].y, __fmaf_rn(pb.x, px[e].x, zb[m].x));
+          zb[m].y = __fmaf_rn(pb.y, px[e].x, __fmaf_rn(pb.x, px[e].y, zb[m].y));
+        }
+      }
+    };
     {
       const float4* src = xsrc(0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xn[k] = src[tid + 512 * k];
-      float4* dst = reinterpret_cast<float4*>(xst[0]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[tid + 512 * k] = xn[k];
+      const float4 x0 = src[0], x1 = src[512], x2 = src[1024], x3 = src[1536];
+      issue_w(0, std::integral_constant<int, 0>{});
+      issue_w(0, std::integral_constant<int, 1>{});
+      float4* dst = reinterpret_cast<float4*>(xst[0]) + tid;
+      dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
     }
     __syncthreads();
-#endif
 #pragma nounroll
-    for (int vc = 0; vc < nvc; ++vc) {
-      const int ch = vc / a.nseg, sg = vc - ch * a.nseg;
-      c32 pa[16], pb[16], px[16];
-      const c32* wca = wpa + (int64_t)vc * kN;
-      const c32* wcb = wpb + (int64_t)vc * kN;
-#if DTX_XC_XLDS
-      if (vc + 1 < nvc) {
-        const float4* src = xsrc(vc + 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = src[tid + 512 * k];
-      }
-      const c32* xc = xst[vc & 1];
-      (void)ch; (void)sg;
-#else
-      const c32* xc = xh + ((int64_t)sg * a.Nc + ch) * kXh;
-#endif
-#if DTX_XC_ABLATE & 1     // timing only: no pair-spectrum loads
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pa[r] = pb[r] = make_float2(1.f, 0.5f);
-#else
-      w_load16(wca, wlo, pa);
-      w_load16(wcb, wlo, pb);
-#endif
-#if DTX_XC_ABLATE & 2     // timing only: no block-spectrum loads
-#pragma unroll
-      for (int r = 0; r < 16; ++r) px[r] = make_float2(0.25f, 1.f);
-#else
-#pragma unroll
-      for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
-#endif
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        // two fused multiply-adds per component (written as a sum of products the compiler
-        // emits mul + fma + add: the kernel is bound by vector-ALU issue)
-        z[m].x = __fmaf_rn(-pa[m].y, px[m].y, __fmaf_rn(pa[m].x, px[m].x, z[m].x));
-        z[m].y = __fmaf_rn(pa[m].y, px[m].x, __fmaf_rn(pa[m].x, px[m].y, z[m].y));
-        zb[m].x = __fmaf_rn(-pb[m].y, px[m].y, __fmaf_rn(pb[m].x, px[m].x, zb[m].x));
-        zb[m].y = __fmaf_rn(pb[m].y, px[m].x, __fmaf_rn(pb[m].x, px[m].y, zb[m].y));
-      }
-#if DTX_XC_XLDS
-      if (vc + 1 < nvc) {
-        float4* dst = reinterpret_cast<float4*>(xst[(vc + 1) & 1]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dst[tid + 512 * k] = xn[k];
-      }
+    for (int i = 0; i < nsteps; ++i) {
+      // (the last step fetches its own operands again instead of branching: with the step straight-line
+      // the scheduling barriers below hold, and a redundant fetch per 11 .. 12 steps costs less than a
+      // compiler that sinks half the MACs behind the next loads)
+      const int nx = min(i + 1, nsteps - 1);    // uniform
+      const float4* src = xsrc(nx);
+      const float4 x0 = src[0], x1 = src[512], x2 = src[1024], x3 = src[1536];
+      __builtin_amdgcn_sched_barrier(0);
+      const c32* xc = xst[i & 1];
+      mac_half(xc, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(nx, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mac_half(xc, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(nx, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      float4* dst = reinterpret_cast<float4*>(xst[(i + 1) & 1]) + tid;
+      dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
       __syncthreads();
-#endif
     }
     fft8192<1>(z, lds, lb, a.tab, tid);
     reduce_rows(z, pr);
@@ -264,10 +285,32 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
                   int64_t Ppad, int64_t Tz, const float* z, const float* fsum, const float* frs,
                   const float* mean_w, const float* rsw, unsigned long long* keys,
                   int64_t pair_begin, int64_t pair_end, int64_t b_begin, int64_t b_end) {
-  const int nseg = L <= kFftMaxL ? 1 : (L + kSegX - 1) / kSegX;
-  const int seglen = nseg == 1 ? L : kSegX;
-  const int V = nseg == 1 ? (kN - L + 1) / 512 * 512 : kSegX;
-  const int nblk = (Pz + V - 1) / V, nblkx = nblk + nseg - 1;
+  // Events up to kFftMaxL samples: one segment.  Longer ones are cut into nseg segments of seglen samples;
+  // a lag block advances by V = 512 floor((kN - seglen + 1) / 512) lags and (block, segment) meets the later
+  // event's padded planes at sample blk V + s seglen (its own block spectrum: nblk x nseg per event and
+  // channel).  nseg is chosen by cost: one transform + epilogue per lag block (~7.5 MAC steps' worth, from
+  // the kernel's timing-only ablations) and one MAC step per (block, segment, channel) that sees data.  At
+  // L = 13 000: segments of 4096 -> 4 blocks x 4 segments (13 products see data); 4 segments of 3250 ->
+  // V = 4608, 3 blocks, 11 products -- a quarter fewer transforms and a sixth fewer MAC steps.
+  const int S = (Pz - 1) / 2;
+  int nseg = 1, seglen = L, V = (kN - L + 1) / 512 * 512;
+  if (L > kFftMaxL) {
+    double best = 1e300;
+    for (int ns = 2; ns <= 16; ++ns) {
+      const int sl0 = (L + ns - 1) / ns;                    // shortest segments that cover the event
+      const int v = std::min(15 * 512, (kN - sl0 + 1) / 512 * 512);
+      if (v < 4 * 512) continue;
+      // the longest segments that advance allows (fewer (block, segment) products see data), every
+      // segment non-empty
+      const int sl = std::min(kN - v + 1, (L + ns - 2) / (ns - 1) - 1);
+      if (sl < sl0) continue;
+      const int nb = (Pz + v - 1) / v;
+      double cost = 0;
+      for (int b = 0; b < nb; ++b) cost += 7.5 + Nc * std::min(ns, std::max(1, (S + L - b * v + sl - 1) / sl));
+      if (cost < best) { best = cost; nseg = ns; seglen = sl; V = v; }
+    }
+  }
+  const int nblk = (Pz + V - 1) / V, nblkx = nblk * nseg;
   const int nvc = Nc * nseg, npr = (N + 1) / 2;
 
   // work items (c, first pair of a unit), unit-major so that concurrent workgroups share the
@@ -309,14 +352,15 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
                      N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
   DTX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
-                     ctx->stream, z, Tz, Nc, V, nblkx, kN, (const c32*)tab, xh);
+                     ctx->stream, z, Tz, Nc, V, nblkx, kN, (const c32*)tab, xh, nseg, nseg == 1 ? 0 : seglen);
   DTX_HIP(ctx, hipGetLastError());
 
   XcFftArgs a;
   a.xh = xh; a.W = W; a.tab = tab; a.items = (const int2*)(base + o_i);
   a.fsum = fsum; a.frs = frs; a.mean_w = mean_w; a.rsw = rsw; a.keys = keys;
   a.Ppad = Ppad; a.pair_begin = pair_begin; a.pair_end = pair_end;
-  a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.nblkx = nblkx; a.V = V; a.Pz = Pz;
+  a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.V = V; a.Pz = Pz;
+  a.seglen = seglen; a.zend = S + L;
   a.per_xcd = per_xcd; a.nwork = nwork;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   switch (V / 512) {

@@ -527,24 +527,25 @@ class SubSpace(object):
         attachPickTimes(), validateClusters() and the threshold setters replace or change these:
         a changed SubSpace never sees a stale bank."""
         key, held = [], []
+
+        def scal(name, st, th, ev, stats, offs):
+            ev = tuple(ev)
+            return (name, tuple(sorted((st or {}).items())), float(th) if need_thr else None, ev,
+                    tuple(float(stats[e]['magnitude']) for e in ev),
+                    tuple(np.asarray(offs, dtype=np.float64).ravel().tolist()))
         if useSubSpaces and sta in self.subspaces:
-            df = self.subspaces[sta]
-            for _, r in df.iterrows():
-                ev = tuple(r.Events)
-                key.append((r.Name, r.NumBasis, bool(r.SVDdefined), tuple(sorted((r.SampleTrims or {}).items())),
-                            float(r.Threshold) if need_thr else None, ev,
-                            tuple(float(r.Stats[e]['magnitude']) for e in ev),
-                            tuple(np.asarray(r.Offsets, dtype=np.float64).ravel().tolist())))
-                held += [r.SVD, r.AlignedTD]
+            df = self.subspaces[sta]                        # (columns zipped: iterrows costs 50 us a row)
+            for name, svd, nb, ok, st, th, ali, ev, stats, offs in zip(
+                    df.Name, df.SVD, df.NumBasis, df.SVDdefined, df.SampleTrims, df.Threshold,
+                    df.AlignedTD, df.Events, df.Stats, df.Offsets):
+                key.append(scal(name, st, th, ev, stats, offs) + (nb, bool(ok)))
+                held += [svd, ali]
         if useSingles and sta in self.singles:
             df = self.singles[sta]
-            for _, r in df.iterrows():
-                ev = tuple(r.Events)
-                key.append((r.Name, tuple(sorted((r.SampleTrims or {}).items())),
-                            float(r.Threshold) if need_thr else None, ev,
-                            tuple(float(r.Stats[e]['magnitude']) for e in ev),
-                            tuple(np.asarray(r.Offsets, dtype=np.float64).ravel().tolist())))
-                held.append(r.MPtd)
+            for name, st, th, mp, ev, stats, offs in zip(df.Name, df.SampleTrims, df.Threshold, df.MPtd,
+                                                         df.Events, df.Stats, df.Offsets):
+                key.append(scal(name, st, th, ev, stats, offs))
+                held.append(mp)
         return repr(key), held
 
     def _build_bank(self, sta, useSubSpaces, useSingles, need_thr):

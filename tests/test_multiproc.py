@@ -237,3 +237,64 @@ def test_configs3_sharding_world2():
         assert failed is not None and 'rank' in failed and 'injected fault' in failed
     # each rank moved about half of the data over the host link (plus the 120 s chunk overlap)
     assert max(up) < 0.52 * total and sum(up) < 1.01 * total
+
+
+def _nccl_worker(rank, world, port, q):
+    """The same three-station run with one process per GPU under RCCL (backend 'nccl'), the real HIP
+    contexts and a pinned fetcher: exercises broadcast_banks / all_gather_object over xGMI."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    from detex_amd import parallel
+    from detex_amd.hip import HipContext
+    from test_host_logic import multi_station_workflow
+    ctx = HipContext(rank)
+    ss, cf, stas, _ = multi_station_workflow(ctx, pin=True)
+    ctx.close()
+    before = dict(parallel.COLLECTIVES)
+    res = ss.detex(subspaceDB=None)                      # device defaults to LOCAL_RANK
+    coll = {k: parallel.COLLECTIVES[k] - before[k] for k in before}
+    q.put((rank, coll, dict(ss.last_run), res['ss_df'].values.tolist(),
+           {sta: {k: v.tolist() for k, v in ss.histSubSpaces[sta].items()} for sta in stas}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_configs3_sharding_world2_nccl():
+    """Skips itself unless the box has two GPUs: the first multi-GPU node this suite meets runs
+    SubSpace.detex with two RCCL ranks against the single-GPU answer."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL world of 2)')
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from detex_amd.hip import HipContext
+    from test_host_logic import multi_station_workflow
+    c1 = HipContext(0)
+    ss1, cf, stas, _ = multi_station_workflow(c1, pin=True)
+    c1.close()
+    ref = ss1.detex(subspaceDB=None, device=0)
+    world = 2
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total = sum(4 * 3 * cf.data[s][0].shape[1] for s in stas)
+    for rank, coll, last, rows, hist in res:
+        assert coll == {'broadcast': 1, 'broadcast_object': 1, 'all_gather_object': 1, 'all_gather': 0}, coll
+        assert last['uploaded_bytes'] == _expected_upload(cf, stas, rank, world)[0] < 0.52 * total
+        assert len(rows) == len(ref['ss_df']) >= 10
+        for got, (_, want) in zip(rows, ref['ss_df'].iterrows()):
+            assert got[3] == want.Name and got[4] == want.Sta and got[2] == want.STMP
+            assert np.allclose([got[0], got[1]] + got[5:], [want.DS, want.DS_STALTA] + list(want.values[5:]),
+                               rtol=1e-5, equal_nan=True)
+        for sta in stas:
+            for nm, h in ss1.histSubSpaces[sta].items():
+                assert hist[sta][nm] == h.tolist()
