@@ -64,7 +64,8 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
 }
 
 #ifndef DTX_XC_ABLATE
-#define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads
+#define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads,
+                             // 4 no epilogue (normalise / max / atomics), 8 no transforms, 16 epilogue without the atomics
 #endif
 struct XcFftArgs {
   const c32* xh;        // [N][nblk][nseg][Nc][kXh] block spectra of the padded planes of every event
@@ -164,10 +165,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
         const unsigned long long o = __shfl_xor(key, off, 64);
         key = o > key ? o : key;
       }
+#if DTX_XC_ABLATE & 16
+      if (key == 12345ull) a.keys[0] = key;
+#else
       if ((tid & 63) == 0 && rowok && r1 > 0.f && key != 0ull) {
         const int64_t idx = condensed_index_x(a.N, b, c);
         if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
       }
+#endif
     }
   };
   // Pairs are taken two at a time: the block spectra (the operand both share) are staged once
@@ -263,11 +268,25 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
       __syncthreads();
     }
+#if DTX_XC_ABLATE & 8
+    if (z[0].x == 1.2345f && zb[3].y == 5.4321f) a.keys[1] = 1ull;     // (keeps the MAC alive)
+#else
     fft8192<1>(z, lds, lb, a.tab, tid);
+#endif
+#if DTX_XC_ABLATE & 4
+    if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
+#else
     reduce_rows(z, pr);
+#endif
     if (has2) {
+#if !(DTX_XC_ABLATE & 8)
       fft8192<1>(zb, lds, lb, a.tab, tid);
+#endif
+#if DTX_XC_ABLATE & 4
+      if (zb[0].x == 1.2345f && zb[5].y == 5.4321f) a.keys[1] = 1ull;
+#else
       reduce_rows(zb, pr + 1);
+#endif
     }
   }
 }

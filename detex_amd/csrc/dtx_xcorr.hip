@@ -249,6 +249,9 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
   xc_epilogue<RM, TN>(acc, a, c, kt, p0);
 }
 
+#ifndef DTX_XCFIN2
+#define DTX_XCFIN2 1        // 1: xc_finish2_kernel for Nc <= 64, 0: xc_finish_kernel always
+#endif
 #ifndef DTX_XCFIN_ABLATE
 #define DTX_XCFIN_ABLATE 0   // timing only: 1 no x_c loads, 2 no LDS reads of x_b (interior iterations)
 #endif
@@ -445,6 +448,199 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
   ss_out[idx] = (float)tau;
 }
 
+// Float64 prefix sums of every event and of its squares: ps[e][t] = sum_{u < t} x_e[u],
+// pq[e][t] = sum_{u < t} x_e[u]^2, t = 0 .. n.  The finishing kernel reads the zero-padded window sums
+// of the reference's normalisation off them in O(1) per lag.
+__global__ __launch_bounds__(256) void xc_prefix_kernel(const float* __restrict__ td, int n,
+                                                        double* __restrict__ ps, double* __restrict__ pq) {
+  __shared__ double ws1[2][4], ws2[2][4];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = td + (int64_t)e * n;
+  double* o1 = ps + (int64_t)e * (n + 1);
+  double* o2 = pq + (int64_t)e * (n + 1);
+  double c1 = 0.0, c2 = 0.0;                            // sums of the tiles before this one
+  int par = 0;
+  for (int j0 = 0; j0 < n; j0 += 256, par ^= 1) {       // coalesced tiles of 256 samples
+    const int j = j0 + tid;
+    const double v = j < n ? (double)x[j] : 0.0;
+    const double s1 = wave_incl_scan(v, lane), s2 = wave_incl_scan(v * v, lane);
+    if (lane == 63) { ws1[par][wave] = s1; ws2[par][wave] = s2; }
+    __syncthreads();                                    // (the other parity's slots are free: one barrier per tile)
+    double b1 = c1, b2 = c2;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) { b1 += ws1[par][w]; b2 += ws2[par][w]; }
+      c1 += ws1[par][w]; c2 += ws2[par][w];
+    }
+    if (j < n) {
+      o1[j] = b1 + s1 - v; o2[j] = b2 + s2 - v * v;     // exclusive
+      if (j == n - 1) { o1[n] = b1 + s1; o2[n] = b2 + s2; }
+    }
+  }
+}
+
+// The finishing kernel, second version (events with Nc <= 64): eight pairs per workgroup -- one wave
+// each -- share the earlier event b.  The winning lag and its two neighbours are re-evaluated in
+// float64 exactly as before; what changed is where the time went (rocprofv3, profiles/x4_*: waves
+// parked 43 % of the time, issue-stalled 30 %, 9 double-rate instructions per element):
+//   * x_b is staged through LDS ALREADY CONVERTED to float64, a chunk ahead in the other half of a
+//     double buffer (one barrier per chunk instead of two with the loads exposed between them);
+//     per element a wave converts only its own x_c sample: 1 convert + 3 fused multiply-adds;
+//   * the window sums sum(w), sum(w^2) of the zero-padded shifted x_c come from the prefix sums
+//     (xc_prefix_kernel) instead of two more accumulations per element;
+//   * a wave walks only the samples its pair's shift leaves inside both events.
+constexpr int kFinCh = 2048;         // x_b samples per staged chunk
+constexpr int kFinPad = 64;
+constexpr int kFinWaves = 8;
+__global__ __launch_bounds__(64 * kFinWaves) void xc_finish2_kernel(
+    const float* __restrict__ td, const unsigned long long* __restrict__ keys,
+    const double* __restrict__ esum, const double* __restrict__ essd,
+    const double* __restrict__ esq, const double* __restrict__ ps, const double* __restrict__ pq,
+    int N, int n, int Nc, int S, int Pz, int trunc, int64_t pair_begin, int64_t pair_end,
+    float* __restrict__ cc_out, int32_t* __restrict__ lag_out, float* __restrict__ ss_out, int T) {
+  __shared__ double x1s[2][kFinCh + 2 * kFinPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // tile walk as in xc_finish_kernel: T x T events per tile, upper triangle of tiles, inside a tile an
+  // XCD owns whole groups of 16 later events and walks every earlier event against them
+  const int per_tile = T * T / kFinWaves;
+  int t = (int)(blockIdx.x / per_tile);
+  const int r = (int)(blockIdx.x - (int64_t)t * per_tile);
+  const int ntile = (N + T - 1) / T;
+  int ti = 0;
+  while (t >= ntile - ti) { t -= ntile - ti; ++ti; }
+  const int tj = ti + t;
+  int lb, lc;
+  if (T % 128 == 0) {
+    const int xcd = r & 7, seq = r >> 3;
+    const int per_cg = T * (16 / kFinWaves);            // blocks per group: T earlier events x 16 / 8
+    const int cg = (seq / per_cg) * 8 + xcd, rem = seq % per_cg;
+    lb = rem / (16 / kFinWaves);
+    lc = cg * 16 + (rem % (16 / kFinWaves)) * kFinWaves + wave;
+  } else {
+    const int local = r * kFinWaves + wave;
+    lb = local / T;
+    lc = local % T;
+  }
+  const int64_t b = (int64_t)ti * T + lb, c = (int64_t)tj * T + lc;
+  bool live = b < c && c < N;
+  int64_t idx = 0;
+  if (live) {
+    idx = condensed_index(N, b, c);
+    live = idx >= pair_begin && idx < pair_end;
+  }
+  unsigned long long key = 0ull;
+  double ssd1 = 0.0, sum1 = 0.0;
+  if (live) {
+    key = keys[idx];
+    ssd1 = essd[b]; sum1 = esum[b];
+    if (key == 0ull || !(ssd1 > 0.0) || !(esq[c] > 0.0)) {
+      // construct.py:463-464: all-NaN CC vector -> (0, 0, 0)
+      if (lane == 0) { cc_out[idx] = 0.f; lag_out[idx] = 0; ss_out[idx] = 0.f; }
+      live = false;
+    }
+  }
+  if (!__syncthreads_or(live)) return;                  // (uniform: nothing to stage for)
+  const int p = live ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+  const float* x1 = td + (b < N ? b : 0) * (int64_t)n;
+  const float* x2 = td + (c < N ? c : 0) * (int64_t)n;
+  const int sh0 = (p - 1 - S) * Nc;                     // lag l pairs x_b[j] with x_c[j + sh0 + l Nc]
+  const int sh1 = sh0 + Nc;
+  // index jm = the x_b index of the MIDDLE lag: x_c element t = jm + sh1 meets x_b[jm + Nc] (lag 0),
+  // x_b[jm] (lag 1), x_b[jm - Nc] (lag 2); x_b is zero outside [0, n) in the staged image, so only
+  // t has to stay inside x_c: jm in [max(-Nc, -sh1), min(n + Nc, n - sh1))
+  const int jlo = live ? max(-Nc, -sh1) : 0, jhi = live ? min(n + Nc, n - sh1) : 0;
+  double dot[3] = {0, 0, 0};
+  auto stage_load = [&](int J0, float (&v)[kFinCh / (64 * kFinWaves) + 1]) {
+#pragma unroll
+    for (int q = 0; q <= kFinCh / (64 * kFinWaves); ++q) {
+      const int i = threadIdx.x + 64 * kFinWaves * q;       // image index: x_b[J0 - Nc + i]
+      const int j = J0 - Nc + i;
+      v[q] = (i < kFinCh + 2 * Nc && j >= 0 && j < n && b < N) ? x1[j] : 0.f;
+    }
+  };
+  auto stage_store = [&](int buf, const float (&v)[kFinCh / (64 * kFinWaves) + 1]) {
+#pragma unroll
+    for (int q = 0; q <= kFinCh / (64 * kFinWaves); ++q) {
+      const int i = threadIdx.x + 64 * kFinWaves * q;
+      if (i < kFinCh + 2 * Nc) x1s[buf][i] = (double)v[q];
+    }
+  };
+  float sv[kFinCh / (64 * kFinWaves) + 1];
+  stage_load(-Nc, sv);
+  stage_store(0, sv);
+  __syncthreads();
+  int buf = 0;
+  for (int J0 = -Nc; J0 < n + Nc; J0 += kFinCh, buf ^= 1) {
+    const bool more = J0 + kFinCh < n + Nc;             // uniform
+    if (more) stage_load(J0 + kFinCh, sv);
+    const double* xs = x1s[buf];
+    // this wave's share of the chunk, in steps of 64 samples from the chunk's start
+    const int c0 = max(J0, jlo), c1 = min(J0 + kFinCh, jhi);
+    if (c0 < c1) {
+      int jb = J0 + (c0 - J0) / 64 * 64;
+      constexpr int kB = 4;
+      for (; jb < c1; jb += 64) {
+        if (jb >= c0 && jb + 64 * kB <= c1) {           // kB whole steps: their loads first, all in flight
+          float vb[kB];
+#pragma unroll
+          for (int k = 0; k < kB; ++k) vb[k] = x2[jb + 64 * k + lane + sh1];
+#pragma unroll
+          for (int k = 0; k < kB; ++k) {
+            const int i = jb + 64 * k + lane - J0 + Nc;
+            const double v = (double)vb[k];
+            dot[0] += xs[i + Nc] * v;
+            dot[1] += xs[i] * v;
+            dot[2] += xs[i - Nc] * v;
+          }
+          jb += 64 * (kB - 1);
+          continue;
+        }
+        const int jm = jb + lane;
+        const bool ok = jm >= c0 && jm < c1;
+        const double v = ok ? (double)x2[min(max(jm + sh1, 0), n - 1)] : 0.0;
+        const int i = jm - J0 + Nc;
+        dot[0] += xs[i + Nc] * v;
+        dot[1] += xs[i] * v;
+        dot[2] += xs[i - Nc] * v;
+      }
+    }
+    if (more) stage_store(buf ^ 1, sv);
+    __syncthreads();
+  }
+  if (!live) return;
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot[l] += __shfl_down(dot[l], off, 64);
+  if (lane != 0) return;
+  const double dn = (double)n;
+  const double* p1 = ps + c * (int64_t)(n + 1);
+  const double* p2 = pq + c * (int64_t)(n + 1);
+  double cv[3];
+  for (int l = 0; l < 3; ++l) {
+    // x_c samples t = j + s with j in [0, n): the rest of the window is zero padding
+    const int s = sh0 + l * Nc;
+    const int t0 = min(max(s, 0), n), t1 = min(max(n + s, 0), n);
+    const double sw = t1 > t0 ? p1[t1] - p1[t0] : 0.0, sq = t1 > t0 ? p2[t1] - p2[t0] : 0.0;
+    const double vw = clamp_var(sq, sw, dn);
+    // zero-variance window: the reference gets +-inf and scrubs it to 0
+    double v = vw > 0.0 ? (dot[l] - sum1 * sw / dn) / sqrt(ssd1 * vw) : 0.0;
+    if (v > 1.0 + (double)kScrubTol || v < -1.0 - (double)kScrubTol) v = 0.0;
+    cv[l] = v;
+  }
+  double tau = 0.0;
+  if (p != 0 && p != Pz - 1) {                       // construct.py:409-410
+    const double cb4 = cv[0], cn = cv[1], caf = cv[2];
+    const double alpha = acos((cb4 + caf) / (2.0 * cn));
+    const double alsi = sin(alpha);
+    tau = -(atan((cb4 - caf) / (2.0 * cn * alsi)) / alpha);
+    if (fabs(tau) > 0.5) tau = (double)p;            // construct.py:418-421 (returns ind)
+  }
+  cc_out[idx] = (float)cv[1];
+  lag_out[idx] = (p + 1 + trunc) * Nc - n;           // construct.py:466
+  ss_out[idx] = (float)tau;
+}
+
 template <int RM>
 int launch_items(dtx_ctx* ctx, XcArgs a, const int2* items_dev, int nitems) {
   if constexpr (RM == kRmMax) {
@@ -569,6 +765,9 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const size_t o_fs = carve((size_t)N * sizeof(float));
   const size_t o_fr = carve((size_t)N * sizeof(float));
   const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
+  const bool fin2 = DTX_XCFIN2 && Nc <= kFinPad;       // the second finishing kernel (float64 image of x_b, prefix sums)
+  const size_t o_ps = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
+  const size_t o_pq = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
   const bool split = !use_fft && ctx->engine != DTX_ENGINE_FP32 && L >= kSplitMinL;
   const int64_t Vz = Tz / 8;
   const size_t o_xt16 = carve(split ? (size_t)nkt * Nc * (Lp / 8) * 2 * kKtMax * 8 * sizeof(uint16_t) : 0);
@@ -674,7 +873,20 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   ctx->kernel_timed = true;
   }
 
-  {
+  if (fin2) {
+    double* ps = (double*)(base + o_ps);
+    double* pq = (double*)(base + o_pq);
+    hipLaunchKernelGGL(xc_prefix_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, td_dev, n, ps, pq);
+    DTX_HIP(ctx, hipGetLastError());
+    const int T = std::min(512, (N + 7) / 8 * 8);
+    const int64_t ntile = (N + T - 1) / T;
+    const int64_t fgrid = ntile * (ntile + 1) / 2 * ((int64_t)T * T / kFinWaves);
+    if (fgrid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "too many events");
+    hipLaunchKernelGGL(xc_finish2_kernel, dim3((unsigned)fgrid), dim3(64 * kFinWaves), 0, ctx->stream,
+                       td_dev, (const unsigned long long*)keys, (const double*)esum,
+                       (const double*)essd, (const double*)esq, (const double*)ps, (const double*)pq, N, n,
+                       Nc, S, Pz, trunc, pair_begin, pair_end, cc_dev, lag_dev, subsamp_dev, T);
+  } else {
     const int T = std::min(512, (N + 3) / 4 * 4);
     const int64_t ntile = (N + T - 1) / T;
     const int64_t fgrid = ntile * (ntile + 1) / 2 * ((int64_t)T * T / 4);
