@@ -829,7 +829,9 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   return DTX_OK;
 }
 
-// xp / mean / den: the channel planes and window statistics dtx_subspace_ds prepared
+// xp: the channel planes; mean / den: the window statistics, being computed on the context's side
+// stream (forked by the caller): the guard pass follows them there, the block spectra are taken on the
+// main stream meanwhile, and the two streams meet in front of the scan kernel
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list) {
   DtxFft& f = ctx->fft;
@@ -877,8 +879,9 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
   const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
-  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                     ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh);
+  hipLaunchKernelGGL(xhat_kernel<false>, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
+                     ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0,
+                     (const float*)nullptr, (int64_t)0);
   DTX_HIP(ctx, hipGetLastError());
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
@@ -898,9 +901,13 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
 #endif
   a.upre = (const int2*)f.upre_dev; a.nfull = nfull; a.nrem = std::max(nrem, 1); a.ngroups = ng;
   std::copy(gb, gb + kMaxGroups + 1, a.gb);
-  hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->stream, den,
+  hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->aux, den,
                      Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list);
   DTX_HIP(ctx, hipGetLastError());
+  {
+    const int rcj = dtx_aux_join(ctx);
+    if (rcj) return rcj;
+  }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {
 #ifndef DTX_FFT_ONLY_VM

@@ -71,6 +71,10 @@ struct dtx_ctx {
   int ncu = 256;                // compute units (grid shaping)
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // side stream of the scan's preparation (window statistics run beside the block spectra) and the
+  // events that fork it from / join it to `stream`; created on first use
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
 
   // basis
@@ -101,8 +105,13 @@ struct DtxPost;
 void dtx_fft_free(dtx_ctx* ctx);
 bool dtx_fft_eligible(int L);
 int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int Nc);
+// xp: the channel planes; mean / den: the window statistics, being computed on the context's side
+// stream (forked by the caller): the guard pass follows them there, the block spectra are taken on the
+// main stream meanwhile, and the two streams meet in front of the scan kernel
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
+int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
+int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.
 // Calibration (tests/test_gpu_engines.py, scripts/sweep_more.py): the error of a quiet window
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it

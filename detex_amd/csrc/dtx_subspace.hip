@@ -31,86 +31,92 @@ using namespace dtx;
 
 namespace {
 
-// ------------------------------------------------------------------ demux
-// Block offset in float64 (sliced partial sums, float64 atomics).  The statistic is
-// invariant to adding a constant to the data block, but its float32 evaluation is
-// not: with a DC offset much larger than the signal and basis rows of non-zero mean,
-// U.w and S mu cancel catastrophically.  Removing an offset first (exact in exact
-// arithmetic: U.(w - m) - S (mu - m) = U.w - S mu) keeps float32 safe.  The offset is
-// the mean of the block's "ordinary" samples: pass 0 takes sum, sum of squares and
-// count of the non-zero samples (zero-filled gaps, getdata fillZeros, must not pull
-// it), pass 1 repeats the mean over the non-zero samples within 3 sigma of the pass-0
-// mean, so that a spike of any size cannot move it either.
-// csum[b] = {sum, sumsq, count, sum', count'}
-constexpr int kMeanSlices = 128;
-constexpr int kCsum = 5;
-template <int PASS>
-__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ x, int64_t M,
-                                                        int64_t chunk_stride,
-                                                        double* __restrict__ csum) {
-  __shared__ double sh[3][4];
+// ------------------------------------------------------------------ block offset, demux
+// Block offset.  The statistic is invariant to adding a constant to the data block, but its
+// float32 evaluation is not: with a DC offset much larger than the signal and basis rows of
+// non-zero mean, U.w and S mu cancel catastrophically.  Removing an offset first (exact in exact
+// arithmetic: U.(w - m) - S (mu - m) = U.w - S mu) keeps float32 safe.  Any estimate of the
+// block's ordinary level does -- it only conditions the arithmetic -- but it must not follow a
+// spike or a burst of any size, nor zero-filled gaps (getdata fillZeros).  A chunk is cut into up
+// to 64 slices; each slice takes the float64 mean of its non-zero samples in ONE pass over the
+// stream (no atomics); the offset is the MEDIAN of the slice means: a spike or a burst moves only
+// the slices it touches.  (Rounds 1-2 took a chunk-wide mean and a 3-sigma clipped second pass:
+// two launches, two reads of the stream, float64 atomics -- 39 + 31 us per station-day.)
+constexpr int kMeanSlices = 64;                 // one slice per lane of the wave that takes the median
+constexpr int kCsum = 2;                       // per slice: {sum, count} of the non-zero samples
+__global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restrict__ x, int64_t M,
+                                                           int64_t chunk_stride, int nsl,
+                                                           double* __restrict__ cslice) {
+  __shared__ double sh[2][4];
   const int b = blockIdx.y, tid = threadIdx.x;
   const float* xb = x + (int64_t)b * chunk_stride;
-  double* cs = csum + (int64_t)b * kCsum;
-  const int64_t per = (M + kMeanSlices - 1) / kMeanSlices;
+  const int64_t per = (M + nsl - 1) / nsl;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, M);
-  double m1 = 0.0, band = 0.0;
-  if (PASS == 1) {
-    const double cnt = cs[2];
-    if (cnt < 0.5) return;
-    m1 = cs[0] / cnt;
-    band = 3.0 * sqrt(fmax(cs[1] / cnt - m1 * m1, 0.0));
-  }
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double s0 = 0.0, s2 = 0.0;
   auto take = [&](float vf) {
-    const double v = (double)vf;
-    if (PASS == 0) {
-      if (vf != 0.f) { s0 += v; s1 += v * v; s2 += 1.0; }
-    } else {
-      if (vf != 0.f && fabs(v - m1) <= band) { s0 += v; s2 += 1.0; }
-    }
+    if (vf != 0.f) { s0 += (double)vf; s2 += 1.0; }
   };
   int64_t i = i0 + tid;
-  for (; i + 3 * 256 < i1; i += 4 * 256) {       // four loads in flight
-    const float v0 = xb[i], v1 = xb[i + 256], v2 = xb[i + 512], v3 = xb[i + 768];
-    take(v0); take(v1); take(v2); take(v3);
+  for (; i + 7 * 256 < i1; i += 8 * 256) {       // eight loads in flight
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = xb[i + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) take(v[k]);
   }
   for (; i < i1; i += 256) take(xb[i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s0 += __shfl_down(s0, off, 64);
-    s1 += __shfl_down(s1, off, 64);
     s2 += __shfl_down(s2, off, 64);
   }
-  if ((tid & 63) == 0) { sh[0][tid >> 6] = s0; sh[1][tid >> 6] = s1; sh[2][tid >> 6] = s2; }
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s0; sh[1][tid >> 6] = s2; }
   __syncthreads();
   if (tid == 0) {
-    const double t0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    const double t1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-    const double t2 = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
-    if (PASS == 0) {
-      atomicAdd(&cs[0], t0); atomicAdd(&cs[1], t1); atomicAdd(&cs[2], t2);
-    } else {
-      atomicAdd(&cs[3], t0); atomicAdd(&cs[4], t2);
-    }
+    double* cs = cslice + ((int64_t)b * nsl + blockIdx.x) * kCsum;
+    cs[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    cs[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
 
-__device__ inline float block_offset(const double* __restrict__ cs) {
-  if (cs[4] >= 0.5) return (float)(cs[3] / cs[4]);
-  if (cs[2] >= 0.5) return (float)(cs[0] / cs[2]);   // every sample equal: sigma 0 keeps them all,
-  return 0.f;                                        // so this is only the all-zero block
+// m0[b] = (lower) median of the means of chunk b's slices that hold any non-zero sample; 0 for an
+// all-zero chunk.  One wave per chunk, ranks by counting: deterministic, every consumer reads the same float
+__global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __restrict__ cslice, int nsl,
+                                                                float* __restrict__ m0) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  double v = 0.0;
+  bool ok = false;
+  if (lane < nsl) {
+    const double* cs = cslice + ((int64_t)b * nsl + lane) * kCsum;
+    if (cs[1] >= 0.5) { v = cs[0] / cs[1]; ok = v == v; }      // (a slice that holds a NaN is left out)
+  }
+  const unsigned long long mask = __ballot(ok);
+  const int nv = __popcll(mask);
+  if (nv == 0) {
+    if (lane == 0) m0[b] = 0.f;
+    return;
+  }
+  int rank = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const double vj = __shfl(v, j, 64);
+    if (((mask >> j) & 1ull) && (vj < v || (vj == v && j < lane))) ++rank;
+  }
+  if (ok && rank == (nv - 1) / 2) m0[b] = (float)v;
 }
 
-// xp[b][c][t] = x_b[Nc*t + c] - mean(x_b) for the samples the windows touch, 0 beyond.
+// xp[b][c][t] = x_b[Nc*t + c] - m0[b] for the samples the windows touch, 0 beyond.
+// list != NULL: only if the list holds anything (list[0] > 0) -- the planes are then built for the repair
+// pass behind the frequency-domain engine, which on ordinary data finds nothing to repair
 __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x, int64_t M,
                                                     int64_t chunk_stride, int Nc, int64_t Tvalid,
-                                                    int64_t Tpad, const double* __restrict__ csum,
-                                                    float* __restrict__ xp) {
+                                                    int64_t Tpad, const float* __restrict__ m0f,
+                                                    float* __restrict__ xp, const int* __restrict__ list) {
+  if (list != nullptr && list[0] <= 0) return;
   const int b = blockIdx.z, c = blockIdx.y;
   const float* xb = x + (int64_t)b * chunk_stride;
   float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
-  const float m0 = block_offset(csum + (int64_t)b * kCsum);
+  const float m0 = m0f[b];
   // four consecutive samples per thread: four gathers in flight, one 16-byte store where the plane
   // allows it
   const bool vec = ((Tpad & 3) == 0) && ((reinterpret_cast<uintptr_t>(xp) & 15) == 0);
@@ -556,30 +562,22 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   float* mean = (float*)ctx->ws_mean.p;
   float* den = (float*)ctx->ws_den.p;
 
-  {
-    const int64_t Tvalid = P + ctx->L - 1;
-    dim3 grid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), (unsigned)Nc,
-              (unsigned)nchunk);
-    const size_t cbytes = (size_t)nchunk * kCsum * sizeof(double);
-    if ((rc = dtx_reserve(ctx, ctx->ws_csum, cbytes))) return rc;
-    double* csum = (double*)ctx->ws_csum.p;
-    DTX_HIP(ctx, hipMemsetAsync(csum, 0, cbytes, ctx->stream));
-    hipLaunchKernelGGL(chunk_sum_kernel<0>, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
-                       ctx->stream, x_dev, M, chunk_stride, csum);
-    hipLaunchKernelGGL(chunk_sum_kernel<1>, dim3(kMeanSlices, (unsigned)nchunk), dim3(256), 0,
-                       ctx->stream, x_dev, M, chunk_stride, csum);
-    hipLaunchKernelGGL(demux_kernel, grid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
-                       Tvalid, Tpad, (const double*)csum, xp);
-    DTX_HIP(ctx, hipGetLastError());
-  }
-  {
-    // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
-    const double scale = (double)n / ((double)n - 1.0);
-    dim3 grid((unsigned)((P + kStatsPB - 1) / kStatsPB), (unsigned)nchunk);
-    hipLaunchKernelGGL(win_stats_kernel, grid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
-                       Nc, ctx->L, P, Ppad, scale, mean, den);
-    DTX_HIP(ctx, hipGetLastError());
-  }
+  const int64_t Tvalid = P + ctx->L - 1;
+  // block offsets (one pass over the stream + a 24-block reduction)
+  const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 256));
+  if ((rc = dtx_reserve(ctx, ctx->ws_csum, (size_t)nchunk * (nsl * kCsum * sizeof(double) + sizeof(float)))))
+    return rc;
+  double* cslice = (double*)ctx->ws_csum.p;
+  float* m0f = (float*)(cslice + (size_t)nchunk * nsl * kCsum);
+  hipLaunchKernelGGL(chunk_offset_kernel, dim3((unsigned)nsl, (unsigned)nchunk), dim3(256), 0, ctx->stream,
+                     x_dev, M, chunk_stride, nsl, cslice);
+  hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
+                     (const double*)cslice, nsl, m0f);
+  DTX_HIP(ctx, hipGetLastError());
+  const dim3 dgrid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), (unsigned)Nc, (unsigned)nchunk);
+  // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
+  const double scale = (double)n / ((double)n - 1.0);
+  const dim3 sgrid((unsigned)((P + kStatsPB - 1) / kStatsPB), (unsigned)nchunk);
 
   const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
                        (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
@@ -587,17 +585,29 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if (!ctx->fft.ok &&
         (rc = dtx_fft_basis_build(ctx, ctx->hdoff.data(), ctx->D, n, Nc)))
       return rc;
-    // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
-    // amplitude in an 8192-sample block, not to the window: a block whose loudest window
-    // holds more than kFftGuard^2 = 4e4 times the energy of its quietest one (a 200-sigma
-    // burst) would put > 4e-6 of error on the quiet windows.  A small kernel lists such blocks
-    // and the float32 MFMA contraction -- whose error is local to a window -- recomputes
-    // them right behind it: a 256-workgroup launch that finds an empty list on ordinary data.
+    // The preparation reads the caller's multiplexed stream directly (rounds 1-2 wrote channel planes
+    // first and read them back twice): the window statistics run on a side stream beside the block
+    // spectra -- both are chains of memory latencies that leave most of the chip idle on their own.
     const int fV = ctx->fft.V;
     const int fnblk = (int)((P + fV - 1) / fV);
     if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
     int* list = (int*)ctx->ws_flag.p;
     DTX_HIP(ctx, hipMemsetAsync(list, 0, sizeof(int), ctx->stream));
+    // channel planes (main stream), then the window statistics on the side stream beside the block
+    // spectra: both are chains of memory latencies that leave most of the chip idle on their own
+    hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
+                       Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
+    if ((rc = dtx_aux_fork(ctx))) return rc;
+    hipLaunchKernelGGL(win_stats_kernel<false>, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
+                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)nullptr, (int64_t)0);
+    DTX_HIP(ctx, hipGetLastError());
+    // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
+    // amplitude in an 8192-sample block, not to the window: a block whose loudest window
+    // holds more than kFftGuard^2 = 4e4 times the energy of its quietest one (a 200-sigma
+    // burst) would put > 4e-6 of error on the quiet windows.  A small kernel lists such blocks
+    // (dtx_fft_scan, behind the statistics on the side stream) and the float32 MFMA contraction --
+    // whose error is local to a window -- recomputes them right behind the scan: a 256-workgroup
+    // launch that finds an empty list on ordinary data.
     if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, list))) return rc;
     for (const DtxKTile& t : ctx->tiles) {
       DsArgs a;
@@ -612,6 +622,12 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post);
     return DTX_OK;
   }
+
+  hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
+                     Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
+  hipLaunchKernelGGL(win_stats_kernel<false>, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
+                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)nullptr, (int64_t)0);
+  DTX_HIP(ctx, hipGetLastError());
 
   i32x4* g16 = nullptr;
   const int64_t V = Tpad / 8;
