@@ -20,6 +20,32 @@ namespace {
 constexpr float kScrubTolF = 1e-5f;   // dtx_xcorr.hip: kScrubTol
 constexpr int kUnitX = 8;             // event pairs per workgroup (they share the window statistics; 4: 402 ms, 8: 392, 16: 390)
 
+// Wave-wide max / min by data-parallel primitives (row operations of the vector ALU: no LDS crossbar,
+// no ds_bpermute round trips): after the four in-row steps every lane of a row of 16 holds the row's
+// result, row_bcast15 / row_bcast31 carry it up the rows; lane 63 ends with the wave's.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, __int_as_float(dpp_mov<0xB1, 0xF>(__float_as_int(v))));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, __int_as_float(dpp_mov<0x4E, 0xF>(__float_as_int(v))));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, __int_as_float(dpp_mov<0x141, 0xF>(__float_as_int(v))));    // row_half_mirror
+  v = fmaxf(v, __int_as_float(dpp_mov<0x140, 0xF>(__float_as_int(v))));    // row_mirror
+  v = fmaxf(v, __int_as_float(dpp_mov<0x142, 0xA>(__float_as_int(v))));    // row_bcast15 -> rows 1, 3
+  v = fmaxf(v, __int_as_float(dpp_mov<0x143, 0xC>(__float_as_int(v))));    // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)dpp_mov<0xB1, 0xF>((int)v));
+  v = min(v, (unsigned)dpp_mov<0x4E, 0xF>((int)v));
+  v = min(v, (unsigned)dpp_mov<0x141, 0xF>((int)v));
+  v = min(v, (unsigned)dpp_mov<0x140, 0xF>((int)v));
+  v = min(v, (unsigned)dpp_mov<0x142, 0xA>((int)v));
+  v = min(v, (unsigned)dpp_mov<0x143, 0xC>((int)v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ inline int64_t condensed_index_x(int64_t N, int64_t b, int64_t c) {
   return N * b - b * (b + 1) / 2 + (c - b - 1);
 }
@@ -106,7 +132,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
     const int p = p0 + tid + 512 * m;
     const bool ok = p < a.Pz;
     mu[m] = ok ? a.mean_w[(int64_t)c * a.Ppad + p] : 0.f;
-    rw[m] = ok ? a.rsw[(int64_t)c * a.Ppad + p] : 0.f;
+    rw[m] = ok ? a.rsw[(int64_t)c * a.Ppad + p] : __builtin_nanf("");       // (see reduce_rows)
   }
   // the thread's 16 frequencies in a stored half spectrum (see ds_fft_kernel)
   const int wv = tid >> 6, ln = tid & 63;
@@ -137,7 +163,12 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   };
 
   // rows 2 pr (real part) and 2 pr + 1 (imaginary part) of a finished transform: normalise,
-  // scrub, max / first argmax over the block's lags, one atomicMax per row and wave
+  // scrub, max / first argmax over the block's lags, one atomicMax per row and wave.
+  // The thread's VM lags are compared as floats (first of equals: the smaller lag), the wave's winner is
+  // found by row operations -- the max of cc, then the smallest lag among the lanes that hold it -- and
+  // only that one candidate is packed into the 64-bit key.  (Rounds 1-2 packed a key per lag and reduced
+  // keys through 12 ds_bpermute round trips per row: the epilogue was 22 of the kernel's 190 ms.)
+  // rw[m] is NaN for lags past Pz: their cc is NaN and never wins a comparison.
   auto reduce_rows = [&](const c32 (&z)[16], int pr) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -145,30 +176,28 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       const bool rowok = b < c;                                   // uniform
       // the pair spectra hold unit-energy rows x_b rs_b: cc = (Y' - (sum x_b) rs_b mu_w) rs_w
       const float r1 = rowok ? a.frs[b] : 0.f, s1 = rowok ? a.fsum[b] * r1 : 0.f;
-      unsigned long long key = 0ull;
+      float best = -INFINITY;
+      int bm = 0;
 #pragma unroll
       for (int m = 0; m < VM; ++m) {
-        const int p = p0 + tid + 512 * m;
         const float y = h ? z[m].y : z[m].x;
         float cc = (y - s1 * mu[m]) * rw[m];
-        if (cc > 1.f + kScrubTolF || cc < -1.f - kScrubTolF) cc = 0.f;   // construct.py:458-462
-        if (p < a.Pz && cc == cc) {
-          const unsigned bits = __float_as_uint(cc);
-          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-          const unsigned long long k2 =
-              ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
-          key = k2 > key ? k2 : key;
-        }
+        cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+        const bool gt = cc > best;
+        best = gt ? cc : best;
+        bm = gt ? m : bm;
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(key, off, 64);
-        key = o > key ? o : key;
-      }
+      const float wmax = wave_max_f32(best);                      // uniform
+      const unsigned pcand = (best == wmax) ? (unsigned)(p0 + tid + 512 * bm) : 0xFFFFFFFFu;
+      const unsigned pmin = wave_min_u32(pcand);
 #if DTX_XC_ABLATE & 16
-      if (key == 12345ull) a.keys[0] = key;
+      if (pmin == 12345u && wmax == 0.5f) a.keys[0] = 1ull;
 #else
-      if ((tid & 63) == 0 && rowok && r1 > 0.f && key != 0ull) {
+      if ((tid & 63) == 0 && rowok && r1 > 0.f && wmax > -INFINITY) {
+        const unsigned bits = __float_as_uint(wmax);
+        const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+        const unsigned long long key =
+            ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
         const int64_t idx = condensed_index_x(a.N, b, c);
         if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
       }
