@@ -89,6 +89,9 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
   for (int m = 0; m < 16; ++m) dst[w_slot(tid + 512 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
 }
 
+#ifndef DTX_XC_DUAL
+#define DTX_XC_DUAL 1        // the two transforms of an iteration taken together (fft8192_x2), the second on the X staging buffers
+#endif
 #ifndef DTX_XC_ABLATE
 #define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads,
                              // 4 no epilogue (normalise / max / atomics), 8 no transforms, 16 epilogue without the atomics
@@ -300,7 +303,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #if DTX_XC_ABLATE & 8
     if (z[0].x == 1.2345f && zb[3].y == 5.4321f) a.keys[1] = 1ull;     // (keeps the MAC alive)
 #else
-    fft8192<1>(z, lds, lb, a.tab, tid);
+    if (DTX_XC_DUAL && has2) {
+      // both transforms together, the second on the (now idle) staging buffers of the block spectra:
+      // 64 KB like the image; the barrier that follows keeps the next iteration's staging stores
+      // behind every wave's last reads of it
+      fft8192_x2<1>(z, zb, lds, &xst[0][0], lb, a.tab, tid);
+    } else {
+      fft8192<1>(z, lds, lb, a.tab, tid);
+    }
 #endif
 #if DTX_XC_ABLATE & 4
     if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #endif
     if (has2) {
 #if !(DTX_XC_ABLATE & 8)
-      fft8192<1>(zb, lds, lb, a.tab, tid);
+      if (!DTX_XC_DUAL) fft8192<1>(zb, lds, lb, a.tab, tid);
 #endif
 #if DTX_XC_ABLATE & 4
       if (zb[0].x == 1.2345f && zb[5].y == 5.4321f) a.keys[1] = 1ull;
@@ -317,6 +327,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       reduce_rows(zb, pr + 1);
 #endif
     }
+    if (DTX_XC_DUAL) __syncthreads();
   }
 }
 
