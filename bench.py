@@ -148,6 +148,9 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
                 'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
                             'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
                             'frac': flop_fft / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                            # the kernel against its OWN floor: its butterflies and MACs at the f32 vector peak
+                            'floor_ms': flop_fft / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3,
+                            'times_floor': kms / (flop_fft / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3),
                             'contraction_equivalent': flops / (kms * 1e-3) / 1e12},
                 # the vector ALUs' share of a round of the ping-pong kernel (one pair per CU and round; DESIGN.md
                 # 4.1, profiles/g9_ablations.txt): 1000 instructions per pair and wave in the <10,false,3>
@@ -246,13 +249,14 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     ctx.set_engine('auto')
     dt, kms, ccm = res['auto']
     dtm, kmsm, _ = res['bf16x3']
-    # frequency-domain lag search (dtx_xcfft.hip): per (later event c, lag block, event pair)
-    # one 8192-point complex transform and a MAC over Nc * nseg virtual channels
-    nseg = (L + 4095) // 4096
-    nblk = (2 * S + 1 + 4095) // 4096
+    # frequency-domain lag search (dtx_xcfft.hip): events of 13 000 samples are cut into 4 segments of
+    # 3585, the 13 001 lags into 3 blocks of 4608; per (later event c, lag block, event pair) one
+    # 8192-point complex transform and one MAC step per (segment that sees data, channel): 11 x Nc steps
+    # per three transforms
+    nblk, nprod = 3, 11
     nfft = (npairs / 2.0) * nblk
-    flop_fft = nfft * (5.0 * 8192 * 13 + 8.0 * Nc * nseg * 8192)
-    l2_bytes = nfft * Nc * nseg * (8192 * 8 + 4096 * 8 / 2.0)      # pair spectrum + half of a shared block spectrum
+    flop_fft = nfft * 5.0 * 8192 * 13 + (npairs / 2.0) * nprod * Nc * 8.0 * 8192
+    l2_bytes = (npairs / 2.0) * nprod * Nc * (8192 * 8 + 4096 * 8 / 2.0)   # pair spectrum + half of a shared block spectrum
     bytes_alg = 4.0 * N * n + 12.0 * npairs                        # events once + 12 B per pair
     # counters of the committed rocprofv3 --pmc passes of scripts/bench_xcorr.py (scripts/profile_xc.sh), newest tag
     import glob
@@ -298,10 +302,10 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
                          'l2': {'unit': 'TB/s', 'model_bytes': l2_bytes,
                                 'achieved': l2_bytes / (kms * 1e-3) / 1e12, 'peak': 34.5,
                                 'frac': l2_bytes / (kms * 1e-3) / 1e12 / 34.5},
-                         'note': 'frequency-domain lag search: %.3g transforms of 8192 points, each with a MAC '
-                                 'over %d virtual channels whose spectra stream from L2 (model: one 64 KB pair '
-                                 'spectrum per transform and channel, block spectra shared by two pairs); '
-                                 'algorithmic HBM bytes = events once + 12 B per pair' % (nfft, Nc * nseg)},
+                         'note': 'frequency-domain lag search: %.3g transforms of 8192 points and %d MAC steps per '
+                                 'three of them, whose spectra stream from L2 (model: one 64 KB pair spectrum per '
+                                 'transform and step, block spectra shared by two pairs); algorithmic HBM bytes = '
+                                 'events once + 12 B per pair' % (nfft, nprod * Nc)},
             'mfma_engine': {'value': npairs / dtm, 'unit': 'pairs/s', 'seconds': dtm,
                             'roofline': {'bound': 'mfma', 'kernel': 'xc_mfma_kernel_s<13,2>', 'kernel_ms': kmsm,
                                          'achieved': flop_pair * npairs / (kmsm * 1e-3) / 1e12,

@@ -17,7 +17,7 @@ st = glob.glob(src + '/trace/**/*_kernel_stats.csv', recursive=True)
 if st:
     shutil.copy(st[0], 'profiles/%s_xcorr_kernel_stats.csv' % tag)
 res = {}
-for kern in ('xc_fft_kernel', 'xc_finish_kernel'):
+for kern in ("xc_fft_kernel", "xc_finish"):
     out = {}
     for d in ['pmc_fetch', 'pmc_write', 'pmc_tcc', 'pmc_sq', 'pmc_sq2']:
         for f in glob.glob('%s/%s/**/*counter_collection.csv' % (src, d), recursive=True):
