@@ -46,16 +46,21 @@ void dtx_free_tiles_internal(dtx_ctx* c) {
 
 int dtx_aux_fork(dtx_ctx* ctx) {
   if (!ctx->aux) {
+    // DETEX_AMD_NO_AUX=1 (measurements): the "side stream" is the context's own -- everything serial
+    const char* e = getenv("DETEX_AMD_NO_AUX");
+    if (e && e[0] == '1') { ctx->aux = ctx->stream; ctx->aux_is_main = true; return DTX_OK; }
     DTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
+  if (ctx->aux_is_main) return DTX_OK;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   DTX_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
   return DTX_OK;
 }
 
 int dtx_aux_join(dtx_ctx* ctx) {
+  if (ctx->aux_is_main) return DTX_OK;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
   DTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   return DTX_OK;
@@ -110,7 +115,7 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   if (!ctx) return DTX_OK;
   DtxDeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+  if (ctx->aux && !ctx->aux_is_main) (void)hipStreamSynchronize(ctx->aux);
   dtx_free_tiles_internal(ctx);
   DtxBuf* bufs[] = {&ctx->ws_xp, &ctx->ws_mean, &ctx->ws_den,
                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3, &ctx->ws_g, &ctx->ws_csum,
@@ -121,7 +126,7 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   hipEvent_t evs[4] = {ctx->ev_t0, ctx->ev_t1, ctx->ev_k0, ctx->ev_k1};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);
-  if (ctx->aux) {
+  if (ctx->aux && !ctx->aux_is_main) {
     (void)hipStreamSynchronize(ctx->aux);
     (void)hipStreamDestroy(ctx->aux);
     (void)hipEventDestroy(ctx->ev_fork);

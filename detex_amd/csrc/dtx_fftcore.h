@@ -695,7 +695,16 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     const bool ok = t < tlim && tb + 512 * r < keep;
     v[r] = make_float2(ok ? (MUX ? x[(int64_t)Nc * t] - off0 : x[t]) : 0.f, 0.f);
   }
+#ifndef DTX_XHAT_ABLATE
+#define DTX_XHAT_ABLATE 0      // timing only: 1 no transform, 2 no sample loads
+#endif
+#if DTX_XHAT_ABLATE & 2
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = make_float2((float)(tid + r), 0.f);
+#endif
+#if !(DTX_XHAT_ABLATE & 1)
   fft8192<-1>(v, lds, lb, tab, tid);
+#endif
 #if DTX_XHAT_ROWSTORE
   // Thread tid holds X[tid + 512 m] in v[m]; slot (f & 7) * 512 + (f >> 3) puts a wave's eight
   // values of one m into eight 64-byte pieces 4 KB apart.  Through the (free) image instead: wave w

@@ -74,6 +74,7 @@ struct dtx_ctx {
   // side stream of the scan's preparation (window statistics run beside the block spectra) and the
   // events that fork it from / join it to `stream`; created on first use
   hipStream_t aux = nullptr;
+  bool aux_is_main = false;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
 
