@@ -18,6 +18,7 @@ SYMBOLS = [
     'dtx_subspace_ds', 'dtx_subspace_scan', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
+    'dtx_device_count', 'dtx_basis_bcast',
 ]
 
 
@@ -89,6 +90,10 @@ def load():
     lib.dtx_ingest_counts.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp]
     lib.dtx_gapfree_run.restype = i32
     lib.dtx_gapfree_run.argtypes = [vp, vp, i32, i64, i64, vp]
+    lib.dtx_device_count.restype = i32
+    lib.dtx_device_count.argtypes = []
+    lib.dtx_basis_bcast.restype = i32
+    lib.dtx_basis_bcast.argtypes = [C.POINTER(vp), i32]
     lib.dtx_timer_start.restype = i32
     lib.dtx_timer_start.argtypes = [vp]
     lib.dtx_timer_stop.restype = i32

@@ -533,6 +533,35 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   return DTX_OK;
 }
 
+int dtx_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx) {
+  if (!ctxs || nctx <= 0 || !ctxs[0]) return DTX_E_ARG;
+  dtx_ctx* src = ctxs[0];
+  if (src->tiles.empty()) return dtx_fail(src, DTX_E_STATE, "dtx_basis_bcast: no basis uploaded on the first context");
+  {
+    DtxDeviceGuard g(src->device);
+    DTX_HIP(src, hipStreamSynchronize(src->stream));     // the source copy of U is complete
+  }
+  for (int i = 1; i < nctx; ++i) {
+    dtx_ctx* c = ctxs[i];
+    if (!c) return dtx_fail(src, DTX_E_ARG, "dtx_basis_bcast: context %d is NULL", i);
+    if (c == src) continue;
+    // dtx_basis_upload copies from any device pointer (hipMemcpyDefault: a peer copy between devices)
+    // and builds every image on the receiving device
+    const int rc = dtx_basis_upload(c, (const float*)src->U_buf.p, src->hdoff.data(), src->D, src->n, src->Nc);
+    if (rc) return dtx_fail(src, rc, "dtx_basis_bcast: context %d: %s", i, c->err.c_str());
+    const int rc2 = dtx_set_engine(c, src->engine);
+    if (rc2) return rc2;
+    DtxDeviceGuard g(c->device);
+    DTX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return DTX_OK;
+}
+
 // post != NULL: also the histogram / maximum / candidate pass over DS (dtx_ds_post semantics)
 static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
                             int nchunk, float* ds_dev, int64_t ldp, const DtxPost* post) {

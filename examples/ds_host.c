@@ -46,6 +46,30 @@ int main(void) {
            (long long)best, plant[d]);
     ok = ok && best == plant[d] && ds[d * P + best] > 0.5f;
   }
+  /* Several GPUs from one process: one context per device, the basis replicated with
+   * dtx_basis_bcast, the data blocks dealt round-robin -- days shard embarrassingly, nothing else is
+   * exchanged.  (With a single device the second context simply shares it.) */
+  {
+    enum { NB = 4 };
+    const int ndev = dtx_device_count();
+    const int nctx = ndev > 1 ? ndev : 2;
+    dtx_ctx** cs = calloc((size_t)nctx, sizeof(dtx_ctx*));
+    cs[0] = ctx;
+    for (int i = 1; i < nctx; ++i)
+      if (dtx_ctx_create(i % ndev, NULL, 1, &cs[i])) { fprintf(stderr, "%s\n", dtx_last_error(NULL)); return 5; }
+    if (dtx_basis_bcast(cs, nctx)) { fprintf(stderr, "%s\n", dtx_last_error(ctx)); return 6; }
+    for (int b = 0; b < NB; ++b) {            /* block b = the same stream shifted by b samples */
+      dtx_ctx* c = cs[b % nctx];
+      if (dtx_subspace_ds_host(c, x + Nc * b, M - Nc * NB, ds)) { fprintf(stderr, "%s\n", dtx_last_error(c)); return 7; }
+      const int64_t Pb = dtx_num_windows(M - Nc * NB, n, Nc);
+      int64_t best = 0;
+      for (int64_t p = 1; p < Pb; ++p) if (ds[p] > ds[best]) best = p;
+      printf("block %d on context %d: detector 0 peaks at window %lld\n", b, b % nctx, (long long)best);
+      ok = ok && best == plant[0] - b;
+    }
+    for (int i = 1; i < nctx; ++i) dtx_ctx_destroy(cs[i]);
+    free(cs);
+  }
   dtx_ctx_destroy(ctx);
   free(U); free(x); free(ds);
   return ok ? 0 : 1;

@@ -77,6 +77,16 @@ const char* dtx_last_error(dtx_ctx* ctx);
 int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
                      int D, int n, int Nc);
 
+/* Multi-device hosts (one process driving several GPUs): number of HIP devices, and the
+ * basis of ctxs[0] replicated into ctxs[1 .. nctx-1] -- the contexts may sit on different devices: the
+ * stacked basis travels device to device (peer copy over xGMI where the devices are linked), every
+ * image (row sums, MFMA tiles, pair spectra) is then built on the receiving device as in
+ * dtx_basis_upload.  Continuous-data days shard embarrassingly: after this call each context scans
+ * its own share with dtx_subspace_scan.  (One process per GPU uses an RCCL broadcast instead:
+ * detex_amd.parallel.broadcast_banks.)  Synchronous. */
+int dtx_device_count(void);
+int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx);
+
 /* Arithmetic engine of dtx_subspace_ds (default DTX_ENGINE_AUTO):
  *   DTX_ENGINE_AUTO    DTX_ENGINE_FFT for templates of 256 .. 32768 samples per channel
  *                      (where it is faster: 8x at 3000 samples, 200 basis vectors),

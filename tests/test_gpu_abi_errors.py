@@ -124,3 +124,42 @@ def test_wrapper_rejects_misshapen_outputs():
     with pytest.raises(ValueError):
         ctx.ds_moments(ds, hist=torch.zeros((3, 400), dtype=torch.int32, device='cuda'))
     ctx.close()
+
+
+def test_basis_bcast_between_contexts():
+    """dtx_device_count / dtx_basis_bcast (multi-device hosts): the basis of the first context
+    replicated into the others, each then scanning its own share of the chunks -- on a one-GPU box both
+    contexts sit on device 0 (the copy is device to device either way); identical results."""
+    import torch
+    from detex_amd import _lib, synth
+    lib = _lib.load()
+    assert lib.dtx_device_count() >= 1
+    Nc, L, D, k = 3, 400, 4, 3
+    n = Nc * L
+    U, off = synth.detector_bank(2, D, k, n)
+    x, plants = synth.continuous_day(3, 4, Nc * 30000, Nc, U, off, nplant=6)
+    hs = (C.c_void_p * 2)()
+    for i in range(2):
+        h = C.c_void_p()
+        dev = i % lib.dtx_device_count()
+        assert lib.dtx_ctx_create(dev, None, 1, C.byref(h)) == 0
+        hs[i] = h
+    assert lib.dtx_basis_bcast(hs, 2) < 0 and b'no basis' in lib.dtx_last_error(hs[0])
+    assert lib.dtx_basis_upload(hs[0], U.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), D, n, Nc) == 0
+    assert lib.dtx_basis_bcast(hs, 2) == 0, lib.dtx_last_error(hs[0])
+    P = lib.dtx_num_windows(Nc * 30000, n, Nc)
+    out = []
+    for i in range(2):                       # every context scores all four chunks here: they must agree bit for bit
+        dev = i % lib.dtx_device_count()
+        with torch.cuda.device(dev):
+            xt = torch.from_numpy(x).cuda()
+            ds = torch.empty((4, D, P), dtype=torch.float32, device='cuda')
+            assert lib.dtx_subspace_ds(hs[i], C.c_void_p(xt.data_ptr()), Nc * 30000, Nc * 30000, 4,
+                                       C.c_void_p(ds.data_ptr()), P) == 0, lib.dtx_last_error(hs[i])
+            assert lib.dtx_ctx_sync(hs[i]) == 0
+            out.append(ds.cpu().numpy())
+    assert np.array_equal(out[0], out[1])
+    for (b, p, d) in plants:
+        assert out[1][b, d, p] > 0.9
+    for i in range(2):
+        lib.dtx_ctx_destroy(hs[i])
