@@ -7,6 +7,8 @@ reference's Python pair loop is replaced by ONE call into the HIP library
 dendrogram cut, alignment by accumulated lags, Harris 2006 App. B) is host logic
 on tiny arrays and follows the reference line by line.
 """
+import os
+
 import numpy as np
 import pandas as pd
 from scipy.cluster.hierarchy import linkage
@@ -149,7 +151,7 @@ def _checkClusterInputs(filt, dtype, trim, decimate):
 def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=None,
                   templateKey=None, trim=[10, 120], saveclust=True, fileName='clust.pkl',
                   decimate=None, dtype='double', eventsOnAllStations=False,
-                  enforceOrigin=False, fillZeros=False, phases=None, device=0, ctx=None):
+                  enforceOrigin=False, fillZeros=False, phases=None, device=None, ctx=None):
     """Create a ClusterStream (detex/construct.py:25-171).
 
     Differences from the reference, all outside the hot path: ``fetch_arg`` is an
@@ -172,6 +174,10 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
             _error('less than 2 events in population have required stations')
     own = ctx is None
     if own:
+        if device is None:
+            # one process per GPU: the launcher's LOCAL_RANK names this process's device
+            from . import parallel
+            device = int(os.environ.get('LOCAL_RANK', 0)) if parallel.dist_info()[1] > 1 else 0
         ctx = HipContext(device)
     try:
         for ind, row in TRDF.iterrows():

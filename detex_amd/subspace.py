@@ -640,6 +640,8 @@ class SubSpace(object):
             # one process per GPU: the launcher's LOCAL_RANK names this process's device
             device = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
         dev = torch.device('cuda', int(device)) if own_ctx else ctx.device
+        if world > 1 and dev.type == 'cuda':
+            torch.cuda.set_device(dev)          # RCCL's object collectives run on the current device
         fetcher = self.cfetcher
         stations = [sta for sta in self.Stations if sta in fetcher.data]
         bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
