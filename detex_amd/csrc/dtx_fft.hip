@@ -251,43 +251,72 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       // The block spectrum of a virtual channel is staged through LDS, a channel ahead: four 16-byte
       // loads per thread instead of sixteen mirrored 8-byte ones (as in xc_fft_kernel, where the
       // sixteen cost as much as all the pair spectra; this kernel too runs one workgroup per CU, so
-      // the LDS beside the image is free).
+      // the LDS beside the image is free).  As there (round 3): the four staged values live in NAMED
+      // registers (as an array the compiler moved them to LDS itself -- load, wait, LDS store, LDS load,
+      // LDS store), the basis spectra come in half-step batches issued a step ahead, and the step is
+      // straight-line (its last pass re-fetches its own operands instead of branching).
       auto xsrc = [&](int vc) {
         const int c = vc / a.nseg, sg = vc - c * a.nseg;   // (channel, template segment)
-        return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + c) * kXh);
+        return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + c) * kXh) + tid;
       };
-      float4 xn[4];
+      const float4* wqa = reinterpret_cast<const float4*>(wpa) + wlo;
+      const float4* wqb = reinterpret_cast<const float4*>(wpb) + wlo;
+      float4 wa[2][4], wb[2][4];
+      auto issue_w = [&](int vc, auto hc) {
+        constexpr int h = hc;
+        const int64_t o = (int64_t)vc * (kN / 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wa[h][j] = (wqa + o + 64 * (4 * h + j))[0];
+          wb[h][j] = (wqb + o + 64 * (4 * h + j))[0];
+        }
+      };
+      auto mac_half = [&](const c32* xc, auto hc) {
+        constexpr int h = hc;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          c32 px[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) px[e] = fix_x(xc[x_slot(8 * h + 4 * g + e)], 8 * h + 4 * g + e);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = 8 * h + 4 * g + e;
+            const float4 ta = wa[h][2 * g + (e >> 1)], tb = wb[h][2 * g + (e >> 1)];
+            const c32 pa = (e & 1) ? make_float2(ta.z, ta.w) : make_float2(ta.x, ta.y);
+            const c32 pb = (e & 1) ? make_float2(tb.z, tb.w) : make_float2(tb.x, tb.y);
+            z[m].x = __fmaf_rn(-pa.y, px[e].y, __fmaf_rn(pa.x, px[e].x, z[m].x));
+            z[m].y = __fmaf_rn(pa.y, px[e].x, __fmaf_rn(pa.x, px[e].y, z[m].y));
+            zb[m].x = __fmaf_rn(-pb.y, px[e].y, __fmaf_rn(pb.x, px[e].x, zb[m].x));
+            zb[m].y = __fmaf_rn(pb.y, px[e].x, __fmaf_rn(pb.x, px[e].y, zb[m].y));
+          }
+        }
+      };
       {
         const float4* src = xsrc(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = src[tid + kT * k];
-        float4* dst = reinterpret_cast<float4*>(xst);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dst[tid + kT * k] = xn[k];
+        const float4 x0 = src[0], x1 = src[kT], x2 = src[2 * kT], x3 = src[3 * kT];
+        issue_w(0, std::integral_constant<int, 0>{});
+        issue_w(0, std::integral_constant<int, 1>{});
+        float4* dst = reinterpret_cast<float4*>(xst) + tid;
+        dst[0] = x0; dst[kT] = x1; dst[2 * kT] = x2; dst[3 * kT] = x3;
       }
       __syncthreads();
 #pragma nounroll
       for (int vc = 0; vc < nvc; ++vc) {
-        c32 pa[16], pb[16], px[16];
-        const c32* wca = wpa + (int64_t)vc * kN;
-        const c32* wcb = wpb + (int64_t)vc * kN;
-        if (vc + 1 < nvc) {
-          const float4* src = xsrc(vc + 1);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) xn[k] = src[tid + kT * k];
-        }
+        const int nx = min(vc + 1, nvc - 1);      // uniform
+        const float4* src = xsrc(nx);
+        const float4 x0 = src[0], x1 = src[kT], x2 = src[2 * kT], x3 = src[3 * kT];
+        __builtin_amdgcn_sched_barrier(0);
         const c32* xc = xst + (vc & 1) * kXh;
-        w_load16(wca, wlo, pa);
-        w_load16(wcb, wlo, pb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) px[r] = fix_x(xc[x_slot(r)], r);
-        mac16(z, pa, px);
-        mac16(zb, pb, px);
-        if (vc + 1 < nvc) {
-          float4* dst = reinterpret_cast<float4*>(xst + ((vc + 1) & 1) * kXh);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) dst[tid + kT * k] = xn[k];
-        }
+        mac_half(xc, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(nx, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mac_half(xc, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(nx, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        float4* dst = reinterpret_cast<float4*>(xst + ((vc + 1) & 1) * kXh) + tid;
+        dst[0] = x0; dst[kT] = x1; dst[2 * kT] = x2; dst[3 * kT] = x3;
         __syncthreads();
       }
       {
