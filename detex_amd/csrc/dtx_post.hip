@@ -21,6 +21,8 @@ typedef float fvec4 __attribute__((ext_vector_type(4)));
 constexpr int kPostItems = DTX_POST_ITEMS;   // values per thread -> kPostItems KiB of DS per block
 
 __device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
+// the float32 images of the float64 edges 1/400 .. 4/400 (dtx_postdev.h: dtx_hist_bin_fast)
+constexpr float kT1 = 0x1.47ae16p-9f, kT2 = 0x1.47ae16p-8f, kT3 = 0x1.eb852p-8f, kT4 = 0x1.47ae16p-7f;
 
 __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   // noise windows all fall into the first bins: keep those counts in registers so the
   // LDS atomics do not serialise on one address
   unsigned low[4] = {0u, 0u, 0u, 0u};
+  unsigned wc[4] = {0u, 0u, 0u, 0u};      // wave-wide cumulative counts of the fast path (uniform)
   const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
   // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
   const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
@@ -70,8 +73,30 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t p = p4 + j;
-      if (p >= P) continue;
       const float v = vv[j];
+      // Nearly every window is noise in the first four bins.  When every lane of the wave holds such a
+      // value (0 <= v < edge 4, inside the row) the wave counts them with three compares and scalar
+      // population counts -- cumulative counts below the float32 images of the float64 edges (the same
+      // thresholds dtx_hist_bin_fast uses) -- instead of classifying and adding per lane.
+      const bool ordinary = p < P && v >= 0.f && v < kT4;
+      if (__builtin_expect(__all(ordinary), 1)) {
+        if (hist) {
+          wc[0] += (unsigned)__popcll(__ballot(v < kT1));
+          wc[1] += (unsigned)__popcll(__ballot(v < kT2));
+          wc[2] += (unsigned)__popcll(__ballot(v < kT3));
+          wc[3] += 64u;
+        }
+        vmax = max(vmax, __float_as_int(v));
+        if (do_cand && v >= th) {
+          const uint32_t slot = atomicAdd(ncand, 1u);
+          if (slot < cand_cap) {
+            cand_key[slot] = ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;  // dtx_cand_pack
+            cand_val[slot] = v;
+          }
+        }
+        continue;
+      }
+      if (p >= P) continue;
       int bits = __float_as_int(v);
       if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
       vmax = max(vmax, bits);
@@ -91,6 +116,13 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
       }
     }
   }
+  }
+  if (hist && (tid & 63) == 0) {
+    // the wave's cumulative counts -> bins 0 .. 3
+    if (wc[0]) atomicAdd(&sh_hist[0], wc[0]);
+    if (wc[1] - wc[0]) atomicAdd(&sh_hist[1], wc[1] - wc[0]);
+    if (wc[2] - wc[1]) atomicAdd(&sh_hist[2], wc[2] - wc[1]);
+    if (wc[3] - wc[2]) atomicAdd(&sh_hist[3], wc[3] - wc[2]);
   }
   if (hist) {
 #pragma unroll
