@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 #ifndef DTX_PP_MU_RES
 #define DTX_PP_MU_RES 1
 #endif
+#ifndef DTX_PP_INLINE_X
+#define DTX_PP_INLINE_X 0      // 1: the ping-pong kernel transforms its block's channels itself (no xhat_kernel, no X^ in HBM)
+#endif
 #ifndef DTX_PP_ABLATE
 #define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong), bit flags: 1 no basis-spectrum loads, 2 no transform fronts,
                                 // 4 no transform tail / epilogue, 8 no MAC
@@ -114,6 +117,10 @@ struct FftArgs {
   short gb[kMaxGroups + 1];
   long long* stamps;    // diagnostic builds (-DDTX_PP_STAMPS): [56 workgroups][2 halves][kStampRounds][16] s_memtime
   int nseg, nblkx;      // template segments (virtual channels per real channel), block spectra stored per chunk
+  // ping-pong kernel with DTX_PP_INLINE_X: the block spectra are taken inside the kernel from the channel planes
+  const float* xp;      // [nchunk][Nc][Tpad]
+  int64_t Tpad;
+  int keep;
 };
 
 #ifndef DTX_DS_NT
@@ -421,8 +428,47 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
     return xx;
   };
   const int wlo = 512 * wv + ln;
-  const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   c32* xs = lds + kLdsC;
+#if DTX_PP_INLINE_X
+  {
+    // The block's spectra, taken here instead of by a kernel of its own (which wrote 172 MB per
+    // station-day for this kernel to read back): half 0 transforms channel 0 on the image while half 1
+    // transforms channel 1 on the last 64 KB of the spectra area (its own destination lies inside:
+    // the outputs wait in registers for the barrier); then half 0 takes channel 2.  Both halves meet
+    // the same six barriers.
+    const int64_t t00 = (int64_t)blk * a.V;
+    const int tb = 8 * (tid & 63) + (tid >> 6);
+    auto forward = [&](int c, c32* img, c32 (&v)[16]) {
+      const float* x = a.xp + ((int64_t)chunk * a.Nc + c) * a.Tpad;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t t = t00 + tb + 512 * r;
+        v[r] = make_float2((t < a.Tpad && tb + 512 * r < a.keep) ? x[t] : 0.f, 0.f);
+      }
+      fft8192<-1>(v, img, lb, a.tab, tid);
+      if (tid == 0) v[0].y = v[8].x;                    // X[kN / 2] rides in the imaginary part of slot 0
+    };
+    auto put = [&](int c, const c32 (&v)[16]) {
+      c32* dst = xs + c * kXh + (tid & 7) * 512 + (tid >> 3);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
+    };
+    c32 v[16];
+    if (half == 0) forward(0, lds, v);
+    else if (NCH > 1) forward(1, xs + kXh, v);
+    else { __syncthreads(); __syncthreads(); }
+    __syncthreads();                                    // every read of the scratch image is done
+    if (half == 0) put(0, v);
+    else if (NCH > 1) put(1, v);
+    if constexpr (NCH > 2) {
+      if (half == 0) forward(2, lds, v);
+      else { __syncthreads(); __syncthreads(); }
+      if (half == 0) put(2, v);
+    }
+    __syncthreads();
+  }
+#else
+  const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   {
     const float4* src = reinterpret_cast<const float4*>(xh);
     float4* dst = reinterpret_cast<float4*>(xs);
@@ -431,6 +477,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       dst[threadIdx.x + 2 * kT * q] = src[threadIdx.x + 2 * kT * q];
     __syncthreads();
   }
+#endif
   const int p1_mode = DTX_PP_P1_IN_MAC;   // where the transform's register-only first pass runs (measured equal)
   c32 z[16];
 #ifdef DTX_PP_STAMPS
@@ -908,10 +955,12 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
   const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
-  hipLaunchKernelGGL(xhat_kernel<false>, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                     ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0,
-                     (const float*)nullptr, (int64_t)0);
-  DTX_HIP(ctx, hipGetLastError());
+  if (!(DTX_PP_INLINE_X && pp)) {
+    hipLaunchKernelGGL(xhat_kernel<false>, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
+                       ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0,
+                       (const float*)nullptr, (int64_t)0);
+    DTX_HIP(ctx, hipGetLastError());
+  }
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
@@ -920,6 +969,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.Nc = Nc; a.D = ctx->D; a.V = V; a.nblk = nblk; a.nchunk = nchunk;
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
   a.nseg = f.nseg; a.nblkx = nblkx;
+  a.xp = xp; a.Tpad = Tpad; a.keep = keep;
   a.stamps = nullptr;
 #ifdef DTX_PP_STAMPS
   const size_t stamp_n = (size_t)kStampWgs * 2 * kStampRounds * 16;
