@@ -239,18 +239,25 @@ def test_configs3_sharding_world2():
     assert max(up) < 0.52 * total and sum(up) < 1.01 * total
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, backend='nccl'):
     """The same three-station run with one process per GPU under RCCL (backend 'nccl'), the real HIP
-    contexts and a pinned fetcher: exercises broadcast_banks / all_gather_object over xGMI."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+    contexts and a pinned fetcher: exercises broadcast_banks / all_gather_object over xGMI.
+    backend='gloo': both processes share GPU 0 (a one-GPU box): the same product code with device tensors
+    in the collectives, real contexts, copy streams and packed uploads -- everything but RCCL itself."""
+    dev = rank if backend == 'nccl' else 0
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(dev),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    torch.cuda.set_device(rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    rank_dev = dev
     from detex_amd import parallel
     from detex_amd.hip import HipContext
     from test_host_logic import multi_station_workflow
-    ctx = HipContext(rank)
+    ctx = HipContext(rank_dev)
     ss, cf, stas, _ = multi_station_workflow(ctx, pin=True)
     ctx.close()
     before = dict(parallel.COLLECTIVES)
@@ -268,6 +275,10 @@ def test_configs3_sharding_world2_nccl():
     SubSpace.detex with two RCCL ranks against the single-GPU answer."""
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip('needs two GPUs (RCCL world of 2)')
+    _check_gpu_world2('nccl')
+
+
+def _check_gpu_world2(backend):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from detex_amd.hip import HipContext
     from test_host_logic import multi_station_workflow
@@ -279,7 +290,7 @@ def test_configs3_sharding_world2_nccl():
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [mpc.Process(target=_nccl_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in range(world))
@@ -298,3 +309,13 @@ def test_configs3_sharding_world2_nccl():
         for sta in stas:
             for nm, h in ss1.histSubSpaces[sta].items():
                 assert hist[sta][nm] == h.tolist()
+
+
+@pytest.mark.gpu
+def test_configs3_sharding_world2_gpu_gloo():
+    """Two processes sharing this box's one GPU (gloo carries the collectives): SubSpace.detex with real
+    HIP contexts, pinned fetchers, packed per-rank uploads and device tensors in the broadcast -- against
+    the single-process answer, row for row."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    _check_gpu_world2('gloo')
