@@ -540,11 +540,19 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # (tests on a one-GPU box: DTX_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and DTX_BENCH_BACKEND=gloo
+    # carries the collectives -- the N > 1 code path without a second GPU; RCCL refuses two ranks per device)
+    if os.environ.get('DTX_BENCH_ONE_DEVICE') == '1':
+        local = 0
+    backend = os.environ.get('DTX_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     use_dist = 'RANK' in os.environ          # launched by torch.distributed.run
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     from detex_amd.hip import HipContext
     from detex_amd import synth
 

@@ -424,3 +424,39 @@ def test_scan_config2_production_grid(ctx):
     for (b, p, d), g in zip(pts, got):
         ref = _spot_ds(x[b], U[off[d]:off[d + 1]], Nc, p)
         assert abs(g - ref) <= 1e-5, (b, p, d, g, ref)
+
+
+@pytest.mark.parametrize('config', [2, 4])
+def test_bench_two_ranks_on_one_gpu(config):
+    """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per
+    rank, basis broadcast, barrier + max-over-ranks timing, one JSON line from rank 0) -- on this one-GPU box
+    with both ranks on GPU 0 and gloo carrying the collectives (RCCL refuses two ranks per device): weak
+    scaling (config 2: one station-day per rank) and BASELINE configs[3] in miniature (config 4)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    extra = ['--config', '4', '--stations', '2', '--days', '3', '--chunks', '4'] if config == 4 else ['--chunks', '6']
+    env = dict(os.environ, DTX_BENCH_ONE_DEVICE='1', DTX_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '2', '--warmup', '1'] + extra,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                               # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['unit'] == 'windows/s' and d['steps'] == 2
+    P = (int(round(3720.0 * 100.0)) * 3 - 9000) // 3 + 1
+    if config == 2:
+        assert d['scaling'] == 'weak' and d['config']['planted_found'] == '50/50'
+        want = 2 * 6 * P                                 # windows per step over both ranks
+    else:
+        assert d['scaling'] == 'strong' and d['config']['planted_found'] == '30/30'
+        want = 6 * 4 * P
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - want) <= 1e-6 * want
