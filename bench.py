@@ -106,6 +106,14 @@ def cpu_baseline_allcores(U, det_off, x, Nc):
         return dict(value=None, unit='windows/s', error=repr(e))
 
 
+def _tag_order(path):
+    """profiles/<letter><number>_...: the newest measurement of a series has the highest number (file times
+    say nothing after a fresh checkout)."""
+    import re
+    m = re.match(r'([a-z]+)(\d+)', os.path.basename(path))
+    return (m.group(1), int(m.group(2))) if m else ('', -1)
+
+
 def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
     """Roofline object of the dominant kernel of one engine (kms: its average launch
     duration from HIP events on the launch stream)."""
@@ -116,7 +124,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         # --pmc passes, gfx950 FETCH_SIZE x2 correction) for the default configuration only
         if not default_cfg:
             return None
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), key=os.path.getmtime)
+        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), key=_tag_order)
         if not pm:
             return None
         with open(pm[-1]) as f:
@@ -261,7 +269,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     # counters of the committed rocprofv3 --pmc passes of scripts/bench_xcorr.py (scripts/profile_xc.sh), newest tag
     import glob
     pmc, pmc_src = {}, None
-    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_xcorr_pmc.json')), key=os.path.getmtime)[-1:]:
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_xcorr_pmc.json')), key=_tag_order)[-1:]:
         with open(fn) as f:
             pmc, pmc_src = json.load(f).get('kernels', {}), 'profiles/' + os.path.basename(fn)
 

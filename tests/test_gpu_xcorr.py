@@ -160,7 +160,11 @@ def test_dead_and_degenerate_events(ctx):
 
 
 @pytest.mark.parametrize('Nc,L,N', [(3, 1024, 9), (1, 2500, 12), (3, 3000, 23), (2, 5200, 8),
-                                    (3, 6500, 7), (1, 9000, 10), (3, 13000, 6)])
+                                    (3, 6500, 7), (1, 9000, 10), (3, 13000, 6),
+                                    # round 3: the host picks segment count / length / lag-block advance by cost
+                                    # (dtx_xcfft_run): just past the single-segment limit, odd step counts, the
+                                    # longest events (16 segments), many channels
+                                    (3, 5700, 6), (2, 7777, 5), (1, 20000, 5), (1, 32768, 4), (6, 6000, 5)])
 def test_long_events_frequency_domain(ctx, Nc, L, N):
     """Events of >= 1024 samples per channel take the frequency-domain lag search under the
     default engine (dtx_xcfft.hip; past 5633 samples cut into segments): same answers as the
