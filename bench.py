@@ -216,6 +216,12 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
 
     for i in range(2):
         done[i].record(main)
+    thr = torch.from_numpy(np.asarray(thr, dtype=np.float32)).cuda()
+    for i in range(2):                       # warm-up: pinned result buffers, side stream
+        upload(i)
+        main.wait_event(ready[i])
+        ctx.subspace_scan(bufs[i], out=ds, thr=thr, hist=hist, lazy=True)[1]()
+        done[i].record(main)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     upload(0)
@@ -478,10 +484,14 @@ def run_config4(a, rank, world, local, use_dist):
 
     found = [0, 0]
 
+    thr_dev = torch.from_numpy(thr).to(dev)       # (a host array would be copied up, synchronously, by every scan)
+
     def step(check=False):
-        fetches = []
+        """Every station-day of this rank: scan enqueued, its results (maxima, candidates) fetched while the
+        next one runs -- all of them, inside the timed region."""
+        prev = None
         for (s, d) in mine:
-            _, f = ctxs[s].subspace_scan(data[(s, d)], out=ds, thr=thr, hist=hists[s], lazy=True)
+            _, f = ctxs[s].subspace_scan(data[(s, d)], out=ds, thr=thr_dev, hist=hists[s], lazy=True)
             if check:
                 cb, cd, cp, cv = f()['cand']
                 for (b, p, dd) in plants[(s, d)]:
@@ -489,8 +499,11 @@ def run_config4(a, rank, world, local, use_dist):
                     found[0] += 1
                 found[1] += len(plants[(s, d)])
             else:
-                fetches.append(f)
-        return [f() for f in fetches[-1:]]        # the last fetch synchronises the stream
+                if prev is not None:
+                    prev()
+                prev = f
+        if prev is not None:
+            prev()
 
     def barrier():
         if use_dist:
@@ -599,9 +612,12 @@ def main():
     thr = np.full(D, 0.3, dtype=np.float32)
     hist = torch.zeros((D, 400), dtype=torch.int32, device='cuda')
 
+    thr_dev = torch.from_numpy(thr).cuda()    # resident like the stream (a host array would be copied up by every scan)
+
     def step():
-        # detection statistic + histogram / max / threshold candidates (dtx_subspace_scan)
-        return ctx.subspace_scan(xt, out=ds, thr=thr, hist=hist)[1]
+        # detection statistic + histogram / max / threshold candidates (dtx_subspace_scan), everything
+        # enqueued; fetch() waits for and returns the step's small results (maxima, candidate list)
+        return ctx.subspace_scan(xt, out=ds, thr=thr_dev, hist=hist, lazy=True)[1]
 
     def barrier():
         if use_dist:
@@ -610,14 +626,22 @@ def main():
 
     kern_ms = []
     for _ in range(a.warmup):
-        res = step()
+        res = step()()
     barrier()
     t0 = time.perf_counter()
+    # K steps, each one's results fetched inside the timed region -- while the next step runs, as
+    # SubSpace.detex does with its stations (the copies to pinned host memory go on a side stream
+    # behind the step's post pass; nothing is skipped, the GPU just does not wait for the host)
+    pending = None
     for _ in range(a.steps):
-        res = step()
-        # dominant-kernel time of this step: HIP events recorded around the MFMA kernel
-        # on the context's stream (waits for that kernel only; ds_post is still queued)
+        fetch = step()
+        if pending is not None:
+            res = pending()
+        # dominant-kernel time of this step: HIP events recorded around the scan kernel on the
+        # context's stream (waits for that kernel only; ds_post is still queued)
         kern_ms.append(ctx.last_kernel_ms())
+        pending = fetch
+    res = pending()
     barrier()
     dt = time.perf_counter() - t0
     kms = float(np.mean(kern_ms))            # average launch duration over the timed region
@@ -661,7 +685,9 @@ def main():
                                % ('configs[1]: ' if default_cfg else 'custom: ', K, D, k, a.chunks,
                                   a.chunk_seconds, Nc, a.sr, n),
                    'engine': eng if a.engine == eng else '%s -> %s' % (a.engine, eng),
-                   'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants))},
+                   'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants)),
+                   'results': 'maxima and candidate lists of every step fetched to the host inside the timed '
+                              'region, each while the next step runs (pinned buffers, side stream)'},
         'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
     }
     extras = rank == 0 and world == 1 and default_cfg and not a.no_extras
@@ -671,10 +697,10 @@ def main():
             if other == eng:
                 continue
             ctx.set_engine(other)
-            step()
+            step()()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            step()
+            step()()
             torch.cuda.synchronize()
             dto = time.perf_counter() - t1
             ko = ctx.last_kernel_ms()
