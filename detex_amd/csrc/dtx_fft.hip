@@ -956,9 +956,8 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   c32* xh = (c32*)ctx->ws_xhat.p;
   const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
   if (!(DTX_PP_INLINE_X && pp)) {
-    hipLaunchKernelGGL(xhat_kernel<false>, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                       ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0,
-                       (const float*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
+                       ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0);
     DTX_HIP(ctx, hipGetLastError());
   }
   FftArgs a;

@@ -671,29 +671,21 @@ __device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32
 // nsub > 1 (the cross-correlation's lag search): stored block j = blk * nsub + s starts at sample
 // blk V + s sub_stride -- the data that segment s of a template cut into segments of sub_stride
 // samples meets in lag block blk (advance V != segment length: every (block, segment) has its own spectrum).
-// MUX: xp is the caller's multiplexed stream (chunk b at xp + b * Tpad samples, channel c of sample t at
-// [Nc t + c]); the transform takes x - m0[chunk] (float32, the block offset) for t < Tvalid, 0 beyond --
-// the values the channel planes would hold, without a pass that writes and re-reads them.
-template <bool MUX = false>
 __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, int64_t Tpad,
                                                   int Nc, int V, int nblk, int keep,
                                                   const c32* __restrict__ tab,
-                                                  c32* __restrict__ xh, int nsub = 1, int sub_stride = 0,
-                                                  const float* __restrict__ m0 = nullptr, int64_t Tvalid = 0) {
+                                                  c32* __restrict__ xh, int nsub = 1, int sub_stride = 0) {
   __shared__ c32 lds[kLdsC];
   const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
   const LdsBases lb = lds_bases(tid);
-  const float* x = MUX ? xp + (int64_t)chunk * Tpad + c : xp + ((int64_t)chunk * Nc + c) * Tpad;
-  const float off0 = MUX ? m0[chunk] : 0.f;
-  const int64_t tlim = MUX ? Tvalid : Tpad;
+  const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
   const int tb = 8 * (tid & 63) + (tid >> 6);          // sample within the block
   const int64_t t0 = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride + tb;
   c32 v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t t = t0 + 512 * r;
-    const bool ok = t < tlim && tb + 512 * r < keep;
-    v[r] = make_float2(ok ? (MUX ? x[(int64_t)Nc * t] - off0 : x[t]) : 0.f, 0.f);
+    v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
   }
 #ifndef DTX_XHAT_ABLATE
 #define DTX_XHAT_ABLATE 0      // timing only: 1 no transform, 2 no sample loads

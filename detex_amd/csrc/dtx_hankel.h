@@ -338,30 +338,19 @@ __device__ inline double wave_incl_scan(double v, int lane) {
   return v;
 }
 
-// MUX = false: channel planes, sample t of channel c of batch b at planes[(b Nc + c) plane_stride + t].
-// MUX = true: the caller's multiplexed stream, chunk b at planes + b * plane_stride, sample t of channel c
-// at [Nc t + c]; the value is x - m0[b] rounded to float32 (the block offset, see chunk_offset_kernel) for
-// t < Tvalid and 0 beyond -- exactly what the channel planes of the contraction engines hold.
-template <bool MUX>
 static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __restrict__ planes,
                                                         int64_t plane_stride, int Nc, int L,
                                                         int64_t P, int64_t Ppad, double scale,
                                                         float* __restrict__ mean,
-                                                        float* __restrict__ ssd,
-                                                        const float* __restrict__ m0 = nullptr,
-                                                        int64_t Tvalid = 0) {
+                                                        float* __restrict__ ssd) {
   constexpr int E = kStatsPB / 256;  // windows per thread
   __shared__ double sh1[4], sh2[4], sh3[4];
   __shared__ double anchor[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
-  const float* xb = planes + (MUX ? (int64_t)b * plane_stride : (int64_t)b * Nc * plane_stride);
-  const float off0 = MUX ? m0[b] : 0.f;
-  const int64_t tlim = MUX ? Tvalid : plane_stride;     // samples per channel that may be read
-  auto at = [&](int c, int64_t t) -> float {
-    if constexpr (MUX) return t < tlim ? xb[(int64_t)Nc * t + c] - off0 : 0.f;
-    else return xb[(int64_t)c * plane_stride + t];
-  };
+  const float* xb = planes + (int64_t)b * Nc * plane_stride;
+  const int64_t tlim = plane_stride;                    // samples per channel that may be read
+  auto at = [&](int c, int64_t t) -> float { return xb[(int64_t)c * plane_stride + t]; };
   const int64_t p0 = (int64_t)blockIdx.x * kStatsPB;
   if (p0 >= P) return;
 
@@ -370,33 +359,7 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   // zero-variance case the statistic defines as 0 -- is decided exactly, however much
   // round-off the float64 sliding sums have picked up from large values elsewhere.
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if constexpr (MUX) {
-    // the anchor window is one contiguous run of the multiplexed stream: Nc L samples from Nc p0,
-    // taken 256 at a time, kAB loads in flight (one load at a time, channel by channel, this sum
-    // was a chain of ~36 exposed memory latencies per block)
-    const float* w0 = xb + (int64_t)Nc * p0;
-    const int nl = Nc * L;
-    constexpr int kAB = 12;
-    for (int j0 = 0; j0 < nl; j0 += 256 * kAB) {
-      float v[kAB], vp[kAB];
-#pragma unroll
-      for (int k = 0; k < kAB; ++k) {
-        const int j = j0 + 256 * k + tid;
-        v[k] = j < nl ? w0[j] - off0 : 0.f;
-        vp[k] = (j < nl && j >= Nc) ? w0[j - Nc] - off0 : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < kAB; ++k) {
-        const int j = j0 + 256 * k + tid;
-        if (j < nl) {
-          const double d = (double)v[k];
-          s1 += d;
-          s2 += d * d;
-          if (j >= Nc) s3 += (v[k] != vp[k]) ? 1.0 : 0.0;
-        }
-      }
-    }
-  } else {
+  {
   // (six loads in flight per pass: taken one at a time this sum was a chain of ~36 exposed memory
   // latencies per block)
   for (int c = 0; c < Nc; ++c) {
@@ -448,60 +411,7 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   const int64_t pt = p0 + (int64_t)E * tid;
   // (the batched loads read up to sample pt + L + E - 1 of the plane whatever P is: only where that
   // stays inside the plane -- the last threads of a chunk's last block take the guarded loop)
-  if constexpr (MUX) {
-    // The thread's E steps need, per channel, the E + 1 samples from window pt's first one and the
-    // E + 1 from its last one: straight from the multiplexed stream that is 2 Nc (E + 1) loads per thread
-    // at a lane stride of E Nc floats (a different cache line per lane: 242 us per station-day).  The
-    // block's two runs of Nc (kStatsPB + 1) consecutive samples are therefore brought in row by row
-    // (coalesced, eight loads in flight) and handed round through LDS (slot q + (q >> 5): the strided
-    // reads spread over the banks).
-    extern __shared__ float stage[];
-    const int nq = Nc * (kStatsPB + 1);
-    float* Hs = stage;
-    float* Ts = stage + nq + (nq >> 5) + 1;
-    const int64_t gH = (int64_t)Nc * p0, gT = (int64_t)Nc * (p0 + L - 1), glim = (int64_t)Nc * tlim;
-    constexpr int kSB = 13;                                    // 2 x 13 loads in flight: Nc = 3 needs two rounds
-    for (int q0 = 0; q0 < nq; q0 += 256 * kSB) {
-      float vh[kSB], vt[kSB];
-#pragma unroll
-      for (int k = 0; k < kSB; ++k) {
-        const int q = q0 + 256 * k + tid;
-        vh[k] = (q < nq && gH + q < glim) ? xb[gH + q] - off0 : 0.f;
-        vt[k] = (q < nq && gT + q < glim) ? xb[gT + q] - off0 : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < kSB; ++k) {
-        const int q = q0 + 256 * k + tid;
-        if (q < nq) { Hs[q + (q >> 5)] = vh[k]; Ts[q + (q >> 5)] = vt[k]; }
-      }
-    }
-    __syncthreads();
-    for (int c = 0; c < Nc; ++c) {
-      float ha[E + 1], tb[E + 1];                              // ha[j] = sample pt + j, tb[j] = sample pt + L - 1 + j
-#pragma unroll
-      for (int j = 0; j <= E; ++j) {
-        const int q = Nc * (E * tid + j) + c;
-        ha[j] = Hs[q + (q >> 5)];
-        tb[j] = Ts[q + (q >> 5)];
-      }
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const double vo = (double)ha[e], vn = (double)tb[e + 1];
-        l1[e] += vn - vo;
-        l2[e] += vn * vn - vo * vo;
-        if (L > 1) l3[e] += ((tb[e + 1] != tb[e]) ? 1.0 : 0.0) - ((ha[e + 1] != ha[e]) ? 1.0 : 0.0);
-      }
-    }
-    double r1 = 0.0, r2 = 0.0, r3 = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      if (pt + e + 1 < P) { r1 += l1[e]; r2 += l2[e]; r3 += l3[e]; }
-      l1[e] = r1;
-      l2[e] = r2;
-      l3[e] = r3;
-    }
-    r1_ = r1; r2_ = r2; r3_ = r3;
-  } else if (DTX_STATS_BATCHED && pt + L + E <= tlim) {
+  if (DTX_STATS_BATCHED && pt + L + E <= tlim) {
   for (int c = 0; c < Nc; ++c) {
     float ha[E + 1], tb[E + 1];                                // ha[j] = o[j], tb[j] = o[L - 1 + j]
     {

@@ -627,8 +627,8 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
                        Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
     if ((rc = dtx_aux_fork(ctx))) return rc;
-    hipLaunchKernelGGL(win_stats_kernel<false>, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
-                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
+                       Nc, ctx->L, P, Ppad, scale, mean, den);
     DTX_HIP(ctx, hipGetLastError());
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window
@@ -654,8 +654,8 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
 
   hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
                      Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
-  hipLaunchKernelGGL(win_stats_kernel<false>, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
-                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)nullptr, (int64_t)0);
+  hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
+                     Nc, ctx->L, P, Ppad, scale, mean, den);
   DTX_HIP(ctx, hipGetLastError());
 
   i32x4* g16 = nullptr;

@@ -410,7 +410,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   hipLaunchKernelGGL(xc_wspec_kernel, dim3((unsigned)(npr * nvc)), dim3(kT), 0, ctx->stream, td_dev,
                      N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
   DTX_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(xhat_kernel<false>, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
+  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
                      ctx->stream, z, Tz, Nc, V, nblkx, kN, (const c32*)tab, xh, nseg, nseg == 1 ? 0 : seglen);
   DTX_HIP(ctx, hipGetLastError());
 

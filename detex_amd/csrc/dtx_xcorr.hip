@@ -842,7 +842,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   DTX_HIP(ctx, hipGetLastError());
   {
     dim3 grid((unsigned)((Pz + kStatsPB - 1) / kStatsPB), (unsigned)N);
-    hipLaunchKernelGGL(win_stats_kernel<false>, grid, dim3(256), 0, ctx->stream, (const float*)z, Tz, Nc, L,
+    hipLaunchKernelGGL(win_stats_kernel, grid, dim3(256), 0, ctx->stream, (const float*)z, Tz, Nc, L,
                        (int64_t)Pz, Ppad, -1.0 /* 1/sqrt mode */, mean_w, rsw);
     DTX_HIP(ctx, hipGetLastError());
   }
