@@ -626,7 +626,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kern_ms = []
     # the clocks of an idle GPU take a few hundred milliseconds of load to settle (20 steps are 70 ms): spin
     # the same step, untimed, for half a second before the W warm-up steps the contract asks for
     t_pre = time.perf_counter()
@@ -644,14 +643,14 @@ def main():
         fetch = step()
         if pending is not None:
             res = pending()
-        # dominant-kernel time of this step: HIP events recorded around the scan kernel on the
-        # context's stream (waits for that kernel only; ds_post is still queued)
-        kern_ms.append(ctx.last_kernel_ms())
         pending = fetch
     res = pending()
     barrier()
     dt = time.perf_counter() - t0
-    kms = float(np.mean(kern_ms))            # average launch duration over the timed region
+    # dominant-kernel time: HIP events the library records around the scan kernel of every call on the
+    # context's stream (a ring of 64 pairs), read here, after the timed region: average launch duration
+    # over its (last 64) steps
+    kms = ctx.kernel_ms_mean(min(a.steps, 64))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -18,7 +18,7 @@ SYMBOLS = [
     'dtx_subspace_ds', 'dtx_subspace_scan', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
-    'dtx_device_count', 'dtx_basis_bcast',
+    'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean',
 ]
 
 
@@ -98,6 +98,8 @@ def load():
     lib.dtx_timer_start.argtypes = [vp]
     lib.dtx_timer_stop.restype = i32
     lib.dtx_timer_stop.argtypes = [vp, pf]
+    lib.dtx_kernel_ms_mean.restype = i32
+    lib.dtx_kernel_ms_mean.argtypes = [vp, i32, pf]
     lib.dtx_last_kernel_ms.restype = i32
     lib.dtx_last_kernel_ms.argtypes = [vp, pf]
     if lib.dtx_version() != ABI_VERSION:

@@ -44,6 +44,18 @@ void dtx_free_tiles_internal(dtx_ctx* c) {
   dtx_fft_free(c);
 }
 
+int dtx_kev_next(dtx_ctx* ctx) {
+  const int slot = (int)(ctx->kev_count % dtx_ctx::kKev);
+  if (!ctx->kev0[slot]) {
+    DTX_HIP(ctx, hipEventCreate(&ctx->kev0[slot]));
+    DTX_HIP(ctx, hipEventCreate(&ctx->kev1[slot]));
+  }
+  ctx->ev_k0 = ctx->kev0[slot];
+  ctx->ev_k1 = ctx->kev1[slot];
+  ++ctx->kev_count;
+  return DTX_OK;
+}
+
 int dtx_aux_fork(dtx_ctx* ctx) {
   if (!ctx->aux) {
     // DETEX_AMD_NO_AUX=1 (measurements): the "side stream" is the context's own -- everything serial
@@ -99,7 +111,7 @@ int dtx_ctx_create(int device, void* stream, int own_stream, dtx_ctx** out) {
     }
     c->own_stream = true;
   }
-  hipEvent_t* evs[4] = {&c->ev_t0, &c->ev_t1, &c->ev_k0, &c->ev_k1};
+  hipEvent_t* evs[2] = {&c->ev_t0, &c->ev_t1};
   for (auto ev : evs) {
     e = hipEventCreate(ev);
     if (e != hipSuccess) {
@@ -123,9 +135,13 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
                     &ctx->ws_trig_doff, &ctx->doff_all};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
-  hipEvent_t evs[4] = {ctx->ev_t0, ctx->ev_t1, ctx->ev_k0, ctx->ev_k1};
+  hipEvent_t evs[2] = {ctx->ev_t0, ctx->ev_t1};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < dtx_ctx::kKev; ++i) {
+    if (ctx->kev0[i]) (void)hipEventDestroy(ctx->kev0[i]);
+    if (ctx->kev1[i]) (void)hipEventDestroy(ctx->kev1[i]);
+  }
   if (ctx->aux && !ctx->aux_is_main) {
     (void)hipStreamSynchronize(ctx->aux);
     (void)hipStreamDestroy(ctx->aux);
@@ -159,6 +175,25 @@ int dtx_timer_stop(dtx_ctx* ctx, float* ms) {
   DTX_HIP(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
   DTX_HIP(ctx, hipEventSynchronize(ctx->ev_t1));
   DTX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_t0, ctx->ev_t1));
+  return DTX_OK;
+}
+
+int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms) {
+  if (!ctx || !ms || n <= 0) return DTX_E_ARG;
+  if (!ctx->kernel_timed) return dtx_fail(ctx, DTX_E_STATE, "no timed kernel has run yet");
+  if (n > dtx_ctx::kKev || n > ctx->kev_count)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_kernel_ms_mean: only the last %d launches are kept (%lld timed so far)",
+                    dtx_ctx::kKev, ctx->kev_count);
+  DtxDeviceGuard g(ctx->device);
+  double sum = 0.0;
+  for (int q = 0; q < n; ++q) {
+    const int slot = (int)((ctx->kev_count - 1 - q) % dtx_ctx::kKev);
+    float t = 0.f;
+    DTX_HIP(ctx, hipEventSynchronize(ctx->kev1[slot]));
+    DTX_HIP(ctx, hipEventElapsedTime(&t, ctx->kev0[slot], ctx->kev1[slot]));
+    sum += t;
+  }
+  *ms = (float)(sum / n);
   return DTX_OK;
 }
 

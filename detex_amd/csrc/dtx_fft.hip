@@ -986,6 +986,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
     const int rcj = dtx_aux_join(ctx);
     if (rcj) return rcj;
   }
+  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {
 #ifndef DTX_FFT_ONLY_VM

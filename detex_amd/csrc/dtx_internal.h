@@ -93,7 +93,12 @@ struct dtx_ctx {
 
   // timing
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer
-  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // dominant-kernel timer
+  // dominant-kernel timer: a ring of event pairs, one per timed launch (ev_k0 / ev_k1 = the current pair), so
+  // that a caller can run several calls ahead and read the durations afterwards (dtx_kernel_ms_mean)
+  static constexpr int kKev = 64;
+  hipEvent_t kev0[kKev] = {}, kev1[kKev] = {};
+  long long kev_count = 0;                        // timed launches so far
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
   bool kernel_timed = false;
 };
 
@@ -111,6 +116,7 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 // main stream meanwhile, and the two streams meet in front of the scan kernel
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
+int dtx_kev_next(dtx_ctx* ctx);      // ev_k0 / ev_k1 := the next pair of the ring
 int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
 int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.

@@ -675,6 +675,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
   }
 
+  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   for (const DtxKTile& t : ctx->tiles) {
     DsArgs a;

@@ -421,6 +421,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.V = V; a.Pz = Pz;
   a.seglen = seglen; a.zend = S + L;
   a.per_xcd = per_xcd; a.nwork = nwork;
+  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   switch (V / 512) {
     case 4: launch_xc<4>(ctx, a, (unsigned)grid); break;

@@ -859,6 +859,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
                             pair_begin, pair_end, b_begin, b_end)))
       return rc;
   } else {
+  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   {
     const int2* p = (const int2*)ctx->ws_misc2.p;

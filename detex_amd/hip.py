@@ -530,6 +530,12 @@ class HipContext(object):
         self._ck(self.lib.dtx_timer_stop(self.h, C.byref(ms)), 'dtx_timer_stop')
         return float(ms.value)
 
+    def kernel_ms_mean(self, n):
+        """Mean duration of the dominant kernel over the last n scan / cross-correlation calls (n <= 64)."""
+        ms = C.c_float()
+        self._ck(self.lib.dtx_kernel_ms_mean(self.h, int(n), C.byref(ms)), 'dtx_kernel_ms_mean')
+        return float(ms.value)
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._ck(self.lib.dtx_last_kernel_ms(self.h, C.byref(ms)), 'dtx_last_kernel_ms')

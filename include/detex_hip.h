@@ -317,6 +317,9 @@ int dtx_timer_stop(dtx_ctx* ctx, float* ms);
  * dtx_xcorr_allpairs call (events recorded around that kernel only; valid
  * after dtx_ctx_sync). */
 int dtx_last_kernel_ms(dtx_ctx* ctx, float* ms);
+/* Mean of that over the last n such calls (1 <= n <= 64; waits for the newest): a caller that runs several
+ * calls ahead of the device reads the durations afterwards instead of synchronising after each. */
+int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms);
 
 #ifdef __cplusplus
 }
