@@ -51,10 +51,11 @@ namespace {
 // windows w0 .. w0 + 2 V - 1 reach sample w0 + 2 V + L - 2 >= w0 + (nseg + 1) V - 1).
 __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ den, int64_t Ppad,
                                                     int64_t P, int V, int nblk, int wspan,
-                                                    int* __restrict__ list) {
+                                                    int* __restrict__ list, const int* __restrict__ pb) {
   __shared__ float red[8];
   const int cb = blockIdx.x, tid = threadIdx.x;
   const int chunk = cb / nblk, blk = cb - chunk * nblk;
+  if (pb != nullptr) P = min(P, (int64_t)pb[chunk]);     // ragged batch: the chunk's own windows
   const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P), w2 = min(w0 + wspan, P);
   const float* d = den + (int64_t)chunk * Ppad;
   float mn = 3.0e38f, mx = 0.f;
@@ -121,6 +122,7 @@ struct FftArgs {
   const float* xp;      // [nchunk][Nc][Tpad]
   int64_t Tpad;
   int keep;
+  const int* pb;        // ragged batch: [nchunk] windows of each chunk (NULL: P for all)
 };
 
 #ifndef DTX_DS_NT
@@ -402,6 +404,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
     cb = a.nfull + j - grp * a.nrem; u0 = a.gb[grp]; u1 = a.gb[grp + 1];
   }
   const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;   // cb = chunk * nblk + blk
+  // ragged batch: a block wholly past its chunk's own windows has nothing to do (uniform: before any barrier)
+  if (a.pb != nullptr && (int64_t)blk * a.V >= (int64_t)a.pb[chunk]) return;
   // this half's pairs: its share of every unit of the group -- whole detectors, contiguous in memory
   const int2 g0 = a.upre[u0], g1 = a.upre[u1];
   const int pbase = half ? a.upre[a.nunits].x + g0.y : g0.x;
@@ -909,7 +913,8 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 // stream (forked by the caller): the guard pass follows them there, the block spectra are taken on the
 // main stream meanwhile, and the two streams meet in front of the scan kernel
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list) {
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list,
+                 const int* pb) {
   DtxFft& f = ctx->fft;
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
   const int Nc = ctx->Nc, V = f.V;
@@ -969,6 +974,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.nunits = f.nunits; a.ntile_b = ntile_b; a.per_xcd = (int)per_xcd;
   a.nseg = f.nseg; a.nblkx = nblkx;
   a.xp = xp; a.Tpad = Tpad; a.keep = keep;
+  a.pb = pp ? pb : nullptr;      // (the one-group kernel of long templates runs every block)
   a.stamps = nullptr;
 #ifdef DTX_PP_STAMPS
   const size_t stamp_n = (size_t)kStampWgs * 2 * kStampRounds * 16;
@@ -980,7 +986,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.upre = (const int2*)f.upre_dev; a.nfull = nfull; a.nrem = std::max(nrem, 1); a.ngroups = ng;
   std::copy(gb, gb + kMaxGroups + 1, a.gb);
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->aux, den,
-                     Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list);
+                     Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list, pb);
   DTX_HIP(ctx, hipGetLastError());
   {
     const int rcj = dtx_aux_join(ctx);

@@ -114,8 +114,10 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 // xp: the channel planes; mean / den: the window statistics, being computed on the context's side
 // stream (forked by the caller): the guard pass follows them there, the block spectra are taken on the
 // main stream meanwhile, and the two streams meet in front of the scan kernel
+// pb != NULL (ragged batch): blocks wholly past their chunk's own pb[chunk] windows are skipped
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list);
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list,
+                 const int* pb = nullptr);
 int dtx_kev_next(dtx_ctx* ctx);      // ev_k0 / ev_k1 := the next pair of the ring
 int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
 int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
@@ -124,8 +126,9 @@ int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
 // under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
 constexpr float kFftGuard = 200.f;
+// pb != NULL (ragged batch): chunk b's own window count; the pass covers p < min(P, pb[b])
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
-                    const DtxPost& po);
+                    const DtxPost& po, const int* pb = nullptr);
 // shortest events (samples per channel) the all-pairs cross-correlation sends through the
 // frequency domain under DTX_ENGINE_AUTO / DTX_ENGINE_FFT (dtx_xcfft.hip)
 constexpr int kXcFftMinL = 1024;

@@ -27,11 +27,16 @@ constexpr float kT1 = 0x1.47ae16p-9f, kT2 = 0x1.47ae16p-8f, kT3 = 0x1.eb852p-8f,
 __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
     float* __restrict__ maxds, const float* __restrict__ thr, uint64_t* __restrict__ cand_key,
-    float* __restrict__ cand_val, uint32_t cand_cap, uint32_t* __restrict__ ncand) {
+    float* __restrict__ cand_val, uint32_t cand_cap, uint32_t* __restrict__ ncand,
+    const int* __restrict__ pb) {
   __shared__ uint32_t sh_hist[DTX_HIST_BINS];
   __shared__ int sh_max[kPostThreads / 64];
   const int tid = threadIdx.x;
   const int det = blockIdx.y, chunk = blockIdx.z;
+  if (pb != nullptr) {        // ragged batch: the chunk's own windows only
+    P = min(P, (int64_t)pb[chunk]);
+    if ((int64_t)blockIdx.x * (kPostThreads * kPostItems) >= P) return;
+  }
   const float* row = ds + ((int64_t)chunk * D + det) * ldp;
   if (hist)
     for (int b = tid; b < DTX_HIST_BINS; b += kPostThreads) sh_hist[b] = 0u;
@@ -217,11 +222,11 @@ __global__ __launch_bounds__(kPostThreads) void ds_moments_kernel(
 }  // namespace
 
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
-                    const DtxPost& po) {
+                    const DtxPost& po, const int* pb) {
   const int64_t per_block = (int64_t)kPostThreads * kPostItems;
   dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
   hipLaunchKernelGGL(ds_post_kernel, grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
-                     po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand);
+                     po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

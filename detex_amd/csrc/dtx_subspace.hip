@@ -45,12 +45,21 @@ namespace {
 constexpr int kMeanSlices = 64;                 // one slice per lane of the wave that takes the median
 constexpr int kCsum = 2;                       // per slice: {sum, count} of the non-zero samples
 constexpr int kOffStride = 8;                  // long slices: one run of 256 samples in eight is read
+// ctab != NULL (ragged batch): chunk b starts at x + ctab[2 b] and holds min(ctab[2 b + 1], M) samples
+__device__ inline const float* chunk_base(const float* x, int64_t chunk_stride, const int64_t* ctab, int b,
+                                          int64_t& M) {
+  if (ctab == nullptr) return x + (int64_t)b * chunk_stride;
+  M = max((int64_t)0, min(M, ctab[2 * b + 1]));
+  return x + ctab[2 * b];
+}
+
 __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restrict__ x, int64_t M,
                                                            int64_t chunk_stride, int nsl,
-                                                           double* __restrict__ cslice) {
+                                                           double* __restrict__ cslice,
+                                                           const int64_t* __restrict__ ctab) {
   __shared__ double sh[2][4];
   const int b = blockIdx.y, tid = threadIdx.x;
-  const float* xb = x + (int64_t)b * chunk_stride;
+  const float* xb = chunk_base(x, chunk_stride, ctab, b, M);
   const int64_t per = (M + nsl - 1) / nsl;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, M);
   double s0 = 0.0, s2 = 0.0;
@@ -87,9 +96,16 @@ __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restri
 
 // m0[b] = (lower) median of the means of chunk b's slices that hold any non-zero sample; 0 for an
 // all-zero chunk.  One wave per chunk, ranks by counting: deterministic, every consumer reads the same float
+// ragged batch: also pb[b] = the chunk's own number of windows (0 when it is not longer than the basis)
 __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __restrict__ cslice, int nsl,
-                                                                float* __restrict__ m0) {
+                                                                float* __restrict__ m0,
+                                                                const int64_t* __restrict__ ctab, int64_t M,
+                                                                int n, int Nc, int* __restrict__ pb) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (ctab != nullptr && lane == 0) {
+    const int64_t Mb = max((int64_t)0, min(M, ctab[2 * b + 1]));
+    pb[b] = Mb > n ? (int)((Mb - n) / Nc + 1) : 0;
+  }
   double v = 0.0;
   bool ok = false;
   if (lane < nsl) {
@@ -117,10 +133,13 @@ __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __
 __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x, int64_t M,
                                                     int64_t chunk_stride, int Nc, int64_t Tvalid,
                                                     int64_t Tpad, const float* __restrict__ m0f,
-                                                    float* __restrict__ xp, const int* __restrict__ list) {
+                                                    float* __restrict__ xp, const int* __restrict__ list,
+                                                    const int64_t* __restrict__ ctab, int n) {
   if (list != nullptr && list[0] <= 0) return;
   const int b = blockIdx.z, c = blockIdx.y;
-  const float* xb = x + (int64_t)b * chunk_stride;
+  const float* xb = chunk_base(x, chunk_stride, ctab, b, M);
+  // ragged batch: the samples the chunk's OWN windows touch, exactly as when it is scanned alone
+  if (ctab != nullptr) Tvalid = M > n ? (M - n) / Nc + n / Nc : 0;
   float* dst = xp + ((int64_t)b * Nc + c) * Tpad;
   const float m0 = m0f[b];
   // four consecutive samples per thread: four gathers in flight, one 16-byte store where the plane
@@ -569,8 +588,10 @@ int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx) {
 }
 
 // post != NULL: also the histogram / maximum / candidate pass over DS (dtx_ds_post semantics)
+// ctab != NULL: a ragged batch (dtx_subspace_scan_ragged): chunk b = ctab[2 b + 1] <= M samples at x_dev + ctab[2 b]
 static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
-                            int nchunk, float* ds_dev, int64_t ldp, const DtxPost* post) {
+                            int nchunk, float* ds_dev, int64_t ldp, const DtxPost* post,
+                            const int64_t* ctab = nullptr) {
   if (!ctx) return DTX_E_ARG;
   if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "dtx_subspace_ds: no basis uploaded");
   if (!x_dev || !ds_dev || nchunk <= 0)
@@ -600,14 +621,17 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   const int64_t Tvalid = P + ctx->L - 1;
   // block offsets (one pass over the stream + a 24-block reduction)
   const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 256));
-  if ((rc = dtx_reserve(ctx, ctx->ws_csum, (size_t)nchunk * (nsl * kCsum * sizeof(double) + sizeof(float)))))
+  if ((rc = dtx_reserve(ctx, ctx->ws_csum,
+                        (size_t)nchunk * (nsl * kCsum * sizeof(double) + sizeof(float) + sizeof(int)))))
     return rc;
   double* cslice = (double*)ctx->ws_csum.p;
   float* m0f = (float*)(cslice + (size_t)nchunk * nsl * kCsum);
+  // ragged batch: every chunk's own window count, for the passes that must not look past it
+  int* pb = ctab ? (int*)(m0f + nchunk) : nullptr;
   hipLaunchKernelGGL(chunk_offset_kernel, dim3((unsigned)nsl, (unsigned)nchunk), dim3(256), 0, ctx->stream,
-                     x_dev, M, chunk_stride, nsl, cslice);
+                     x_dev, M, chunk_stride, nsl, cslice, ctab);
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
-                     (const double*)cslice, nsl, m0f);
+                     (const double*)cslice, nsl, m0f, ctab, M, n, Nc, pb);
   DTX_HIP(ctx, hipGetLastError());
   const dim3 dgrid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), (unsigned)Nc, (unsigned)nchunk);
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
@@ -631,7 +655,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     // channel planes (main stream), then the window statistics on the side stream beside the block
     // spectra: both are chains of memory latencies that leave most of the chip idle on their own
     hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
-                       Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
+                       Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr, ctab, n);
     if ((rc = dtx_aux_fork(ctx))) return rc;
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
                        Nc, ctx->L, P, Ppad, scale, mean, den);
@@ -643,7 +667,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     // (dtx_fft_scan, behind the statistics on the side stream) and the float32 MFMA contraction --
     // whose error is local to a window -- recomputes them right behind the scan: a 256-workgroup
     // launch that finds an empty list on ordinary data.
-    if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, list))) return rc;
+    if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, list, pb))) return rc;
     for (const DtxKTile& t : ctx->tiles) {
       DsArgs a;
       a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
@@ -654,12 +678,12 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
       a.list = list; a.lV = fV; a.lnblk = fnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
       if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
     }
-    if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post);
+    if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
     return DTX_OK;
   }
 
   hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, ctx->stream, x_dev, M, chunk_stride, Nc,
-                     Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr);
+                     Tvalid, Tpad, (const float*)m0f, xp, (const int*)nullptr, ctab, n);
   hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
                      Nc, ctx->L, P, Ppad, scale, mean, den);
   DTX_HIP(ctx, hipGetLastError());
@@ -689,7 +713,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   ctx->kernel_timed = true;
-  if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post);
+  if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
   return DTX_OK;
 }
 
@@ -712,6 +736,23 @@ int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
   return subspace_ds_impl(ctx, x_dev, M, chunk_stride, nchunk, ds_dev, ldp, &po);
+}
+
+int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* chunk_tab_dev, int64_t M,
+                             int nchunk, float* ds_dev, int64_t ldp, uint32_t* hist_dev,
+                             float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
+                             float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!chunk_tab_dev) return dtx_fail(ctx, DTX_E_ARG, "dtx_subspace_scan_ragged: no chunk table");
+  if (nchunk > 65535 || ctx->D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
+  if (maxds_dev && nchunk > 0) {
+    DtxDeviceGuard g(ctx->device);
+    DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->stream));
+  }
+  DtxPost po;
+  po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
+  po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
+  return subspace_ds_impl(ctx, x_dev, M, 0, nchunk, ds_dev, ldp, &po, chunk_tab_dev);
 }
 
 int dtx_set_engine(dtx_ctx* ctx, int engine) {

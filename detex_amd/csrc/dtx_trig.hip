@@ -18,6 +18,7 @@ constexpr int kTrigHead = 6;      // leading doubles of an output row, then one 
 struct TrigArgs {
   const float* x;        // multiplexed chunks, chunk b at x + b * stride
   int64_t M, stride;
+  const int64_t* ctab;   // ragged batch: chunk b = min(ctab[2 b + 1], M) samples at x + ctab[2 b] (NULL: uniform)
   const float* ds;       // [nchunk][D][ldp]
   int64_t P, ldp;
   const int32_t* trig;   // [ntrig][5]: chunk, detector, window index, first sample of the STA window (-1: none), of the LTA window
@@ -85,7 +86,7 @@ __device__ inline float select_rank(const float* __restrict__ v, int count, int 
 }
 
 // pre-event noise of one trigger (every thread of the workgroup calls it; thread 0's return value is stored)
-__device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t a0, float* scr, double* red,
+__device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t Mc, int64_t a0, float* scr, double* red,
                                     double* seg1, double* seg2, unsigned* hist, unsigned* sh) {
   const int tid = threadIdx.x, n = a.n;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
@@ -96,7 +97,7 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
   int64_t pe0;
   int npe;
   if (a0 > 5 * (int64_t)n) { pe0 = a0 - 5 * (int64_t)n; npe = 5 * n; }
-  else { pe0 = a0; npe = (int)min((int64_t)7 * n, a.M - a0); }
+  else { pe0 = a0; npe = (int)min((int64_t)7 * n, Mc - a0); }
   const float* pe = xc + pe0;
   const int count = npe - n + 1;
   double noise = nan;
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
     const int32_t* tr = a.trig + 5 * (int64_t)t;
     const int chunk = tr[0], det = tr[1], p = tr[2], sta_lo = tr[3], lta_lo = tr[4];
     double* out = a.out + (int64_t)t * (kTrigHead + a.emax);
-    const float* xc = a.x + (int64_t)chunk * a.stride;
+    const float* xc = a.ctab ? a.x + a.ctab[2 * chunk] : a.x + (int64_t)chunk * a.stride;
+    const int64_t Mc = a.ctab ? max((int64_t)0, min(a.M, a.ctab[2 * chunk + 1])) : a.M;   // the chunk's samples
     const int64_t a0 = (int64_t)p * a.Nc;
     const float* w = xc + a0;
     if (task == 1) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
       continue;
     }
     if (task == 2) {
-      const double noise = trig_noise(a, xc, a0, scr, red, seg1, seg2, hist, sh);
+      const double noise = trig_noise(a, xc, Mc, a0, scr, red, seg1, seg2, hist, sh);
       if (tid == 0) out[5] = noise;
       __syncthreads();
       continue;
@@ -339,11 +341,11 @@ extern "C" int dtx_normcorr(dtx_ctx* ctx, const float* t_dev, int n, const float
   return DTX_OK;
 }
 
-extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
-                                 const float* ds_dev, int64_t P, int64_t ldp,
-                                 const int32_t* trig_dev, int ntrig, int sta_len, int lta_len,
-                                 const float* ewf_dev, const int32_t* ewf_off_dev, int emax,
-                                 double* out_dev) {
+static int trigger_stats_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                              const int64_t* ctab, const float* ds_dev, int64_t P, int64_t ldp,
+                              const int32_t* trig_dev, int ntrig, int sta_len, int lta_len,
+                              const float* ewf_dev, const int32_t* ewf_off_dev, int emax,
+                              double* out_dev) {
   if (!ctx) return DTX_E_ARG;
   if (ctx->tiles.empty()) return dtx_fail(ctx, DTX_E_STATE, "dtx_trigger_stats: no basis uploaded");
   if (ntrig == 0) return DTX_OK;
@@ -358,7 +360,7 @@ extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, in
   const int64_t scap = 6 * (int64_t)ctx->n + 1;
   if ((rc = dtx_reserve(ctx, ctx->ws_trig, (size_t)grid * scap * sizeof(float)))) return rc;
   TrigArgs a;
-  a.x = x_dev; a.M = M; a.stride = chunk_stride; a.ds = ds_dev; a.P = P; a.ldp = ldp;
+  a.x = x_dev; a.M = M; a.stride = chunk_stride; a.ctab = ctab; a.ds = ds_dev; a.P = P; a.ldp = ldp;
   a.trig = trig_dev; a.ntrig = ntrig; a.sta_len = sta_len; a.lta_len = lta_len;
   a.U = (const float*)ctx->U_buf.p; a.doff = (const int32_t*)ctx->doff_all.p;
   a.ewf = ewf_dev; a.eoff = ewf_off_dev; a.out = out_dev;
@@ -368,4 +370,24 @@ extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, in
   hipLaunchKernelGGL(trig_stats_kernel, dim3(grid, a.full ? 3u : 1u), dim3(kTT), 0, ctx->stream, a);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
+}
+
+extern "C" int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
+                                 const float* ds_dev, int64_t P, int64_t ldp,
+                                 const int32_t* trig_dev, int ntrig, int sta_len, int lta_len,
+                                 const float* ewf_dev, const int32_t* ewf_off_dev, int emax,
+                                 double* out_dev) {
+  return trigger_stats_impl(ctx, x_dev, M, chunk_stride, nullptr, ds_dev, P, ldp, trig_dev, ntrig, sta_len,
+                            lta_len, ewf_dev, ewf_off_dev, emax, out_dev);
+}
+
+extern "C" int dtx_trigger_stats_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* chunk_tab_dev,
+                                        int64_t M, const float* ds_dev, int64_t P, int64_t ldp,
+                                        const int32_t* trig_dev, int ntrig, int sta_len, int lta_len,
+                                        const float* ewf_dev, const int32_t* ewf_off_dev, int emax,
+                                        double* out_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!chunk_tab_dev && ntrig > 0) return dtx_fail(ctx, DTX_E_ARG, "dtx_trigger_stats_ragged: no chunk table");
+  return trigger_stats_impl(ctx, x_dev, M, 0, chunk_tab_dev, ds_dev, P, ldp, trig_dev, ntrig, sta_len,
+                            lta_len, ewf_dev, ewf_off_dev, emax, out_dev);
 }

@@ -2,6 +2,7 @@
 (detex/detect.py:390-445, 526-557) run on the sparse list of above-threshold
 samples the GPU returns instead of on the full detection-statistic vector."""
 import contextlib
+import os
 
 import numpy as np
 
@@ -362,15 +363,22 @@ class StationScan(object):
         self.st = dict(names=names, kinds=kinds, offsets=offsets, thr_arr=thr_arr, thr_dev=thr_dev, hist=hist,
                        bounds=bounds, Nc=Nc, n=n, D=D, sr=sr, LTA=triggerLTATime * sr, STA=triggerSTATime * sr,
                        mbank=mbank)
-        for (i0, i1, stride) in _chunk_batches(bounds):
+        groups = _chunk_batches(bounds)
+        if len(groups) > 1 and os.environ.get('DETEX_AMD_RAGGED', '1') != '0':
+            # chunks of several lengths (the first and the last chunk of a request, chunks trimmed to
+            # their data): ONE ragged launch instead of one set of launches per length
+            try:
+                self._start_ragged(groups, rawdev, xdev, dec, sr, sr_raw, thr_dev, hist if calcHist else None)
+                groups = []
+            except DetexHipError as e:
+                # the reference loses a failing chunk, not the station (detect.py:160-174): launch by launch
+                _warn('ragged launch failed on %s (%s): scanning one chunk length at a time' % (sta, e))
+        for (i0, i1, stride) in groups:
             try:
                 s0, cnt = bounds[i0][0], bounds[i0][1]
                 M = _dec_len(cnt, dec) * Nc
                 if raw:
-                    planes = torch.stack([rawdev[:, bounds[k][0]:bounds[k][0] + cnt] for k in range(i0, i1)])
-                    if dec > 1:                                      # construct.py:1016-1017
-                        planes = ctx.decimate(planes, dec, sr_raw)
-                    xb = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
+                    xb = self._filtered(rawdev, i0, i1, dec, sr, sr_raw)
                     xarg, xM, xstride, cstride = xb, None, None, int(xb.stride(0))
                 else:
                     xb = xdev[s0 * Nc:]
@@ -378,7 +386,7 @@ class StationScan(object):
                 ds, fetch = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else i1 - i0,
                                               thr=thr_dev, hist=hist if calcHist else None, cand_cap=CAND_CAP,
                                               lazy=True)
-                self.batches.append((i0, i1, xb, M, cstride, ds, fetch))
+                self.batches.append((i0, i1, xb, M, cstride, ds, fetch, None))
             except DetexHipError as e:
                 self._skip(i0, i1, e)
         # the histograms follow the last scan to pinned host memory; finish() waits for this event
@@ -390,6 +398,41 @@ class StationScan(object):
             self.hist_host.copy_(hist, non_blocking=True)
             self.hist_ev = torch.cuda.Event()
             self.hist_ev.record(_stream_of(ctx, hist.device))
+
+    def _filtered(self, rawdev, i0, i1, dec, sr, sr_raw):
+        """Chunks i0 .. i1 - 1 (equal lengths) of the unfiltered planes: decimated, detrended, band-passed
+        and multiplexed like the reference's per-chunk _applyFilter -> [i1 - i0, Nc * samples]."""
+        import torch
+        b = self.st['bounds']
+        cnt = b[i0][1]
+        planes = torch.stack([rawdev[:, b[k][0]:b[k][0] + cnt] for k in range(i0, i1)])
+        if dec > 1:                                      # construct.py:1016-1017
+            planes = self.ctx.decimate(planes, dec, sr_raw)
+        return self.ctx.preprocess(planes, filt=self.ss.clusters.filt, sampling_rate=sr)
+
+    def _start_ragged(self, groups, rawdev, xdev, dec, sr, sr_raw, thr_dev, hist):
+        """All chunks of the station in one dtx_subspace_scan_ragged launch."""
+        import torch
+        from ._lib import DetexHipError
+        ctx, b, Nc = self.ctx, self.st['bounds'], self.st['Nc']
+        lens = np.array([_dec_len(c[1], dec) * Nc for c in b], dtype=np.int64)
+        if rawdev is not None:
+            # every group of equal length is filtered on its own, into rows of one buffer
+            Mmax = int(lens.max())
+            xb = torch.zeros((len(b), Mmax), dtype=torch.float32, device=ctx.device)
+            for (i0, i1, _) in groups:
+                try:
+                    xb[i0:i1, :int(lens[i0])] = self._filtered(rawdev, i0, i1, dec, sr, sr_raw)
+                except DetexHipError as e:
+                    self._skip(i0, i1, e)
+                    lens[i0:i1] = 0                      # (a chunk without windows: nothing is counted)
+            starts = np.arange(len(b), dtype=np.int64) * Mmax
+        else:
+            xb = xdev
+            starts = np.array([c[0] * Nc for c in b], dtype=np.int64)
+        ctab = ctx.chunk_table(starts, lens)
+        ds, fetch = ctx.subspace_scan(xb, thr=thr_dev, hist=hist, cand_cap=CAND_CAP, lazy=True, chunk_tab=ctab)
+        self.batches.append((0, len(b), xb, int(lens.max()), None, ds, fetch, ctab))
 
     def _skip(self, i0, i1, e):
         # detect.py:169-174: "failing to run detector on ... from ... to ..." and go on
@@ -406,10 +449,10 @@ class StationScan(object):
         st = self.st
         self.picked = []
         with self._guard():
-            for (i0, i1, xb, M, cstride, ds, fetch) in self.batches:
+            for (i0, i1, xb, M, cstride, ds, fetch, ctab) in self.batches:
                 try:
                     self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
-                                                               i0, i1, xb, M, cstride, ds, fetch))
+                                                               i0, i1, xb, M, cstride, ds, fetch, ctab))
                 except DetexHipError as e:
                     self._skip(i0, i1, e)
 
@@ -522,10 +565,10 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
     return out
 
 
-def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch):
-    """One launch group of equal-length chunks, first host half: candidates -> triggers; the
-    trigger-time kernel is enqueued and its (device) result returned with them:
-    (trigs, bad, stats)."""
+def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, ctab=None):
+    """One launch group of chunks (equal lengths, or a ragged batch with its chunk table), first
+    host half: candidates -> triggers; the trigger-time kernel is enqueued and its (device) result
+    returned with them: (trigs, bad, stats)."""
     import torch
     names, kinds, offsets, thr_arr, thr_dev = st['names'], st['kinds'], st['offsets'], st['thr_arr'], st['thr_dev']
     bounds, Nc, n, D, sr, LTA, STA, bank = (st['bounds'], st['Nc'], st['n'], st['D'], st['sr'], st['LTA'],
@@ -543,6 +586,12 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
     P = int(ds.shape[2])
     maxds = res['maxds'].cpu().numpy() if res['maxds'].is_cuda else res['maxds'].numpy()
     cb, cd, cp, cv = res['cand']
+    # windows of every chunk of the group (ragged batch: its own)
+    Pb = np.full(nb, P, dtype=np.int64)
+    if ctab is not None:
+        Pb = np.where(ctab[1][:, 1] > n, (ctab[1][:, 1] - n) // Nc + 1, 0)
+        live = cp < Pb[cb]                               # (the re-listed candidates of an overflow are not cut)
+        cb, cd, cp, cv = cb[live], cd[live], cp[live], cv[live]
     # candidates grouped by (chunk, detector); pairs without one cannot trigger
     key = cb.astype(np.int64) * D + cd
     order = np.argsort(key, kind='stable')               # keeps p ascending per pair
@@ -552,7 +601,7 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
     for kk, f0, f1 in zip(ks, first, last):
         b, d = int(kk // D), int(kk % D)
         sel = order[f0:f1]
-        for (ti, coef) in pick_triggers_sparse(cp[sel], cv[sel], P, float(thr_arr[d]), sr,
+        for (ti, coef) in pick_triggers_sparse(cp[sel], cv[sel], int(Pb[b]), float(thr_arr[d]), sr,
                                                float(maxds[b, d])):
             if coef > 1.05:                              # detect.py:199-204
                 continue
@@ -565,12 +614,13 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
             tab[r, :3] = (b, d, ti)
             if not fillZeros:
                 try:
-                    tab[r, 3] = ti if STA == 0 else _centered_lo(ti, STA, P)
-                    tab[r, 4] = _centered_lo(ti, LTA, P)
+                    tab[r, 3] = ti if STA == 0 else _centered_lo(ti, STA, int(Pb[b]))
+                    tab[r, 4] = _centered_lo(ti, LTA, int(Pb[b]))
                 except IndexError:
                     bad[r] = True
         stats = ctx.trigger_stats(xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
-                                  bank.ewf if estimateMags else None, bank.eoff, bank.emax)
+                                  bank.ewf if estimateMags else None, bank.eoff, bank.emax,
+                                  **({} if ctab is None else {'chunk_tab': ctab}))
         if stats.is_cuda:
             # on its way to pinned host memory behind the kernel; _batch_rows waits for the event
             host = torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True)

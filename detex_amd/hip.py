@@ -237,15 +237,38 @@ class HipContext(object):
         return hist, maxds, thr_t, key, val, cnt
 
     @_on_ctx_stream
+    @_on_ctx_stream
+    def chunk_table(self, starts, lengths):
+        """The device table of a ragged batch (dtx_subspace_scan_ragged): int64 [nchunk, 2] =
+        (offset of the chunk's first sample in the flat buffer, its samples)."""
+        tab = np.ascontiguousarray(np.stack([np.asarray(starts, dtype=np.int64),
+                                             np.asarray(lengths, dtype=np.int64)], axis=1))
+        if tab.ndim != 2 or len(tab) == 0 or (tab < 0).any():
+            raise ValueError('chunk table: one non-negative (start, length) pair per chunk')
+        return h2d_async(tab, self.device), tab
+
+    @_on_ctx_stream
     def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None,
-                      hist=None, want_max=True, cand_cap=1 << 20, lazy=False):
+                      hist=None, want_max=True, cand_cap=1 << 20, lazy=False, chunk_tab=None):
         """subspace_ds + ds_post in one call (dtx_subspace_scan).
         Returns (ds, result dict as ds_post).  lazy=True returns (ds, fetch) instead, where
         fetch() synchronises and builds that dict: nothing here then waits for the device, so
-        independent scans (other contexts on other streams) can be enqueued behind each other."""
+        independent scans (other contexts on other streams) can be enqueued behind each other.
+
+        chunk_tab = self.chunk_table(starts, lengths): a ragged batch (dtx_subspace_scan_ragged) --
+        chunk b is x.flatten()[start_b : start_b + length_b]; ds has the row length of the longest
+        chunk, entries past a chunk's own window count are unspecified, and histogram / maximum /
+        candidates do not cover them."""
         if x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError('x must be a float32 CUDA tensor')
-        if M is None:
+        if chunk_tab is not None:
+            tab_dev, tab = chunk_tab
+            if not x.is_contiguous():
+                raise ValueError('a ragged batch reads one flat buffer')
+            if int((tab[:, 0] + tab[:, 1]).max()) > x.numel():
+                raise ValueError('flat buffer too small for the chunk table')
+            nchunk, M, chunk_stride = len(tab), int(tab[:, 1].max()), 0
+        elif M is None:
             if x.dim() == 1:
                 x = x[None, :]
             if x.stride(-1) != 1:
@@ -265,9 +288,14 @@ class HipContext(object):
             self._check_out(out, nchunk, P)
         hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, self.D, x.device, thr, hist,
                                                                want_max, cand_cap)
-        rc = self.lib.dtx_subspace_scan(self.h, _ptr(x), int(M), int(chunk_stride), int(nchunk),
-                                        _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
-                                        _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
+        if chunk_tab is not None:
+            rc = self.lib.dtx_subspace_scan_ragged(self.h, _ptr(x), _ptr(tab_dev), int(M), int(nchunk),
+                                                   _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
+                                                   _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
+        else:
+            rc = self.lib.dtx_subspace_scan(self.h, _ptr(x), int(M), int(chunk_stride), int(nchunk),
+                                            _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
+                                            _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
             return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap)
@@ -387,7 +415,7 @@ class HipContext(object):
         return out
 
     @_on_ctx_stream
-    def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax):
+    def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None):
         """dtx_trigger_stats: STA / LTA means and the magnitude / SNR ingredients at triggers.
 
         x, M, chunk_stride, ds: the buffers of the subspace_scan call the triggers come from;
@@ -402,10 +430,16 @@ class HipContext(object):
             return out
         tdev = h2d_async(trig, ds.device)
         nchunk, D, P = (int(v) for v in ds.shape)
-        rc = self.lib.dtx_trigger_stats(self.h, _ptr(x), int(M), int(chunk_stride), _ptr(ds), P,
-                                        int(ds.stride(1)), _ptr(tdev), nt, int(sta_len), int(lta_len),
-                                        _ptr(ewf) if ewf is not None else None,
-                                        _ptr(eoff) if ewf is not None else None, int(emax), _ptr(out))
+        if chunk_tab is not None:       # the triggers of a ragged batch (M = its longest chunk)
+            rc = self.lib.dtx_trigger_stats_ragged(self.h, _ptr(x), _ptr(chunk_tab[0]), int(M), _ptr(ds), P,
+                                                   int(ds.stride(1)), _ptr(tdev), nt, int(sta_len), int(lta_len),
+                                                   _ptr(ewf) if ewf is not None else None,
+                                                   _ptr(eoff) if ewf is not None else None, int(emax), _ptr(out))
+        else:
+            rc = self.lib.dtx_trigger_stats(self.h, _ptr(x), int(M), int(chunk_stride), _ptr(ds), P,
+                                            int(ds.stride(1)), _ptr(tdev), nt, int(sta_len), int(lta_len),
+                                            _ptr(ewf) if ewf is not None else None,
+                                            _ptr(eoff) if ewf is not None else None, int(emax), _ptr(out))
         self._ck(rc, 'dtx_trigger_stats')
         return out
 

@@ -162,6 +162,24 @@ int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
                       float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
                       float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* The same for a RAGGED batch: chunks of different lengths at arbitrary positions in one launch.
+ * The reference cuts a station's record at multiples of conDatDuration (detex/getdata.py:869-886
+ * _divideIntoChunks, 494-524 getConData: the first and the last chunk of a request hold less data
+ * than the others), and
+ * _applyFilter trims chunks to their data (construct.py:1003-1023); equal-length batches then cost one
+ * set of launches per distinct length.
+ *   chunk_tab_dev  [nchunk][2] int64 on the device: {offset of chunk b's first sample from x_dev,
+ *                  its samples M_b}; M_b is clamped to [0, M]
+ *   M              the longest chunk of the batch: sizes the workspaces and the DS rows exactly as a
+ *                  uniform batch of M-sample chunks does (ds_dev [nchunk][D][ldp], ldp >= P(M))
+ * Chunk b has P_b = (M_b - n) / Nc + 1 windows (none if M_b <= n): DS[b][d][p] for p < P_b is what
+ * dtx_subspace_scan returns for that chunk alone; entries at p >= P_b are unspecified.  Histogram,
+ * maximum and candidates cover p < P_b only.  Asynchronous. */
+int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* chunk_tab_dev,
+                             int64_t M, int nchunk, float* ds_dev, int64_t ldp, uint32_t* hist_dev,
+                             float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
+                             float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
+
 /* False-alarm statistics of a DS tensor (detex/fas.py:72-86: np.histogram(dss,
  * np.linspace(-.01, 1, 401)) and scipy.stats.beta.fit(dss, floc=0, fscale=1)).
  *   hist_dev  [D][nbins] uint32, accumulated, uniform np.linspace(lo, hi, nbins+1)
@@ -202,6 +220,12 @@ int dtx_trigger_stats(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
                       const float* ds_dev, int64_t P, int64_t ldp, const int32_t* trig_dev,
                       int ntrig, int sta_len, int lta_len, const float* ewf_dev,
                       const int32_t* ewf_off_dev, int emax, double* out_dev);
+/* ... for the triggers of a dtx_subspace_scan_ragged call: chunk_tab_dev and M as there (a trigger's
+ * data windows stay inside its own chunk's M_b samples). */
+int dtx_trigger_stats_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* chunk_tab_dev, int64_t M,
+                             const float* ds_dev, int64_t P, int64_t ldp, const int32_t* trig_dev,
+                             int ntrig, int sta_len, int lta_len, const float* ewf_dev,
+                             const int32_t* ewf_off_dev, int emax, double* out_dev);
 
 /* fast_normcorr(t, s) (construct.py:469-483; callers detect.py:484, subspace.py:765): Pearson
  * correlation of the n-sample template t with every length-n window of the m-sample series s

@@ -74,16 +74,23 @@ class OracleCtx(object):
             return [x[b].numpy() for b in range(x.shape[0])], int(x.shape[1])
         return [x[b * chunk_stride: b * chunk_stride + M].numpy() for b in range(nchunk)], int(M)
 
-    def _post(self, ds, thr, hist, cand_cap):
+    def chunk_table(self, starts, lengths):
+        tab = np.stack([np.asarray(starts, np.int64), np.asarray(lengths, np.int64)], axis=1)
+        return torch.from_numpy(tab), tab
+
+    def _post(self, ds, thr, hist, cand_cap, Pb=None):
         nb, D, P = ds.shape
-        res = dict(hist=hist, maxds=torch.from_numpy(ds.max(axis=2)), cand=None, ncand=0)
+        Pb = np.full(nb, P) if Pb is None else np.asarray(Pb)
+        own = np.arange(P)[None, None, :] < Pb[:, None, None]          # a ragged batch: the chunk's own windows
+        res = dict(hist=hist, maxds=torch.from_numpy(np.where(own, ds, 0).max(axis=2).astype(np.float32)),
+                   cand=None, ncand=0)
         if hist is not None:
             for b in range(nb):
                 for d in range(D):
-                    hist[d] += torch.from_numpy(orc.ds_histogram(ds[b, d]).astype(np.int32))
+                    hist[d] += torch.from_numpy(orc.ds_histogram(ds[b, d, :Pb[b]]).astype(np.int32))
         if thr is not None:
             thr = np.broadcast_to(np.asarray(thr.numpy() if isinstance(thr, torch.Tensor) else thr, np.float32), (D,))
-            b, d, p = np.nonzero(ds >= thr[None, :, None])
+            b, d, p = np.nonzero((ds >= thr[None, :, None]) & own)
             res['ncand'] = len(b)
             m = min(len(b), cand_cap)
             res['cand'] = (b[:m].astype(np.int64), d[:m].astype(np.int64), p[:m].astype(np.int64),
@@ -91,16 +98,29 @@ class OracleCtx(object):
         return res
 
     def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None, hist=None,
-                      want_max=True, cand_cap=1 << 20, lazy=False):
-        chunks, M = self._chunks(x, M, chunk_stride, nchunk)
-        ds = np.stack([np.stack([orc.scrub_ds(orc.mpxds_fft(c.astype(np.float64),
-                                                            self.U[self.off[d]:self.off[d + 1]],
-                                                            self.Nc))[0]
-                                 for d in range(self.D)]) for c in chunks]).astype(np.float32)
+                      want_max=True, cand_cap=1 << 20, lazy=False, chunk_tab=None):
+        Pb = None
+        if chunk_tab is not None:
+            # a ragged batch: rows as long as the longest chunk's, 0.999 where the device leaves them unspecified
+            flat = x.reshape(-1).numpy()
+            chunks = [flat[a:a + m] for (a, m) in chunk_tab[1]]
+            M = int(chunk_tab[1][:, 1].max())
+            Pb = [max(0, self.num_windows(len(c))) if len(c) > self.n else 0 for c in chunks]
+        else:
+            chunks, M = self._chunks(x, M, chunk_stride, nchunk)
+        P = self.num_windows(M)
+        ds = np.full((len(chunks), self.D, P), 0.999, dtype=np.float32)
+        for b, c in enumerate(chunks):
+            if len(c) <= self.n:
+                continue
+            for d in range(self.D):
+                v = orc.scrub_ds(orc.mpxds_fft(c.astype(np.float64), self.U[self.off[d]:self.off[d + 1]],
+                                               self.Nc))[0]
+                ds[b, d, :len(v)] = v
         self.calls.append(('scan', len(chunks), M))
         if hist is None:
             hist = torch.zeros((self.D, 400), dtype=torch.int32)
-        res = self._post(ds, thr, hist, cand_cap)
+        res = self._post(ds, thr, hist, cand_cap, Pb)
         return torch.from_numpy(ds), ((lambda: res) if lazy else res)
 
     def ds_post(self, ds, thr=None, hist=None, want_max=True, cand_cap=1 << 20):
@@ -108,13 +128,17 @@ class OracleCtx(object):
             hist = torch.zeros((ds.shape[1], 400), dtype=torch.int32)
         return self._post(ds.numpy(), thr, hist, cand_cap)
 
-    def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax):
+    def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None):
         trig = np.asarray(trig).reshape(-1, 5)
         out = np.full((len(trig), 6 + emax), np.nan)
         x = x.reshape(-1) if x.dim() == 2 and x.is_contiguous() else x
         eoff = eoff.numpy()
         for r, (b, d, p, slo, llo) in enumerate(trig):
-            xc = (x[b] if x.dim() == 2 else x[b * chunk_stride: b * chunk_stride + M]).numpy()
+            if chunk_tab is not None:
+                a, m = (int(v) for v in chunk_tab[1][b])
+                xc = x.reshape(-1)[a:a + m].numpy()
+            else:
+                xc = (x[b] if x.dim() == 2 else x[b * chunk_stride: b * chunk_stride + M]).numpy()
             ev = ewf[eoff[d]:eoff[d + 1]].numpy() if ewf is not None else np.zeros((0, self.U.shape[1]))
             row = orc.trigger_stats_row(int(p), self.Nc, xc, self.U[self.off[d]:self.off[d + 1]],
                                         ev, ds=ds[b, d].numpy().astype(np.float64),

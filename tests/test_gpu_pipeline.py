@@ -329,3 +329,25 @@ def test_stream_contract_non_default_current_stream(workflow):
     with torch.cuda.stream(torch.cuda.Stream()):
         got = ss.detex(subspaceDB=None, useSingles=True)
     assert len(ref['ss_df']) >= 3 and got['ss_df'].equals(ref['ss_df']) and got['sg_df'].equals(ref['sg_df'])
+
+
+def test_ragged_launch_equals_one_launch_per_length(workflow, monkeypatch):
+    """The product path scans the full chunks and the short tail of a station in ONE ragged launch
+    (dtx_subspace_scan_ragged); DETEX_AMD_RAGGED=0 launches once per chunk length as rounds 1-2 did: the
+    same tables (the raw fetchers of tests/test_gpu_preproc.py take the ragged path against the oracle)."""
+    ss = workflow['ss']
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    ss.setSinglesThresholds(threshold=0.4)
+    got = ss.detex(subspaceDB=None, useSingles=True)
+    monkeypatch.setenv('DETEX_AMD_RAGGED', '0')
+    ref = ss.detex(subspaceDB=None, useSingles=True)
+    monkeypatch.delenv('DETEX_AMD_RAGGED')
+    assert len(ref['ss_df']) >= 3
+    for k in ('ss_df', 'sg_df'):
+        assert len(got[k]) == len(ref[k])
+        assert (got[k].Name.values == ref[k].Name.values).all()
+        for col in ('DS', 'DS_STALTA', 'STMP', 'Mag', 'SNR', 'ProEnMag'):
+            assert np.allclose(got[k][col].values.astype(float), ref[k][col].values.astype(float),
+                               rtol=1e-5, atol=1e-7, equal_nan=True), (k, col)
+    for nm, h in ss.histSubSpaces['TA.M17A'].items():
+        assert int(np.sum(h)) > 0

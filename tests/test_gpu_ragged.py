@@ -1,0 +1,138 @@
+"""Ragged batches (dtx_subspace_scan_ragged / dtx_trigger_stats_ragged): chunks of different lengths at
+arbitrary positions of one buffer in ONE launch give, chunk by chunk, what dtx_subspace_scan gives
+for that chunk alone -- the reference scans every chunk on its own (detex/detect.py:154-218), whatever
+its length (getdata.py:494-524: the first and the last chunk of a request are shorter)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from detex_amd import synth  # noqa: E402
+from detex_amd.hip import HipContext  # noqa: E402
+from oracle import detex_oracle as orc  # noqa: E402
+
+
+def _layout(n, Nc, big):
+    """(start, length) of six chunks in one flat buffer: overlapping, out of order, one of the longest
+    length twice, one ending with a partial sample frame, one not longer than the basis (no windows)."""
+    return [(5 * Nc, big), (big - 40 * Nc, big // 3 + 1), (3 * big, big), (2 * big + 7, n),
+            (2 * big + 100 * Nc, 2 * big // 3 + 2), (big // 2, max(n + 25 * Nc, 64 * 256 + 1))]
+
+
+@pytest.mark.parametrize('engine,L,big', [('fft', 300, 30000), ('fft', 1200, 52000), ('bf16x3', 300, 30000),
+                                          ('fp32', 40, 9000)])
+def test_ragged_scan_equals_chunk_by_chunk(engine, L, big):
+    Nc, D, k = 3, 6, 3
+    n = Nc * L
+    big *= Nc
+    U, off = synth.detector_bank(5, D, k, n)
+    lay = _layout(n, Nc, big)
+    total = max(a + m for a, m in lay)
+    rs = np.random.RandomState(1)
+    flat = rs.standard_normal(total).astype(np.float32)
+    # planted events, some right at chunk ends (the last windows of a short chunk must count, the ones
+    # behind it must not)
+    for (a, m) in lay:
+        if m > n + 4 * Nc:
+            p_last = (m - n) // Nc
+            for p in (p_last, p_last // 2):
+                d = int(rs.randint(D))
+                flat[a + p * Nc: a + p * Nc + n] += 12.0 * np.sqrt(n) * U[off[d]] / np.linalg.norm(U[off[d]])
+    x = torch.from_numpy(flat).cuda()
+    ctx = HipContext(0)
+    ctx.set_engine(engine)
+    ctx.upload_basis(U, off, Nc)
+    thr = np.full(D, 0.25, np.float32)
+    tab = ctx.chunk_table([a for a, _ in lay], [m for _, m in lay])
+    ds, res = ctx.subspace_scan(x, thr=thr, chunk_tab=tab, cand_cap=1 << 16)
+    Pmax = ctx.num_windows(max(m for _, m in lay))
+    assert tuple(ds.shape) == (len(lay), D, Pmax)
+    hist = torch.zeros_like(res['hist'])
+    cands = set()
+    dsr = ds.cpu().numpy()
+    for b, (a, m) in enumerate(lay):
+        if m <= n:
+            assert float(res['maxds'][b].max()) == 0.0
+            continue
+        one, r1 = ctx.subspace_scan(x[a:a + m][None].contiguous(), thr=thr, hist=hist, cand_cap=1 << 16)
+        Pb = int(one.shape[2])
+        assert Pb == (m - n) // Nc + 1
+        w = one.cpu().numpy()[0]
+        g = dsr[b, :, :Pb]
+        if engine == 'fft' and m >= 64 * 256:
+            assert np.array_equal(g, w), (b, np.abs(g - w).max())       # the same blocks, the same offset: bit for bit
+        else:
+            assert np.allclose(g, w, atol=2e-6), (b, np.abs(g - w).max())
+        assert np.allclose(res['maxds'][b].cpu().numpy(), r1['maxds'][0].cpu().numpy(), atol=2e-6)
+        cb, cd, cp, cv = r1['cand']
+        cands |= {(b, int(d), int(p)) for d, p in zip(cd, cp)}
+        if b == 1:          # and against the CPU oracle for one short chunk
+            want = np.stack([orc.scrub_ds(orc.mpxds_fft(flat[a:a + m].astype(np.float64),
+                                                        U[off[d]:off[d + 1]].astype(np.float64), Nc))[0]
+                             for d in range(D)])
+            assert np.abs(g - want).max() < 1e-5
+    cb, cd, cp, cv = res['cand']
+    got = {(int(b), int(d), int(p)) for b, d, p in zip(cb, cd, cp)}
+    if engine == 'fft':
+        assert got == cands and len(got) >= 8
+        assert torch.equal(res['hist'], hist)
+    else:
+        # chunks shorter than 64 slices of 256 take their offset from fewer, longer slices when they are
+        # scanned alone: values a rounding error apart may change a bin or cross the threshold
+        assert len(got ^ cands) <= 2 and len(got) >= 8
+        assert int((res['hist'] - hist).abs().sum()) <= 8
+    assert int(res['hist'].sum()) == D * sum((m - n) // Nc + 1 for _, m in lay if m > n)
+    ctx.close()
+
+
+def test_ragged_trigger_stats_equal_chunk_by_chunk():
+    Nc, D, k, L = 3, 4, 2, 260
+    n = Nc * L
+    U, off = synth.detector_bank(9, D, k, n)
+    lay = [(0, 6 * n), (4 * n + Nc, 40 * n + 2), (60 * n, 30 * n)]     # (the first: a noise window cut by the chunk's end)
+    rs = np.random.RandomState(2)
+    flat = rs.standard_normal(max(a + m for a, m in lay)).astype(np.float32)
+    x = torch.from_numpy(flat).cuda()
+    ctx = HipContext(0)
+    ctx.upload_basis(U, off, Nc)
+    tab = ctx.chunk_table([a for a, _ in lay], [m for _, m in lay])
+    ds, _ = ctx.subspace_scan(x, chunk_tab=tab)
+    ewf = torch.from_numpy(rs.standard_normal((2 * D, n)).astype(np.float32)).cuda()
+    eoff = torch.arange(0, 2 * D + 1, 2, dtype=torch.int32).cuda()
+    from detex_amd import detect
+    trig, per = [], {}
+    for b, (a, m) in enumerate(lay):
+        Pb = (m - n) // Nc + 1
+        for d, ti in ((0, 3), (1, Pb - 1), (2, Pb // 2), (3, min(Pb - 1, 6 * L))):
+            row = [b, d, ti, detect._centered_lo(ti, 5, Pb), detect._centered_lo(ti, 40, Pb)]
+            trig.append(row)
+            per.setdefault(b, []).append([0] + row[1:])
+    got = ctx.trigger_stats(x, max(m for _, m in lay), None, ds, np.array(trig, np.int32), 5, 40, ewf, eoff, 2,
+                            chunk_tab=tab).cpu().numpy()
+    r = 0
+    for b, (a, m) in enumerate(lay):
+        xc = x[a:a + m][None].contiguous()
+        one = ctx.subspace_ds(xc)
+        want = ctx.trigger_stats(xc, m, m, one, np.array(per[b], np.int32), 5, 40, ewf, eoff, 2).cpu().numpy()
+        for w in want:
+            # (the detection statistic of a chunk shorter than 64 x 256 samples differs by its rounding)
+            assert np.allclose(got[r], w, rtol=5e-6, atol=1e-9, equal_nan=True), (b, got[r], w)
+            r += 1
+    ctx.close()
+
+
+def test_ragged_batch_argument_errors():
+    from detex_amd import DetexHipError
+    Nc, L = 3, 300
+    U, off = synth.detector_bank(1, 2, 2, Nc * L)
+    ctx = HipContext(0)
+    ctx.upload_basis(U, off, Nc)
+    x = torch.zeros(50000, device='cuda')
+    with pytest.raises(ValueError):
+        ctx.subspace_scan(x, chunk_tab=ctx.chunk_table([0, 40000], [20000, 20000]))     # past the buffer
+    with pytest.raises(ValueError):
+        ctx.chunk_table([0, -1], [10, 10])
+    with pytest.raises(DetexHipError):                                                  # no chunk longer than the basis
+        ctx.subspace_scan(x, chunk_tab=ctx.chunk_table([0, 100], [Nc * L, 10]))
+    ctx.close()

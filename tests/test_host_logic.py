@@ -428,7 +428,16 @@ def test_detex_host_logic_on_cpu(tmp_path):
     want, hist = oracle_scan(ss, cf, 'TA.M17A', SR, NC)
     check_detex(res, want, hist, ss, 'TA.M17A')
     scans = [c for c in ctx.calls if c[0] == 'scan']
-    assert [c[1] for c in scans] == [3, 1]                             # 3 full chunks in one launch + the short tail
+    assert [c[1] for c in scans] == [4]                                # 3 full chunks + the short tail: one ragged launch
+    # ... and as one launch per chunk length (DETEX_AMD_RAGGED=0): the same tables
+    os.environ['DETEX_AMD_RAGGED'] = '0'
+    try:
+        ctx.calls.clear()
+        res_u = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx)
+    finally:
+        del os.environ['DETEX_AMD_RAGGED']
+    assert [c[1] for c in ctx.calls if c[0] == 'scan'] == [3, 1]
+    check_detex(res_u, want, hist, ss, 'TA.M17A')
     found = sum(bool((np.abs(res['ss_df'].STMP - (1.2e6 + (t + 5) / SR)) < 1.0).any())
                 for (t, f, a) in plants)
     assert found >= 3
@@ -473,6 +482,13 @@ def test_candidate_overflow_and_failing_batch(caplog, monkeypatch):
             if self.seen == self.which:
                 raise DetexHipError('dtx_subspace_scan failed (-2): injected fault')
             return OracleCtx.subspace_scan(self, x, **kw)
+    # a failing ragged launch is repeated one chunk length at a time: nothing is lost
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger='detex_amd.detect'):
+        got = ss.detex(subspaceDB=None, ctx=FailsOnce(1))
+    assert any('ragged launch failed' in r.message for r in caplog.records)
+    assert got['ss_df'].equals(ref['ss_df'])
+    monkeypatch.setenv('DETEX_AMD_RAGGED', '0')                          # one launch per chunk length
     for which, keep in ((2, lambda t: t < 1.2e6 + 360), (1, lambda t: t >= 1.2e6 + 360)):
         caplog.clear()
         with caplog.at_level(logging.WARNING, logger='detex_amd.detect'):

@@ -144,7 +144,8 @@ def test_product_entry_points_world2():
         for nm, h in ss1.histSubSpaces['TA.M17A'].items():
             assert hist[nm] == h.tolist()
     # the four chunks were split two and two: each rank scanned only its share
-    assert [c[1] for c in res[0][2]] == [2] and [c[1] for c in res[1][2]] == [1, 1]
+    # (rank 1's two chunks differ in length: one ragged launch)
+    assert [c[1] for c in res[0][2]] == [2] and [c[1] for c in res[1][2]] == [2]
 
 
 def _expected_upload(cf, stas, rank, world):
