@@ -12,7 +12,7 @@ constexpr int kPostThreads = 256;
 #define DTX_POST_ITEMS 64
 #endif
 #ifndef DTX_POST_NT
-#define DTX_POST_NT 0
+#define DTX_POST_NT 1
 #endif
 #ifndef DTX_POST_BATCH
 #define DTX_POST_BATCH 4
@@ -48,13 +48,15 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   // LDS atomics do not serialise on one address
   unsigned low[4] = {0u, 0u, 0u, 0u};
   unsigned wc[4] = {0u, 0u, 0u, 0u};      // wave-wide cumulative counts of the fast path (uniform)
-  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
   // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
   const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
   constexpr int kBatch = DTX_POST_BATCH;      // 16-byte loads in flight per thread
   static_assert(kPostItems / 4 % kBatch == 0, "whole batches");
+  const unsigned t4bits = __float_as_uint(kT4);
+  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
   for (int it0 = 0; it0 < kPostItems / 4; it0 += kBatch) {
   float vb[kBatch][4];
+  bool whole = vec;                       // every load of this lane's batch is a 16-byte load inside the row
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) {
     const int64_t p4 = base + ((int64_t)(it0 + u) * kPostThreads + tid) * 4;
@@ -65,42 +67,48 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
                                   : *reinterpret_cast<const fvec4*>(row + p4);
       vb[u][0] = q.x; vb[u][1] = q.y; vb[u][2] = q.z; vb[u][3] = q.w;
     } else {
+      whole = false;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (p4 + j < P) vb[u][j] = row[p4 + j];
     }
   }
+  // Nearly every window is noise in the first four bins.  One test per batch: the largest bit pattern of
+  // the lane's 16 values, compared as unsigned, is below that of edge 4 exactly when all of them lie in
+  // [+0, edge 4) (negative values and NaN have larger patterns) -- and below the threshold when none is a
+  // candidate.  When that holds for the whole wave the batch is counted branch-free: three compares per
+  // value against the float32 images of the float64 edges (the thresholds dtx_hist_bin_fast uses), scalar
+  // population counts, one running maximum.
+  unsigned mb = 0u;
 #pragma unroll
-  for (int u = 0; u < kBatch; ++u) {
-    const int it = it0 + u;
-    const int64_t p4 = base + ((int64_t)it * kPostThreads + tid) * 4;
-    const float (&vv)[4] = vb[u];
+  for (int u = 0; u < kBatch; ++u)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t p = p4 + j;
-      const float v = vv[j];
-      // Nearly every window is noise in the first four bins.  When every lane of the wave holds such a
-      // value (0 <= v < edge 4, inside the row) the wave counts them with three compares and scalar
-      // population counts -- cumulative counts below the float32 images of the float64 edges (the same
-      // thresholds dtx_hist_bin_fast uses) -- instead of classifying and adding per lane.
-      const bool ordinary = p < P && v >= 0.f && v < kT4;
-      if (__builtin_expect(__all(ordinary), 1)) {
-        if (hist) {
+    for (int j = 0; j < 4; ++j) mb = max(mb, __float_as_uint(vb[u][j]));
+  const bool quiet = whole && mb < t4bits && !(do_cand && __uint_as_float(mb) >= th);
+  if (__builtin_expect(__all(quiet), 1)) {
+    if (hist) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = vb[u][j];
           wc[0] += (unsigned)__popcll(__ballot(v < kT1));
           wc[1] += (unsigned)__popcll(__ballot(v < kT2));
           wc[2] += (unsigned)__popcll(__ballot(v < kT3));
-          wc[3] += 64u;
         }
-        vmax = max(vmax, __float_as_int(v));
-        if (do_cand && v >= th) {
-          const uint32_t slot = atomicAdd(ncand, 1u);
-          if (slot < cand_cap) {
-            cand_key[slot] = ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;  // dtx_cand_pack
-            cand_val[slot] = v;
-          }
-        }
-        continue;
-      }
+      wc[3] += 64u * 4u * kBatch;
+    }
+    vmax = max(vmax, (int)mb);
+    continue;
+  }
+  // anything else (values from bin 4 up, candidates, the row's ragged end, odd values): value by value
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const int64_t p4 = base + ((int64_t)(it0 + u) * kPostThreads + tid) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = p4 + j;
+      const float v = vb[u][j];
       if (p >= P) continue;
       int bits = __float_as_int(v);
       if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
