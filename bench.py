@@ -304,9 +304,11 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
                          'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0,
                          'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False} if hbm else None),
                          'bytes_per_launch': bytes_alg,
-                         'bound_actual': 'L2 -> CU stream of the pair spectra (counters: %s) -- the algorithmic HBM '
-                                         'bytes the schema prices are 3 orders of magnitude below what the '
-                                         'frequency-domain search moves on chip' % pmc_src,
+                         'bound_actual': 'the sum of its two phases, run one after the other by one workgroup per CU: '
+                                         'products (L2 -> L1 stream of the pair spectra, ~0.85 of the L1 fill rate) '
+                                         'and transforms (counters: %s; DESIGN 4.3) -- the algorithmic HBM bytes the '
+                                         'schema prices are 3 orders of magnitude below what the frequency-domain '
+                                         'search moves on chip' % pmc_src,
                          'l2_counters': ({'TCC_REQ_sum': l2req, 'bytes_at_128B': 128.0 * l2req,
                                           'TBps': 128.0 * l2req / (kms * 1e-3) / 1e12,
                                           'hit_rate': cnt('xc_fft_kernel', 'TCC_HIT_sum') / l2req,
