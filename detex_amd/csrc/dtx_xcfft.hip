@@ -21,16 +21,22 @@ constexpr float kScrubTolF = 1e-5f;   // dtx_xcorr.hip: kScrubTol
 // Work list (scripts/ab_xc.sh, configs[2], kernel ms): rounds 1-2 gave a workgroup 8 pairs, which it walked two at
 // a time, streaming its block spectra from HBM once per two pairs (12 MB of them in flight per XCD) past 4.3 MB
 // of pair spectra: UNIT 8 / GROUP 1 181.4, 4 / 1 174.3, 2 / 1 181.3, 16 / 1 195.9.  Now a workgroup takes ONE
-// step of two pairs and the workgroups of a later event's 16 units run side by side, sharing its block
-// spectra in L2: 2 / 2 167.4, 2 / 8 168.3, 2 / 16 165.1 -- the sum of the kernel's two phases taken alone
-// (products 87 ms + transforms 62 + epilogue 15, profiles/x5 ablations), which one workgroup per CU runs one
-// after the other.
+// step of two pairs, the workgroups of a later event's GROUP units run side by side and share its block
+// spectra in L2 (2 / 2 167.4, 2 / 16 165.1, 2 / 32 216: the group's pair spectra must stay in the Infinity
+// Cache), and CTILE later events are walked together inside a group so that a unit's pair spectra serve
+// them all from L2: CTILE 2 / GROUP 16 162.4, 2 / 8 157.5, 4 / 8 156.1, 6 / 8 160.0, 8 / 8 162.2, 4 / 4 161.8.
+// What is left is the sum of the kernel's two phases (products, transforms), which one workgroup per CU runs
+// one after the other.
 #ifndef DTX_XC_UNIT
 #define DTX_XC_UNIT 2
 #endif
 #ifndef DTX_XC_GROUP
-#define DTX_XC_GROUP 16
+#define DTX_XC_GROUP 8
 #endif
+#ifndef DTX_XC_CTILE
+#define DTX_XC_CTILE 4
+#endif
+constexpr int kCtileX = DTX_XC_CTILE; // later events walked together inside a group
 constexpr int kGroupX = DTX_XC_GROUP; // units whose workgroups run side by side for the same later event
 constexpr int kUnitX = DTX_XC_UNIT;   // event pairs per workgroup
 
@@ -389,17 +395,18 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // work items (c, first pair of a unit), unit-major so that concurrent workgroups share the
   // unit's pair spectra in L2
   std::vector<int2> items;
-  // kGroupX units are walked together, later event by later event: the workgroups of one later event
-  // (one per unit of the group) run side by side and share its block spectra in L2 as the units of a
-  // group share theirs
+  // kGroupX units are walked together, kCtileX later events at a time: the workgroups of one later event
+  // (one per unit of the group) share its block spectra in L2, those of one unit (one per later event of
+  // the tile and lag block) its pair spectra
   for (int g0 = 0; g0 < npr; g0 += kUnitX * kGroupX) {
     const int64_t g_lo = 2 * (int64_t)g0, g_hi = 2 * (int64_t)(g0 + kUnitX * kGroupX) - 1;
     if (g_hi < b_begin || g_lo > b_end) continue;
-    for (int c = std::max<int64_t>(g_lo + 1, 1); c < N; ++c)
+    for (int c0 = (int)std::max<int64_t>(g_lo + 1, 1); c0 < N; c0 += kCtileX)
       for (int pr0 = g0; pr0 < std::min(npr, g0 + kUnitX * kGroupX); pr0 += kUnitX) {
         const int64_t r_lo = 2 * (int64_t)pr0, r_hi = 2 * (int64_t)(pr0 + kUnitX) - 1;
-        if (r_hi < b_begin || r_lo > b_end || c <= r_lo) continue;
-        items.push_back(make_int2(c, pr0));
+        if (r_hi < b_begin || r_lo > b_end) continue;
+        for (int c = c0; c < std::min(N, c0 + kCtileX); ++c)
+          if (c > r_lo) items.push_back(make_int2(c, pr0));
       }
   }
   if (items.empty()) return DTX_OK;
