@@ -137,6 +137,7 @@ template <int VM>
 __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftArgs a) {
   __shared__ c32 lds[kLdsC];
   __shared__ c32 xst[2][kXh];     // the block spectrum of the current / next virtual channel (see the MAC loop)
+  __shared__ unsigned long long wred[4][kT / 64];   // the waves' lag-search candidates of an iteration's four rows
   const int tid = threadIdx.x;
   // workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of the
   // (unit-major) work list so that the workgroups sharing an L2 share a unit's pair spectra
@@ -192,13 +193,18 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   // only that one candidate is packed into the 64-bit key.  (Rounds 1-2 packed a key per lag and reduced
   // keys through 12 ds_bpermute round trips per row: the epilogue was 22 of the kernel's 190 ms.)
   // rw[m] is NaN for lags past Pz: their cc is NaN and never wins a comparison.
-  auto reduce_rows = [&](const c32 (&z)[16], int pr) {
+  // (r1v / s1v: the rows' 1 / sqrt(ssd) and sum x_b / sqrt(ssd), fetched before the products: read here, the two
+  // dependent scalar loads per row stood exposed in front of every row's arithmetic)
+  // The wave's candidate of each row goes to wred[row of the iteration][wave]; after the iteration's closing barrier
+  // four threads fold the eight waves' candidates and issue ONE atomicMax per row (eight per row: 9 of the kernel's
+  // 156 ms were atomics).
+  auto reduce_rows = [&](const c32 (&z)[16], int pr, const float* r1v, const float* s1v, int which) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int b = 2 * pr + h;
       const bool rowok = b < c;                                   // uniform
       // the pair spectra hold unit-energy rows x_b rs_b: cc = (Y' - (sum x_b) rs_b mu_w) rs_w
-      const float r1 = rowok ? a.frs[b] : 0.f, s1 = rowok ? a.fsum[b] * r1 : 0.f;
+      const float r1 = r1v[h], s1 = s1v[h];
       float best = -INFINITY;
       int bm = 0;
 #pragma unroll
@@ -216,13 +222,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #if DTX_XC_ABLATE & 16
       if (pmin == 12345u && wmax == 0.5f) a.keys[0] = 1ull;
 #else
-      if ((tid & 63) == 0 && rowok && r1 > 0.f && wmax > -INFINITY) {
-        const unsigned bits = __float_as_uint(wmax);
-        const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-        const unsigned long long key =
-            ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
-        const int64_t idx = condensed_index_x(a.N, b, c);
-        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+      if ((tid & 63) == 0) {
+        unsigned long long key = 0ull;                            // (0 = no candidate: below every real key)
+        if (rowok && r1 > 0.f && wmax > -INFINITY) {
+          const unsigned bits = __float_as_uint(wmax);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
+        }
+        wred[2 * which + h][tid >> 6] = key;
       }
 #endif
     }
@@ -242,6 +249,14 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
     const bool has2 = q + 1 < npr;
     const float4* wqa = reinterpret_cast<const float4*>(a.W + (int64_t)pr * nvc * kN);
     const float4* wqb = wqa + (has2 ? (int64_t)nvc * (kN / 2) : 0);
+    float r1v[4], s1v[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int b = 2 * pr + h;
+      const bool rowok = b < c && (h < 2 || has2);                // uniform
+      r1v[h] = rowok ? a.frs[b] : 0.f;
+      s1v[h] = rowok ? a.fsum[b] * r1v[h] : 0.f;
+    }
     c32 z[16], zb[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #if DTX_XC_ABLATE & 4
     if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
 #else
-    reduce_rows(z, pr);
+    reduce_rows(z, pr, r1v, s1v, 0);
 #endif
     if (has2) {
 #if !(DTX_XC_ABLATE & 8)
@@ -344,10 +359,22 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #if DTX_XC_ABLATE & 4
       if (zb[0].x == 1.2345f && zb[5].y == 5.4321f) a.keys[1] = 1ull;
 #else
-      reduce_rows(zb, pr + 1);
+      reduce_rows(zb, pr + 1, r1v + 2, s1v + 2, 1);
 #endif
     }
-    if (DTX_XC_DUAL) __syncthreads();
+    __syncthreads();
+#if !(DTX_XC_ABLATE & (4 | 16))
+    if (tid < (has2 ? 4 : 2)) {
+      unsigned long long key = wred[tid][0];
+#pragma unroll
+      for (int w = 1; w < kT / 64; ++w) key = max(key, wred[tid][w]);
+      const int b = 2 * pr + tid;
+      if (key != 0ull && b < c) {
+        const int64_t idx = condensed_index_x(a.N, b, c);
+        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+      }
+    }
+#endif
   }
 }
 
