@@ -281,7 +281,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
         c32 px[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          constexpr int dummy = 0; (void)dummy;
           const int r = 8 * h + 4 * g + e;
 #if DTX_XC_ABLATE & 2     // timing only: no block-spectrum loads
           px[e] = make_float2(0.25f, 1.f);
