@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 #ifndef DTX_PP_INLINE_X
 #define DTX_PP_INLINE_X 0      // 1: the ping-pong kernel transforms its block's channels itself (no xhat_kernel, no X^ in HBM)
 #endif
+#ifndef DTX_PP_DEFER_CLOSE
+#define DTX_PP_DEFER_CLOSE 1    // a closing pair's statistic is formed by the half's next role (see the kernel)
+#endif
 #ifndef DTX_PP_ABLATE
 #define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong), bit flags: 1 no basis-spectrum loads, 2 no transform fronts,
                                 // 4 no transform tail / epilogue, 8 no MAC
@@ -508,6 +511,13 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #pragma unroll
     for (int m = 0; m < VM; ++m) mures[m] = (mean + 512 * m)[tid];
   }
+  // a closing pair's statistic (division by the window norms, DS stores) is formed by the NEXT role of this half,
+  // behind the round's first barrier and under the first pair-spectrum loads of that role's products: between a
+  // round's second barrier and the next round's first this half has the longer instruction stream (transform
+  // tail + accumulation + statistic against the other half's first pass)
+  // (not where two accumulator sets leave no room for the window norms beside the first loads: no scratch)
+  constexpr bool kDefer = DTX_PP_DEFER_CLOSE && !(TWO && VM >= 13);
+  [[maybe_unused]] int2 pend = make_int2(-1, -1);          // detectors whose accumulators wait to be closed (uniform)
   auto stamp_round = [&](int r) {
 #ifdef DTX_PP_STAMPS
     stamp.p = (stamped && r < kStampRounds) ? a.stamps + ((((int64_t)(blockIdx.x / kStampEvery) * 2 + half) * kStampRounds + r) * 16) : nullptr;
@@ -537,29 +547,17 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < VM; ++m) dn[m] = 0.f;
-        if (kDnEarly && pd.x >= 0) {
+        if (kDnEarly && !kDefer && pd.x >= 0) {
 #pragma unroll
           for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
         }
   };
-  auto finish_pair = [&](int te, const float4 pi, const int2 pd, float (&mu)[kMuRes ? 1 : VM], float (&dn)[VM]) {
-        const bool two = TWO && pd.y >= 0;
-        const bool closes = pd.x >= 0;
-#pragma unroll
-        for (int m = 0; m < VM; ++m) {
-          /* explicit fma chain: every instantiation of the kernels rounds the same way */
-          if constexpr (!kMuRes && !kMuEarly) mu[m] = (mean + 512 * m)[te];
-          const float mum = kMuRes ? mures[m] : mu[kMuRes ? 0 : m];
-          const float re = __fmaf_rn(-pi.x, mum, z[m].x), im = __fmaf_rn(-pi.y, mum, z[m].y);
-          const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
-          acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
-          if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
-        }
-        if (closes) {
+  auto close_pair = [&](int te, const int2 pd, float (&dn)[VM]) {
+          const bool two = TWO && pd.y >= 0;
           float* row0 = a.ds + ((int64_t)chunk * a.D + pd.x) * a.ldp + p0;         // uniform
           float* row1 = a.ds + ((int64_t)chunk * a.D + (two ? pd.y : pd.x)) * a.ldp + p0;
           const int lim = (int)min((int64_t)kN, a.P - p0);                    // windows left in the chunk
-          if constexpr (!kDnEarly) {
+          if constexpr (!kDnEarly && !kDefer) {
 #pragma unroll
             for (int m = 0; m < VM; ++m) dn[m] = (den + 512 * m)[te];
           }
@@ -582,6 +580,23 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
               acc1[m] = 0.f;
             }
           }
+  };
+  auto finish_pair = [&](int te, const float4 pi, const int2 pd, float (&mu)[kMuRes ? 1 : VM], float (&dn)[VM]) {
+        const bool two = TWO && pd.y >= 0;
+        const bool closes = pd.x >= 0;
+#pragma unroll
+        for (int m = 0; m < VM; ++m) {
+          /* explicit fma chain: every instantiation of the kernels rounds the same way */
+          if constexpr (!kMuRes && !kMuEarly) mu[m] = (mean + 512 * m)[te];
+          const float mum = kMuRes ? mures[m] : mu[kMuRes ? 0 : m];
+          const float re = __fmaf_rn(-pi.x, mum, z[m].x), im = __fmaf_rn(-pi.y, mum, z[m].y);
+          const float i0 = two ? 0.f : im, i1 = two ? im : 0.f;
+          acc0[m] = __fmaf_rn(i0, i0, __fmaf_rn(re, re, acc0[m]));
+          if (TWO) acc1[m] = __fmaf_rn(i1, i1, acc1[m]);
+        }
+        if (closes) {
+          if constexpr (kDefer) pend = pd;
+          else close_pair(te, pd, dn);
         }
   };
   auto front_role = [&](int q) {
@@ -613,6 +628,17 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   auto mac_role = [&](int q) {
       const bool mac = q >= 0 && (q >> 1) < nmine && !(DTX_PP_ABLATE & 8);       // a pair's products to form
       __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
+      [[maybe_unused]] const int2 pnd = pend;
+      [[maybe_unused]] float dnp[kDefer ? VM : 1];
+      [[maybe_unused]] int ot = 0;
+      if constexpr (kDefer) {
+        pend = make_int2(-1, -1);
+        asm volatile("v_mov_b32 %0, 0" : "=v"(ot));
+        if (pnd.x >= 0) {
+#pragma unroll
+          for (int m = 0; m < VM; ++m) dnp[m] = (den + 512 * m)[tid + ot];
+        }
+      }
       // ---- MAC of pair q / 2: half-channel batches of four 16-byte loads, three batches in flight
       if (mac) {
         const int pr = pbase + (q >> 1);
@@ -635,6 +661,10 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 #endif
         };
         dtx::static_for<0, kDepth>([&](auto bc) { issue(bc); });
+        if constexpr (kDefer) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (pnd.x >= 0) close_pair(tid + ot, pnd, dnp);     // under the loads just issued
+        }
         __builtin_amdgcn_sched_barrier(0);
         dtx::static_for<0, kBatches>([&](auto bc) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;
@@ -666,6 +696,9 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         DTX_STAMP(st);                             // 5: products done
         if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
       }
+      else if constexpr (kDefer) {
+        if (pnd.x >= 0) close_pair(tid + ot, pnd, dnp);
+      }
       __syncthreads();                           // the second barrier of the round
   };
   const int rounds2 = (rounds + 1) >> 1;       // (an odd count is padded with a round of bare barriers)
@@ -684,6 +717,14 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       front_role(2 * i - 1);
       stamp_round(2 * i + 1);
       mac_role(2 * i);
+    }
+  }
+  if constexpr (kDefer) {
+    if (pend.x >= 0) {        // half 0 ends on a transform: its last statistic
+      float dnp[VM];
+#pragma unroll
+      for (int m = 0; m < VM; ++m) dnp[m] = (den + 512 * m)[tid];
+      close_pair(tid, pend, dnp);
     }
   }
 }
