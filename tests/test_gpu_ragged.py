@@ -136,3 +136,39 @@ def test_ragged_batch_argument_errors():
     with pytest.raises(DetexHipError):                                                  # no chunk longer than the basis
         ctx.subspace_scan(x, chunk_tab=ctx.chunk_table([0, 100], [Nc * L, 10]))
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_ragged_random_layouts(seed):
+    """Random chunk tables (lengths from just above the basis to several transform blocks, arbitrary -- also
+    unaligned and overlapping -- offsets, one to seven chunks, 1 to 4 channels, templates on either side of the
+    engines' crossover): every chunk of the ragged launch equals its own uniform launch."""
+    rs = np.random.RandomState(100 + seed)
+    Nc = int(rs.choice([1, 2, 3, 4]))
+    L = int(rs.choice([24, 130, 300, 700, 2100]))
+    D, k = int(rs.randint(1, 5)), int(rs.randint(1, 4))
+    n = Nc * L
+    U, off = synth.detector_bank(seed, D, k, n)
+    nchunk = int(rs.randint(1, 8))
+    lens = [int(n + rs.randint(1, 40)) if rs.rand() < 0.25 else int(rs.randint(n + 10, n + 9000 * Nc))
+            for _ in range(nchunk)]
+    total = max(lens) * 3
+    starts = [int(rs.randint(0, total - m + 1)) for m in lens]
+    flat = rs.standard_normal(total).astype(np.float32)
+    flat[rs.randint(0, total, 20)] *= 30.0
+    x = torch.from_numpy(flat).cuda()
+    ctx = HipContext(0)
+    ctx.upload_basis(U, off, Nc)
+    thr = np.full(D, 0.5, np.float32)
+    ds, res = ctx.subspace_scan(x, thr=thr, chunk_tab=ctx.chunk_table(starts, lens))
+    dsr = ds.cpu().numpy()
+    hist = torch.zeros_like(res['hist'])
+    for b, (a, m) in enumerate(zip(starts, lens)):
+        one, r1 = ctx.subspace_scan(x[a:a + m].clone()[None], thr=thr, hist=hist)
+        Pb = int(one.shape[2])
+        w = one.cpu().numpy()[0]
+        assert np.allclose(dsr[b, :, :Pb], w, atol=3e-6), (seed, b, np.abs(dsr[b, :, :Pb] - w).max())
+        assert np.allclose(res['maxds'][b].cpu().numpy(), r1['maxds'][0].cpu().numpy(), atol=3e-6)
+    assert int(res['hist'].sum()) == int(hist.sum()) == D * sum((m - n) // Nc + 1 for m in lens)
+    assert int((res['hist'] - hist).abs().sum()) <= 6      # (values a rounding error apart may change bin)
+    ctx.close()
