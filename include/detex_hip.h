@@ -165,9 +165,8 @@ int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
 /* The same for a RAGGED batch: chunks of different lengths at arbitrary positions in one launch.
  * The reference cuts a station's record at multiples of conDatDuration (detex/getdata.py:869-886
  * _divideIntoChunks, 494-524 getConData: the first and the last chunk of a request hold less data
- * than the others), and
- * _applyFilter trims chunks to their data (construct.py:1003-1023); equal-length batches then cost one
- * set of launches per distinct length.
+ * than the others), and _applyFilter trims chunks to their data (construct.py:1003-1023);
+ * equal-length batches then cost one set of launches per distinct length.
  *   chunk_tab_dev  [nchunk][2] int64 on the device: {offset of chunk b's first sample from x_dev,
  *                  its samples M_b}; M_b is clamped to [0, M]
  *   M              the longest chunk of the batch: sizes the workspaces and the DS rows exactly as a
