@@ -426,6 +426,50 @@ def test_scan_config2_production_grid(ctx):
         assert abs(g - ref) <= 1e-5, (b, p, d, g, ref)
 
 
+def test_scan_config2_ragged_day(ctx):
+    """A station-day of configs[1] as the product path meets it (request not aligned with the hour marks:
+    a short first chunk, 23 full ones, a short last one -- getdata.py:869-886) in ONE ragged launch on
+    the production grid (25 x 73 blocks, 73 of them past their chunk's end, in the full workgroups and in
+    the split remainder): bit-identical to the three uniform launches of rounds 1-2, histograms equal,
+    every plant found; and the closed form at the chunks' last windows."""
+    Nc, L, D, k, T = 3, 3000, 25, 8, 372000
+    n = Nc * L
+    U, off = synth.detector_bank(1, D, k, n)
+    day, plants = synth.continuous_day(1002, 1, Nc * 8640000, Nc, U, off, nplant=40)
+    xt = torch.from_numpy(day[0]).cuda()
+    # (start sample, samples) per chunk: 1320 s, then 3720 s every 3600 s, then the 2400 s that are left
+    bounds = [(0, 132000)] + [(120000 + 360000 * i, T) for i in range(23)] + [(8400000, 240000)]
+    ctx.set_engine('auto')
+    ctx.upload_basis(U, off, Nc)
+    thr = np.full(D, 0.3, np.float32)
+    tab = ctx.chunk_table([s * Nc for s, _ in bounds], [c * Nc for _, c in bounds])
+    ds, res = ctx.subspace_scan(xt, thr=thr, chunk_tab=tab)
+    hist = torch.zeros_like(res['hist'])
+    found = set()
+    for (i0, i1) in ((0, 1), (1, 24), (24, 25)):
+        s0, cnt = bounds[i0]
+        one, r1 = ctx.subspace_scan(xt[s0 * Nc:], M=cnt * Nc, chunk_stride=360000 * Nc, nchunk=i1 - i0,
+                                    thr=thr, hist=hist)
+        Pb = int(one.shape[2])
+        assert torch.equal(ds[i0:i1, :, :Pb], one), (i0, float((ds[i0:i1, :, :Pb] - one).abs().max()))
+        assert torch.equal(res['maxds'][i0:i1].cpu(), r1['maxds'].cpu())
+        cb, cd, cp, cv = r1['cand']
+        found |= {(int(b) + i0, int(d), int(p)) for b, d, p in zip(cb, cd, cp)}
+    assert torch.equal(res['hist'], hist)
+    cb, cd, cp, cv = res['cand']
+    assert {(int(b), int(d), int(p)) for b, d, p in zip(cb, cd, cp)} == found
+    # every plant that lies inside some chunk is a candidate there
+    for (_, p, d) in plants:
+        hits = [(b, p - s0) for b, (s0, cnt) in enumerate(bounds) if s0 <= p and p + L <= s0 + cnt]
+        assert hits and all((b, d, q) in found for b, q in hits), (p, d)
+    for b in (0, 24, 12):
+        s0, cnt = bounds[b]
+        for p in (0, cnt - L):
+            for d in (0, D - 1):
+                ref = _spot_ds(day[0][s0 * Nc:(s0 + cnt) * Nc], U[off[d]:off[d + 1]], Nc, p)
+                assert abs(float(ds[b, d, p]) - ref) <= 1e-5, (b, p, d)
+
+
 @pytest.mark.parametrize('config', [2, 4])
 def test_bench_two_ranks_on_one_gpu(config):
     """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per
