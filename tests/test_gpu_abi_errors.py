@@ -163,3 +163,42 @@ def test_basis_bcast_between_contexts():
         assert out[1][b, d, p] > 0.9
     for i in range(2):
         lib.dtx_ctx_destroy(hs[i])
+
+
+def test_kernel_timing_ring_and_ragged_arguments(raw):
+    """dtx_kernel_ms_mean: the durations of the dominant kernel of the last n calls, read after the calls
+    were enqueued (the ring holds 64); asking for more than were timed, or than the ring holds, is an error.
+    dtx_subspace_scan_ragged / dtx_trigger_stats_ragged without a chunk table are errors too."""
+    lib, h = raw
+    ms = C.c_float()
+    assert lib.dtx_kernel_ms_mean(h, 1, C.byref(ms)) == -3 and 'no timed kernel' in _msg(lib, h)
+    Nc, L = 3, 400
+    n = Nc * L
+    rs = np.random.RandomState(0)
+    U = np.linalg.qr(rs.standard_normal((n, 4)))[0].T.astype(np.float32).copy()
+    off = np.array([0, 2, 4], np.int32)
+    assert lib.dtx_basis_upload(h, U.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), 2, n, Nc) == 0
+    M = Nc * 40000
+    stream = torch.cuda.ExternalStream(lib.dtx_ctx_stream(h))
+    with torch.cuda.stream(stream):
+        x = torch.randn(M, device='cuda')
+        P = (M - n) // Nc + 1
+        ds = torch.empty((1, 2, P), device='cuda')
+        for _ in range(5):
+            assert lib.dtx_subspace_ds(h, C.c_void_p(x.data_ptr()), M, M, 1, C.c_void_p(ds.data_ptr()), P) == 0
+        assert lib.dtx_kernel_ms_mean(h, 5, C.byref(ms)) == 0 and 0.0 < ms.value < 50.0
+        one = C.c_float()
+        assert lib.dtx_last_kernel_ms(h, C.byref(one)) == 0 and 0.0 < one.value < 50.0
+        assert lib.dtx_kernel_ms_mean(h, 6, C.byref(ms)) == -1 and 'only the last' in _msg(lib, h)
+        assert lib.dtx_kernel_ms_mean(h, 65, C.byref(ms)) == -1
+        assert lib.dtx_kernel_ms_mean(h, 0, C.byref(ms)) == -1
+        rc = lib.dtx_subspace_scan_ragged(h, C.c_void_p(x.data_ptr()), None, M, 1, C.c_void_p(ds.data_ptr()), P,
+                                          None, None, None, None, None, 0, None)
+        assert rc == -1 and 'chunk table' in _msg(lib, h)
+        trig = torch.zeros((1, 5), dtype=torch.int32, device='cuda')
+        out = torch.zeros((1, 6), dtype=torch.float64, device='cuda')
+        rc = lib.dtx_trigger_stats_ragged(h, C.c_void_p(x.data_ptr()), None, M, C.c_void_p(ds.data_ptr()), P, P,
+                                          C.c_void_p(trig.data_ptr()), 1, 1, 10, None, None, 0,
+                                          C.c_void_p(out.data_ptr()))
+        assert rc == -1 and 'chunk table' in _msg(lib, h)
+    assert lib.dtx_ctx_sync(h) == 0
