@@ -97,11 +97,18 @@ __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restri
 // m0[b] = (lower) median of the means of chunk b's slices that hold any non-zero sample; 0 for an
 // all-zero chunk.  One wave per chunk, ranks by counting: deterministic, every consumer reads the same float
 // ragged batch: also pb[b] = the chunk's own number of windows (0 when it is not longer than the basis)
+// It also clears what later passes of the same call accumulate into (two fill launches less per call): the
+// guard's list counter and the chunk's row of maxima (zmax: [nchunk][D], may be NULL).
 __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __restrict__ cslice, int nsl,
                                                                 float* __restrict__ m0,
                                                                 const int64_t* __restrict__ ctab, int64_t M,
-                                                                int n, int Nc, int* __restrict__ pb) {
+                                                                int n, int Nc, int* __restrict__ pb,
+                                                                int* __restrict__ zlist, float* __restrict__ zmax,
+                                                                int D) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (zlist != nullptr && b == 0 && lane == 0) zlist[0] = 0;
+  if (zmax != nullptr)
+    for (int d = lane; d < D; d += 64) zmax[(int64_t)b * D + d] = 0.f;
   if (ctab != nullptr && lane == 0) {
     const int64_t Mb = max((int64_t)0, min(M, ctab[2 * b + 1]));
     pb[b] = Mb > n ? (int)((Mb - n) / Nc + 1) : 0;
@@ -700,29 +707,34 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   float* m0f = (float*)(cslice + (size_t)nchunk * nsl * kCsum);
   // ragged batch: every chunk's own window count, for the passes that must not look past it
   int* pb = ctab ? (int*)(m0f + nchunk) : nullptr;
+  const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
+                       (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
+  int* list = nullptr;
+  int fV = 0, fnblk = 0;
+  if (use_fft) {
+    if (!ctx->fft.ok &&
+        (rc = dtx_fft_basis_build(ctx, ctx->hdoff.data(), ctx->D, n, Nc)))
+      return rc;
+    fV = ctx->fft.V;
+    fnblk = (int)((P + fV - 1) / fV);
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
+    list = (int*)ctx->ws_flag.p;
+  }
   hipLaunchKernelGGL(chunk_offset_kernel, dim3((unsigned)nsl, (unsigned)nchunk), dim3(256), 0, ctx->stream,
                      x_dev, M, chunk_stride, nsl, cslice, ctab);
+  // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
-                     (const double*)cslice, nsl, m0f, ctab, M, n, Nc, pb);
+                     (const double*)cslice, nsl, m0f, ctab, M, n, Nc, pb, list,
+                     post ? post->maxds : (float*)nullptr, ctx->D);
   DTX_HIP(ctx, hipGetLastError());
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
   const double scale = (double)n / ((double)n - 1.0);
   const dim3 sgrid((unsigned)((P + kStatsPB - 1) / kStatsPB), (unsigned)nchunk);
 
-  const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
-                       (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
   if (use_fft) {
-    if (!ctx->fft.ok &&
-        (rc = dtx_fft_basis_build(ctx, ctx->hdoff.data(), ctx->D, n, Nc)))
-      return rc;
     // The preparation reads the caller's multiplexed stream directly (rounds 1-2 wrote channel planes
     // first and read them back twice): the window statistics run on a side stream beside the block
     // spectra -- both are chains of memory latencies that leave most of the chip idle on their own.
-    const int fV = ctx->fft.V;
-    const int fnblk = (int)((P + fV - 1) / fV);
-    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
-    int* list = (int*)ctx->ws_flag.p;
-    DTX_HIP(ctx, hipMemsetAsync(list, 0, sizeof(int), ctx->stream));
     // channel planes (main stream), then the window statistics on the side stream beside the block
     // spectra: both are chains of memory latencies that leave most of the chip idle on their own
     launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp,
@@ -799,10 +811,6 @@ int dtx_subspace_scan(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk
                       float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev) {
   if (!ctx) return DTX_E_ARG;
   if (nchunk > 65535 || ctx->D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
-  if (maxds_dev && nchunk > 0) {
-    DtxDeviceGuard g(ctx->device);
-    DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->stream));
-  }
   DtxPost po;
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
@@ -816,10 +824,6 @@ int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
   if (!ctx) return DTX_E_ARG;
   if (!chunk_tab_dev) return dtx_fail(ctx, DTX_E_ARG, "dtx_subspace_scan_ragged: no chunk table");
   if (nchunk > 65535 || ctx->D > 65535) return dtx_fail(ctx, DTX_E_ARG, "nchunk / D > 65535");
-  if (maxds_dev && nchunk > 0) {
-    DtxDeviceGuard g(ctx->device);
-    DTX_HIP(ctx, hipMemsetAsync(maxds_dev, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->stream));
-  }
   DtxPost po;
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
