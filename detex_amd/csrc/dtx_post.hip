@@ -24,12 +24,19 @@ __device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
 // the float32 images of the float64 edges 1/400 .. 4/400 (dtx_postdev.h: dtx_hist_bin_fast)
 constexpr float kT1 = 0x1.47ae16p-9f, kT2 = 0x1.47ae16p-8f, kT3 = 0x1.eb852p-8f, kT4 = 0x1.47ae16p-7f;
 
-__global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
+#ifndef DTX_POST_WAVES
+#define DTX_POST_WAVES 8      // waves per SIMD the pass is compiled for (<= 64 registers: 154.7 -> 143.8 us; 7: 148.3)
+#endif
+__global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
     float* __restrict__ maxds, const float* __restrict__ thr, uint64_t* __restrict__ cand_key,
     float* __restrict__ cand_val, uint32_t cand_cap, uint32_t* __restrict__ ncand,
     const int* __restrict__ pb) {
   __shared__ uint32_t sh_hist[DTX_HIST_BINS];
+  // the float32 images of the 401 float64 edges i / 400 (for a float v and a float64 edge e, (double)v < e  <=>
+  // v < up(e), up(e) the smallest float32 >= e): the general classification is a multiply, two LDS reads and
+  // compares instead of a float64 search (646 -> 494 us per station-day when every value lies above bin 3)
+  __shared__ float sh_edge[DTX_HIST_BINS + 1];
   __shared__ int sh_max[kPostThreads / 64];
   const int tid = threadIdx.x;
   const int det = blockIdx.y, chunk = blockIdx.z;
@@ -38,9 +45,24 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     if ((int64_t)blockIdx.x * (kPostThreads * kPostItems) >= P) return;
   }
   const float* row = ds + ((int64_t)chunk * D + det) * ldp;
-  if (hist)
+  if (hist) {
     for (int b = tid; b < DTX_HIST_BINS; b += kPostThreads) sh_hist[b] = 0u;
+    for (int b = tid; b <= DTX_HIST_BINS; b += kPostThreads) {
+      const double e = b == DTX_HIST_BINS ? 1.0 : (double)b * (1.0 / 400.0);       // dtx_hist_bin's edges
+      float f = (float)e;
+      if ((double)f < e) f = __uint_as_float(__float_as_uint(f) + 1u);            // (e > 0 here: next float up)
+      sh_edge[b] = f;
+    }
+  }
   __syncthreads();
+  // bin of v by the table: e_i <= v < e_{i+1}, the last bin also v == 1; -1 outside [0, 1] and for NaN
+  auto bin_of = [&](float v) -> int {
+    if (!(v >= 0.f) || v > 1.f) return -1;
+    int i = min((int)(v * 400.f), DTX_HIST_BINS - 1);
+    while (i > 0 && v < sh_edge[i]) --i;
+    while (i < DTX_HIST_BINS - 1 && v >= sh_edge[i + 1]) ++i;
+    return i;
+  };
   const float th = thr ? thr[det] : 0.f;
   const bool do_cand = thr && cand_key && cand_val && ncand;
   int vmax = 0;   // bit pattern; DS >= 0 so integer order == float order, NaN sorts highest
@@ -84,7 +106,8 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
   for (int u = 0; u < kBatch; ++u)
 #pragma unroll
     for (int j = 0; j < 4; ++j) mb = max(mb, __float_as_uint(vb[u][j]));
-  const bool quiet = whole && mb < t4bits && !(do_cand && __uint_as_float(mb) >= th);
+  // (without a histogram any finite non-negative value is ordinary)
+  const bool quiet = whole && mb < (hist ? t4bits : 0x7f800000u) && !(do_cand && __uint_as_float(mb) >= th);
   if (__builtin_expect(__all(quiet), 1)) {
     if (hist) {
 #pragma unroll
@@ -101,31 +124,29 @@ __global__ __launch_bounds__(kPostThreads) void ds_post_kernel(
     vmax = max(vmax, (int)mb);
     continue;
   }
-  // anything else (values from bin 4 up, candidates, the row's ragged end, odd values): value by value
-#pragma unroll
-  for (int u = 0; u < kBatch; ++u) {
-    const int64_t p4 = base + ((int64_t)(it0 + u) * kPostThreads + tid) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t p = p4 + j;
-      const float v = vb[u][j];
-      if (p >= P) continue;
-      int bits = __float_as_int(v);
-      if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
-      vmax = max(vmax, bits);
-      if (hist) {
-        const int b = hist_bin(v);
-        if (b >= 4) atomicAdd(&sh_hist[b], 1u);
-        else if (b >= 0) {
-          low[0] += (b == 0); low[1] += (b == 1); low[2] += (b == 2); low[3] += (b == 3);
-        }
+  // anything else (values from bin 4 up, candidates, the row's ragged end, odd values): value by value, read
+  // again (cache hits) in a rolled loop -- sixteen unrolled copies of this path cost the common one its
+  // registers (74, or 53 spilled at 64)
+#pragma unroll 1
+  for (int q = 0; q < 4 * kBatch; ++q) {
+    const int64_t p = base + ((int64_t)(it0 + (q >> 2)) * kPostThreads + tid) * 4 + (q & 3);
+    if (p >= P) continue;
+    const float v = row[p];
+    int bits = __float_as_int(v);
+    if (bits < 0) bits = (v != v) ? 0x7fc00000 : 0;   // negative zero / -NaN
+    vmax = max(vmax, bits);
+    if (hist) {
+      const int b = bin_of(v);
+      if (b >= 4) atomicAdd(&sh_hist[b], 1u);
+      else if (b >= 0) {
+        low[0] += (b == 0); low[1] += (b == 1); low[2] += (b == 2); low[3] += (b == 3);
       }
-      if (do_cand && v >= th) {
-        const uint32_t slot = atomicAdd(ncand, 1u);
-        if (slot < cand_cap) {
-          cand_key[slot] = ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;  // dtx_cand_pack
-          cand_val[slot] = v;
-        }
+    }
+    if (do_cand && v >= th) {
+      const uint32_t slot = atomicAdd(ncand, 1u);
+      if (slot < cand_cap) {
+        cand_key[slot] = ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;  // dtx_cand_pack
+        cand_val[slot] = v;
       }
     }
   }

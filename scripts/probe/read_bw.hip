@@ -136,11 +136,11 @@ int main() {
     hipMemset(hist, 0, 25 * 400 * 4); hipMemset(cnt, 0, 4);
     std::vector<float> th(25, 0.3f);
     hipMemcpy(thr, th.data(), 100, hipMemcpyHostToDevice);
-    for (int data = 0; data < 2; ++data) {
-      if (data == 1) {
+    for (int data = 0; data < 3; ++data) {
+      if (data >= 1) {
         std::vector<float> h(1 << 22);
         unsigned r = 12345u;
-        for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (r >> 8) * (0.009f / 16777216.f); }
+        for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (r >> 8) * ((data == 1 ? 0.009f : 0.5f) / 16777216.f); }
         for (long o = 0; o < n4 * 4; o += (long)h.size())
           hipMemcpy((float*)x + o, h.data(), (size_t)std::min<long>((long)h.size(), n4 * 4 - o) * 4, hipMemcpyHostToDevice);
       }
@@ -154,7 +154,7 @@ int main() {
           dtx_timer_stop(ctx, &ms);
           best = fminf(best, ms / 10);
         }
-        printf("dtx_ds_post data=%s mode=%d : %7.1f us  %.2f TB/s\n", data ? "noise" : "zeros", mode, best * 1e3,
+        printf("dtx_ds_post data=%s mode=%d : %7.1f us  %.2f TB/s\n", data == 0 ? "zeros" : data == 1 ? "noise" : "loud ", mode, best * 1e3,
                369001.0 * 25 * 24 * 4 / best / 1e9);
       }
       run_rows<64, 4, 0, 1>(xf, out);
