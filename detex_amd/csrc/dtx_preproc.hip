@@ -238,6 +238,36 @@ __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ 
   }
 }
 
+// The same without a trend for NC channels, 16 bytes per access on both sides: a thread takes four sample frames,
+// one 16-byte load from each plane, NC 16-byte stores of the 4 NC consecutive multiplexed floats.  (The kernel
+// above scatters 4-byte stores NC floats apart: 95 us per station-day against 41 - 50.)
+template <int NC>
+__global__ __launch_bounds__(256) void pp_copy_vec_kernel(const float* __restrict__ raw, int64_t ser_stride,
+                                                          int64_t T, int64_t mp_stride,
+                                                          float* __restrict__ out_mp) {
+  typedef float fv4 __attribute__((ext_vector_type(4)));
+  const int chunk = blockIdx.y;
+  const float* r = raw + (int64_t)chunk * NC * ser_stride;
+  float* o = out_mp + (int64_t)chunk * mp_stride;
+  for (int64_t t = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); t < T; t += 4 * (int64_t)gridDim.x * 256) {
+    float v[4 * NC];
+    if (t + 3 < T) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const fv4 w = __builtin_nontemporal_load(reinterpret_cast<const fv4*>(r + (int64_t)c * ser_stride + t));
+        v[c] = w.x; v[NC + c] = w.y; v[2 * NC + c] = w.z; v[3 * NC + c] = w.w;
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q)
+        *reinterpret_cast<float4*>(o + t * NC + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+      for (int k = 0; t + k < T; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[(t + k) * NC + c] = r[(int64_t)c * ser_stride + t + k];
+    }
+  }
+}
+
 // host-side preparation shared by dtx_preprocess and dtx_decimate: normalised sections,
 // block transition matrix M and M^seg, workspace carving
 struct PpPlan {
@@ -416,6 +446,25 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     DTX_HIP(ctx, hipGetLastError());
   }
   if (nsec == 0) {
+    // no trend, 16-byte aligned planes and output: the vector kernel
+    const bool vec = trend == nullptr && (ser_stride & 3) == 0 && (mp_stride & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(mp_dev) & 15) == 0;
+    const dim3 vgrid((unsigned)std::min<int64_t>((T + 1023) / 1024, 4096), (unsigned)(nser / std::max(Nc, 1)));
+#define DTX_PP_COPY_VEC(NC)                                                                                  \
+    hipLaunchKernelGGL(pp_copy_vec_kernel<NC>, vgrid, dim3(256), 0, ctx->stream, raw_dev, ser_stride, T,     \
+                       mp_stride, mp_dev)
+    if (vec && (Nc == 1 || Nc == 2 || Nc == 3 || Nc == 4 || Nc == 6)) {
+      switch (Nc) {
+        case 1: DTX_PP_COPY_VEC(1); break;
+        case 2: DTX_PP_COPY_VEC(2); break;
+        case 3: DTX_PP_COPY_VEC(3); break;
+        case 4: DTX_PP_COPY_VEC(4); break;
+        default: DTX_PP_COPY_VEC(6); break;
+      }
+      DTX_HIP(ctx, hipGetLastError());
+      return DTX_OK;
+    }
+#undef DTX_PP_COPY_VEC
     dim3 grid((unsigned)std::min<int64_t>((T + 255) / 256, 4096), (unsigned)nser);
     hipLaunchKernelGGL(pp_copy_kernel, grid, dim3(256), 0, ctx->stream, raw_dev, ser_stride,
                        (const double*)trend, T, Nc, mp_stride, mp_dev);
