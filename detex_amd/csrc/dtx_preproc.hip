@@ -308,6 +308,19 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
   pl->mid = (double*)(base + o_mid);
   if (nsec == 0) return DTX_OK;
 
+  // the transition matrices depend on the sections and on seg only: built once, kept on the device (rounds 1-2
+  // rebuilt and copied them per call and synchronised the stream for the copy's host buffer -- a raw-counts
+  // SubSpace.detex waited for the previous station's scan at every chunk group)
+  std::vector<double> key;
+  key.push_back((double)nsec); key.push_back((double)pl->seg); key.push_back((double)kPB);
+  key.insert(key.end(), sos, sos + 6 * (size_t)nsec);
+  const int slot = need_mid || strcmp(who, "dtx_preprocess") == 0 ? 0 : 1;
+  DtxBuf& Mbuf = ctx->pp_M[slot];
+  std::vector<double>& Mkey = ctx->pp_key[slot];
+  if (Mbuf.p != nullptr && key == Mkey) {
+    pl->Mdev = (double*)Mbuf.p;
+    return DTX_OK;
+  }
   // state transition over one block: column k = free response of unit state k
   std::vector<double> M((size_t)ns * ns, 0.0);
   for (int k = 0; k < ns; ++k) {
@@ -338,9 +351,13 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
     }
     M.insert(M.end(), P.begin(), P.end());
   }
-  DTX_HIP(ctx, hipMemcpyAsync(pl->Mdev, M.data(), (size_t)2 * ns * ns * sizeof(double),
-                              hipMemcpyHostToDevice, ctx->stream));
-  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // M is a stack-lifetime host buffer
+  Mkey.clear();
+  // (kernels of earlier calls may still read the old matrices: wait for them before overwriting)
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = dtx_reserve(ctx, Mbuf, (size_t)2 * kMaxSec * 2 * kMaxSec * 2 * sizeof(double)))) return rc;
+  DTX_HIP(ctx, hipMemcpy(Mbuf.p, M.data(), (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice));
+  Mkey = key;
+  pl->Mdev = (double*)Mbuf.p;
   return DTX_OK;
 }
 
