@@ -132,9 +132,11 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   DtxBuf* bufs[] = {&ctx->ws_xp, &ctx->ws_mean, &ctx->ws_den,
                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3, &ctx->ws_g, &ctx->ws_csum,
                     &ctx->ws_xhat, &ctx->ws_flag, &ctx->U_buf, &ctx->srow_all, &ctx->ws_trig,
-                    &ctx->ws_trig_doff, &ctx->doff_all, &ctx->pp_M[0], &ctx->pp_M[1]};
+                    &ctx->ws_trig_doff, &ctx->doff_all};
   for (auto b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (auto& b : ctx->pp_M)
+    if (b.p) (void)hipFree(b.p);
   hipEvent_t evs[2] = {ctx->ev_t0, ctx->ev_t1};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);

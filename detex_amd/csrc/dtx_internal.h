@@ -91,8 +91,10 @@ struct dtx_ctx {
   DtxBuf ws_xp, ws_mean, ws_den, ws_misc, ws_misc2, ws_misc3, ws_g, ws_csum, ws_xhat, ws_flag, ws_trig, ws_trig_doff;
   // pre-processing: the filter's block-transition matrices on the device, kept for the filter / geometry they
   // were built for (pp_key) -- rebuilding them per call cost a stream synchronisation per call
-  DtxBuf pp_M[2];                    // [0] dtx_preprocess, [1] dtx_decimate
-  std::vector<double> pp_key[2];
+  static constexpr int kPpCache = 8;   // (a station's chunk groups differ in length: one entry per geometry)
+  DtxBuf pp_M[kPpCache];
+  std::vector<double> pp_key[kPpCache];
+  int pp_next = 0;                     // round-robin replacement
   int engine = DTX_ENGINE_AUTO;
 
   // timing

@@ -314,13 +314,15 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
   std::vector<double> key;
   key.push_back((double)nsec); key.push_back((double)pl->seg); key.push_back((double)kPB);
   key.insert(key.end(), sos, sos + 6 * (size_t)nsec);
-  const int slot = need_mid || strcmp(who, "dtx_preprocess") == 0 ? 0 : 1;
+  for (int e = 0; e < dtx_ctx::kPpCache; ++e)
+    if (ctx->pp_M[e].p != nullptr && key == ctx->pp_key[e]) {
+      pl->Mdev = (double*)ctx->pp_M[e].p;
+      return DTX_OK;
+    }
+  const int slot = ctx->pp_next;
+  ctx->pp_next = (ctx->pp_next + 1) % dtx_ctx::kPpCache;
   DtxBuf& Mbuf = ctx->pp_M[slot];
   std::vector<double>& Mkey = ctx->pp_key[slot];
-  if (Mbuf.p != nullptr && key == Mkey) {
-    pl->Mdev = (double*)Mbuf.p;
-    return DTX_OK;
-  }
   // state transition over one block: column k = free response of unit state k
   std::vector<double> M((size_t)ns * ns, 0.0);
   for (int k = 0; k < ns; ++k) {

@@ -764,6 +764,19 @@ class SubSpace(object):
             cache[key] = _StationUploader(dev)
         return cache[key]
 
+    def _side_ctx(self, device, k):
+        """Helper context k of a device, on a stream of its own: pre-processing of a station's short chunk
+        groups beside the long one (detect.StationScan._start_ragged)."""
+        import torch
+        from .hip import HipContext
+        cache = self.__dict__.setdefault('_side_ctxs', {})
+        dev = torch.device(device) if not isinstance(device, int) else torch.device('cuda', device)
+        key = (str(dev), int(k))
+        if key not in cache:
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                cache[key] = HipContext(dev.index or 0)   # (a context keeps the stream current at its creation)
+        return cache[key]
+
     def _station_ctx(self, device, sta, keep=16):
         """One HipContext per (device, station), kept for the life of the object (the `keep`
         most recently used): its workspaces (channel planes, window statistics, block
@@ -782,7 +795,7 @@ class SubSpace(object):
 
     def __getstate__(self):
         d = dict(self.__dict__)
-        for k in ('_hip_ctx', '_bank_cache', '_bank_aux', '_uploaders', '_rank_banks'):
+        for k in ('_hip_ctx', '_bank_cache', '_bank_aux', '_uploaders', '_rank_banks', '_side_ctxs'):
             d.pop(k, None)                                  # device contexts / buffers are not picklable
         return d
 

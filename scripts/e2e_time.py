@@ -43,7 +43,9 @@ for k in range(nplant):
     e = int(rs.randint(len(td)))
     t = int(rs.randint(0, T - L))
     con[:, t:t + L] += 3.0 * td[e].reshape(L, NC).T / np.std(td[e])
-cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+# E2E_RAW=1: the fetcher holds UNFILTERED planes; every chunk is detrended and band-passed on the device
+# (detect.py:231 _applyFilter per chunk) before its scan
+cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], raw=os.environ.get('E2E_RAW', '0') == '1')
 for sta in STAS:
     cf.add(sta, con if sta == STAS[0] else con.copy(), starttime=1.5e9)
 if os.environ.get('E2E_PIN', '1') == '1':
