@@ -96,6 +96,9 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 //   RUN = true : start from the true entry state, write the output (pass 3);
 //                LAST selects the float32 result: multiplexed x[Nc t + c] (dec <= 1) or
 //                the series' own plane keeping every dec-th sample (dtx_decimate)
+#ifndef DTX_PP_LOADS
+#define DTX_PP_LOADS 16
+#endif
 constexpr int kSub = 32;
 template <bool FIRST, bool RUN, bool LAST>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
@@ -120,12 +123,23 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
   for (int k = 0; k < 2 * f.nsec; ++k) z[k] = (RUN && valid) ? st[k] : 0.0;
 
   for (int jj = 0; jj < kPB; jj += kSub) {
-#pragma unroll 4
-    for (int mm = 0; mm < kSub; ++mm) {
-      const int idx = mm * 256 + tid;
-      const int b = idx / kSub, j = idx - b * kSub;
-      const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
-      tile[b][j] = (g0 + b < nblk && i < T) ? pp_input<FIRST>(r, m, tr, T, i, rev) : 0.0;
+    // (DTX_PP_LOADS loads in flight: four at a time the 32 of a sub-tile were eight exposed latencies)
+#pragma unroll 1
+    for (int m0 = 0; m0 < kSub; m0 += DTX_PP_LOADS) {
+      double v[DTX_PP_LOADS];
+#pragma unroll
+      for (int q = 0; q < DTX_PP_LOADS; ++q) {
+        const int idx = (m0 + q) * 256 + tid;
+        const int b = idx / kSub, j = idx - b * kSub;
+        const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
+        v[q] = (g0 + b < nblk && i < T) ? pp_input<FIRST>(r, m, tr, T, i, rev) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < DTX_PP_LOADS; ++q) {
+        const int idx = (m0 + q) * 256 + tid;
+        const int b = idx / kSub, j = idx - b * kSub;
+        tile[b][j] = v[q];
+      }
     }
     __syncthreads();
     if (valid) {
