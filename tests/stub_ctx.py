@@ -45,11 +45,16 @@ class OracleCtx(object):
 
     def preprocess(self, raw, filt=None, sampling_rate=None, detrend=True, out=None):
         if filt is None and not detrend:
-            return torch.stack([torch.from_numpy(orc.multiplex(list(p.numpy())).astype(np.float32))
-                                for p in raw])
-        return torch.stack([torch.from_numpy(orc.multiplex(orc.apply_filter(list(p.numpy()), filt, sampling_rate,
-                                                                            detrend)).astype(np.float32))
-                            for p in raw])
+            res = torch.stack([torch.from_numpy(orc.multiplex(list(p.numpy())).astype(np.float32))
+                               for p in raw])
+        else:
+            res = torch.stack([torch.from_numpy(orc.multiplex(orc.apply_filter(list(p.numpy()), filt, sampling_rate,
+                                                                               detrend)).astype(np.float32))
+                               for p in raw])
+        if out is not None:                   # rows of a wider buffer (the device call writes with a row pitch)
+            out[:, :res.shape[1]] = res
+            return out
+        return res
 
     def ingest_counts(self, counts, frags, Nc, T, want_run=True):
         cnt = counts.numpy()
