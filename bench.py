@@ -426,6 +426,25 @@ def e2e_detex(local):
             dt = (time.perf_counter() - t0) / reps
             out[key] = {'value': windows / dt, 'ms_per_call': 1e3 * dt, 'ms_per_station_day': 1e3 * dt / NSTA,
                         'detections': int(len(res['ss_df']))}
+    # the same with an UNFILTERED fetcher: every chunk is detrended and band-passed on the device before its scan
+    # (the reference's own order of work, detect.py:231 _applyFilter per chunk)
+    cfr = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], raw=True)
+    for i, sta in enumerate(stas):
+        cfr.add(sta, cf.data[sta][0], starttime=1.5e9)
+    cfr.pin()
+    ssr = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cfr)
+    ssr.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
+    ssr.SVD(selectCriteria=4, selectValue=7, threshold=0.3, useSingles=False)
+    resr = ssr.detex(subspaceDB=None, estimateMags=True, device=local)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        resr = ssr.detex(subspaceDB=None, estimateMags=True, device=local)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out['raw_fetcher'] = {'value': windows / dt, 'ms_per_call': 1e3 * dt, 'ms_per_station_day': 1e3 * dt / NSTA,
+                          'detections': int(len(resr['ss_df'])),
+                          'note': 'per-chunk detrend + zero-phase band-pass on the device inside the timed region'}
     got = res['ss_df']
     out['planted'] = nplant * NSTA
     out['detections_with_magnitude'] = int(got.Mag.notna().sum())
