@@ -44,6 +44,26 @@ void dtx_free_tiles_internal(dtx_ctx* c) {
   dtx_fft_free(c);
 }
 
+int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (bytes == 0) return DTX_OK;
+  const int k = ctx->stage_next;
+  ctx->stage_next = (k + 1) % dtx_ctx::kStage;
+  if (!ctx->stage_ev[k]) DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+  else DTX_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));      // (eight copies ago: long done)
+  if (ctx->stage_cap[k] < bytes) {
+    if (ctx->stage_buf[k]) DTX_HIP(ctx, hipHostFree(ctx->stage_buf[k]));
+    ctx->stage_buf[k] = nullptr;
+    ctx->stage_cap[k] = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+    DTX_HIP(ctx, hipHostMalloc(&ctx->stage_buf[k], want, hipHostMallocDefault));
+    ctx->stage_cap[k] = want;
+  }
+  memcpy(ctx->stage_buf[k], src_host, bytes);
+  DTX_HIP(ctx, hipMemcpyAsync(dst_dev, ctx->stage_buf[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+  DTX_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->stream));
+  return DTX_OK;
+}
+
 int dtx_kev_next(dtx_ctx* ctx) {
   const int slot = (int)(ctx->kev_count % dtx_ctx::kKev);
   if (!ctx->kev0[slot]) {
@@ -137,6 +157,10 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->pp_M)
     if (b.p) (void)hipFree(b.p);
+  for (int k = 0; k < dtx_ctx::kStage; ++k) {
+    if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    if (ctx->stage_buf[k]) (void)hipHostFree(ctx->stage_buf[k]);
+  }
   hipEvent_t evs[2] = {ctx->ev_t0, ctx->ev_t1};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);

@@ -97,6 +97,14 @@ struct dtx_ctx {
   int pp_next = 0;                     // round-robin replacement
   int engine = DTX_ENGINE_AUTO;
 
+  // small host tables on their way to the device without a stream synchronisation: a ring of page-locked
+  // staging buffers, each guarded by the event recorded behind its last copy (dtx_stage_h2d)
+  static constexpr int kStage = 8;
+  void* stage_buf[kStage] = {};
+  size_t stage_cap[kStage] = {};
+  hipEvent_t stage_ev[kStage] = {};
+  int stage_next = 0;
+
   // timing
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // user timer
   // dominant-kernel timer: a ring of event pairs, one per timed launch (ev_k0 / ev_k1 = the current pair), so
@@ -124,6 +132,8 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
                  int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list,
                  const int* pb = nullptr);
+// dst_dev <- bytes of src_host, asynchronously on the context's stream; src_host may be reused at once
+int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int dtx_kev_next(dtx_ctx* ctx);      // ev_k0 / ev_k1 := the next pair of the ring
 int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
 int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux

@@ -583,10 +583,10 @@ int dtx_ingest_counts(dtx_ctx* ctx, const int32_t* counts_dev, const int64_t* fr
   DTX_HIP(ctx, hipMemsetAsync(planes_dev, 0, (size_t)Nc * T * sizeof(float), ctx->stream));
   if (nfrag > 0) {
     if ((rc = dtx_reserve(ctx, ctx->ws_misc2, (size_t)nfrag * sizeof(IngestFrag)))) return rc;
-    // a few dozen bytes per fragment; the descriptors are host data of the caller
-    DTX_HIP(ctx, hipMemcpyAsync(ctx->ws_misc2.p, frag_host, (size_t)nfrag * sizeof(IngestFrag),
-                                hipMemcpyHostToDevice, ctx->stream));
-    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frag_host may be reused by the caller
+    // a few dozen bytes per fragment; the descriptors are host data of the caller: through the context's
+    // staging ring (a stream synchronisation here made every station of a raw-counts SubSpace.detex wait
+    // for the scans queued before it)
+    if ((rc = dtx_stage_h2d(ctx, ctx->ws_misc2.p, frag_host, (size_t)nfrag * sizeof(IngestFrag)))) return rc;
     int64_t longest = 1;
     for (int i = 0; i < nfrag; ++i) longest = std::max(longest, frag_host[4 * (int64_t)i + 3]);
     const unsigned gx = (unsigned)std::min<int64_t>((longest + 255) / 256, 1024);

@@ -326,7 +326,7 @@ class StationScan(object):
         if counts is not None:
             # raw int32 counts in fragments: merged with zero fill on the device
             # (construct.py:1038 / 1070); the per-chunk trimming follows below
-            planes_dev = _ingest_station(ctx, counts, Nc, T)
+            planes_dev = _ingest_station(ctx, counts, Nc, T, getattr(fetcher, 'counts_pinned', {}).get(sta))
         elif planes_dev is None:
             planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
         sr_raw = sr
@@ -508,9 +508,15 @@ class StationScan(object):
         return out
 
 
-def _ingest_station(ctx, counts, Nc, T):
-    """All fragments of a station in one dtx_ingest_counts call -> zero-filled [Nc, T] planes."""
+def _ingest_station(ctx, counts, Nc, T, pinned=None):
+    """All fragments of a station in one dtx_ingest_counts call -> zero-filled [Nc, T] planes.
+    pinned: (page-locked int32 buffer of the fragments end to end, their table, the fragment list it was
+    built from) -- ContinuousFetcher.pin()."""
     import torch
+    if pinned is not None and pinned[2] is counts:
+        cdev = pinned[0].to(ctx.device, non_blocking=True)
+        planes, _ = ctx.ingest_counts(cdev, pinned[1], Nc, T, want_run=False)
+        return planes
     off, frs = 0, []
     for (c, t0, x) in counts:
         frs.append((c, off, t0, len(x)))

@@ -46,7 +46,14 @@ for k in range(nplant):
 # E2E_RAW=1: the fetcher holds UNFILTERED planes; every chunk is detrended and band-passed on the device
 # (detect.py:231 _applyFilter per chunk) before its scan
 cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], raw=os.environ.get('E2E_RAW', '0') == '1')
-for sta in STAS:
+if os.environ.get('E2E_COUNTS', '0') == '1':
+    # E2E_COUNTS=1: int32 counts in fragments (one gap per channel), merged / trimmed / filtered on the device
+    cnt = np.round(con * 1000.0).astype(np.int32)
+    for sta in STAS:
+        cf.add_counts(sta, [(c, 0, cnt[c, :T // 2 - 50 * c]) for c in range(NC)] +
+                      [(c, T // 2 + 30, cnt[c, T // 2 + 30:]) for c in range(NC)], T, starttime=1.5e9)
+else:
+  for sta in STAS:
     cf.add(sta, con if sta == STAS[0] else con.copy(), starttime=1.5e9)
 if os.environ.get('E2E_PIN', '1') == '1':
     cf.pin()        # page-locked host memory: the H2D copy runs at PCIe rate on a copy stream
