@@ -323,10 +323,26 @@ class StationScan(object):
         else:
             counts, bounds, planes_dev, T = shard['counts'], list(shard['bounds']), shard['planes'], shard['T']
         del shard
+        trimmed = False
         if counts is not None:
             # raw int32 counts in fragments: merged with zero fill on the device
-            # (construct.py:1038 / 1070); the per-chunk trimming follows below
-            planes_dev = _ingest_station(ctx, counts, Nc, T, getattr(fetcher, 'counts_pinned', {}).get(sta))
+            # (construct.py:1038 / 1070), then the per-chunk trimming.  Both on a helper context with a stream
+            # of its own: the upload runs beside the scans queued on this station's stream, and the host's
+            # wait for the longest gap-free runs is a wait for that helper stream only
+            pinned = getattr(fetcher, 'counts_pinned', {}).get(sta)
+            main = getattr(ctx, 'stream', None)
+            side = getattr(ss, '_side_ctx', None) if main is not None else None
+            if side is not None:
+                h = side(ctx.device, 2)
+                with torch.cuda.stream(h.stream):
+                    planes_dev = _ingest_station(h, counts, Nc, T, pinned)
+                    if not fillZeros:
+                        bounds = _trim_to_gapfree(h, planes_dev, counts, bounds, fetcher.sampling_rate, sta)
+                        trimmed = True
+                planes_dev.record_stream(main)
+                main.wait_stream(h.stream)
+            else:
+                planes_dev = _ingest_station(ctx, counts, Nc, T, pinned)
         elif planes_dev is None:
             planes_dev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
         sr_raw = sr
@@ -345,7 +361,7 @@ class StationScan(object):
         from .hip import h2d_async
         thr_dev = h2d_async(thr_arr, ctx.device)
         hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
-        if counts is not None and not fillZeros:
+        if counts is not None and not fillZeros and not trimmed:
             bounds = _trim_to_gapfree(ctx, rawdev, counts, bounds, fetcher.sampling_rate, sta)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
         bounds = [b for b in bounds
