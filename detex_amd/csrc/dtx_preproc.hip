@@ -99,6 +99,9 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 #ifndef DTX_PP_LOADS
 #define DTX_PP_LOADS 16
 #endif
+#ifndef DTX_PP_SCAN
+#define DTX_PP_SCAN 1        // entry states by pp_scan_kernel (0: pp_chain_kernel)
+#endif
 constexpr int kSub = 32;
 template <bool FIRST, bool RUN, bool LAST>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
@@ -229,6 +232,59 @@ __global__ __launch_bounds__(64) void pp_chain_kernel(double* __restrict__ fstat
     for (int k = 0; k < ns; ++k) p[k] += h[k];
     matvec(Ms, ns, h, tmp);
     for (int k = 0; k < ns; ++k) h[k] = tmp[k];
+  }
+}
+
+// The same entry states by a parallel scan: one workgroup of 256 threads per series walks the blocks in tiles of
+// 256; inside a tile the recurrence E_{i+1} = M E_i + f_i is an inclusive scan of h (h_0 = f_0 + M carry,
+// h_i = f_i) under "shift by 2^k blocks = multiply by M^(2^k)" -- eight steps with the eight matrices
+// Mpow[k] = M^(2^k) -- instead of one lane walking its segment block by block (pp_chain_kernel: 110 - 150 us per
+// launch whatever the size, two launches per zero-phase filter).
+constexpr int kScanT = 256, kScanSteps = 8;
+__global__ __launch_bounds__(kScanT) void pp_scan_kernel(double* __restrict__ fstate,
+                                                         const double* __restrict__ Mpow, int nblk, int ns) {
+  __shared__ double Ms[kScanSteps][4 * kMaxSec * kMaxSec];
+  __shared__ double P[2][kScanT][2 * kMaxSec + 1];
+  __shared__ double carry_s[2 * kMaxSec];
+  const int ser = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < kScanSteps * ns * ns; k += kScanT) Ms[k / (ns * ns)][k % (ns * ns)] = Mpow[k];
+  if (tid < 2 * kMaxSec) carry_s[tid] = 0.0;
+  __syncthreads();
+  double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
+  for (int t0 = 0; t0 < nblk; t0 += kScanT) {
+    const int b = t0 + tid;
+    const bool valid = b < nblk;
+    double h[2 * kMaxSec], tmp[2 * kMaxSec];
+    for (int k = 0; k < ns; ++k) h[k] = valid ? fs[(int64_t)b * (2 * kMaxSec) + k] : 0.0;
+    if (tid == 0) {
+      double c[2 * kMaxSec];
+      for (int k = 0; k < ns; ++k) c[k] = carry_s[k];
+      matvec(Ms[0], ns, c, tmp);
+      for (int k = 0; k < ns; ++k) h[k] += tmp[k];
+    }
+    int cur = 0;
+    for (int k = 0; k < ns; ++k) P[0][tid][k] = h[k];
+    __syncthreads();
+    for (int step = 0; step < kScanSteps; ++step) {
+      const int d = 1 << step;
+      if (tid >= d) {
+        double nb[2 * kMaxSec];
+        for (int k = 0; k < ns; ++k) nb[k] = P[cur][tid - d][k];
+        matvec(Ms[step], ns, nb, tmp);
+        for (int k = 0; k < ns; ++k) h[k] += tmp[k];
+      }
+      for (int k = 0; k < ns; ++k) P[cur ^ 1][tid][k] = h[k];
+      cur ^= 1;
+      __syncthreads();
+    }
+    // h = inclusive prefix = the entry state of block b + 1; block b's own entry state is its left neighbour's
+    if (valid)
+      for (int k = 0; k < ns; ++k)
+        fs[(int64_t)b * (2 * kMaxSec) + k] = tid == 0 ? carry_s[k] : P[cur][tid - 1][k];
+    __syncthreads();
+    if (tid == kScanT - 1)
+      for (int k = 0; k < ns; ++k) carry_s[k] = h[k];
+    __syncthreads();
   }
 }
 
@@ -367,11 +423,24 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
     }
     M.insert(M.end(), P.begin(), P.end());
   }
+  {  // M^(2^k), k = 0 .. kScanSteps - 1, for pp_scan_kernel
+    std::vector<double> P(M.begin(), M.begin() + (size_t)ns * ns), Q((size_t)ns * ns);
+    for (int e = 0; e < kScanSteps; ++e) {
+      M.insert(M.end(), P.begin(), P.end());
+      for (int r = 0; r < ns; ++r)
+        for (int c = 0; c < ns; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < ns; ++k) acc += P[(size_t)r * ns + k] * P[(size_t)k * ns + c];
+          Q[(size_t)r * ns + c] = acc;
+        }
+      P.swap(Q);
+    }
+  }
   Mkey.clear();
   // (kernels of earlier calls may still read the old matrices: wait for them before overwriting)
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if ((rc = dtx_reserve(ctx, Mbuf, (size_t)2 * kMaxSec * 2 * kMaxSec * 2 * sizeof(double)))) return rc;
-  DTX_HIP(ctx, hipMemcpy(Mbuf.p, M.data(), (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = dtx_reserve(ctx, Mbuf, (size_t)2 * kMaxSec * 2 * kMaxSec * (2 + kScanSteps) * sizeof(double)))) return rc;
+  DTX_HIP(ctx, hipMemcpy(Mbuf.p, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
   Mkey = key;
   pl->Mdev = (double*)Mbuf.p;
   return DTX_OK;
@@ -544,8 +613,16 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
                      (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
-  hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                     (const double*)(Mdev + ns * ns), nblk, seg, ns);
+  auto chain = [&]() {
+#if DTX_PP_SCAN
+    hipLaunchKernelGGL(pp_scan_kernel, cgrid, dim3(kScanT), 0, ctx->stream, fstate,
+                       (const double*)(Mdev + 2 * ns * ns), nblk, ns);
+#else
+    hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
+                       (const double*)(Mdev + ns * ns), nblk, seg, ns);
+#endif
+  };
+  chain();
   if (zerophase) {
     hipLaunchKernelGGL((pp_tiled_kernel<true, true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                        ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate, mid,
@@ -554,8 +631,7 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
                        ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
                        (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
-    hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                       (const double*)(Mdev + ns * ns), nblk, seg, ns);
+    chain();
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
     hipLaunchKernelGGL((pp_tiled_kernel<false, true, true>), grid, dim3(256), 0, ctx->stream, nof,
                        ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
