@@ -241,49 +241,73 @@ __global__ __launch_bounds__(64) void pp_chain_kernel(double* __restrict__ fstat
 // Mpow[k] = M^(2^k) -- instead of one lane walking its segment block by block (pp_chain_kernel: 110 - 150 us per
 // launch whatever the size, two launches per zero-phase filter).
 constexpr int kScanT = 256, kScanSteps = 8;
+// NS = 2 x sections at compile time: with a runtime count every loop below runs to the 16 states of eight
+// sections under predication (78 us per launch for two sections; 150 for the walk)
+template <int NS>
 __global__ __launch_bounds__(kScanT) void pp_scan_kernel(double* __restrict__ fstate,
-                                                         const double* __restrict__ Mpow, int nblk, int ns) {
-  __shared__ double Ms[kScanSteps][4 * kMaxSec * kMaxSec];
-  __shared__ double P[2][kScanT][2 * kMaxSec + 1];
-  __shared__ double carry_s[2 * kMaxSec];
+                                                         const double* __restrict__ Mpow, int nblk) {
+  __shared__ double Ms[kScanSteps][NS * NS];
+  __shared__ double P[2][kScanT][NS + 1];
+  __shared__ double carry_s[NS];
   const int ser = blockIdx.x, tid = threadIdx.x;
-  for (int k = tid; k < kScanSteps * ns * ns; k += kScanT) Ms[k / (ns * ns)][k % (ns * ns)] = Mpow[k];
-  if (tid < 2 * kMaxSec) carry_s[tid] = 0.0;
+  for (int k = tid; k < kScanSteps * NS * NS; k += kScanT) Ms[k / (NS * NS)][k % (NS * NS)] = Mpow[k];
+  if (tid < NS) carry_s[tid] = 0.0;
   __syncthreads();
+  auto mv = [&](const double* Mk, const double (&v)[NS], double (&out)[NS]) {
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) acc += Mk[r * NS + c] * v[c];
+      out[r] = acc;
+    }
+  };
   double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
   for (int t0 = 0; t0 < nblk; t0 += kScanT) {
     const int b = t0 + tid;
     const bool valid = b < nblk;
-    double h[2 * kMaxSec], tmp[2 * kMaxSec];
-    for (int k = 0; k < ns; ++k) h[k] = valid ? fs[(int64_t)b * (2 * kMaxSec) + k] : 0.0;
+    double h[NS], tmp[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) h[k] = valid ? fs[(int64_t)b * (2 * kMaxSec) + k] : 0.0;
     if (tid == 0) {
-      double c[2 * kMaxSec];
-      for (int k = 0; k < ns; ++k) c[k] = carry_s[k];
-      matvec(Ms[0], ns, c, tmp);
-      for (int k = 0; k < ns; ++k) h[k] += tmp[k];
+      double c[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) c[k] = carry_s[k];
+      mv(Ms[0], c, tmp);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) h[k] += tmp[k];
     }
     int cur = 0;
-    for (int k = 0; k < ns; ++k) P[0][tid][k] = h[k];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) P[0][tid][k] = h[k];
     __syncthreads();
+#pragma unroll
     for (int step = 0; step < kScanSteps; ++step) {
       const int d = 1 << step;
       if (tid >= d) {
-        double nb[2 * kMaxSec];
-        for (int k = 0; k < ns; ++k) nb[k] = P[cur][tid - d][k];
-        matvec(Ms[step], ns, nb, tmp);
-        for (int k = 0; k < ns; ++k) h[k] += tmp[k];
+        double nb[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) nb[k] = P[cur][tid - d][k];
+        mv(Ms[step], nb, tmp);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) h[k] += tmp[k];
       }
-      for (int k = 0; k < ns; ++k) P[cur ^ 1][tid][k] = h[k];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) P[cur ^ 1][tid][k] = h[k];
       cur ^= 1;
       __syncthreads();
     }
     // h = inclusive prefix = the entry state of block b + 1; block b's own entry state is its left neighbour's
-    if (valid)
-      for (int k = 0; k < ns; ++k)
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
         fs[(int64_t)b * (2 * kMaxSec) + k] = tid == 0 ? carry_s[k] : P[cur][tid - 1][k];
+    }
     __syncthreads();
-    if (tid == kScanT - 1)
-      for (int k = 0; k < ns; ++k) carry_s[k] = h[k];
+    if (tid == kScanT - 1) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) carry_s[k] = h[k];
+    }
     __syncthreads();
   }
 }
@@ -615,8 +639,16 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
                      (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
   auto chain = [&]() {
 #if DTX_PP_SCAN
-    hipLaunchKernelGGL(pp_scan_kernel, cgrid, dim3(kScanT), 0, ctx->stream, fstate,
-                       (const double*)(Mdev + 2 * ns * ns), nblk, ns);
+    const double* Mp = (const double*)(Mdev + 2 * ns * ns);
+    switch (ns) {
+#define DTX_SCAN_CASE(NS) case NS: hipLaunchKernelGGL(pp_scan_kernel<NS>, cgrid, dim3(kScanT), 0, ctx->stream, fstate, Mp, nblk); break
+      DTX_SCAN_CASE(2); DTX_SCAN_CASE(4); DTX_SCAN_CASE(6); DTX_SCAN_CASE(8);
+      DTX_SCAN_CASE(10); DTX_SCAN_CASE(12); DTX_SCAN_CASE(14); DTX_SCAN_CASE(16);
+#undef DTX_SCAN_CASE
+      default:
+        hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
+                           (const double*)(Mdev + ns * ns), nblk, seg, ns);
+    }
 #else
     hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
                        (const double*)(Mdev + ns * ns), nblk, seg, ns);
