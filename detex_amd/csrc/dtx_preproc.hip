@@ -39,6 +39,20 @@ __device__ inline double sos_step(const Sos& f, double x, double* z) {
   return x;
 }
 
+// the same with the section count at compile time: with a runtime count the loop is unrolled to the eight
+// sections the state array holds, under predication (a two-section band-pass paid for eight)
+template <int NSEC>
+__device__ __forceinline__ double sos_step_t(const Sos& f, double x, double* z) {
+#pragma unroll
+  for (int s = 0; s < NSEC; ++s) {
+    const double y = f.b0[s] * x + z[2 * s];
+    z[2 * s] = f.b1[s] * x - f.a1[s] * y + z[2 * s + 1];
+    z[2 * s + 1] = f.b2[s] * x - f.a2[s] * y;
+    x = y;
+  }
+  return x;
+}
+
 // per series: sums for the least-squares line a + b t (scipy.signal.detrend
 // type='linear'); kTrendSlices workgroups per series add their partial sums of
 // x and x (t - tc) with float64 atomics; trend_of() turns them into (a, b)
@@ -147,12 +161,25 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
     __syncthreads();
     if (valid) {
       const int64_t i0 = (int64_t)g * kPB + jj;
+      auto run = [&](auto nc) {
+        constexpr int NSEC = decltype(nc)::value;
 #pragma unroll 4
-      for (int j = 0; j < kSub; ++j) {
-        if (i0 + j < T) {
-          const double y = sos_step(f, tile[tid][j], z);
-          if (RUN) tile[tid][j] = y;
+        for (int j = 0; j < kSub; ++j) {
+          if (i0 + j < T) {
+            const double y = sos_step_t<NSEC>(f, tile[tid][j], z);
+            if (RUN) tile[tid][j] = y;
+          }
         }
+      };
+      switch (f.nsec) {                       // (uniform)
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
+        case 7: run(std::integral_constant<int, 7>{}); break;
+        default: run(std::integral_constant<int, 8>{}); break;
       }
     }
     if (RUN) {
