@@ -497,6 +497,23 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
   return DTX_OK;
 }
 
+// entry states of every block of every series: the scan kernel for its state count (the per-lane walk for an
+// odd one)
+static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int nser, int nblk, int seg, int ns) {
+  const dim3 cgrid((unsigned)nser);
+#if DTX_PP_SCAN
+  const double* Mp = Mdev + 2 * ns * ns;
+  switch (ns) {
+#define DTX_SCAN_CASE(NS) case NS: hipLaunchKernelGGL(pp_scan_kernel<NS>, cgrid, dim3(kScanT), 0, ctx->stream, fstate, Mp, nblk); return
+    DTX_SCAN_CASE(2); DTX_SCAN_CASE(4); DTX_SCAN_CASE(6); DTX_SCAN_CASE(8);
+    DTX_SCAN_CASE(10); DTX_SCAN_CASE(12); DTX_SCAN_CASE(14); DTX_SCAN_CASE(16);
+#undef DTX_SCAN_CASE
+    default: break;
+  }
+#endif
+  hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, Mdev, Mdev + ns * ns, nblk, seg, ns);
+}
+
 // ---------------------------------------------------------------- raw-count ingest
 // The front half of _applyFilter (detex/construct.py:1005-1022): a chunk arrives as FRAGMENTS of
 // raw int32 digitiser counts (ObsPy traces of one channel each, with gaps between them).
@@ -657,30 +674,13 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     return DTX_OK;
   }
   dim3 grid((unsigned)((nblk + 255) / 256), (unsigned)nser);
-  dim3 cgrid((unsigned)nser);
   const double* nod = nullptr;
   const float* nof = nullptr;
   // forward pass: raw - trend -> (mid | output)
   hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
                      (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
-  auto chain = [&]() {
-#if DTX_PP_SCAN
-    const double* Mp = (const double*)(Mdev + 2 * ns * ns);
-    switch (ns) {
-#define DTX_SCAN_CASE(NS) case NS: hipLaunchKernelGGL(pp_scan_kernel<NS>, cgrid, dim3(kScanT), 0, ctx->stream, fstate, Mp, nblk); break
-      DTX_SCAN_CASE(2); DTX_SCAN_CASE(4); DTX_SCAN_CASE(6); DTX_SCAN_CASE(8);
-      DTX_SCAN_CASE(10); DTX_SCAN_CASE(12); DTX_SCAN_CASE(14); DTX_SCAN_CASE(16);
-#undef DTX_SCAN_CASE
-      default:
-        hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                           (const double*)(Mdev + ns * ns), nblk, seg, ns);
-    }
-#else
-    hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, (const double*)Mdev,
-                       (const double*)(Mdev + ns * ns), nblk, seg, ns);
-#endif
-  };
+  auto chain = [&]() { launch_chain(ctx, fstate, (const double*)Mdev, nser, nblk, seg, ns); };
   chain();
   if (zerophase) {
     hipLaunchKernelGGL((pp_tiled_kernel<true, true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
@@ -722,9 +722,7 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
                      (float*)nullptr, 1, out_stride, 0);
-  hipLaunchKernelGGL(pp_chain_kernel, dim3((unsigned)nser), dim3(64), 0, ctx->stream, pl.fstate,
-                     (const double*)pl.Mdev, (const double*)(pl.Mdev + pl.ns * pl.ns), pl.nblk,
-                     pl.seg, pl.ns);
+  launch_chain(ctx, pl.fstate, (const double*)pl.Mdev, nser, pl.nblk, pl.seg, pl.ns);
   // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
   hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
                      ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
