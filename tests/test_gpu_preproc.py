@@ -111,6 +111,15 @@ def test_detex_on_raw_continuous_data(ctx, dec):
     assert len(got) == len(want) >= 3
     for (_, g), w in zip(got.iterrows(), sorted(want)):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and np.isfinite(g.SNR)
+    # the same call under another current stream (the short chunk groups are filtered on helper contexts with
+    # streams of their own, ordered against the station's stream) and with the per-station contexts of the
+    # SubSpace instead of the caller's: the same table
+    with torch.cuda.stream(torch.cuda.Stream()):
+        again = ss.detex(subspaceDB=None, estimateMags=True)
+    assert len(again['ss_df']) == len(got)
+    a2 = again['ss_df'].sort_values('STMP')
+    assert np.array_equal(a2.STMP.values, got.STMP.values) and np.allclose(a2.DS.values, got.DS.values, atol=1e-6)
+    assert np.allclose(a2.Mag.values.astype(float), got.Mag.values.astype(float), rtol=1e-5, equal_nan=True)
     # false-alarm statistics over every chunk of the same raw fetcher (fas.py:88-117)
     ss.getFAS(conDatNum=len(alld), staltalimit=None, seed=0)
     fas = ss.subspaces['XX.STA'].FAS.iloc[0]
