@@ -90,7 +90,7 @@ def _makeDFcclags(eventList, row, ctx):
     td = np.ascontiguousarray([row.MPtd[e] for e in eventList], dtype=np.float32)
     N = len(eventList)
     rank, world = parallel.dist_info()
-    if world > 1:
+    if parallel.dist_active():
         # one process per GPU: every rank correlates a contiguous range of the condensed pair
         # list (every pair costs the same), the slices are all-gathered
         npairs = N * (N - 1) // 2
@@ -177,7 +177,7 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
         if device is None:
             # one process per GPU: the launcher's LOCAL_RANK names this process's device
             from . import parallel
-            device = int(os.environ.get('LOCAL_RANK', 0)) if parallel.dist_info()[1] > 1 else 0
+            device = parallel.local_device()
         ctx = HipContext(device)
     try:
         for ind, row in TRDF.iterrows():

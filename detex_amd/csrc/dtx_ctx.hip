@@ -66,14 +66,19 @@ int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t byte
 
 int dtx_kev_next(dtx_ctx* ctx) {
   const int slot = (int)(ctx->kev_count % dtx_ctx::kKev);
-  if (!ctx->kev0[slot]) {
-    DTX_HIP(ctx, hipEventCreate(&ctx->kev0[slot]));
-    DTX_HIP(ctx, hipEventCreate(&ctx->kev1[slot]));
-  }
+  // (each event of the pair on its own: a create that failed half-way is completed by the next call)
+  if (!ctx->kev0[slot]) DTX_HIP(ctx, hipEventCreate(&ctx->kev0[slot]));
+  if (!ctx->kev1[slot]) DTX_HIP(ctx, hipEventCreate(&ctx->kev1[slot]));
   ctx->ev_k0 = ctx->kev0[slot];
   ctx->ev_k1 = ctx->kev1[slot];
-  ++ctx->kev_count;
   return DTX_OK;
+}
+
+// The pair handed out by dtx_kev_next has been recorded on both sides of the kernel: only now does the
+// slot count (a launch path that failed in between leaves the ring as it was -- the slot is reused).
+void dtx_kev_commit(dtx_ctx* ctx) {
+  ++ctx->kev_count;
+  ctx->kernel_timed = true;
 }
 
 int dtx_aux_fork(dtx_ctx* ctx) {

@@ -1066,7 +1066,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   }
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  ctx->kernel_timed = true;
+  dtx_kev_commit(ctx);
 #ifdef DTX_PP_STAMPS
   if (a.stamps) {       // dump the last launch's stamps: [workgroup][half][round][16], zeros = not taken
     std::vector<long long> h(stamp_n);

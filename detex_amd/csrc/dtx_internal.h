@@ -135,6 +135,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
 // dst_dev <- bytes of src_host, asynchronously on the context's stream; src_host may be reused at once
 int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int dtx_kev_next(dtx_ctx* ctx);      // ev_k0 / ev_k1 := the next pair of the ring
+void dtx_kev_commit(dtx_ctx* ctx);   // ... both recorded: the pair counts (dtx_kernel_ms_mean)
 int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
 int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.

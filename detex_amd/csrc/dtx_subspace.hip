@@ -795,7 +795,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  ctx->kernel_timed = true;
+  dtx_kev_commit(ctx);
   if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
   return DTX_OK;
 }

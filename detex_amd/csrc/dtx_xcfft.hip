@@ -495,6 +495,6 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   }
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  ctx->kernel_timed = true;
+  dtx_kev_commit(ctx);
   return DTX_OK;
 }

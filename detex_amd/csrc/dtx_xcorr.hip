@@ -250,6 +250,7 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
 }
 
 #ifndef DTX_XCFIN2
+static constexpr size_t kFin2PrefixBudget = (size_t)4 << 30;   // bytes of float64 prefix sums xc_finish2 may carve
 #define DTX_XCFIN2 1        // 1: xc_finish2_kernel for Nc <= 64, 0: xc_finish_kernel always
 #endif
 #ifndef DTX_XCFIN_ABLATE
@@ -765,7 +766,11 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   const size_t o_fs = carve((size_t)N * sizeof(float));
   const size_t o_fr = carve((size_t)N * sizeof(float));
   const size_t o_keys = carve((size_t)npairs * sizeof(unsigned long long));
-  const bool fin2 = DTX_XCFIN2 && Nc <= kFinPad;       // the second finishing kernel (float64 image of x_b, prefix sums)
+  // the second finishing kernel (float64 image of x_b, prefix sums of EVERY event: 16 (n + 1) bytes each --
+  // 1.25 GB at configs[2]).  Past kFin2PrefixBudget the first finishing kernel (no prefix workspace) takes
+  // over: 20 000 events would otherwise ask for 12 GB per context.
+  const bool fin2 = DTX_XCFIN2 && Nc <= kFinPad &&
+                    (size_t)2 * N * ((size_t)n + 1) * sizeof(double) <= kFin2PrefixBudget;
   const size_t o_ps = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
   const size_t o_pq = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
   const bool split = !use_fft && ctx->engine != DTX_ENGINE_FP32 && L >= kSplitMinL;
@@ -871,7 +876,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
     }
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  ctx->kernel_timed = true;
+  dtx_kev_commit(ctx);
   }
 
   if (fin2) {

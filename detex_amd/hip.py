@@ -84,7 +84,9 @@ class HipContext(object):
     In that case the context's stream first waits for the caller's (inputs produced there are
     complete) and the caller's stream waits for the context's afterwards (results are ordered
     for whatever the caller enqueues next): a call behaves as if it had been enqueued on the
-    caller's stream."""
+    caller's stream.  Result tensors are allocated from the context stream's pool: a caller that
+    consumes them on yet another stream than the one the call was made from orders that stream
+    itself (``t.record_stream(s)`` / ``s.wait_stream(ctx.stream)``), as with any torch tensor."""
 
     def __init__(self, device=0):
         self.lib = _lib.load()
@@ -120,9 +122,13 @@ class HipContext(object):
             yield
             return
         self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            yield
-        cur.wait_stream(self._stream)
+        try:
+            with torch.cuda.stream(self._stream):
+                yield
+        finally:
+            # also when the body raised (a failing batch is logged and skipped, detect.py:160-174):
+            # whatever it did enqueue stays ordered in front of the caller's next work
+            cur.wait_stream(self._stream)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -236,7 +242,6 @@ class HipContext(object):
             cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
         return hist, maxds, thr_t, key, val, cnt
 
-    @_on_ctx_stream
     @_on_ctx_stream
     def chunk_table(self, starts, lengths):
         """The device table of a ragged batch (dtx_subspace_scan_ragged): int64 [nchunk, 2] =

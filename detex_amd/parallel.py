@@ -24,6 +24,20 @@ def dist_info():
     return 0, 1
 
 
+def dist_active():
+    """True when a default process group exists -- also one of world size 1.  The product's
+    collectives (broadcast_banks, gather_rows, gather_condensed) run whenever this holds, so a
+    single-GPU box exercises RCCL exactly as an 8-GPU node does (only the peer count differs)."""
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized())
+
+
+def local_device():
+    """The GPU of this process: the launcher's LOCAL_RANK under a process group, else 0."""
+    import os
+    return int(os.environ.get('LOCAL_RANK', 0)) if dist_active() else 0
+
+
 def shard_units(nunits, rank, world):
     """Indices of the (station, day) units this rank scans: round-robin, so
     consecutive days of one station spread over all GPUs."""
@@ -116,7 +130,7 @@ def gather_rows(rows):
     gets the list over ranks.  Host objects, a few KB: not on the data path."""
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if not dist_active():
         return [rows]
     out = [None] * world
     COLLECTIVES['all_gather_object'] += 1
@@ -133,16 +147,20 @@ def broadcast_banks(banks, device, src=0):
     Returns [(U float32 ndarray, det_off int32, thresholds float64)] on every rank."""
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if not dist_active():
         return [(None if U is None else np.asarray(U, dtype=np.float32),
                  None if U is None else np.asarray(off, np.int32), thr) for (U, off, thr) in banks]
     meta = [None]
     if rank == src:
-        meta[0] = [None if U is None else (tuple(np.shape(U)), [int(v) for v in off],
-                                           [float(v) for v in thr]) for (U, off, thr) in banks]
+        # (a string instead of the list: `src` could not build its banks -- every rank raises together)
+        meta[0] = banks if isinstance(banks, str) else [
+            None if U is None else (tuple(np.shape(U)), [int(v) for v in off], [float(v) for v in thr])
+            for (U, off, thr) in banks]
     COLLECTIVES['broadcast_object'] += 1
     dist.broadcast_object_list(meta, src=src)
     meta = meta[0]
+    if isinstance(meta, str):
+        raise RuntimeError('rank %d could not build the detector banks: %s' % (src, meta))
     total = sum(m[0][0] * m[0][1] for m in meta if m is not None)
     if rank == src:
         flat = np.concatenate([np.asarray(U, dtype=np.float32).ravel() for (U, _, _) in banks
@@ -207,7 +225,7 @@ def gather_condensed(parts, ranges, npairs, device):
     every rank.  Used only to assemble the similarity matrix after the scan."""
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if not dist_active():
         return parts
     width = max(e - b for b, e in ranges)
     buf = torch.zeros(width, dtype=parts.dtype, device=device)

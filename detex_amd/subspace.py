@@ -613,7 +613,7 @@ class SubSpace(object):
               triggerLTATime=5, triggerSTATime=0, multiprocess=False, delOldCorrs=True,
               calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=True,
               classifyEvents=None, eventCorFile='EventCors', utcSaves=None, fillZeros=False,
-              device=0, ctx=None):
+              device=None, ctx=None):
         # (device / ctx: the GPU and, optionally, an existing HipContext to run on)
         """subspace.py:1745-1902: run every detector over the continuous data.
 
@@ -634,48 +634,50 @@ class SubSpace(object):
         if self.cfetcher is None:
             _error('no continuous-data fetcher attached (conDatFetcher)')
         rank, world = parallel.dist_info()
+        active = parallel.dist_active()     # a process group exists (also of one rank): the collectives run
         if subspaceDB is not None and delOldCorrs and rank == 0 and os.path.exists(subspaceDB):
             os.remove(subspaceDB)                           # subspace.py:1847-1854
         own_ctx = ctx is None
         if device is None:
             # one process per GPU: the launcher's LOCAL_RANK names this process's device
-            device = int(os.environ.get('LOCAL_RANK', 0)) if world > 1 else 0
+            device = parallel.local_device()
         dev = torch.device('cuda', int(device)) if own_ctx else ctx.device
-        if world > 1 and dev.type == 'cuda':
+        if active and dev.type == 'cuda':
             torch.cuda.set_device(dev)          # RCCL's object collectives run on the current device
         fetcher = self.cfetcher
         stations = [sta for sta in self.Stations if sta in fetcher.data]
-        bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
-        banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
+        results, failure = {}, None
+        bounds, banks = {}, {}
+        try:
+            bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
+            banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
+        except Exception as e:                              # noqa: BLE001
+            if not active:
+                raise
+            # the other ranks are (or will be) waiting in the broadcast below: take part in every
+            # collective of the call, then fail on every rank (the gather carries the marker)
+            failure = '%s: %s' % (type(e).__name__, e)
         sel = {sta: None for sta in stations}
-        if world > 1:
+        if active:
             # One process per GPU.  (station, day) units of ALL stations are dealt round-robin
             # (parallel.deal_station_chunks, as bench.py --config 4 deals them); rank 0's bases and
             # thresholds go to every rank in ONE broadcast (RCCL over xGMI, the only collective on
             # the data path); the rows come back in ONE gather after the last station.
-            per = max(1, int(round(86400.0 / fetcher.conDatDuration)))
-            dealt = parallel.deal_station_chunks([len(bounds[s]) for s in stations], per, rank, world)
-            sel = dict(zip(stations, dealt))
-            sent = parallel.broadcast_banks(
-                [(banks[s][2], banks[s][3], [banks[s][5][nm] for nm in banks[s][0]]) if banks[s][0]
-                 else (None, None, None) for s in stations], dev)
-            for sta, (Ub, offb, thrb) in zip(stations, sent):
-                if Ub is None:
-                    continue
-                names, kinds, U, det_off, offsets, thr = banks[sta]
-                # every rank (rank 0 too) scans with the numbers that were sent; the bank object is kept
-                # while they are the ones already resident (its basis images stay on the device)
-                held = self.__dict__.setdefault('_rank_banks', {}).get(sta)
-                if (held is not None and held[0][0] == names and np.array_equal(held[1], Ub) and
-                        np.array_equal(held[2], thrb)):
-                    banks[sta] = held[0]
-                else:
-                    banks[sta] = (names, kinds, Ub, offb, offsets, dict(zip(names, thrb)))
-                    self._rank_banks[sta] = (banks[sta], Ub, thrb)
-        todo = [sta for sta in stations if sel[sta] is None or len(sel[sta])]
+            try:
+                payload = failure if failure is not None else [
+                    (banks[s][2], banks[s][3], [banks[s][5][nm] for nm in banks[s][0]]) if banks[s][0]
+                    else (None, None, None) for s in stations]
+                sent = parallel.broadcast_banks(payload, dev)
+                if failure is None:
+                    per = max(1, int(round(86400.0 / fetcher.conDatDuration)))
+                    dealt = parallel.deal_station_chunks([len(bounds[s]) for s in stations], per, rank, world)
+                    sel = dict(zip(stations, dealt))
+                    self._adopt_sent_banks(stations, banks, sent)
+            except Exception as e:                          # noqa: BLE001
+                failure = failure or '%s: %s' % (type(e).__name__, e)
+        todo = [] if failure is not None else [sta for sta in stations if sel[sta] is None or len(sel[sta])]
         up = self._uploader(dev)
         up.reset()
-        results, failure = {}, None
 
         def collect(job):
             """Second half of a station: triggers, trigger-time estimates, rows."""
@@ -722,7 +724,7 @@ class SubSpace(object):
             while queue:
                 collect(queue.pop(0))
         except Exception as e:                              # noqa: BLE001
-            if world == 1:
+            if not active:
                 raise
             # the other ranks are (or will be) waiting in the gather below: take part in it with an
             # error marker instead of leaving them hung, then fail on every rank
@@ -730,9 +732,9 @@ class SubSpace(object):
                 job.close()
             failure = '%s: %s' % (type(e).__name__, e)
         self.last_run = dict(rank=rank, world=world, uploaded_bytes=up.bytes_uploaded,
-                             chunks={sta: (len(bounds[sta]) if sel[sta] is None else len(sel[sta]))
+                             chunks={sta: (len(bounds.get(sta, ())) if sel[sta] is None else len(sel[sta]))
                                      for sta in stations})
-        if world > 1:
+        if active:
             parts = parallel.gather_rows((results, failure))
             bad = [(r, p[1]) for r, p in enumerate(parts) if p[1] is not None]
             if bad:
@@ -755,6 +757,21 @@ class SubSpace(object):
         if subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         return out
+
+    def _adopt_sent_banks(self, stations, banks, sent):
+        """Every rank (rank 0 too) scans with the numbers that were broadcast; a bank object is kept
+        while they are the ones already resident (its basis images stay on the device)."""
+        for sta, (Ub, offb, thrb) in zip(stations, sent):
+            if Ub is None:
+                continue
+            names, kinds, U, det_off, offsets, thr = banks[sta]
+            held = self.__dict__.setdefault('_rank_banks', {}).get(sta)
+            if (held is not None and held[0][0] == names and np.array_equal(held[1], Ub) and
+                    np.array_equal(held[2], thrb)):
+                banks[sta] = held[0]
+            else:
+                banks[sta] = (names, kinds, Ub, offb, offsets, dict(zip(names, thrb)))
+                self._rank_banks[sta] = (banks[sta], Ub, thrb)
 
     def _uploader(self, dev):
         """One _StationUploader (copy stream + three device buffers) per device, kept for the life

@@ -186,7 +186,26 @@ def _configs3_worker(rank, world, port, q):
         failed = None
     except Exception as e:
         failed = str(e)
-    q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed))
+    # ... and neither must a failure BEFORE the basis broadcast: a rank that cannot build its
+    # banks still takes part in every collective of the call; whichever rank it is, all of them raise
+    early = []
+    for bad_rank in (1, 0):
+        orig = ss._detector_bank
+        if rank == bad_rank:
+            def boom(*a, **kw):
+                raise ValueError('no bank on rank %d' % rank)
+            ss._detector_bank = boom
+        try:
+            ss.detex(subspaceDB=None, ctx=ctx)
+            early.append(None)
+        except Exception as e:
+            early.append(str(e))
+        ss.__dict__.pop('_detector_bank', None)
+        assert ss._detector_bank == orig
+    # the group is still usable afterwards: same tables as before
+    again = ss.detex(subspaceDB=None, ctx=ctx)
+    assert again['ss_df'].values.tolist() == res['ss_df'].values.tolist()
+    q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed, early))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -216,7 +235,7 @@ def test_configs3_sharding_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     up = []
-    for rank, coll, last, scans, rows, hist, failed in res:
+    for rank, coll, last, scans, rows, hist, failed, early in res:
         # three collectives per call: shapes / thresholds (object), the bases (tensor), the rows
         assert coll == {'broadcast': 1, 'broadcast_object': 1, 'all_gather_object': 1, 'all_gather': 0}, coll
         want_bytes, dealt = _expected_upload(cf, stas, rank, world)
@@ -236,6 +255,7 @@ def test_configs3_sharding_world2():
             for nm, h in ss1.histSubSpaces[sta].items():
                 assert hist[sta][nm] == h.tolist()
         assert failed is not None and 'rank' in failed and 'injected fault' in failed
+        assert len(early) == 2 and all(e is not None and 'no bank on rank' in e for e in early), early
     # each rank moved about half of the data over the host link (plus the 120 s chunk overlap)
     assert max(up) < 0.52 * total and sum(up) < 1.01 * total
 
@@ -320,3 +340,13 @@ def test_configs3_sharding_world2_gpu_gloo():
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     _check_gpu_world2('gloo')
+
+
+def test_device_defaults_to_local_rank():
+    """SubSpace.detex and createCluster take the GPU from LOCAL_RANK when none is named
+    (one process per GPU); a literal default of 0 would put every rank on cuda:0."""
+    import inspect
+    from detex_amd import construct, parallel, subspace
+    assert inspect.signature(subspace.SubSpace.detex).parameters['device'].default is None
+    assert inspect.signature(construct.createCluster).parameters['device'].default is None
+    assert parallel.local_device() == 0 and not parallel.dist_active()        # no process group here
