@@ -248,6 +248,52 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
                     % (x.nbytes / 1e6)}
 
 
+def dist_overhead(local, timed_loop, steps, ms_plain, Uh, det_off, n):
+    """The same timed loop with a process group initialised: RCCL (backend 'nccl') at world size 1 on this
+    one GPU -- the rendezvous, the basis broadcast, the barriers around the timed region and the
+    max-over-ranks reduction of the driver's N > 1 contract all execute, only the peer count differs.
+    Reported next to the plain step so that the cost of being launched under torch.distributed is visible
+    in the N = 1 line (the N > 1 curve itself is the driver's to measure)."""
+    import socket
+    import torch.distributed as dist
+    from detex_amd import parallel
+    if dist.is_initialized():
+        return None
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dev = torch.device('cuda', local)
+    t0 = time.perf_counter()
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_init = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Ut, off = parallel.broadcast_basis(Uh, det_off, n, dev)        # three RCCL broadcasts (sizes, offsets, basis)
+        torch.cuda.synchronize()
+        t_bc = time.perf_counter() - t0
+        assert np.array_equal(Ut.cpu().numpy(), Uh) and list(off) == list(det_off)
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+        timed_loop(min(steps, 5), barrier)
+        dt, _ = timed_loop(steps, barrier)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finally:
+        dist.destroy_process_group()
+    ms = 1e3 * dt / steps
+    return {'backend': 'nccl (RCCL)', 'world_size': 1, 'steps': steps, 'ms_per_step_plain': ms_plain,
+            'ms_per_step_dist': ms, 'ratio': ms / ms_plain, 'init_s': t_init, 'basis_broadcast_ms': 1e3 * t_bc,
+            'note': 'process group initialised in-process; barrier + synchronize on both sides of the timed '
+                    'region, all_reduce(MAX) of the elapsed time -- the driver\'s N > 1 bracket at N = 1'}
+
+
 def xcorr_full(ctx, synth, Nc, cpu=True):
     """BASELINE configs[2] at full size: 2000 events x (3 x 13000) samples, 1 999 000 pairs."""
     N, L = 2000, 13000
@@ -510,6 +556,7 @@ def run_config4(a, rank, world, local, use_dist):
     hists = {s: torch.zeros((D, 400), dtype=torch.int32, device=dev) for s in ctxs}
 
     found = [0, 0]
+    digest = [0, 0]                                # candidates of the checked step: count, sum of window indices
 
     thr_dev = torch.from_numpy(thr).to(dev)       # (a host array would be copied up, synchronously, by every scan)
 
@@ -521,6 +568,8 @@ def run_config4(a, rank, world, local, use_dist):
             _, f = ctxs[s].subspace_scan(data[(s, d)], out=ds, thr=thr_dev, hist=hists[s], lazy=True)
             if check:
                 cb, cd, cp, cv = f()['cand']
+                digest[0] += int(len(cp))
+                digest[1] += int(cp.sum())
                 for (b, p, dd) in plants[(s, d)]:
                     assert ((cb == b) & (cd == dd) & (np.abs(cp - p) <= 2)).any(), (s, d, b, p, dd)
                     found[0] += 1
@@ -552,9 +601,9 @@ def run_config4(a, rank, world, local, use_dist):
         dt = float(t.item())
     windows = len(units) * a.chunks * P * a.steps
     if use_dist:
-        t = torch.tensor(found, dtype=torch.int64, device=dev)
+        t = torch.tensor(found + digest, dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        found = [int(v) for v in t.tolist()]
+        found, digest = [int(v) for v in t.tolist()[:2]], [int(v) for v in t.tolist()[2:]]
     for c in ctxs.values():
         c.close()
     return {'metric': 'detection windows/sec (24h 3-ch 100Hz, 200 templates)', 'value': windows / dt,
@@ -567,6 +616,7 @@ def run_config4(a, rank, world, local, use_dist):
                                       Nc, a.sr, world),
                        'engine': a.engine, 'station_days_per_gpu_max': -(-len(units) // world),
                        'planted_found': '%d/%d' % tuple(found),
+                       'candidates': {'n': digest[0], 'index_sum': digest[1]},
                        'resident_stream_gb_per_gpu': sum(v.numel() for v in data.values()) * 4 / 1e9,
                        'basis_broadcast_and_upload_s': t_up}}
 
@@ -588,6 +638,15 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when its first
+    # communicator comes up (flushed at exit, i.e. behind the line), and other libraries may print too: from
+    # here on file descriptor 1 is stderr; the line goes out through the saved descriptor (emit).
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(out_fd, (json.dumps(obj) + '\n').encode())
     # (tests on a one-GPU box: DTX_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and DTX_BENCH_BACKEND=gloo
     # carries the collectives -- the N > 1 code path without a second GPU; RCCL refuses two ranks per device)
     if os.environ.get('DTX_BENCH_ONE_DEVICE') == '1':
@@ -613,7 +672,7 @@ def main():
     if a.config == 4:
         out = run_config4(a, rank, world, local, use_dist)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -658,20 +717,24 @@ def main():
         step()()
     for _ in range(a.warmup):
         res = step()()
-    barrier()
-    t0 = time.perf_counter()
-    # K steps, each one's results fetched inside the timed region -- while the next step runs, as
-    # SubSpace.detex does with its stations (the copies to pinned host memory go on a side stream
-    # behind the step's post pass; nothing is skipped, the GPU just does not wait for the host)
-    pending = None
-    for _ in range(a.steps):
-        fetch = step()
-        if pending is not None:
-            res = pending()
-        pending = fetch
-    res = pending()
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_loop(steps, barrier):
+        # K steps, each one's results fetched inside the timed region -- while the next step runs, as
+        # SubSpace.detex does with its stations (the copies to pinned host memory go on a side stream
+        # behind the step's post pass; nothing is skipped, the GPU just does not wait for the host)
+        barrier()
+        t0 = time.perf_counter()
+        pending = res = None
+        for _ in range(steps):
+            fetch = step()
+            if pending is not None:
+                res = pending()
+            pending = fetch
+        res = pending()
+        barrier()
+        return time.perf_counter() - t0, res
+
+    dt, res = timed_loop(a.steps, barrier)
     # dominant-kernel time: HIP events the library records around the scan kernel of every call on the
     # context's stream (a ring of 64 pairs), read here, after the timed region: average launch duration
     # over its (last 64) steps
@@ -717,6 +780,8 @@ def main():
                                   a.chunk_seconds, Nc, a.sr, n),
                    'engine': eng if a.engine == eng else '%s -> %s' % (a.engine, eng),
                    'prewarm_s': a.prewarm, 'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants)),
+                   # digest of the last step's candidate list: equal between launch modes (plain / torchrun) on one box
+                   'candidates': {'n': int(len(cp)), 'index_sum': int(cp.sum()), 'value_sum': float(np.sum(cv, dtype=np.float64))},
                    'results': 'maxima and candidate lists of every step fetched to the host inside the timed '
                               'region, each while the next step runs (pinned buffers, side stream)'},
         'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
@@ -738,6 +803,11 @@ def main():
             out[key] = {'value': a.chunks * P / dto, 'unit': 'windows/s',
                         'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
         ctx.set_engine(a.engine)
+        try:
+            out['dist_overhead'] = dist_overhead(local, timed_loop, min(a.steps, 100), 1e3 * dt / a.steps,
+                                                 Uh, det_off, n)
+        except Exception as e:                         # noqa: BLE001 -- a secondary field never takes the line down
+            out['dist_overhead'] = {'error': repr(e)}
         out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, min(a.steps, 50))
         out['xcorr_full'] = xcorr_full(ctx, synth, Nc, cpu=not a.no_cpu_baseline)
         out['config5'] = config5(ctx, synth)
@@ -768,7 +838,7 @@ def main():
     else:
         out['cpu_baseline'] = None
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

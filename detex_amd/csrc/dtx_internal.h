@@ -143,6 +143,10 @@ int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
 // under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
 constexpr float kFftGuard = 200.f;
+// split-bf16 engine: windows per guard block, and the share of a window's energy one sample (times the basis'
+// largest column energy) may hold before the block goes to the float32 engine (dtx_subspace.hip)
+constexpr int kSplitGuardV = 1024;
+constexpr float kSplitGuardTau = 0.1f;
 // pb != NULL (ragged batch): chunk b's own window count; the pass covers p < min(P, pb[b])
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
                     const DtxPost& po, const int* pb = nullptr);

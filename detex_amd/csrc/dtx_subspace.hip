@@ -527,6 +527,72 @@ __global__ __launch_bounds__(256) void basis_tile_kernel(const float* __restrict
   }
 }
 
+// cmax = max over detectors d and columns q of sum_{k in d} U[k][q]^2: the largest share of a detector's
+// statistic a single sample can carry (split_guard_kernel).  One thread per (column, detector); the maximum of
+// non-negative floats is taken on their bit patterns.
+__global__ __launch_bounds__(256) void basis_colmax_kernel(const float* __restrict__ U, int n,
+                                                           const int32_t* __restrict__ doff,
+                                                           float* __restrict__ cmax) {
+  const int d = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  if (q < n)
+    for (int k = doff[d]; k < doff[d + 1]; ++k) {
+      const float u = U[(size_t)k * n + q];
+      s = fmaf(u, u, s);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = fmaxf(s, __shfl_xor(s, off, 64));
+  if ((threadIdx.x & 63) == 0 && s > 0.f) atomicMax(reinterpret_cast<unsigned*>(cmax), __float_as_uint(s));
+}
+
+// Guard of the split-bf16 contraction (ds_mfma_kernel_s).  Its products carry a relative error of ~2^-16
+// each; over a window they average out -- unless ONE sample carries the window (a spike, a glitch): then
+// delta DS ~ 2 * 2^-16 * (sum_k U[k][j]^2) * x_j^2 / den, up to 3e-5 when that sample's share of the statistic is
+// of order one.  A block of kSplitGuardV windows is listed for the float32 engine (whose products are exact
+// fused multiply-adds) when cmax * max x^2 over the samples its windows read exceeds kSplitGuardTau times the
+// smallest live window energy of the block: the listed blocks are recomputed right behind the split launch,
+// like the frequency-domain engine's guard list.  On ordinary data (no sample above a few sigma, orthonormal
+// bases of realistic length: cmax ~ K / n) the list is empty.
+__global__ __launch_bounds__(256) void split_guard_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc,
+                                                          int L, const float* __restrict__ den, int64_t Ppad,
+                                                          int64_t P, int V, int nblk,
+                                                          const float* __restrict__ cmax, float tau,
+                                                          int* __restrict__ list, const int* __restrict__ pb) {
+  __shared__ float red[8];
+  const int cb = blockIdx.x, tid = threadIdx.x;
+  const int chunk = cb / nblk, blk = cb - chunk * nblk;
+  if (pb != nullptr) P = min(P, (int64_t)pb[chunk]);     // ragged batch: the chunk's own windows
+  const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P);
+  if (w0 >= w1) return;
+  const float* d = den + (int64_t)chunk * Ppad;
+  float mn = 3.0e38f, mx = 0.f;
+  for (int64_t p = w0 + tid; p < w1; p += 256) {
+    const float dn = d[p];
+    if (dn > 0.f) mn = fminf(mn, dn);
+  }
+  const int64_t t1 = w1 + L - 1;                         // samples [w0, t1) of every channel plane
+  for (int c = 0; c < Nc; ++c) {
+    const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
+    for (int64_t t = w0 + tid; t < t1; t += 256) {
+      const float v = x[t];
+      mx = fmaxf(mx, v * v);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, off, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  }
+  if ((tid & 63) == 0) { red[tid >> 6] = mn; red[4 + (tid >> 6)] = mx; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[4 + q]); }
+    // (mn stays 3e38 when no window of the block is live: nothing to repair; a NaN sample lists the block)
+    if (!(cmax[0] * mx <= tau * mn)) list[1 + atomicAdd(list, 1)] = cb;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -560,7 +626,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   int rc;
   dtx_free_tiles_internal(ctx);
   if ((rc = dtx_reserve(ctx, ctx->U_buf, (size_t)Ktot * n * sizeof(float)))) return rc;
-  if ((rc = dtx_reserve(ctx, ctx->srow_all, (size_t)Ktot * sizeof(float)))) return rc;
+  if ((rc = dtx_reserve(ctx, ctx->srow_all, ((size_t)Ktot + 1) * sizeof(float)))) return rc;   // + cmax
   float* Ud = (float*)ctx->U_buf.p;
   float* srow_all = (float*)ctx->srow_all.p;
   hipPointerAttribute_t at;
@@ -579,6 +645,11 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   }
   hipLaunchKernelGGL(basis_rowsum_kernel, dim3((unsigned)Ktot), dim3(256), 0, ctx->stream,
                      (const float*)Ud, n, srow_all);
+  DTX_HIP(ctx, hipGetLastError());
+  // the split engine's guard constant (split_guard_kernel), behind the row sums in the same buffer
+  DTX_HIP(ctx, hipMemsetAsync(srow_all + Ktot, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(basis_colmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)D), dim3(256), 0, ctx->stream,
+                     (const float*)Ud, n, (const int32_t*)ctx->doff_all.p, srow_all + Ktot);
   DTX_HIP(ctx, hipGetLastError());
 
   // greedy packing of whole detectors into K-tiles of <= 208 rows; every image is built on the
@@ -720,6 +791,16 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
     list = (int*)ctx->ws_flag.p;
   }
+  // split-bf16 contraction: blocks of windows a single sample dominates go to the float32 engine
+  // (split_guard_kernel); templates shorter than kSplitMinL samples per channel stay on the float32 engine:
+  // with so few products per window the split products' 2^-17 errors do not average out (and the padding of
+  // L to the 32-sample steps of the bf16 MFMA would dominate anyway)
+  const bool split = !use_fft && ctx->engine != DTX_ENGINE_FP32 && ctx->L >= kSplitMinL;
+  const int gnblk = split ? (int)((P + kSplitGuardV - 1) / kSplitGuardV) : 0;
+  if (split) {
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * gnblk + 1) * sizeof(int)))) return rc;
+    list = (int*)ctx->ws_flag.p;              // (its counter is cleared by chunk_offset_final_kernel)
+  }
   hipLaunchKernelGGL(chunk_offset_kernel, dim3((unsigned)nsl, (unsigned)nchunk), dim3(256), 0, ctx->stream,
                      x_dev, M, chunk_stride, nsl, cslice, ctab);
   // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
@@ -773,10 +854,13 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
 
   i32x4* g16 = nullptr;
   const int64_t V = Tpad / 8;
-  // templates shorter than kSplitMinL samples per channel stay on the float32 engine:
-  // with so few products per window the split products' 2^-17 errors do not average out
-  // (and the padding of L to the 32-sample steps of the bf16 MFMA would dominate anyway)
-  if (ctx->engine != DTX_ENGINE_FP32 && ctx->L >= kSplitMinL) {
+  if (split) {
+    hipLaunchKernelGGL(split_guard_kernel, dim3((unsigned)(nchunk * gnblk)), dim3(256), 0, ctx->stream,
+                       (const float*)xp, Tpad, Nc, ctx->L, (const float*)den, Ppad, P, kSplitGuardV, gnblk,
+                       (const float*)ctx->srow_all.p + ctx->Ktot, kSplitGuardTau, list, (const int*)pb);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  if (split) {
     if ((rc = dtx_reserve(ctx, ctx->ws_g, (size_t)nchunk * Nc * 16 * V * sizeof(i32x4)))) return rc;
     g16 = (i32x4*)ctx->ws_g.p;
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
@@ -796,6 +880,17 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   dtx_kev_commit(ctx);
+  if (split)      // the guard's blocks again, on the float32 engine (a 256-workgroup launch that finds an empty list on ordinary data)
+    for (const DtxKTile& t : ctx->tiles) {
+      DsArgs a;
+      a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
+      a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
+      a.mean = mean; a.den = den; a.ds = ds_dev;
+      a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
+      a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
+      a.list = list; a.lV = kSplitGuardV; a.lnblk = gnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
+      if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
+    }
   if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
   return DTX_OK;
 }

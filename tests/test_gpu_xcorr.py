@@ -63,26 +63,44 @@ def _check_pair(x1, x2, Nc, got, what):
     return 'ok'
 
 
+# The 14 golden cases on which the build deliberately differs from the reference.  The two
+# events are identical (or identical up to a constant offset): the true maximum is cc = 1 at lag 0, but the
+# reference's float64 round-off lands a hair ABOVE 1 there, its scrub (construct.py:458-462: every value > 1 or
+# < -1 is set to 0 and the maximum taken again) removes the true peak and a side lobe wins.  The build scrubs at
+# |cc| > 1 + 1e-5 and keeps the peak.  name: (reference cc, reference lag) -- read from the fixture and asserted
+# below -- against the build's (1.0, 0).  Every OTHER case (56, the 20 zero_tail / zeroed_chan ones included) must
+# equal the reference's own output.
+KNIFE = {
+    'c008': (0.7901441, -1), 'c010': (0.5618626, -1), 'c016': (0.8101324, 3), 'c018': (0.5822324, 3),
+    'c024': (0.5824542, 3), 'c030': (0.8168820, -3), 'c032': (0.8192597, -3), 'c036': (0.8231192, 3),
+    'c038': (0.7938896, 3), 'c052': (0.6192905, 6), 'c058': (0.4627540, -2), 'c060': (0.2692443, -8),
+    'c064': (0.4729424, -2), 'c066': (0.3145494, -8),
+}
+
+
 def test_golden_ccx2_pairs(ctx):
-    """Every golden _CCX2 case as a 2-event problem; compared with the reference
-    output where the case is not a knife-edge, and with the oracle always."""
+    """Every golden _CCX2 case as a 2-event problem against the REFERENCE's output (cc 1e-5, lag exact,
+    subsamp 1e-4), except the 14 listed knife-edge cases, which are held to the build's documented answer
+    with the reference's value beside it."""
     z = np.load(os.path.join(G, 'ccx2.npz'))
-    stats = {'ok': 0, 'knife': 0, 'tie': 0}
-    nref = 0
+    seen = set()
     for nm in z['names']:
         key = nm.split(':')[0]
         x1, x2, Nc = z[key + '_x1'], z[key + '_x2'], int(z[key + '_Nc'])
         cc, lag, ss = _gpu(ctx, np.stack([x1, x2]), Nc)
         got = (float(cc[0]), int(lag[0]), float(ss[0]))
-        kind = _check_pair(x1, x2, Nc, got, nm)
-        stats[kind] += 1
         ref = z[key + '_out']
-        if kind == 'ok' and 'zero' not in nm:
-            assert abs(got[0] - ref[0]) <= 1e-5 and got[1] == ref[1], (nm, got, ref)
-            if abs(ref[2]) <= .5:
-                assert abs(got[2] - ref[2]) <= 1e-4, (nm, got, ref)
-            nref += 1
-    assert stats["ok"] >= 45 and nref >= 28, (stats, nref)
+        if key in KNIFE:
+            seen.add(key)
+            assert 'identical' in nm or 'offset' in nm
+            assert abs(ref[0] - KNIFE[key][0]) <= 1e-6 and int(ref[1]) == KNIFE[key][1], (nm, ref)   # the reference's answer
+            assert abs(got[0] - 1.0) <= 1e-5 and got[1] == 0, (nm, got)                              # the build's
+            continue
+        assert abs(got[0] - ref[0]) <= 1e-5 and got[1] == int(ref[1]), (nm, got, ref)
+        if abs(ref[2]) <= .5:
+            assert abs(got[2] - ref[2]) <= 1e-4, (nm, got, ref)
+        _check_pair(x1, x2, Nc, got, nm)                    # and the oracle agrees
+    assert seen == set(KNIFE) and len(z['names']) == 70
 
 
 def test_golden_cclags_matrix(ctx):
