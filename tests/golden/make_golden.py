@@ -27,6 +27,8 @@ Reference entry points exercised (file:line in /root/reference):
                               486-504 _alignTD (+ _ensureUnique, _makeCC2LagMap,
                               the createSubSpace lines 273-285 around them)
                                               -> delays.npz
+  detex/construct.py:425-466  _CCX2 at n = 39 000, detex/detect.py:559-578 _MPXDS at
+                              M = 1 116 000 (BASELINE sizes, inputs from seeds) -> fullsize.npz
   detex/results.py:371-400    _deleteDetDups, 403-458 _associateDetections,
                               476-503 _createDetTable / _createAutoTable,
                               231-293 _verifyEvents -> assoc.json
@@ -565,6 +567,55 @@ def gen_assoc():
     print('assoc.json written', [(len(c['Dets']), len(c['Autos']), len(c['Vers'])) for c in cases])
 
 
+# ---------------------------------------------------------------- full-size cases
+# The pairs / window samples of fullsize.npz (shared with the tests through the fixture itself)
+FULL_XC = dict(seed=11, nfam=2, nper=4, Nc=3, L=13000, pairs=[(0, 1), (0, 4), (1, 3), (2, 7)])
+FULL_DS = dict(bank_seed=12, day_seed=13, K=8, Nc=3, L=3000, M=1116000, nplant=5, nsample=2000)
+
+
+def gen_fullsize():
+    """The reference at the BASELINE sizes: _CCX2 on four pairs of 3 x 13 000
+    samples (n = 39 000: configs[2]) and _MPXDS on one chunk of 1 116 000 samples against one 8-vector
+    detector of n = 9000 (configs[1]).  Inputs are NOT stored: they are regenerated from the seeds with
+    detex_amd/synth.py (NumPy RandomState streams, float32 values handed to the reference as float64);
+    stored are (cc, lag, subsamp) per pair and 2000 sampled DS values."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from detex_amd import synth
+    out = {}
+    c = FULL_XC
+    td = synth.event_families(c['seed'], c['nfam'], c['nper'], c['Nc'], c['L']).astype(np.float64)
+    fd = lambda x: scipy.fftpack.fft(x, n=2 ** int(2 * len(x)).bit_length())  # noqa: E731
+    res = []
+    for (b, e) in c['pairs']:
+        cc, lag, ss = construct._CCX2(fd(td[b]), fd(td[e]), td[b], td[e], [0] * c['Nc'], [0] * c['Nc'])
+        res.append([cc, lag, ss])
+    out['xc_params'] = np.array([c['seed'], c['nfam'], c['nper'], c['Nc'], c['L']], dtype=np.int64)
+    out['xc_pairs'] = np.array(c['pairs'], dtype=np.int64)
+    out['xc_out'] = np.array(res, dtype=np.float64)
+    d = FULL_DS
+    n = d['Nc'] * d['L']
+    U, off = synth.detector_bank(d['bank_seed'], 1, d['K'], n)
+    x, plants = synth.continuous_day(d['day_seed'], 1, d['M'], d['Nc'], U, off, nplant=d['nplant'])
+    ds = _ref_mpxds(x[0].astype(np.float64), U.astype(np.float64), d['Nc'])
+    P = (d['M'] - n) // d['Nc'] + 1
+    assert len(ds) == P
+    rs = np.random.RandomState(14)
+    idx = set(int(v) for v in rs.choice(P, d['nsample'] - 3 * len(plants) - 2, replace=False))
+    for (_, p, _) in plants:                       # the peaks and their flanks
+        idx.update([p - 1, p, p + 1])
+    idx.update([0, P - 1])
+    idx = np.array(sorted(i for i in idx if 0 <= i < P), dtype=np.int64)
+    out['ds_params'] = np.array([d['bank_seed'], d['day_seed'], d['K'], d['Nc'], d['L'], d['M'], d['nplant']],
+                                dtype=np.int64)
+    out['ds_plants'] = np.array([p for (_, p, _) in plants], dtype=np.int64)
+    out['ds_index'] = idx
+    out['ds_value'] = np.asarray(ds, dtype=np.float64)[idx]
+    out['ds_max'] = np.array([float(np.max(ds)), float(np.argmax(ds))])
+    np.savez_compressed(os.path.join(HERE, 'fullsize.npz'), **out)
+    print('fullsize.npz: %d pairs at n = %d, %d DS samples of %d windows; cc %s'
+          % (len(res), c['Nc'] * c['L'], len(idx), P, np.round(out['xc_out'][:, 0], 4)))
+
+
 if __name__ == '__main__':
     gen_ccx2()
     gen_cclags()
@@ -575,3 +626,4 @@ if __name__ == '__main__':
     gen_svd()
     gen_delays()
     gen_assoc()
+    gen_fullsize()

@@ -504,3 +504,36 @@ def test_bench_two_ranks_on_one_gpu(config):
         assert d['scaling'] == 'strong' and d['config']['planted_found'] == '30/30'
         want = 6 * 4 * P
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - want) <= 1e-6 * want
+
+
+def test_fullsize_reference_fixture(ctx):
+    """The HIP path at the BASELINE sizes against outputs of the REFERENCE ITSELF run at those sizes
+    (tests/golden/fullsize.npz, make_golden.gen_fullsize): _CCX2 on four pairs of
+    n = 39 000 samples -- cc 1e-5, lag exact, subsamp 1e-4 -- and _MPXDS on 2000 sampled windows (planted
+    peaks and their flanks included) of one 1 116 000-sample chunk x one 8-vector detector -- 1e-5."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_golden import fullsize_inputs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fullsize.npz'))
+    td, Nc, U, off, x, dNc = fullsize_inputs(z)
+    N = len(td)
+    ctx.set_engine('auto')
+    cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).cuda(), Nc)
+    ctx.sync()
+    cc, lag, ss = cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy()
+    for (b, c), ref in zip(z['xc_pairs'], z['xc_out']):
+        i = _cidx(N, int(b), int(c))
+        assert abs(cc[i] - ref[0]) <= 1e-5 and lag[i] == int(ref[1]), ((b, c), cc[i], lag[i], ref)
+        assert abs(ss[i] - ref[2]) <= 1e-4, ((b, c), ss[i], ref)
+    for eng in ('auto', 'bf16x3'):
+        ctx.set_engine(eng)
+        ctx.upload_basis(U, off, dNc)
+        ds = ctx.subspace_ds(torch.from_numpy(x).cuda())
+        ctx.sync()
+        got = ds[0, 0].cpu().numpy().astype(np.float64)
+        assert len(got) == (x.shape[1] - U.shape[1]) // dNc + 1
+        err = float(np.max(np.abs(got[z['ds_index']] - z['ds_value'])))
+        assert err <= 1e-5, (eng, err)
+        assert int(np.argmax(got)) == int(z['ds_max'][1]) and abs(float(got.max()) - z['ds_max'][0]) <= 1e-5
+    ctx.set_engine('auto')

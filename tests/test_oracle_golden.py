@@ -215,3 +215,29 @@ def test_svd_basis_properties():
         x = np.concatenate([rs.randn(300) * 0.01, w, rs.randn(300) * 0.01])
         ds = orc.mpxds_direct(x, U[:, :nd].T, 1)
         assert ds.max() > thr * 0.9
+
+
+def fullsize_inputs(z):
+    """The inputs of fullsize.npz, regenerated from its seeds with detex_amd/synth.py (the fixture stores
+    the reference's outputs only: make_golden.gen_fullsize)."""
+    from detex_amd import synth
+    seed, nfam, nper, Nc, L = (int(v) for v in z['xc_params'])
+    td = synth.event_families(seed, nfam, nper, Nc, L)
+    bank_seed, day_seed, K, dNc, dL, M, nplant = (int(v) for v in z['ds_params'])
+    U, off = synth.detector_bank(bank_seed, 1, K, dNc * dL)
+    x, plants = synth.continuous_day(day_seed, 1, M, dNc, U, off, nplant=nplant)
+    assert [p for (_, p, _) in plants] == z['ds_plants'].tolist()
+    return td, Nc, U, off, x, dNc
+
+
+def test_oracle_at_baseline_sizes_matches_reference():
+    """The oracle at the BASELINE sizes against the reference run there (fullsize.npz): _CCX2 on four pairs
+    of n = 39 000 samples, _MPXDS on 2000 windows of a 1 116 000-sample chunk x one 8-vector detector."""
+    z = _load('fullsize.npz')
+    td, Nc, U, off, x, dNc = fullsize_inputs(z)
+    for (b, c), ref in zip(z['xc_pairs'], z['xc_out']):
+        cc, lag, ss, _ = orc.ccx2_fft(td[b].astype(np.float64), td[c].astype(np.float64), Nc)
+        assert abs(cc - ref[0]) <= 1e-9 and lag == ref[1] and abs(ss - ref[2]) <= 1e-6, ((b, c), cc, lag, ss, ref)
+    ds = orc.mpxds_fft(x[0].astype(np.float64), U.astype(np.float64), dNc)
+    assert np.max(np.abs(ds[z['ds_index']] - z['ds_value'])) <= 1e-9
+    assert int(np.argmax(ds)) == int(z['ds_max'][1]) and abs(float(ds.max()) - z['ds_max'][0]) <= 1e-9
