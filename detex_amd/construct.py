@@ -7,14 +7,12 @@ reference's Python pair loop is replaced by ONE call into the HIP library
 dendrogram cut, alignment by accumulated lags, Harris 2006 App. B) is host logic
 on tiny arrays and follows the reference line by line.
 """
-import os
-
 import numpy as np
 import pandas as pd
 from scipy.cluster.hierarchy import linkage
 
 from ._lib import DetexHipError
-from .getdata import EventFetcher, multiplex
+from .getdata import EventFetcher, multiplex, trim_window
 
 
 def _error(msg, exc=DetexHipError):
@@ -26,20 +24,143 @@ def _error(msg, exc=DetexHipError):
 # event loading                                   construct.py:615-706
 # --------------------------------------------------------------------------
 
-def _loadEvents(fetcher, dtype):
-    """construct.py:615-655 on an EventFetcher: one row per station with
-    Events (sorted), MPtd {event: multiplexed float array}, Channels, Stats."""
+def _warn(msg):
+    """detex.log(level='warning', pri=True)."""
+    import logging
+    logging.getLogger('detex_amd.construct').warning(msg)
+
+
+def _preprocess_events(ctx, fetcher, sta, filt, trim, decimate, fillZeros=False):
+    """Raw template records of one station -> filtered waveforms, on the device: what the reference's
+    ``fetcher.getTemData(temkey, csta, trim[0], trim[1])`` + ``_applyFilter(st, filt, decimate, dtype)``
+    do per event (construct.py:866-869, 990-1030; getdata.py:441-444), in the reference's order:
+
+      cut [origin - trim[0], origin + trim[1]] out of the record (ObsPy trim, getdata.trim_window)
+      -> a record in several traces per channel: merged with zero fill and cut to its longest stretch
+         without a gap or a zero in any channel (_mergeChannels, 1033-1066; dtx_ingest_counts +
+         dtx_gapfree_run), dropped if that stretch is still in several traces ('Stream is too fractured',
+         1011-1018); fillZeros: merged only (_mergeChannelsFill)
+      -> decimate (1016-1017, dtx_decimate) -> detrend('linear') + band-pass (1024-1028, dtx_preprocess)
+
+    Events of equal length go through the kernels as one batch.  Returns [(name, [Nc, L'] float32 array,
+    time of the first sample)] in event-name order."""
+    import torch
+    from .detect import _trim_to_gapfree
+    sr = fetcher.sampling_rate
+    Nc = len(fetcher.channels)
+    dec = int(decimate or 1)
+    cut = []                                   # (name, [Nc, cnt] host array or device planes, start time)
+    for name, rec in fetcher.getTemData(sta):
+        t0, T = rec['starttime'], rec['nsamples']
+        i0, cnt = trim_window(t0, T, sr, rec['origintime'] - trim[0], rec['origintime'] + trim[1])
+        if cnt <= 0:
+            _warn('no data on %s around %s' % (sta, name))
+            continue
+        if rec['counts'] is None:
+            cut.append((name, np.asarray(rec['data'][:, i0:i0 + cnt], dtype=np.float32), t0 + i0 / sr))
+            continue
+        # the traces that reach into the window, clipped to it and re-based to its first sample
+        frs = []
+        for (c, f0, x) in rec['counts']:
+            lo, hi = max(f0, i0), min(f0 + len(x), i0 + cnt)
+            if hi > lo:
+                frs.append((c, lo - i0, x[lo - f0:hi - f0]))
+        off, tab = 0, []
+        for (c, f0, x) in frs:
+            tab.append((c, off, f0, len(x)))
+            off += len(x)
+        flat = np.concatenate([x for (_, _, x) in frs]) if frs else np.zeros(0, np.int32)
+        planes, _ = ctx.ingest_counts(torch.from_numpy(flat).to(ctx.device), tab, Nc, cnt, want_run=False)
+        bounds = [(0, cnt, t0 + i0 / sr, 0)]
+        if fillZeros:
+            if len(set(c for (c, _, _) in frs)) < Nc:
+                _warn('%s on %s is fractured or channels are missing' % (name, sta))
+                continue
+        else:
+            bounds = _trim_to_gapfree(ctx, planes, frs, bounds, sr, sta)
+        if not bounds:
+            _warn('%s on %s is fractured or channels are missing, skipping' % (name, sta))   # construct.py:878-883
+            continue
+        s0, m, ts, _ = bounds[0]
+        cut.append((name, planes[:, s0:s0 + m], ts))
+    # batches of equal length through decimate / detrend / band-pass / multiplex
+    out = {}
+    groups = {}
+    for k, (name, arr, ts) in enumerate(cut):
+        groups.setdefault(int(arr.shape[1]), []).append(k)
+    for m, ks in groups.items():
+        if all(isinstance(cut[k][1], np.ndarray) for k in ks):
+            planes = torch.from_numpy(np.stack([cut[k][1] for k in ks])).to(ctx.device)     # one upload
+        else:
+            planes = torch.stack([cut[k][1] if torch.is_tensor(cut[k][1])
+                                  else torch.from_numpy(cut[k][1]).to(ctx.device) for k in ks])
+        if dec > 1:
+            planes = ctx.decimate(planes, dec, sr)
+        mp = ctx.preprocess(planes, filt=list(filt) if isinstance(filt, (list, tuple)) else None,
+                            sampling_rate=sr / dec)
+        ctx.sync()
+        mp = mp.cpu().numpy()
+        Lm = mp.shape[1] // Nc
+        for row, k in zip(mp, ks):
+            out[cut[k][0]] = (row.reshape(Lm, Nc).T, cut[k][2])
+    return [(name, out[name][0], out[name][1]) for (name, _, _) in cut]
+
+
+def _loadEvents(fetcher, dtype, filt=None, trim=None, decimate=None, enforceOrigin=False, fillZeros=False,
+                ctx=None):
+    """construct.py:615-655 (+ _loadStream 852-925) on an EventFetcher: one row per station with
+    Events (sorted), MPtd {event: multiplexed float array}, Channels, Stats.  Raw records
+    (EventFetcher.add_raw / add_counts) are cut, decimated and filtered on the device first
+    (_preprocess_events); waveforms added with ``add`` are taken as already processed."""
     np_dtype = np.float32 if dtype == 'single' else np.float64
     rows = []
+    Nc = len(fetcher.channels)
     for sta in fetcher.stations():
         mptd, stats, chans = {}, {}, {}
-        for name, rec in fetcher.getTemData(sta):
-            mptd[name] = multiplex(list(np.asarray(rec['data'], dtype=np_dtype)))
-            stats[name] = dict(Nc=len(fetcher.channels), sampling_rate=fetcher.sampling_rate,
-                               starttime=rec['starttime'], origintime=rec['origintime'],
-                               magnitude=rec['magnitude'],
-                               offset=rec['starttime'] - rec['origintime'])
+        raw = fetcher.has_raw(sta)
+        if raw:
+            if not all(rec.get('raw') for _, rec in fetcher.getTemData(sta)):
+                _error('station %s mixes raw and pre-processed events' % sta, ValueError)
+            if ctx is None:
+                _error('raw template events need a GPU context')
+            done = _preprocess_events(ctx, fetcher, sta, filt, trim, decimate, fillZeros)
+            sr = fetcher.sampling_rate / int(decimate or 1)
+        else:
+            done = [(name, rec['data'], rec['starttime']) for name, rec in fetcher.getTemData(sta)]
+            sr = fetcher.sampling_rate
+        allzeros, lens = [], {}
+        for name, data, start in done:
+            rec = fetcher.events[sta][name]
+            data = np.asarray(data, dtype=np_dtype)
+            if enforceOrigin and raw:
+                # construct.py:884-885: st.trim(starttime=originTime, pad=True, fill_value=0.0)
+                k = int(round((rec['origintime'] - start) * sr))
+                data = data[:, k:] if k >= 0 else np.concatenate(
+                    [np.zeros((data.shape[0], -k), dtype=np_dtype), data], axis=1)
+                start = start + k / sr
+            if data.shape[1] == 0:
+                continue
+            if any(not np.any(c) for c in data):                  # construct.py:896-897
+                allzeros.append(name)
+            mptd[name] = multiplex(list(data))
+            lens[name] = data.size                                # STlens: total samples of the stream
+            stats[name] = dict(Nc=Nc, sampling_rate=sr, starttime=start, origintime=rec['origintime'],
+                               magnitude=rec['magnitude'], offset=start - rec['origintime'])
             chans[name] = list(fetcher.channels)
+        if raw and mptd:
+            # construct.py:901-916: fractured / very short waveforms (< 20 % of the median length) and
+            # waveforms with an all-zero channel are removed
+            mlen = np.median(list(lens.values()))
+            for key in [k for k in mptd if lens[k] < mlen * .2]:
+                _warn('%s is fractured or missing data, removing' % key)
+                mptd.pop(key), stats.pop(key), chans.pop(key)
+            for key in set(allzeros):
+                if key in mptd:
+                    _warn('%s has at least one channel that is all zeros, deleting' % key)
+                    mptd.pop(key), stats.pop(key), chans.pop(key)
+            if len(mptd) < 2:                                     # construct.py:918-922
+                _warn('Less than 2 events survived preprocessing for station %s' % sta)
+                continue
         if not mptd:
             continue
         # construct.py:679-694 _testStreamLengths: trim to the smallest length that is
@@ -148,30 +269,39 @@ def _checkClusterInputs(filt, dtype, trim, decimate):
         _error('decimate must be None or a positive int', ValueError)
 
 
+_WARNED_DOUBLE = [False]
+
+
+def _warn_double_once(dtype):
+    """construct.py:34, 199-201: dtype='double' is the reference's default.  The device path computes in
+    float32 (float64 window statistics and accumulations) whatever is asked for."""
+    if dtype == 'double' and not _WARNED_DOUBLE[0]:
+        _WARNED_DOUBLE[0] = True
+        _warn("dtype='double': host arrays are float64, the HIP kernels compute in float32 with float64 "
+              "accumulations (detection statistics and CC coefficients within 1e-5 of the float64 path)")
+
+
 def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=None,
                   templateKey=None, trim=[10, 120], saveclust=True, fileName='clust.pkl',
                   decimate=None, dtype='double', eventsOnAllStations=False,
                   enforceOrigin=False, fillZeros=False, phases=None, device=None, ctx=None):
     """Create a ClusterStream (detex/construct.py:25-171).
 
-    Differences from the reference, all outside the hot path: ``fetch_arg`` is an
-    ``EventFetcher`` holding pre-processed waveforms (ObsPy I/O and filtering are
-    out of scope); ``stationKey`` / ``templateKey`` / ``phases`` are accepted and
-    stored but the station and event lists come from the fetcher; ``filt``,
-    ``trim`` and ``decimate`` are recorded (they describe how the data WERE
-    processed).  ``device`` / ``ctx`` select the GPU context."""
+    ``fetch_arg`` is an ``EventFetcher``.  Raw records in it (``add_raw`` / ``add_counts``) are cut to
+    [origin - trim[0], origin + trim[1]], decimated by ``decimate``, detrended and band-passed with ``filt``
+    on the device before they are correlated (construct.py:852-925, 990-1030); waveforms it holds as already
+    processed (``add``) are taken as they are, and ``filt`` / ``trim`` / ``decimate`` then only describe how
+    they WERE processed (they are still what SubSpace.detex applies to raw continuous data).  Outside the
+    hot path: ``stationKey`` / ``templateKey`` / ``phases`` are accepted and stored, the station and event
+    lists come from the fetcher (ObsPy I/O is out of scope).  ``dtype='double'`` (the reference's default)
+    selects float64 host arrays; the device arithmetic is float32 with float64 accumulations, within 1e-5
+    of the float64 path (BASELINE north_star) -- warned about once.  ``device`` / ``ctx`` select the GPU."""
     from .subspace import ClusterStream
     from .hip import HipContext
     _checkClusterInputs(filt, dtype, trim, decimate)
     if not isinstance(fetch_arg, EventFetcher):
         _error('fetch_arg must be a detex_amd.getdata.EventFetcher', TypeError)
-    TRDF = _loadEvents(fetch_arg, dtype)
-    if len(TRDF) < 1:
-        _error('No events survived pre-processing, check DataFetcher and event quality')
-    if eventsOnAllStations:
-        eventList = sorted(set.intersection(*[set(x) for x in TRDF.Events]))
-        if len(eventList) < 2:
-            _error('less than 2 events in population have required stations')
+    _warn_double_once(dtype)
     own = ctx is None
     if own:
         if device is None:
@@ -180,6 +310,13 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
             device = parallel.local_device()
         ctx = HipContext(device)
     try:
+        TRDF = _loadEvents(fetch_arg, dtype, filt, trim, decimate, enforceOrigin, fillZeros, ctx)
+        if len(TRDF) < 1:
+            _error('No events survived pre-processing, check DataFetcher and event quality')
+        if eventsOnAllStations:
+            eventList = sorted(set.intersection(*[set(x) for x in TRDF.Events]))
+            if len(eventList) < 2:
+                _error('less than 2 events in population have required stations')
         for ind, row in TRDF.iterrows():
             if not eventsOnAllStations:
                 eventList = list(row.Events)

@@ -19,13 +19,32 @@ def multiplex(chans):
     return np.vstack([c[:L] for c in chans]).flatten(order='F')
 
 
-class EventFetcher(object):
-    """Template-event waveforms of one or more stations, already filtered and
-    trimmed (the ``fetcher.getTemData`` + ``_applyFilter`` output of
-    detex/construct.py:852-869).
+def trim_window(t0, T, sr, start, end):
+    """Samples ObsPy's ``Trace.trim(starttime=start, endtime=end)`` (nearest_sample=True, no padding) keeps
+    of a trace of T samples starting at time t0: (first sample, count).  Third-party behaviour, restated:
+    the left cut is ``round((start - t0) sr)`` samples, the right cut ``round((t_last - end) sr)``; negative
+    cuts (the window reaches past the data) cut nothing.  The reference's fetcher hands every template
+    through it (detex/getdata.py:441-444 -> getStream -> trim)."""
+    T = int(T)
+    if T <= 0:
+        return 0, 0
+    lo = max(int(round((float(start) - t0) * sr)), 0)
+    hi = max(int(round((t0 + (T - 1) / sr - float(end)) * sr)), 0)
+    return lo, max(T - hi - lo, 0)
 
-    events[station][name] = dict(data=[Nc, L] array, starttime=float epoch
-    seconds of the first sample, origintime=float, magnitude=float)
+
+class EventFetcher(object):
+    """Template-event waveforms of one or more stations.
+
+    ``add``: waveforms already filtered and trimmed (the ``fetcher.getTemData`` + ``_applyFilter`` output
+    of detex/construct.py:852-869).  ``add_raw`` / ``add_counts``: an UNPROCESSED record around the event
+    (float samples, or int32 counts in fragments as they come off the digitiser); createCluster then cuts
+    [origin - trim[0], origin + trim[1]] out of it (getdata.py:441-444), merges / decimates / detrends /
+    band-passes it on the device (construct.py:990-1030 _applyFilter) and multiplexes it.
+
+    events[station][name] = dict(data=[Nc, L] array, starttime=float epoch seconds of the first sample,
+    origintime=float, magnitude=float[, raw=True, counts=[(channel, first sample, int32 array)],
+    nsamples=int])
     """
     method = 'memory'
 
@@ -44,6 +63,31 @@ class EventFetcher(object):
             origintime=float(starttime if origintime is None else origintime),
             magnitude=float(magnitude))
         return self
+
+    def add_raw(self, station, name, data, starttime, origintime, magnitude=np.nan):
+        """An unfiltered [Nc, T] record that holds the event: sample 0 at ``starttime``."""
+        self.add(station, name, data, starttime, origintime, magnitude)
+        rec = self.events[station][name]
+        rec.update(raw=True, counts=None, nsamples=int(rec['data'].shape[1]))
+        return self
+
+    def add_counts(self, station, name, fragments, nsamples, starttime, origintime, magnitude=np.nan):
+        """The record as int32 count fragments [(channel index, first sample, counts), ...] -- one entry
+        per ObsPy trace, gaps between them -- of a record of ``nsamples`` samples starting at
+        ``starttime`` (cf. ContinuousFetcher.add_counts)."""
+        frs = sorted(((int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments),
+                     key=lambda f: (f[0], f[1]))
+        for c, t0, x in frs:
+            if not (0 <= c < len(self.channels)) or t0 < 0 or t0 + len(x) > nsamples:
+                raise ValueError('fragment of channel %d at sample %d does not fit the record' % (c, t0))
+        self.events.setdefault(station, {})[name] = dict(
+            data=None, starttime=float(starttime), origintime=float(origintime), magnitude=float(magnitude),
+            raw=True, counts=frs, nsamples=int(nsamples))
+        return self
+
+    def has_raw(self, station=None):
+        stas = [station] if station is not None else list(self.events)
+        return any(rec.get('raw') for sta in stas for rec in self.events.get(sta, {}).values())
 
     def stations(self):
         return sorted(self.events.keys())

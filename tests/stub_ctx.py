@@ -56,6 +56,11 @@ class OracleCtx(object):
             return out
         return res
 
+    def decimate(self, raw, factor, sampling_rate):
+        flat = raw.reshape(-1, raw.shape[-1]).numpy()
+        out = np.stack(orc.decimate(list(flat), int(factor), sampling_rate)).astype(np.float32)
+        return torch.from_numpy(out.reshape(tuple(raw.shape[:-1]) + (out.shape[-1],)))
+
     def ingest_counts(self, counts, frags, Nc, T, want_run=True):
         cnt = counts.numpy()
         planes = orc.merge_fill([(c, t0, cnt[off:off + m]) for (c, off, t0, m) in frags], Nc, T)

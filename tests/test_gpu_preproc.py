@@ -296,3 +296,80 @@ def test_detex_on_raw_counts_with_gaps(ctx):
     assert len(gz) == len(wz) >= len(want)
     for (_, g), w in zip(gz.iterrows(), sorted(wz)):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and g.DS_STALTA == 0.0
+
+
+@pytest.mark.parametrize('dec', [None, 2])
+def test_raw_templates_and_raw_continuous_equal_prefiltered_run(ctx, dec):
+    """f4 end to end: RAW template records + RAW continuous data through
+    createCluster(filt, trim, decimate) -> createSubSpace -> SVD -> detex, everything cut / decimated /
+    detrended / band-passed on the device, against the same workflow on waveforms and chunks pre-processed
+    beforehand with the CPU restatement (oracle.decimate / apply_filter): same events and clusters, lags
+    exact, CCs and detection statistics to 1e-5, the same detections."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
+    from test_host_logic import prefiltered_from_raw, raw_event_records
+    recs, sr, Nc = raw_event_records(seed=9, nev=9)
+    q = dec or 1
+    # (without the 1000-count offset of the CPU test's records when decimating: the causal low-pass would ring
+    # on it at the start of every window -- reference behaviour, but it blurs the families)
+    if dec:
+        for r in recs:
+            r['data'] = (r['data'] - 1000.0).astype(np.float32)
+    filt, trim = [1, 8, 2, True], [5, 20]
+    efr = EventFetcher(sr, ['E', 'N', 'Z'])
+    for r in recs:
+        efr.add_raw('XX.RAW', r['name'], r['data'], r['starttime'], r['origintime'], r['magnitude'])
+    # continuous data: noise + drift + copies of the two families' records around their arrivals
+    rs = np.random.RandomState(2)
+    T = int(2400 * sr)
+    con = rs.standard_normal((Nc, T)) * 6.0 + (0.0 if dec else 1000.0) + 0.002 * np.arange(T)[None, :]
+    pre = int(30 * sr)
+    plants = [int(200 * sr), int(700 * sr), int(1150 * sr), int(1700 * sr), int(2100 * sr)]
+    for j, t in enumerate(plants):
+        src = recs[j % 2]['data']
+        seg = src[:, pre:pre + int(20 * sr)] - np.median(src, axis=1, keepdims=True)
+        con[:, t:t + seg.shape[1]] += 1.3 * seg
+    con = np.round(con).astype(np.float32)
+    cfr = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=60, raw=True)
+    cfr.add('XX.RAW', con, starttime=9.0e5)
+    # the pre-filtered twin: chunk by chunk on the CPU restatement
+    efp = prefiltered_from_raw(recs, sr, Nc, filt, trim, dec)
+
+    def run(ef, cf, **kw):
+        cl = createCluster(CCreq=0.6, fetch_arg=ef, filt=filt, trim=trim, decimate=dec, ctx=ctx, saveclust=False)
+        ss = createSubSpace(clust=cl, conDatFetcher=cf)
+        ss.attachPickTimes(6.0, 10.0)
+        ss.SVD(selectCriteria=4, selectValue=0, threshold=0.4, useSingles=False)
+        return cl, ss
+    cla, ssa = run(efr, cfr)
+    clb, ssb = run(efp, None)
+    ra, rb = cla.trdf.iloc[0], clb.trdf.iloc[0]
+    assert list(ra.Events) == list(rb.Events) and len(ra.Events) == 9
+    for ev in ra.Events:
+        wa, wb = cla._mptd['XX.RAW'][ev], clb._mptd['XX.RAW'][ev]
+        assert len(wa) == len(wb) and np.max(np.abs(wa - wb)) <= 2e-6 * np.max(np.abs(wb)) + 1e-4
+    assert np.allclose(ra.CCs.values.astype(float), rb.CCs.values.astype(float), atol=1e-5, equal_nan=True)
+    assert np.array_equal(np.nan_to_num(ra.Lags.values.astype(float), nan=-1),
+                          np.nan_to_num(rb.Lags.values.astype(float), nan=-1))
+    assert sorted(map(sorted, cla['RAW'].clusts)) == sorted(map(sorted, clb['RAW'].clusts)) and len(cla['RAW'].clusts) == 2
+    res = ssa.detex(subspaceDB=None, ctx=ctx, estimateMags=True)
+    # the reference's per-chunk _applyFilter on the CPU restatement, scanned with the pre-filtered run's detectors
+    names, kinds, U, off, offsets, thr = ssb._detector_bank('XX.RAW', useSingles=False)
+    srd = sr / q
+    want = []
+    for chunk, t0 in cfr.getConData('XX.RAW'):
+        ch = [np.asarray(c, np.float32) for c in chunk]
+        if dec:
+            ch = [np.asarray(c, np.float32) for c in orc.decimate(ch, dec, sr)]
+        x = orc.multiplex(orc.apply_filter(ch, filt, srd))
+        for d, nm in enumerate(names):
+            ds = orc.mpxds_fft(x, U[off[d]:off[d + 1]].astype(np.float32), Nc)
+            if orc.eval_trig_con(ds.max(), np.float32(thr[nm])):
+                want += [(t['STMP'], nm, t['DS']) for t in orc.pick_triggers(ds, np.float32(thr[nm]), srd, t0)]
+    got = res['ss_df'].sort_values(['STMP', 'Name'])
+    want.sort()
+    assert len(got) == len(want) >= len(plants)
+    for (_, g), w in zip(got.iterrows(), want):
+        assert abs(g.STMP - w[0]) < 1e-6 and g.Name == w[1] and abs(g.DS - w[2]) <= 1e-5, (g.STMP, g.Name, g.DS, w)

@@ -618,3 +618,122 @@ def test_raw_counts_trimming_is_gated_like_applyFilter():
     assert len(got) == len(want) >= 4
     for (_, g), w in zip(got.iterrows(), sorted(want)):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5
+
+
+def raw_event_records(seed=5, sr=40.0, Nc=3, nev=7, pre=30.0, post=50.0):
+    """Unprocessed records around template events (two families + a loner): drifting offsets, a slow trend
+    and noise on top of band-limited wavelets; origin `pre` seconds into each record."""
+    rs = np.random.RandomState(seed)
+    T = int((pre + post) * sr)
+    L = int(12 * sr)
+    k = np.hanning(9)
+    wavs = [[np.convolve(rs.standard_normal(L + 8), k / k.sum(), 'valid') * np.exp(-np.arange(L) / (0.3 * L)) * 400
+             for _ in range(Nc)] for _ in range(2)]
+    recs = []
+    for e in range(nev):
+        fam = e % 2 if e < nev - 1 else -1
+        data = rs.standard_normal((Nc, T)) * 6.0 + 1000.0 + 0.05 * np.arange(T)[None, :] * rs.uniform(-1, 1, (Nc, 1))
+        arr = int((pre + 2.0) * sr) + int(rs.randint(0, 12))
+        if fam >= 0:
+            a = rs.uniform(.6, 1.5)
+            for c in range(Nc):
+                data[c, arr:arr + L] += a * wavs[fam][c]
+        else:
+            data[:, arr:arr + L] += rs.standard_normal((Nc, L)) * 80
+        t0 = 7200.0 * e + 100.0
+        recs.append(dict(name='ev%02d' % e, data=np.round(data).astype(np.float32), starttime=t0, origintime=t0 + pre,
+                         magnitude=1.0 + 0.1 * e))
+    return recs, sr, Nc
+
+
+def prefiltered_from_raw(recs, sr, Nc, filt, trim, dec):
+    """The reference's order of work on the CPU oracle: ObsPy-trim the window, decimate, detrend, band-pass
+    (getdata.py:441-444, construct.py:1016-1028)."""
+    from detex_amd.getdata import trim_window
+    ef = EventFetcher(sr / (dec or 1), ['E', 'N', 'Z'][:Nc])
+    for r in recs:
+        i0, cnt = trim_window(r['starttime'], r['data'].shape[1], sr, r['origintime'] - trim[0], r['origintime'] + trim[1])
+        ch = [np.asarray(c, np.float32) for c in r['data'][:, i0:i0 + cnt]]
+        if dec:
+            ch = orc.decimate(ch, dec, sr)
+        ch = orc.apply_filter([np.asarray(c, np.float32) for c in ch], filt, sr / (dec or 1))
+        ef.add('XX.RAW', r['name'], np.array(ch), starttime=r['starttime'] + i0 / sr, origintime=r['origintime'],
+               magnitude=r['magnitude'])
+    return ef
+
+
+@pytest.mark.parametrize('dec', [None, 2])
+def test_raw_template_events_host_logic(dec):
+    """createCluster on RAW template records (EventFetcher.add_raw): window [origin - trim[0], origin + trim[1]]
+    -> decimate -> detrend -> band-pass -> multiplex (construct.py:852-925, 990-1030) gives the clusters,
+    CCs, lags and start times of the run on waveforms pre-processed the same way beforehand.  CPU stand-in
+    context: the host logic; the device kernels are held to the same comparison in test_gpu_preproc.py."""
+    recs, sr, Nc = raw_event_records()
+    filt, trim = [1, 8, 2, True], [5, 20]
+    efr = EventFetcher(sr, ['E', 'N', 'Z'])
+    for r in recs:
+        efr.add_raw('XX.RAW', r['name'], r['data'], r['starttime'], r['origintime'], r['magnitude'])
+    a = createCluster(CCreq=0.5, fetch_arg=efr, filt=filt, trim=trim, decimate=dec, ctx=OracleCtx(), saveclust=False)
+    b = createCluster(CCreq=0.5, fetch_arg=prefiltered_from_raw(recs, sr, Nc, filt, trim, dec), filt=filt, trim=trim,
+                      decimate=dec, ctx=OracleCtx(), saveclust=False)
+    ra, rb = a.trdf.iloc[0], b.trdf.iloc[0]
+    assert list(ra.Events) == list(rb.Events) and len(ra.Events) == 7
+    assert np.allclose(ra.CCs.values.astype(float), rb.CCs.values.astype(float), atol=1e-6, equal_nan=True)
+    assert np.array_equal(np.nan_to_num(ra.Lags.values.astype(float), nan=-1), np.nan_to_num(rb.Lags.values.astype(float), nan=-1))
+    assert sorted(map(sorted, a['RAW'].clusts)) == sorted(map(sorted, b['RAW'].clusts))
+    # (decimation runs BEFORE the detrend, as in the reference: the causal low-pass rings on the records' 1000-count
+    # offset at the start of every window and the families blur -- two clusters only without it)
+    assert len(a['RAW'].clusts) == (2 if dec is None else 1)
+    q = dec or 1
+    want_len = Nc * (((int(round(25 * sr)) + 1) + q - 1) // q)       # inclusive ObsPy window, then data[::q]
+    for ev in ra.Events:
+        assert len(a._mptd['XX.RAW'][ev]) == want_len
+        sa, sb = ra.Stats[ev], rb.Stats[ev]
+        assert sa['sampling_rate'] == sr / q and abs(sa['starttime'] - sb['starttime']) < 1e-9
+        assert abs(sa['offset'] + trim[0]) < 1e-9                    # the window starts trim[0] before the origin
+    # enforceOrigin (construct.py:884-885): the waveforms start at the origin time
+    c = createCluster(CCreq=0.5, fetch_arg=efr, filt=filt, trim=trim, decimate=dec, enforceOrigin=True,
+                      ctx=OracleCtx(), saveclust=False)
+    for ev in c.trdf.iloc[0].Events:
+        assert abs(c.trdf.iloc[0].Stats[ev]['offset']) < 1e-9
+        assert np.array_equal(c._mptd['XX.RAW'][ev], a._mptd['XX.RAW'][ev][Nc * int(round(trim[0] * sr / q)):])
+
+
+def test_raw_template_events_fragments_and_drop_rules(caplog):
+    """Raw int32 count fragments as templates: a record with a gap keeps its longest gap-free stretch
+    (_mergeChannels), a record still in several traces after that is dropped as fractured; a record that is
+    much too short (< 20 % of the median) and one with an all-zero channel are removed (construct.py:897-916)."""
+    import logging
+    recs, sr, Nc = raw_event_records(nev=8)
+    filt, trim = [1, 8, 2, True], [5, 20]
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    T = recs[0]['data'].shape[1]
+    for i, r in enumerate(recs):
+        cnt = r['data'].astype(np.int32)
+        frs = [(c, 0, cnt[c]) for c in range(Nc)]
+        if i == 1:      # a gap BEFORE the window on one channel: the window itself is whole
+            frs = [(0, 0, cnt[0, :200]), (0, 260, cnt[0, 260:])] + [(c, 0, cnt[c]) for c in (1, 2)]
+        if i == 2:      # a gap inside the window, near its start: the long stretch behind it is kept
+            g0 = int((30 - 5) * sr) + 40
+            frs = [(0, 0, cnt[0, :g0]), (0, g0 + 30, cnt[0, g0 + 30:])] + [(c, 0, cnt[c]) for c in (1, 2)]
+        if i == 3:      # the record ends 3 s after the window opens: far too short
+            frs = [(c, 0, cnt[c, :int((30 - 5 + 3) * sr)]) for c in range(Nc)]
+        if i == 4:      # dead channel
+            frs = [(0, 0, cnt[0]), (1, 0, cnt[1]), (2, 0, np.zeros(T, np.int32))]
+        ef.add_counts('XX.RAW', r['name'], frs, T, r['starttime'], r['origintime'], r['magnitude'])
+    with caplog.at_level(logging.WARNING, logger='detex_amd.construct'):
+        cl = createCluster(CCreq=0.4, fetch_arg=ef, filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
+    row = cl.trdf.iloc[0]
+    # ev03 (short) and ev04 (dead channel) are gone; ev02 survives shortened -> every event is trimmed to it
+    # only if it is within 90 % of the median length, else it is dropped too (_testStreamLengths)
+    assert 'ev03' not in row.Events and 'ev04' not in row.Events and 'ev01' in row.Events
+    assert any('fractured or missing data' in m for m in caplog.messages)
+    assert any('all zeros' in m for m in caplog.messages)
+    full = Nc * (int(round(25 * sr)) + 1)
+    assert 'ev02' in row.Events and len(cl._mptd['XX.RAW']['ev00']) == full - Nc * 70
+    # the whole-window events equal the float-record run, cut to the common length
+    efr = EventFetcher(sr, ['E', 'N', 'Z'])
+    for r in recs:
+        efr.add_raw('XX.RAW', r['name'], r['data'], r['starttime'], r['origintime'], r['magnitude'])
+    ref = createCluster(CCreq=0.4, fetch_arg=efr, filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
+    assert np.allclose(cl._mptd['XX.RAW']['ev00'], ref._mptd['XX.RAW']['ev00'][:full - Nc * 70], atol=1e-6)
