@@ -101,6 +101,33 @@ def stalta_at(fetch, i, P, LTA, STA):
         return float(np.divide(st, lt))
 
 
+def stalta_array(C, LTA, STA):
+    """detect.py:501-524 as a whole vector (the product evaluates it at the triggers only, on the device:
+    dtx_trigger_stats; this host form serves the utcSaves rows): |C| (STA == 0) or its centred rolling mean
+    over STA samples, divided by the centred rolling mean over LTA samples, the NaN ends of a rolling mean
+    replaced as _replaceNanWithMean does (the front by element first + 1, the back by the last valid one)."""
+    C = np.abs(np.asarray(C, dtype=np.float64))
+    P = len(C)
+
+    def centred(n):
+        n = int(n)
+        out = np.full(P, np.nan)
+        if n < 1 or n > P:
+            raise IndexError('window longer than the detection statistic')
+        cs = np.concatenate([[0.0], np.cumsum(C)])
+        rm = (cs[n:] - cs[:-n]) / n                        # rm[j] = mean(C[j:j + n])
+        first = n - 1 - (n - 1) // 2
+        last = first + (P - n)
+        out[first:last + 1] = rm
+        if first > 0:
+            out[:first] = out[first + 1] if first + 1 <= P - 1 else np.nan
+        out[last + 1:] = out[last]
+        return out
+    st = C if STA == 0 else centred(STA)
+    with np.errstate(all='ignore'):
+        return np.divide(st, centred(LTA))
+
+
 # --------------------------------------------------------------------------
 # one station: chunks -> GPU detection statistic -> triggers   detect.py:137-218
 # --------------------------------------------------------------------------
@@ -267,13 +294,17 @@ class StationScan(object):
     COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
 
     def __init__(self, ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
-                 useSingles, fillZeros, device=0, ctx=None, estimateMags=True, shard=None, bank=None):
+                 useSingles, fillZeros, device=0, ctx=None, estimateMags=True, shard=None, bank=None,
+                 fetcher=None, utcSaves=None):
         from .hip import HipContext
         self.ss, self.sta = ss, sta
         self.args = (utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags)
         self.bank = bank if bank is not None else ss._detector_bank(sta, useSubSpaces, useSingles)
         self.shard = shard
-        self.empty = (not self.bank[0]) or sta not in ss.cfetcher.data
+        # the data scanned: the SubSpace's continuous fetcher, or the template events of a classifyEvents run
+        self.fetcher = fetcher if fetcher is not None else ss.cfetcher
+        self.utc_saves = None if utcSaves is None else np.asarray(utcSaves, dtype=np.float64)
+        self.empty = (not self.bank[0]) or sta not in self.fetcher.data
         self.own = ctx is None and not self.empty
         self.ctx = HipContext(device) if self.own else ctx
         self.batches = []
@@ -302,7 +333,7 @@ class StationScan(object):
         ss, sta, ctx = self.ss, self.sta, self.ctx
         utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, fillZeros, estimateMags = self.args
         names, kinds, U, det_off, offsets, thr = self.bank
-        fetcher = ss.cfetcher
+        fetcher = self.fetcher
         sr = fetcher.sampling_rate
         Nc = len(fetcher.channels)
         n = U.shape[1]
@@ -507,6 +538,7 @@ class StationScan(object):
         keys = {'ss': [], 'sg': []}
         for (i0, trigs, bad, stats) in self.picked:
             _batch_rows(self.sta, st, self.args[5], self.args[6], i0, trigs, bad, stats, rows, keys)
+        utc_rows = self._utc_rows() if self.utc_saves is not None else None
         self.batches, self.picked = [], None
         if self.hist_ev is not None:
             self.hist_ev.synchronize()
@@ -521,7 +553,55 @@ class StationScan(object):
             out['key_' + k] = np.asarray(v, dtype=np.int64).reshape(-1, 3)
         out['hist_ss'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'ss'}
         out['hist_sg'] = {nm: h[i] for i, nm in enumerate(names) if kinds[i] == 'sg'}
+        # the largest detection statistic of every (chunk, detector): {chunk index: [D] array} (classifyEvents)
+        out['maxds'] = dict(st.get('maxds', {}))
+        out['names'] = list(names)
+        if utc_rows is not None:
+            out['utc'] = utc_rows
         return out
+
+    def _utc_rows(self):
+        """detect.py:297-318 _makeUTCSaveDF: for every chunk that covers one of the utcSaves times, one row
+        per detector with the chunk's multiplexed data and its whole detection-statistic vector, copied
+        back from the resident DS tensor (a debugging aid: these copies wait for the device)."""
+        st = self.st
+        names, thr, offsets, Nc, n, sr = st['names'], st['thr_arr'], st['offsets'], st['Nc'], st['n'], st['sr']
+        fillZeros = self.args[5]
+        rows = []
+        for (i0, i1, xb, M, cstride, ds, fetch, ctab) in self.batches:
+            for b in range(i1 - i0):
+                if ctab is not None:
+                    a, m = (int(v) for v in ctab[1][b])
+                    mp = xb.reshape(-1)[a:a + m]
+                elif xb.dim() == 2:
+                    mp = xb[b, :M]
+                else:
+                    mp = xb[b * cstride: b * cstride + M]
+                m = int(mp.numel())
+                if m <= n:
+                    continue
+                ts1 = st['bounds'][i0 + b][2]
+                ts2 = ts1 + m / (sr * float(Nc))
+                inside = (self.utc_saves > ts1) & (self.utc_saves < ts2)
+                if not inside.any():
+                    continue
+                Pb = (m - n) // Nc + 1
+                mp_h = mp.cpu().numpy()
+                ds_h = ds[b, :, :Pb].cpu().numpy()
+                for d, nm in enumerate(names):
+                    C = ds_h[d].astype(np.float64)
+                    sl = None
+                    if not fillZeros:
+                        try:
+                            sl = stalta_array(C, st['LTA'], st['STA'])
+                        except IndexError:
+                            sl = None                           # detect.py:289-295: logged, left empty
+                    rows.append(dict(Station=self.sta, Name=nm, Threshold=float(thr[d]), offset=offsets[nm],
+                                     TS1=ts1, TS2=ts2, utcSaves=self.utc_saves[inside], MPcon=mp_h, SSdetect=C,
+                                     STALTA=sl, TimeStamp=ts1, SampRate=sr, MaxDS=float(C.max()),
+                                     MaxSTALTA=(float(np.nanmax(sl)) if sl is not None else np.nan), Nc=Nc,
+                                     File=np.nan, chunk=st['bounds'][i0 + b][3]))
+        return rows
 
 
 def _ingest_station(ctx, counts, Nc, T, pinned=None):
@@ -631,6 +711,8 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
         res['cand'], res['ncand'] = again['cand'], again['ncand']
     P = int(ds.shape[2])
     maxds = res['maxds'].cpu().numpy() if res['maxds'].is_cuda else res['maxds'].numpy()
+    for b in range(nb):                                  # (kept per chunk: classifyEvents reports them)
+        st.setdefault('maxds', {})[bounds[i0 + b][3]] = np.array(maxds[b], dtype=np.float64)
     cb, cd, cp, cv = res['cand']
     # windows of every chunk of the group (ragged batch: its own)
     Pb = np.full(nb, P, dtype=np.int64)

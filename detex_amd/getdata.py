@@ -99,6 +99,39 @@ class EventFetcher(object):
             yield name, evs[name]
 
 
+class EventChunks(object):
+    """Template events laid end to end as the "continuous data" of a ``SubSpace.detex(classifyEvents=...)``
+    run (detex/detect.py:51-55, 151-152: the detectors are run over event waveforms instead of continuous
+    data): one chunk per event, each with the start time of its waveform.  The waveforms are pre-processed
+    already (raw records went through construct._preprocess_events)."""
+    method = 'memory'
+    raw = False
+    conDatDuration = 86400          # one event = one sharding unit in a multi-process run
+    conBuff = 0
+
+    def __init__(self, sampling_rate, channels):
+        self.sampling_rate = float(sampling_rate)
+        self.channels = list(channels)
+        self.data, self.bounds, self.names = {}, {}, {}
+
+    def add(self, station, events):
+        """events: [(name, [Nc, L] array, time of the first sample)]"""
+        events = [(nm, np.asarray(d, dtype=np.float32), float(t)) for (nm, d, t) in events if np.shape(d)[1] > 0]
+        if not events:
+            return self
+        off, bounds = 0, []
+        for (_, d, t) in events:
+            bounds.append((off, int(d.shape[1]), t))
+            off += int(d.shape[1])
+        self.data[station] = (np.concatenate([d for (_, d, _) in events], axis=1), events[0][2])
+        self.bounds[station] = bounds
+        self.names[station] = [nm for (nm, _, _) in events]
+        return self
+
+    def chunk_bounds(self, station, utcStart=None, utcEnd=None):
+        return list(self.bounds[station])
+
+
 class ContinuousFetcher(object):
     """Continuous pre-processed data of each station as one [Nc, T] array with a
     start time.  ``getConData`` cuts it into the reference's chunks: starts on

@@ -269,6 +269,12 @@ def _merge_ranks(parts, names_order=None):
             for nm, h in p[hk].items():
                 acc[nm] = acc[nm] + h if nm in acc else np.array(h, copy=True)
         out[hk] = acc
+    out['names'] = parts[0].get('names', [])
+    out['maxds'] = {}
+    for p in parts:                                  # every chunk was scanned by exactly one rank
+        out['maxds'].update(p.get('maxds', {}))
+    if any('utc' in p for p in parts):
+        out['utc'] = sorted((r for p in parts for r in p.get('utc', [])), key=lambda r: r['chunk'])
     return out
 
 
@@ -629,9 +635,15 @@ class SubSpace(object):
         from .detect import StationScan
         if multiprocess or trigCon != 0:                    # subspace.py:1843-1845
             _error('multiprocessing and trigcon other than 0 not supported')
-        if classifyEvents is not None or utcSaves is not None:
-            _error('classifyEvents / utcSaves are not supported')
-        if self.cfetcher is None:
+        utc = None
+        if utcSaves is not None:                            # detect.py:63-75
+            if isinstance(utcSaves, (str, bytes)) or not hasattr(utcSaves, '__iter__'):
+                _error('UTCSaves must be a list or tupple')
+            try:
+                utc = np.array([float(getattr(x, 'timestamp', x)) for x in utcSaves], dtype=np.float64)
+            except (TypeError, ValueError):
+                _error('Not all elements in utcSaves are readable as epoch seconds')
+        if classifyEvents is None and self.cfetcher is None:
             _error('no continuous-data fetcher attached (conDatFetcher)')
         rank, world = parallel.dist_info()
         active = parallel.dist_active()     # a process group exists (also of one rank): the collectives run
@@ -645,10 +657,15 @@ class SubSpace(object):
         if active and dev.type == 'cuda':
             torch.cuda.set_device(dev)          # RCCL's object collectives run on the current device
         fetcher = self.cfetcher
-        stations = [sta for sta in self.Stations if sta in fetcher.data]
+        stations = []
         results, failure = {}, None
         bounds, banks = {}, {}
         try:
+            if classifyEvents is not None:
+                # detect.py:51-55, 151-152: the detectors run over the event waveforms of the cluster's
+                # own event fetcher instead of over continuous data
+                fetcher = self._event_chunks(classifyEvents, device if own_ctx else None, ctx)
+            stations = [sta for sta in self.Stations if sta in fetcher.data]
             bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
             banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
         except Exception as e:                              # noqa: BLE001
@@ -707,7 +724,7 @@ class SubSpace(object):
                     up.start(fetcher, todo[i + 1], bounds[todo[i + 1]], sel[todo[i + 1]])
                 job = StationScan(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
                                   useSubSpaces, useSingles, fillZeros, device, ctx, estimateMags,
-                                  shard=shard, bank=banks[sta])
+                                  shard=shard, bank=banks[sta], fetcher=fetcher, utcSaves=utc)
                 del shard
                 job.start()
                 up.release(stream)
@@ -756,7 +773,87 @@ class SubSpace(object):
             out[k] = pd.concat(out[k], ignore_index=True) if out[k] else pd.DataFrame(columns=cols)
         if subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
+        if classifyEvents is not None:
+            out['event_cors'] = self._event_cors(fetcher, stations, results, banks, eventCorFile, rank)
+        if utc is not None:
+            out['utc_saves'] = self._utc_saves(stations, results, rank)
         return out
+
+    def _event_chunks(self, classifyEvents, device, ctx):
+        """The events a classifyEvents run scans, as one chunk each (getdata.EventChunks).  classifyEvents:
+        a template key -- DataFrame with a NAME column or the path of such a csv -- or a list of event names,
+        or True for every event of the cluster's event fetcher (the reference reads the key and asks that
+        fetcher for the events in it, detect.py:51-55).  Raw records are cut / decimated / filtered like the
+        templates were (clusters.trim / decimate / filt)."""
+        from . import construct
+        from .getdata import EventChunks
+        ef = self.clusters.fetcher
+        if ef is None or not hasattr(ef, 'getTemData'):
+            _error('classifyEvents needs the event fetcher of the ClusterStream')
+        if classifyEvents is True:
+            wanted = None
+        elif isinstance(classifyEvents, str):
+            wanted = set(str(v) for v in pd.read_csv(classifyEvents).NAME)
+        elif isinstance(classifyEvents, pd.DataFrame):
+            wanted = set(str(v) for v in classifyEvents.NAME)
+        else:
+            wanted = set(str(v) for v in classifyEvents)
+        cl = self.clusters
+        dec = int(cl.decimate or 1)
+        out = EventChunks(ef.sampling_rate / (dec if ef.has_raw() else 1), ef.channels)
+        for sta in ef.stations():
+            if sta not in self.Stations:
+                continue
+            if ef.has_raw(sta):
+                own = ctx is None
+                c = self._station_ctx(device, sta) if own else ctx
+                done = construct._preprocess_events(c, ef, sta, cl.filt, cl.trim, cl.decimate)
+            else:
+                done = [(nm, rec['data'], rec['starttime']) for nm, rec in ef.getTemData(sta)]
+            out.add(sta, [(nm, d, t) for (nm, d, t) in done if wanted is None or nm in wanted])
+        return out
+
+    def _event_cors(self, fetcher, stations, results, banks, eventCorFile, rank):
+        """The table the reference documents for classifyEvents (subspace.py:1821-1825): the highest
+        detection statistic of every event on every station for every detector; pickled per station to
+        ``eventCorFile + '_<station>.pkl'`` (detect.py:88-95)."""
+        rows = []
+        for sta in stations:
+            res = results.get(sta)
+            if res is None:
+                continue
+            thr = banks[sta][5]
+            srows = []
+            for k, ev in enumerate(fetcher.names[sta]):
+                mx = res['maxds'].get(k)
+                if mx is None:                              # (the event was shorter than the detectors)
+                    continue
+                for d, nm in enumerate(res['names']):
+                    srows.append(dict(Event=ev, Sta=sta, Name=nm, MaxDS=float(mx[d]), Threshold=float(thr[nm]),
+                                      Triggered=bool(mx[d] > thr[nm]), STMP=fetcher.bounds[sta][k][2]))
+            if srows and eventCorFile is not None and rank == 0:
+                pd.DataFrame(srows).to_pickle('%s_%s.pkl' % (eventCorFile, sta))
+            rows += srows
+        return pd.DataFrame(rows, columns=['Event', 'Sta', 'Name', 'MaxDS', 'Threshold', 'Triggered', 'STMP'])
+
+    def _utc_saves(self, stations, results, rank):
+        """detect.py:97-110: the rows of every station, joined with what an earlier run left in
+        'UTCsaves.pkl', written back there."""
+        cols = ['Station', 'Name', 'Threshold', 'offset', 'TS1', 'TS2', 'utcSaves', 'MPcon', 'SSdetect', 'STALTA',
+                'TimeStamp', 'SampRate', 'MaxDS', 'MaxSTALTA', 'Nc', 'File']
+        rows = [r for sta in stations if results.get(sta) is not None for r in results[sta].get('utc', [])]
+        df = pd.DataFrame([{c: r[c] for c in cols} for r in rows], columns=cols)
+        if not len(df):
+            from .detect import _warn
+            _warn('Failed to save data in utcSaves')        # detect.py:108-110
+            return df
+        if rank == 0:
+            try:
+                df = pd.concat([df, pd.read_pickle('UTCsaves.pkl')], ignore_index=True)
+            except Exception:                               # noqa: BLE001 -- "try and read, pass" (detect.py:101-105)
+                pass
+            df.to_pickle('UTCsaves.pkl')
+        return df
 
     def _adopt_sent_banks(self, stations, banks, sent):
         """Every rank (rank 0 too) scans with the numbers that were broadcast; a bank object is kept

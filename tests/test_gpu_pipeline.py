@@ -351,3 +351,41 @@ def test_ragged_launch_equals_one_launch_per_length(workflow, monkeypatch):
                                rtol=1e-5, atol=1e-7, equal_nan=True), (k, col)
     for nm, h in ss.histSubSpaces['TA.M17A'].items():
         assert int(np.sum(h)) > 0
+
+
+def test_classifyEvents_and_utcSaves_on_the_device(workflow, tmp_path, monkeypatch):
+    """classifyEvents (the detectors over the template events, detect.py:51-55, 151-152) and utcSaves (the
+    resident DS vector and the chunk of every listed time copied out, detect.py:297-318) through the HIP
+    path: event maxima and the saved DS vectors equal the oracle's to 1e-5, the ordinary tables are unchanged."""
+    monkeypatch.chdir(tmp_path)
+    ss, cf, ef = workflow['ss'], workflow['cf'], workflow['ef']
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A', True, False)
+    plain = ss.detex(subspaceDB=None, estimateMags=False)
+    b = cf.chunk_bounds('TA.M17A')
+    t_in = b[2][2] + 100.0
+    res = ss.detex(subspaceDB=None, estimateMags=False, utcSaves=[t_in])
+    assert res['ss_df'].values.tolist() == plain['ss_df'].values.tolist()
+    df = res['utc_saves']
+    assert sorted(df.Name) == sorted(names) and os.path.exists('UTCsaves.pkl')
+    chunk = cf.data['TA.M17A'][0][:, b[2][0]:b[2][0] + b[2][1]]
+    mp = multiplex(list(chunk)).astype(np.float64)
+    for _, r in df.iterrows():
+        d = names.index(r.Name)
+        want = orc.scrub_ds(orc.mpxds_fft(mp, U[off[d]:off[d + 1]].astype(np.float32), NC))[0]
+        assert np.array_equal(r.MPcon, mp.astype(np.float32))
+        assert len(r.SSdetect) == len(want) and np.max(np.abs(r.SSdetect - want)) <= 1e-5
+        sl = orc.get_stalta(np.asarray(r.SSdetect, np.float64).copy(), 5 * SR, 0)
+        assert np.allclose(r.STALTA, sl, rtol=1e-9, equal_nan=True)
+    ev = ss.detex(subspaceDB=None, estimateMags=False, classifyEvents=True, eventCorFile='EvCor')
+    ec = ev['event_cors']
+    assert len(ec) == 11 * len(names) and os.path.exists('EvCor_TA.M17A.pkl')
+    for name, rec in ef.getTemData('TA.M17A'):
+        x = multiplex(list(np.asarray(rec['data'], np.float32))).astype(np.float64)
+        for d, nm in enumerate(names):
+            want = orc.scrub_ds(orc.mpxds_fft(x, U[off[d]:off[d + 1]].astype(np.float32), NC))[0].max()
+            got = float(ec[(ec.Event == name) & (ec.Name == nm)].MaxDS.iloc[0])
+            assert abs(got - want) <= 1e-5, (name, nm, got, want)
+    for _, row in ss.subspaces['TA.M17A'].iterrows():
+        for e in row.Events:
+            assert ec[ec.Event == e].set_index('Name').MaxDS.idxmax() == row.Name

@@ -737,3 +737,79 @@ def test_raw_template_events_fragments_and_drop_rules(caplog):
         efr.add_raw('XX.RAW', r['name'], r['data'], r['starttime'], r['origintime'], r['magnitude'])
     ref = createCluster(CCreq=0.4, fetch_arg=efr, filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
     assert np.allclose(cl._mptd['XX.RAW']['ev00'], ref._mptd['XX.RAW']['ev00'][:full - Nc * 70], atol=1e-6)
+
+
+def test_utcSaves_rows_match_the_reference_layout(tmp_path, monkeypatch):
+    """SubSpace.detex(utcSaves=[...]) (detect.py:63-75, 183-185, 297-318): one row per detector for every chunk
+    that covers a listed time, holding the chunk's multiplexed data, its whole detection-statistic vector and
+    the STA/LTA vector; written to UTCsaves.pkl, an earlier file appended."""
+    monkeypatch.chdir(tmp_path)
+    ctx = OracleCtx()
+    ss, cf, plants, (SR, NC, L) = small_workflow(ctx)
+    b = cf.chunk_bounds('TA.M17A')
+    t_in = b[1][2] + 30.0                                  # inside chunk 1 only (chunks overlap by 20 s)
+    res = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx, utcSaves=[t_in, 5.0])
+    df = res['utc_saves']
+    names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A', True, True)
+    assert list(df.columns) == ['Station', 'Name', 'Threshold', 'offset', 'TS1', 'TS2', 'utcSaves', 'MPcon', 'SSdetect',
+                                'STALTA', 'TimeStamp', 'SampRate', 'MaxDS', 'MaxSTALTA', 'Nc', 'File']
+    assert sorted(df.Name) == sorted(names) and set(df.TS1) == {b[1][2]}
+    chunk = cf.data['TA.M17A'][0][:, b[1][0]:b[1][0] + b[1][1]]
+    mp = orc.multiplex(list(chunk))
+    for _, r in df.iterrows():
+        d = names.index(r.Name)
+        assert np.array_equal(r.MPcon, mp.astype(np.float32)) and list(r.utcSaves) == [t_in]
+        want = orc.scrub_ds(orc.mpxds_fft(mp.astype(np.float64), U[off[d]:off[d + 1]], NC))[0]
+        assert np.allclose(r.SSdetect, want, atol=1e-6) and abs(r.MaxDS - want.max()) < 1e-6
+        sl = orc.get_stalta(np.asarray(r.SSdetect, np.float64).copy(), 5 * SR, 0)
+        assert np.allclose(r.STALTA, sl, rtol=1e-9, equal_nan=True)
+        assert r.TS2 == r.TS1 + len(mp) / (SR * NC) and r.Threshold == np.float32(thr[r.Name])
+    assert len(pd_read(tmp_path / 'UTCsaves.pkl')) == len(df)
+    again = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx, utcSaves=(t_in,))
+    assert len(again['utc_saves']) == 2 * len(df)          # the earlier file is appended (detect.py:101-105)
+    # the plain table is unchanged by the option
+    plain = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx)
+    assert plain['ss_df'].values.tolist() == res['ss_df'].values.tolist() and 'utc_saves' not in plain
+    with pytest.raises(Exception):
+        ss.detex(subspaceDB=None, ctx=ctx, utcSaves='2015-01-01')
+
+
+def pd_read(path):
+    import pandas as pd
+    return pd.read_pickle(str(path))
+
+
+def test_classifyEvents_scans_the_template_events(tmp_path, monkeypatch):
+    """SubSpace.detex(classifyEvents=...) (detect.py:51-55, 151-152; subspace.py:1813-1825): the detectors
+    run over the event waveforms of the cluster's event fetcher; the highest detection statistic of every
+    (event, station, detector) is returned and pickled to eventCorFile_<station>.pkl."""
+    monkeypatch.chdir(tmp_path)
+    ctx = OracleCtx()
+    ss, cf, plants, (SR, NC, L) = small_workflow(ctx)
+    ss.cfetcher = None                                     # no continuous data needed
+    res = ss.detex(subspaceDB=None, useSingles=False, ctx=ctx, classifyEvents=True, eventCorFile='EvCor')
+    ec = res['event_cors']
+    df = ss.subspaces['TA.M17A']
+    assert set(ec.Event) == set('ev%02d' % i for i in range(9)) and set(ec.Name) == set(df.Name)
+    assert len(ec) == 9 * len(df)
+    # every member event of a subspace is best matched by its own detector, well above the threshold
+    for _, row in df.iterrows():
+        for ev in row.Events:
+            mine = ec[(ec.Event == ev)].set_index('Name').MaxDS
+            assert mine.idxmax() == row.Name and mine[row.Name] > 0.5
+    # the values are the oracle's maxima over the event's own windows
+    names, kinds, U, off, offsets, thr = ss._detector_bank('TA.M17A', True, False)
+    rec = ss.clusters.fetcher.events['TA.M17A']['ev03']
+    mp = orc.multiplex(list(np.asarray(rec['data'], np.float32)))
+    for d, nm in enumerate(names):
+        want = orc.scrub_ds(orc.mpxds_fft(mp.astype(np.float64), U[off[d]:off[d + 1]], NC))[0].max()
+        got = float(ec[(ec.Event == 'ev03') & (ec.Name == nm)].MaxDS.iloc[0])
+        assert abs(got - want) < 1e-6
+    assert len(pd_read(tmp_path / 'EvCor_TA.M17A.pkl')) == len(ec)
+    # a template key (DataFrame with NAME) restricts the run
+    import pandas as pd
+    few = ss.detex(subspaceDB=None, useSingles=False, ctx=ctx, classifyEvents=pd.DataFrame({'NAME': ['ev01', 'ev05']}),
+                   eventCorFile=None)
+    assert sorted(set(few['event_cors'].Event)) == ['ev01', 'ev05']
+    # detections at the events' own times come out in the ordinary table too
+    assert len(res['ss_df']) >= 8
