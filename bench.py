@@ -92,18 +92,20 @@ def cpu_baseline(U, det_off, x_chunk, Nc, nvec):
     from oracle import cpu_bench
     model, ncores, logical = cpu_bench.cpu_info()
     return dict(value=P / full, unit='windows/s', cores=1, kind='port', cpu_model=model,
-                physical_cores=ncores, os_cpu_count=logical,
+                physical_cores=ncores, os_cpu_count=logical, effective_cores=cpu_bench.effective_cores(),
+                cgroup_cpu_limit=cpu_bench.cgroup_cpu_limit(),
                 sample='1 chunk (%d samples) x %d of %d basis vectors, float64 FFT path, '
                        '%.1f s measured, scaled linearly to %d vectors' % (len(x), done, K, dt, K))
 
 
-def cpu_baseline_allcores(U, det_off, x, Nc):
+def cpu_baseline_allcores(U, det_off, x, Nc, onecore_rate=None):
     """The same CPU restatement on every physical core of the host (SURVEY.md 8d / BASELINE.md 3):
     one worker process per core, each one chunk x 8 basis vectors (one detector).  The reference itself is
     single-threaded; this is the generous CPU figure."""
     from oracle import cpu_bench
     try:
-        return cpu_bench.allcores_baseline(U, det_off, x, Nc, nvec_per_worker=8, timeout=240.0)
+        return cpu_bench.allcores_baseline(U, det_off, x, Nc, nvec_per_worker=8, timeout=240.0,
+                                           onecore_rate=onecore_rate)
     except Exception as e:          # a bounded leg: never take the bench line down
         return dict(value=None, unit='windows/s', error=repr(e))
 
@@ -116,12 +118,25 @@ def _tag_order(path):
     return (m.group(1), int(m.group(2))) if m else ('', -1)
 
 
+def kernel_source_digest():
+    """sha1 over detex_amd/csrc/*.hip|*.h, as scripts/summarize_profile.py records it with a counter summary."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, 'detex_amd', 'csrc')
+    for fn in sorted(glob.glob(os.path.join(base, '*.hip')) + glob.glob(os.path.join(base, '*.h'))):
+        h.update(os.path.basename(fn).encode())
+        with open(fn, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
     """Roofline object of the dominant kernel of one engine (kms: its average launch
     duration from HIP events on the launch stream)."""
     import glob
     rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
-    def pmc(pattern):
+    def pmc(pattern, instance=None):
         # HBM-side bytes per launch: PMC counters collected by scripts/profile.sh (separate
         # --pmc passes, gfx950 FETCH_SIZE x2 correction) for the default configuration only
         if not default_cfg:
@@ -130,10 +145,18 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         if not pm:
             return None
         with open(pm[-1]) as f:
-            b = json.load(f).get('counters', {}).get('hbm_bytes_per_launch_corrected')
+            prof = json.load(f)
+        b = prof.get('counters', {}).get('hbm_bytes_per_launch_corrected')
         # NOT a live counter: read from the committed rocprofv3 --pmc summary of the same command
-        # (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
-        return {'bytes': b, 'source': 'profiles/' + os.path.basename(pm[-1]), 'live': False}
+        # (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes).  The summary names the kernel
+        # instantiation(s) it counted and the sha1 of the kernel sources it was built from: a summary of an
+        # older kernel, or of another instantiation than the one that just ran, is flagged here
+        inst = prof.get('kernel_instances')
+        sha = prof.get('source_sha1')
+        return {'bytes': b, 'source': 'profiles/' + os.path.basename(pm[-1]), 'live': False,
+                'same_kernel_source': (sha == kernel_source_digest()) if sha else None,
+                'same_instantiation': (any(instance.replace(' ', '') in k.replace(' ', '') for k in inst)
+                                       if inst and instance else None)}
     if eng == 'fft':
         N = 8192
         V = (N - L + 1) // 512 * 512 if L <= 5633 else 4096      # segmented templates advance by 4096
@@ -153,7 +176,8 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         kname = ('ds_fft_pp_kernel<%d>' if pp else 'ds_fft_kernel<%d>') % (V // 512)
         return {'bound': 'hbm', 'kernel': kname, 'achieved': gbs, 'peak': 8000.0,
                 'unit': 'GB/s', 'frac': gbs / 8000.0,
-                'traffic': pmc('*_bench_pmc_ds_fft_pp_kernel.json' if pp else '*_bench_pmc_ds_fft_kernel.json'),
+                'traffic': pmc('*_bench_pmc_ds_fft_pp_kernel.json' if pp else '*_bench_pmc_ds_fft_kernel.json',
+                               ('ds_fft_pp_kernel<%d,false,%d>' % (V // 512, Nc)) if pp else None),
                 'kernel_ms': kms, 'bytes_per_launch': bytes_alg, 'engine': 'fft',
                 'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
                             'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
@@ -326,10 +350,13 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     bytes_alg = 4.0 * N * n + 12.0 * npairs                        # events once + 12 B per pair
     # counters of the committed rocprofv3 --pmc passes of scripts/bench_xcorr.py (scripts/profile_xc.sh), newest tag
     import glob
-    pmc, pmc_src = {}, None
+    pmc, pmc_src, pmc_same = {}, None, None
     for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_xcorr_pmc.json')), key=_tag_order)[-1:]:
         with open(fn) as f:
-            pmc, pmc_src = json.load(f).get('kernels', {}), 'profiles/' + os.path.basename(fn)
+            prof = json.load(f)
+        pmc, pmc_src = prof.get('kernels', {}), 'profiles/' + os.path.basename(fn)
+        if prof.get('source_sha1'):
+            pmc_same = prof['source_sha1'] == kernel_source_digest()
 
     def cnt(kern, name):
         v = pmc.get(kern, {}).get(name)
@@ -343,7 +370,8 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
         from oracle import cpu_bench
         try:
             cpu_leg = cpu_bench.xcorr_onecore(td_host, Nc, npairs=400)
-            cpu_leg['all_cores'] = cpu_bench.xcorr_allcores(td_host, Nc, pairs_per_worker=60)
+            cpu_leg['all_cores'] = cpu_bench.xcorr_allcores(td_host, Nc, pairs_per_worker=60,
+                                                            onecore_rate=cpu_leg['value'])
         except Exception as e:                          # noqa: BLE001 -- a bounded leg never takes the line down
             cpu_leg = dict(value=None, unit='pairs/s', error=repr(e))
     return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,
@@ -352,7 +380,8 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
             'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
                          'achieved': bytes_alg / (kms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0,
-                         'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False} if hbm else None),
+                         'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False,
+                                      'same_kernel_source': pmc_same} if hbm else None),
                          'bytes_per_launch': bytes_alg,
                          'bound_actual': 'the sum of its two phases, run one after the other by one workgroup per CU: '
                                          'products (L2 -> L1 stream of the pair spectra, ~0.85 of the L1 fill rate) '
@@ -834,7 +863,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
         if default_cfg and not a.no_extras:
-            out['cpu_baseline']['all_cores'] = cpu_baseline_allcores(Uh, det_off, x, Nc)
+            out['cpu_baseline']['all_cores'] = cpu_baseline_allcores(Uh, det_off, x, Nc,
+                                                                     onecore_rate=out['cpu_baseline']['value'])
     else:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -50,6 +50,73 @@ def cpu_info():
     return model, max(1, min(nphys, usable)), logical
 
 
+def cgroup_cpu_limit():
+    """CPUs the container may use according to its cgroup CPU controller, or None when unlimited / unreadable:
+    cgroup v2 ``cpu.max`` ("<quota> <period>" or "max ..."), cgroup v1 ``cpu.cfs_quota_us / cpu.cfs_period_us``.
+    sched_getaffinity does not show such a quota."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            q = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def cgroup_throttle():
+    """(nr_throttled, throttled microseconds) of the container's cgroup so far, or None."""
+    for path in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat'):
+        try:
+            d = {}
+            with open(path) as f:
+                for line in f:
+                    k, v = line.split()[:2]
+                    d[k] = float(v)
+            us = d.get('throttled_usec', d.get('throttled_time', 0.0) / 1e3)
+            return d.get('nr_throttled', 0.0), us
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def effective_cores():
+    """Cores a worker pool can really occupy here: physical cores this process may run on, capped by the
+    cgroup CPU quota when there is one."""
+    _, ncores, _ = cpu_info()
+    lim = cgroup_cpu_limit()
+    return ncores if lim is None else max(1, min(ncores, int(lim + 0.999)))
+
+
+def _pool_report(res, wall, workers, onecore_rate, rate, thr0):
+    """What shows whether an all-cores leg really ran on `workers` cores: the workers' own CPU seconds over
+    the wall clock (time-sliced or throttled workers accumulate less CPU time than wall time; workers that
+    stall on a shared memory system accumulate it in full and still do not scale), the cgroup's quota and its
+    throttling during the leg, per-worker seconds, and the speed-up over the one-core leg."""
+    cpu_s = sum(r.get('cpu_seconds', r['seconds']) for r in res)
+    thr1 = cgroup_throttle()
+    out = dict(workers=workers, effective_cores=cpu_s / wall if wall > 0 else None,
+               cgroup_cpu_limit=cgroup_cpu_limit(),
+               worker_seconds=dict(mean=float(np.mean([r['seconds'] for r in res])),
+                                   max=float(max(r['seconds'] for r in res)),
+                                   min=float(min(r['seconds'] for r in res))),
+               worker_cpu_seconds_mean=cpu_s / len(res))
+    if thr0 is not None and thr1 is not None:
+        out['cgroup_throttled'] = dict(periods=thr1[0] - thr0[0], seconds=(thr1[1] - thr0[1]) / 1e6)
+    if onecore_rate:
+        out['speedup_vs_one_core'] = rate / onecore_rate
+        out['parallel_efficiency'] = rate / onecore_rate / workers
+        # the same work on one otherwise idle core would take each worker this long
+        out['worker_seconds_if_alone'] = out['worker_seconds']['mean'] * rate / onecore_rate / workers
+    return out
+
+
 def _mem_available_gb():
     try:
         with open('/proc/meminfo') as f:
@@ -77,7 +144,7 @@ def _worker(workdir, i):
         if time.time() > deadline:
             sys.exit(2)
         time.sleep(0.005)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     xFD = scipy.fftpack.fft(x, n=rbi)                            # detect.py:255-256
     nv = 0
     for d in range(len(off) - 1):
@@ -85,20 +152,21 @@ def _worker(workdir, i):
         nv += int(off[d + 1] - off[d])
     dt = time.perf_counter() - t0
     with open(os.path.join(workdir, 'done%d.json' % i), 'w') as f:
-        json.dump(dict(nvec=nv, seconds=dt), f)
+        json.dump(dict(nvec=nv, seconds=dt, cpu_seconds=time.process_time() - c0), f)
 
 
 def allcores_baseline(U, det_off, x_chunks, Nc, nvec_per_worker=40, max_workers=None,
-                      timeout=600.0):
+                      timeout=600.0, onecore_rate=None):
     """windows/s of the reference algorithm with one worker per physical core, each on one
     chunk x ``nvec_per_worker`` basis vectors; the rate is scaled linearly to all K vectors
     (the cost is one IFFT per vector and chunk)."""
     model, ncores, logical = cpu_info()
     # ~1.2 GB peak per worker (8-vector detector: spectra, products and inverse transforms
     # of 2^21 complex128 points each)
-    workers = max(1, min(ncores, int(_mem_available_gb() / 1.5)))
+    workers = max(1, min(effective_cores(), int(_mem_available_gb() / 1.5)))
     if max_workers:
         workers = min(workers, int(max_workers))
+    thr0 = cgroup_throttle()
     D = len(det_off) - 1
     K, n = U.shape
     x_chunks = np.atleast_2d(x_chunks)
@@ -142,6 +210,7 @@ def allcores_baseline(U, det_off, x_chunks, Nc, nvec_per_worker=40, max_workers=
     value = P * (nvec / float(K)) / wall
     return dict(value=value, unit='windows/s', cores=workers, kind='port', cpu_model=model,
                 physical_cores=ncores, os_cpu_count=logical,
+                pool=_pool_report(res, wall, workers, onecore_rate, value, thr0),
                 sample='%d worker processes (one per physical core) x 1 chunk x %d basis vectors '
                        'each, float64 FFT path, %.1f s wall (slowest worker %.1f s), scaled linearly '
                        'to %d vectors' % (workers, nvec // workers, wall,
@@ -185,20 +254,21 @@ def _xc_worker(workdir, i):
         if time.time() > deadline:
             sys.exit(2)
         time.sleep(0.005)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for k in range(npairs):
         b, c = pairs[k % len(pairs)]
         orc.ccx2_fft(ev[b], ev[c], Nc, fds[b], fds[c])
     with open(os.path.join(workdir, 'done%d.json' % i), 'w') as f:
-        json.dump(dict(npairs=npairs, seconds=time.perf_counter() - t0), f)
+        json.dump(dict(npairs=npairs, seconds=time.perf_counter() - t0, cpu_seconds=time.process_time() - c0), f)
 
 
-def xcorr_allcores(td, Nc, pairs_per_worker=24, max_workers=None, timeout=300.0):
+def xcorr_allcores(td, Nc, pairs_per_worker=24, max_workers=None, timeout=300.0, onecore_rate=None):
     """pairs/s of the same restatement with one worker process per physical core."""
     model, ncores, logical = cpu_info()
-    workers = max(1, min(ncores, int(_mem_available_gb() / 0.25)))
+    workers = max(1, min(effective_cores(), int(_mem_available_gb() / 0.25)))
     if max_workers:
         workers = min(workers, int(max_workers))
+    thr0 = cgroup_throttle()
     procs = []
     with tempfile.TemporaryDirectory(prefix='dtx_cpux_') as wd:
         for w in range(workers):
@@ -230,6 +300,7 @@ def xcorr_allcores(td, Nc, pairs_per_worker=24, max_workers=None, timeout=300.0)
     total = sum(r['npairs'] for r in res)
     return dict(value=total / wall, unit='pairs/s', cores=workers, kind='port', cpu_model=model,
                 physical_cores=ncores, os_cpu_count=logical,
+                pool=_pool_report(res, wall, workers, onecore_rate, total / wall, thr0),
                 sample='%d worker processes x %d pairs of n = %d each, %.1f s wall (slowest worker %.1f s)'
                        % (workers, pairs_per_worker, int(np.shape(td)[1]), wall, max(r['seconds'] for r in res)))
 

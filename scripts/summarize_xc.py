@@ -7,7 +7,9 @@ MI355X_MICROARCH.md)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import shutil
 import sys
 
@@ -34,5 +36,9 @@ for kern in ("xc_fft_kernel", "xc_finish"):
         out['hbm_bytes_per_launch_corrected'] = (2 * out['FETCH_SIZE']['mean_per_launch'] +
                                                  out['WRITE_SIZE']['mean_per_launch']) * 1024
     res[kern] = out
-json.dump({'tag': tag, 'kernels': res}, open('profiles/%s_xcorr_pmc.json' % tag, 'w'), indent=1)
+h = hashlib.sha1()          # the kernel sources the counters belong to (bench.py flags a stale summary)
+for fn in sorted(glob.glob('detex_amd/csrc/*.hip') + glob.glob('detex_amd/csrc/*.h')):
+    h.update(os.path.basename(fn).encode())
+    h.update(open(fn, 'rb').read())
+json.dump({'tag': tag, 'source_sha1': h.hexdigest(), 'kernels': res}, open('profiles/%s_xcorr_pmc.json' % tag, 'w'), indent=1)
 print(json.dumps(res, indent=1))
