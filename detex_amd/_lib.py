@@ -19,7 +19,7 @@ SYMBOLS = [
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
     'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean', 'dtx_subspace_scan_ragged',
-    'dtx_trigger_stats_ragged',
+    'dtx_trigger_stats_ragged', 'dtx_chunk_table_check',
 ]
 
 
@@ -71,6 +71,8 @@ def load():
     lib.dtx_subspace_scan.argtypes = [vp, vp, i64, i64, i32, vp, i64, vp, vp, vp, vp, vp, u32, vp]
     lib.dtx_subspace_scan_ragged.restype = i32
     lib.dtx_subspace_scan_ragged.argtypes = [vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, u32, vp]
+    lib.dtx_chunk_table_check.restype = i32
+    lib.dtx_chunk_table_check.argtypes = [vp, i32, i64, i64]
     lib.dtx_ds_post.restype = i32
     lib.dtx_ds_post.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, u32, vp]
     lib.dtx_ds_moments.restype = i32

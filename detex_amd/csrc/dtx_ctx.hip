@@ -1,5 +1,6 @@
 // Context, error reporting, workspaces and HIP-event timers of libdetexhip.so.
 #include "dtx_internal.h"
+#include "dtx_plan.h"
 
 static thread_local std::string g_create_err;
 
@@ -23,7 +24,7 @@ int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes) {
     b.p = nullptr;
     b.bytes = 0;
   }
-  size_t want = bytes + bytes / 8 + 256;
+  size_t want = dtxplan::reserve_capacity(bytes);
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
     b.p = nullptr;
@@ -54,7 +55,7 @@ int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t byte
     if (ctx->stage_buf[k]) DTX_HIP(ctx, hipHostFree(ctx->stage_buf[k]));
     ctx->stage_buf[k] = nullptr;
     ctx->stage_cap[k] = 0;
-    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+    const size_t want = dtxplan::stage_capacity(bytes);
     DTX_HIP(ctx, hipHostMalloc(&ctx->stage_buf[k], want, hipHostMallocDefault));
     ctx->stage_cap[k] = want;
   }
@@ -65,7 +66,7 @@ int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t byte
 }
 
 int dtx_kev_next(dtx_ctx* ctx) {
-  const int slot = (int)(ctx->kev_count % dtx_ctx::kKev);
+  const int slot = dtxplan::ring_next_slot(ctx->kev_count, dtx_ctx::kKev);
   // (each event of the pair on its own: a create that failed half-way is completed by the next call)
   if (!ctx->kev0[slot]) DTX_HIP(ctx, hipEventCreate(&ctx->kev0[slot]));
   if (!ctx->kev1[slot]) DTX_HIP(ctx, hipEventCreate(&ctx->kev1[slot]));
@@ -106,6 +107,11 @@ int dtx_aux_join(dtx_ctx* ctx) {
 extern "C" {
 
 int dtx_version(void) { return DTX_ABI_VERSION; }
+
+int dtx_chunk_table_check(const int64_t* chunk_tab_host, int nchunk, int64_t M, int64_t numel) {
+  if (!chunk_tab_host || nchunk <= 0 || M < 0 || numel < 0) return 1;
+  return dtxplan::check_chunk_table(chunk_tab_host, nchunk, M, numel);
+}
 
 const char* dtx_last_error(dtx_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_err.c_str();
@@ -212,13 +218,14 @@ int dtx_timer_stop(dtx_ctx* ctx, float* ms) {
 int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms) {
   if (!ctx || !ms || n <= 0) return DTX_E_ARG;
   if (!ctx->kernel_timed) return dtx_fail(ctx, DTX_E_STATE, "no timed kernel has run yet");
-  if (n > dtx_ctx::kKev || n > ctx->kev_count)
+  int slots[dtx_ctx::kKev];
+  if (!dtxplan::ring_last_slots(ctx->kev_count, dtx_ctx::kKev, n, slots))
     return dtx_fail(ctx, DTX_E_ARG, "dtx_kernel_ms_mean: only the last %d launches are kept (%lld timed so far)",
                     dtx_ctx::kKev, ctx->kev_count);
   DtxDeviceGuard g(ctx->device);
   double sum = 0.0;
   for (int q = 0; q < n; ++q) {
-    const int slot = (int)((ctx->kev_count - 1 - q) % dtx_ctx::kKev);
+    const int slot = slots[q];
     float t = 0.f;
     DTX_HIP(ctx, hipEventSynchronize(ctx->kev1[slot]));
     DTX_HIP(ctx, hipEventElapsedTime(&t, ctx->kev0[slot], ctx->kev1[slot]));

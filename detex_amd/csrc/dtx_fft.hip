@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "dtx_fftcore.h"
+#include "dtx_plan.h"
 
 namespace {
 
@@ -843,83 +844,31 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   // too: Y[p] = sum_s corr(segment s, data at p + s kSeg), and with advance == segment length
   // "data at p + s kSeg" is simply block (blk + s) -- its spectrum is already there.  Each
   // (channel, segment) is a virtual channel of the MAC.
+  // The pairs, the units (runs of whole detectors' pairs, closed at DTX_FFT_UNIT = 8: the block spectra a
+  // workgroup stages in LDS serve all its pairs) and the split of every unit between the two halves of the
+  // ping-pong kernel are host arithmetic on det_off alone: dtxplan::plan_fft_basis (dtx_plan.h, the
+  // translation unit the CPU sanitizer build covers).
   constexpr int kSeg = kN / 2;
-  f.nseg = L <= kFftMaxL ? 1 : (L + kSeg - 1) / kSeg;
-  f.V = f.nseg == 1 ? (kN - L + 1) / 512 * 512 : kSeg;
-
-  // pairs: consecutive vectors of a detector (an odd one out pairs with a zero row); two
-  // consecutive single-vector detectors share a pair.  units: runs of whole detectors' pairs,
-  // closed once they hold kUnitPairs = 8 (a detector with more pairs is a unit of its own) -- the
-  // block spectra a workgroup stages in LDS serve all its pairs
-  const int kUnitPairs = DTX_FFT_UNIT;
-  std::vector<int4> units;
-  std::vector<int2> pdet;
-  std::vector<int2> prow;   // per pair: row of the real part, row of the imaginary part (-1: none)
-  int ufirst = 0;
-  int cum0 = 0, cum1 = 0;   // pairs given to half 0 / half 1 of the ping-pong kernel so far
-  auto close_unit = [&]() {
-    const int np = (int)prow.size() - ufirst;
-    if (np > 0) {
-      // pairs [0, z) go to half 0 of the ping-pong kernel: the detector boundary that leaves the two
-      // halves' running totals closest (any run of units is then balanced to within a detector or two)
-      int best = np, bestd = 1 << 30;
-      for (int q = 0; q <= np; ++q) {
-        if (q > 0 && pdet[ufirst + q - 1].x < 0) continue;        // inside a detector
-        const int dd = std::abs((cum0 + q) - (cum1 + np - q));
-        if (dd < bestd) { best = q; bestd = dd; }
-      }
-      cum0 += best; cum1 += np - best;
-      units.push_back(make_int4(ufirst, np, best, 0));
-    }
-    ufirst = (int)prow.size();
-  };
-  for (int d = 0; d < D;) {
-    const int r0 = det_off[d], k = det_off[d + 1] - r0;
-    const bool shared = k == 1 && d + 1 < D && det_off[d + 2] - det_off[d + 1] == 1;
-    const int np = shared ? 1 : (k + 1) / 2;
-    if ((int)prow.size() - ufirst + np > kUnitPairs) close_unit();
-    if (shared) {
-      f.two = true;
-      pdet.push_back(make_int2(d, d + 1));
-      prow.push_back(make_int2(r0, r0 + 1));
-      d += 2;
-    } else {
-      for (int q = 0; q < k; q += 2) {
-        const bool has2 = q + 1 < k;
-        pdet.push_back(make_int2(q + 2 >= k ? d : -1, -1));
-        prow.push_back(make_int2(r0 + q, has2 ? r0 + q + 1 : -1));
-      }
-      d += 1;
-    }
-  }
-  close_unit();
-  f.nunits = (int)units.size();
-  f.npairs = (int)prow.size();
-  std::vector<int2> upre(units.size() + 1);
-  for (size_t u = 0; u < units.size(); ++u)
-    upre[u + 1] = make_int2(upre[u].x + units[u].z, upre[u].y + units[u].y - units[u].z);
+  dtxplan::FftBasisPlan pl = dtxplan::plan_fft_basis(det_off, D, L, kN, kFftMaxL, DTX_FFT_UNIT);
+  f.nseg = pl.nseg;
+  f.V = pl.V;
+  f.two = pl.two;
+  f.nunits = pl.nunits;
+  f.npairs = pl.npairs;
   {
     const char* e = getenv("DTX_FFT_PP");
     // the ping-pong kernel keeps the block spectra in LDS (single-segment templates, one or three
     // channels) and is worth it when the halves are balanced: at least 0.8 pairs per round
-    const int pp_rounds = std::max(2 * cum0 + 1, 2 * cum1 + 2);
-    f.pingpong = DTX_FFT_XLDS && f.nseg == 1 && (Nc == 1 || Nc == 3) && 5 * f.npairs >= 4 * pp_rounds &&
-                 !(e && e[0] == '0');
+    f.pingpong = DTX_FFT_XLDS && f.nseg == 1 && (Nc == 1 || Nc == 3) && pl.balanced && !(e && e[0] == '0');
   }
   if (f.pingpong) {
     // store the pairs half 0's first: each half-workgroup then walks a contiguous run of pairs
-    std::vector<int2> pdet2, prow2;
-    for (int h = 0; h < 2; ++h)
-      for (const int4& un : units)
-        for (int q = h ? un.z : 0; q < (h ? un.y : un.z); ++q) {
-          pdet2.push_back(pdet[un.x + q]);
-          prow2.push_back(prow[un.x + q]);
-        }
-    pdet.swap(pdet2);
-    prow.swap(prow2);
-    f.unit_pairs.resize(units.size());
-    for (size_t u = 0; u < units.size(); ++u) f.unit_pairs[u] = units[u].y;
+    dtxplan::reorder_pairs_for_halves(pl);
+    f.unit_pairs = pl.unit_pairs;
   }
+  static_assert(sizeof(int4) == sizeof(dtxplan::I4) && sizeof(int2) == sizeof(dtxplan::I2), "plan tables are int2 / int4");
+  const std::vector<dtxplan::I4>& units = pl.units;
+  const std::vector<dtxplan::I2>&pdet = pl.pdet, &prow = pl.prow, &upre = pl.upre;
 
   const int nvc = Nc * f.nseg;
   static const std::vector<float2> tab = [] {          // e^{+2 pi i m / kN}, once per process
@@ -979,28 +928,13 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   int nfull = 0, nrem = 0, ng = 1;
   short gb[kMaxGroups + 1] = {0};
   if (pp) {
+    static_assert(kMaxGroups == dtxplan::kPlanMaxGroups, "group table size");
     const char* e = getenv("DTX_PP_GROUPS");     // experiments: this many groups for every block
-    const int force = e ? atoi(e) : 0;
-    const int64_t nb = (int64_t)nchunk * nblk;
-    const int ncu = std::max(1, ctx->ncu);
-    nfull = force > 0 ? 0 : (int)(nb / ncu * ncu);
-    nrem = (int)(nb - nfull);
-    double best = 1e300;
-    for (int g = 1; g <= std::min(f.nunits, kMaxGroups) && nrem > 0; ++g) {
-      if (force > 0 && g != std::min(std::min(force, f.nunits), kMaxGroups)) continue;
-      // unit borders nearest to k / g of the pairs
-      short b[kMaxGroups + 1];
-      int u = 0, acc = 0, maxp = 0, last = 0, n = 0;
-      b[0] = 0;
-      for (int k = 1; k <= g; ++k) {
-        const int target = (int)((int64_t)f.npairs * k / g);
-        while (u < f.nunits && (k == g || acc + f.unit_pairs[u] - target <= target - acc)) acc += f.unit_pairs[u++];
-        if (u > b[n]) { b[++n] = (short)u; maxp = std::max(maxp, acc - last); last = acc; }
-      }
-      const double cost = (double)(((int64_t)nrem * n + ncu - 1) / ncu) * (maxp + 3.0);
-      if (cost < best) { best = cost; ng = n; std::copy(b, b + n + 1, gb); }
-    }
-    grid = (int64_t)nfull + (int64_t)nrem * ng;
+    const dtxplan::PpGridPlan gp = dtxplan::plan_pp_grid((int64_t)nchunk * nblk, ctx->ncu, f.nunits, f.npairs,
+                                                         f.unit_pairs.data(), e ? atoi(e) : 0);
+    nfull = gp.nfull; nrem = gp.nrem; ng = gp.ng;
+    std::copy(gp.gb, gp.gb + kMaxGroups + 1, gb);
+    grid = gp.grid;
   }
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;

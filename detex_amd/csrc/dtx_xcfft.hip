@@ -14,6 +14,7 @@
 // re-evaluated in float64 by xc_finish_kernel exactly as before, so the float32 transforms
 // only have to pick the lag.
 #include "dtx_fftcore.h"
+#include "dtx_plan.h"
 
 namespace {
 
@@ -397,44 +398,20 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // the kernel's timing-only ablations) and one MAC step per (block, segment, channel) that sees data.  At
   // L = 13 000: segments of 4096 -> 4 blocks x 4 segments (13 products see data); 4 segments of 3250 ->
   // V = 4608, 3 blocks, 11 products -- a quarter fewer transforms and a sixth fewer MAC steps.
+  // (host arithmetic: dtxplan::plan_xc_segments / plan_xc_items, dtx_plan.h -- covered by the CPU sanitizer build)
   const int S = (Pz - 1) / 2;
-  int nseg = 1, seglen = L, V = (kN - L + 1) / 512 * 512;
-  if (L > kFftMaxL) {
-    double best = 1e300;
-    for (int ns = 2; ns <= 16; ++ns) {
-      const int sl0 = (L + ns - 1) / ns;                    // shortest segments that cover the event
-      const int v = std::min(15 * 512, (kN - sl0 + 1) / 512 * 512);
-      if (v < 4 * 512) continue;
-      // the longest segments that advance allows (fewer (block, segment) products see data), every
-      // segment non-empty
-      const int sl = std::min(kN - v + 1, (L + ns - 2) / (ns - 1) - 1);
-      if (sl < sl0) continue;
-      const int nb = (Pz + v - 1) / v;
-      double cost = 0;
-      for (int b = 0; b < nb; ++b) cost += 7.5 + Nc * std::min(ns, std::max(1, (S + L - b * v + sl - 1) / sl));
-      if (cost < best) { best = cost; nseg = ns; seglen = sl; V = v; }
-    }
-  }
-  const int nblk = (Pz + V - 1) / V, nblkx = nblk * nseg;
+  const dtxplan::XcSegPlan sp = dtxplan::plan_xc_segments(L, Pz, Nc, kN, kFftMaxL);
+  const int nseg = sp.nseg, seglen = sp.seglen, V = sp.V;
+  const int nblk = sp.nblk, nblkx = nblk * nseg;
   const int nvc = Nc * nseg, npr = (N + 1) / 2;
 
   // work items (c, first pair of a unit), unit-major so that concurrent workgroups share the
-  // unit's pair spectra in L2
-  std::vector<int2> items;
+  // unit's pair spectra in L2.
   // kGroupX units are walked together, kCtileX later events at a time: the workgroups of one later event
   // (one per unit of the group) share its block spectra in L2, those of one unit (one per later event of
   // the tile and lag block) its pair spectra
-  for (int g0 = 0; g0 < npr; g0 += kUnitX * kGroupX) {
-    const int64_t g_lo = 2 * (int64_t)g0, g_hi = 2 * (int64_t)(g0 + kUnitX * kGroupX) - 1;
-    if (g_hi < b_begin || g_lo > b_end) continue;
-    for (int c0 = (int)std::max<int64_t>(g_lo + 1, 1); c0 < N; c0 += kCtileX)
-      for (int pr0 = g0; pr0 < std::min(npr, g0 + kUnitX * kGroupX); pr0 += kUnitX) {
-        const int64_t r_lo = 2 * (int64_t)pr0, r_hi = 2 * (int64_t)(pr0 + kUnitX) - 1;
-        if (r_hi < b_begin || r_lo > b_end) continue;
-        for (int c = c0; c < std::min(N, c0 + kCtileX); ++c)
-          if (c > r_lo) items.push_back(make_int2(c, pr0));
-      }
-  }
+  static_assert(sizeof(int2) == sizeof(dtxplan::I2), "work items are int2");
+  const std::vector<dtxplan::I2> items = dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
   const int64_t nwork = (int64_t)items.size() * nblk;
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;

@@ -270,9 +270,10 @@ class HipContext(object):
             tab_dev, tab = chunk_tab
             if not x.is_contiguous():
                 raise ValueError('a ragged batch reads one flat buffer')
-            if int((tab[:, 0] + tab[:, 1]).max()) > x.numel():
-                raise ValueError('flat buffer too small for the chunk table')
             nchunk, M, chunk_stride = len(tab), int(tab[:, 1].max()), 0
+            bad = self.lib.dtx_chunk_table_check(tab.ctypes.data_as(C.c_void_p), nchunk, M, int(x.numel()))
+            if bad:
+                raise ValueError('flat buffer too small for the chunk table (chunk %d)' % (bad - 1))
         elif M is None:
             if x.dim() == 1:
                 x = x[None, :]

@@ -179,6 +179,12 @@ int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
                              float* maxds_dev, const float* thr_dev, uint64_t* cand_key_dev,
                              float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* Host-side check of the chunk table of a ragged batch BEFORE it goes to the device (the device passes clamp
+ * M_b to [0, M] but trust the offsets): chunk_tab_host [nchunk][2] int64 as for dtx_subspace_scan_ragged,
+ * numel = samples in the flat buffer behind x_dev.  Returns 0 when every chunk lies inside the buffer and holds
+ * at most M samples, else 1 + the index of the first chunk that does not.  No context, no device work. */
+int dtx_chunk_table_check(const int64_t* chunk_tab_host, int nchunk, int64_t M, int64_t numel);
+
 /* False-alarm statistics of a DS tensor (detex/fas.py:72-86: np.histogram(dss,
  * np.linspace(-.01, 1, 401)) and scipy.stats.beta.fit(dss, floc=0, fscale=1)).
  *   hist_dev  [D][nbins] uint32, accumulated, uniform np.linspace(lo, hi, nbins+1)
