@@ -528,6 +528,75 @@ def e2e_detex(local):
     return out
 
 
+def e2e_detex_240(local):
+    """BASELINE configs[3]'s volume through the PRODUCT API on one GPU: 8 stations x 30 days = 240 station-days
+    (720 hourly chunks of 3720 s per station) through SubSpace.detex(estimateMags=True) -- without a DB, with
+    the SQLite file, and with an unfiltered fetcher (per-chunk detrend + band-pass on the device).  A station's
+    record is scanned in day units (SubSpace._scan_units), three units in flight.  Host memory stays bounded:
+    the eight stations share ONE page-locked 30-day record (3.1 GB; one day of noise + 50 planted events,
+    repeated), so every station-day still crosses PCIe on its own."""
+    import tempfile
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace, synth
+    SR, NC, L, NFAM, NPER, NSTA, NDAY = 100.0, 3, 3300, 25, 8, 8, 30
+    rs = np.random.RandomState(0)
+    td = synth.event_families(1, NFAM, NPER, NC, L, maxshift=20, snr=8.0)
+    stas = ['TA.S%02dA' % i for i in range(NSTA)]
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    for sta in stas:
+        for e in range(len(td)):
+            ef.add(sta, 'ev%03d' % e, td[e].reshape(L, NC).T, starttime=1000.0 + 100 * e,
+                   origintime=990.0 + 100 * e, magnitude=1.0 + (e % 5) * .2)
+    T1 = int(24 * 3600 * SR)
+    day = rs.standard_normal((NC, T1)).astype(np.float32)
+    nplant = 50
+    for k in range(nplant):
+        e = int(rs.randint(len(td)))
+        t = int(rs.randint(L, T1 - 2 * L))
+        day[:, t:t + L] += 3.0 * td[e].reshape(L, NC).T / np.std(td[e])
+    rec = torch.empty((NC, NDAY * T1), dtype=torch.float32).pin_memory()
+    for d in range(NDAY):
+        rec[:, d * T1:(d + 1) * T1] = torch.from_numpy(day)
+    t_start = 1499997600.0                                   # on the hour: 720 chunks, the last one 3600 s
+
+    def fetcher(raw):
+        cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], raw=raw)
+        for sta in stas:
+            cf.add(sta, rec.numpy(), starttime=t_start)
+        cf.pinned = {sta: rec for sta in stas}               # (what ContinuousFetcher.pin() sets up, shared)
+        return cf
+
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, device=local, saveclust=False)
+    out = {'workload': '%d stations x %d days = %d station-days (720 chunks of 3720 s per station, 3-ch 100 Hz) through '
+                       'SubSpace.detex(estimateMags=True), day units, one shared pinned 30-day record'
+                       % (NSTA, NDAY, NSTA * NDAY), 'unit': 'windows/s', 'planted': nplant * NDAY * NSTA}
+    with tempfile.TemporaryDirectory() as tmp:
+        for key, raw, db in (('no_db', False, None), ('sqlite', False, os.path.join(tmp, 'SubSpace.db')),
+                             ('raw_fetcher', True, None)):
+            cf = fetcher(raw)
+            ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+            ss.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
+            ss.SVD(selectCriteria=4, selectValue=7, threshold=0.3, useSingles=False)
+            names, kinds, U, off, _, _ = ss._detector_bank(stas[0], useSingles=False)
+            n = U.shape[1]
+            windows = NSTA * sum((int(b[1]) * NC - n) // NC + 1 for b in cf.chunk_bounds(stas[0]))
+            res = ss.detex(subspaceDB=db, estimateMags=True, device=local)          # warm: contexts, buffers
+            torch.cuda.synchronize()
+            reps = 2 if key == 'no_db' else 1
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = ss.detex(subspaceDB=db, estimateMags=True, device=local)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            out[key] = {'value': windows / dt, 's_per_call': dt, 'ms_per_station_day': 1e3 * dt / (NSTA * NDAY),
+                        'detections': int(len(res['ss_df'])), 'units': NSTA * NDAY,
+                        'uploaded_gb': ss.last_run['uploaded_bytes'] / 1e9}
+            assert len(res['ss_df']) >= 0.9 * nplant * NDAY * NSTA, (key, len(res['ss_df']))
+            del ss, cf, res
+            torch.cuda.empty_cache()
+    out['value'] = out['no_db']['value']
+    return out
+
+
 def run_config4(a, rank, world, local, use_dist):
     """BASELINE configs[3]: `stations` x `days` station-days of the configs[1] workload, dealt
     round-robin over the GPUs (detex_amd.parallel.shard_units); every station has its own
@@ -860,6 +929,11 @@ def main():
             out['e2e_detex'] = e2e_detex(local)
         except Exception as e:                         # noqa: BLE001
             out['e2e_detex'] = {'value': None, 'error': repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            out['e2e_detex_240'] = e2e_detex_240(local)
+        except Exception as e:                         # noqa: BLE001
+            out['e2e_detex_240'] = {'value': None, 'error': repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(Uh, det_off, x[0], Nc, a.cpu_vectors)
         if default_cfg and not a.no_extras:

@@ -183,10 +183,11 @@ class _StationUploader(object):
             self.slots[k] = slot
         return k, slot
 
-    def start(self, fetcher, sta, bounds, sel=None):
+    def start(self, fetcher, sta, bounds, sel=None, key=None):
         """bounds: the station's chunks (ContinuousFetcher.chunk_bounds); sel: the chunk indices
         scanned here (None: all, the whole record is uploaded).  The chunks are handed to the scan
-        as (first sample in the uploaded buffer, samples, start time, chunk index)."""
+        as (first sample in the uploaded buffer, samples, start time, chunk index).  key: what get()
+        asks for (default: the station; detex scans a long record in several units)."""
         import torch
         from . import parallel
         data = fetcher.data[sta][0]
@@ -201,7 +202,7 @@ class _StationUploader(object):
             if counts is not None:
                 counts = parallel.rebase_fragments(counts, runs)
         job = dict(planes=None, ready=None, slot=None, bounds=local, T=T, counts=counts)
-        self.pending[sta] = job
+        self.pending[sta if key is None else key] = job
         if counts is not None or T == 0:
             # raw counts: scan_station ingests the fragments (their upload is counted here)
             self.bytes_uploaded += sum(4 * len(x) for (_, _, x) in (counts or []))
@@ -247,22 +248,27 @@ class _StationUploader(object):
 
 
 def _merge_ranks(parts, names_order=None):
-    """Results of one station from every rank (each scanned its share of the chunks): detection
-    rows in the order a single process produces them -- by (chunk, detector, order found), the
-    key StationScan.finish returns next to the tables --, histogram counts added."""
+    """Results of one station in several parts -- from every rank (each scanned its share of the chunks)
+    and / or from the units a long record is scanned in: detection rows in the order one launch over the
+    whole record produces them -- by (chunk, detector, order found), the key StationScan.finish returns
+    next to the tables --, histogram counts added."""
     parts = [p for p in parts if p is not None]
     if not parts:
         return None
+    if len(parts) == 1:
+        return parts[0]
     out = {}
     for kind in ('ss', 'sg'):
         dfs = [p[kind] for p in parts if len(p[kind])]
         if not dfs:
             out[kind] = parts[0][kind]
+            out['key_' + kind] = np.zeros((0, 3), dtype=np.int64)
             continue
         keys = np.concatenate([np.asarray(p['key_' + kind], dtype=np.int64).reshape(-1, 3)
                                for p in parts if len(p[kind])])
         order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
         out[kind] = pd.concat(dfs, ignore_index=True).iloc[order].reset_index(drop=True)
+        out['key_' + kind] = keys[order]
     for hk in ('hist_ss', 'hist_sg'):
         acc = {}
         for p in parts:
@@ -276,6 +282,74 @@ def _merge_ranks(parts, names_order=None):
     if any('utc' in p for p in parts):
         out['utc'] = sorted((r for p in parts for r in p.get('utc', [])), key=lambda r: r['chunk'])
     return out
+
+
+class _DbWriter(object):
+    """The SQLite file of a SubSpace.detex call, written by a thread of its own: the detection rows of
+    every finished unit are queued and appended there while the next units are scanned (the reference
+    appends every 500 rows from inside its chunk loop, detect.py:207-210, util.saveSQLite).  Rows go in
+    through one executemany per flush into tables with the schema pandas' to_sql gives them (REAL / TEXT
+    columns, no index) -- results.py and the reference's readers use pd.read_sql on them."""
+    FLUSH = 500
+    COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
+    TYPES = ['REAL', 'REAL', 'REAL', 'TEXT', 'TEXT', 'REAL', 'REAL', 'REAL', 'REAL', 'REAL']
+
+    def __init__(self, path):
+        import queue
+        import threading
+        self.path = path
+        self.q = queue.Queue()
+        self.error = None
+        self.thread = threading.Thread(target=self._run, name='detex-db-writer', daemon=True)
+        self.thread.start()
+
+    def put(self, table, df):
+        if df is not None and len(df):
+            self.q.put(('rows', table, df[self.COLS].values.tolist()))
+
+    def call(self, fn):
+        """fn(connection) on the writer thread, behind everything queued so far."""
+        self.q.put(('call', fn, None))
+
+    def _run(self):
+        try:
+            con = sqlite3.connect(self.path)
+            pending = {}
+
+            def flush(table=None):
+                for tab in ([table] if table else list(pending)):
+                    rows = pending.pop(tab, [])
+                    if rows:
+                        con.execute('CREATE TABLE IF NOT EXISTS "%s" (%s)' % (
+                            tab, ', '.join('"%s" %s' % ct for ct in zip(self.COLS, self.TYPES))))
+                        con.executemany('INSERT INTO "%s" VALUES (%s)' % (tab, ','.join('?' * len(self.COLS))),
+                                        rows)
+                        con.commit()
+            try:
+                while True:
+                    kind, a, b = self.q.get()
+                    if kind == 'stop':
+                        if not a:
+                            flush()
+                        break
+                    if kind == 'rows':
+                        pending.setdefault(a, []).extend(b)
+                        if len(pending[a]) >= self.FLUSH:
+                            flush(a)
+                    else:
+                        flush()
+                        a(con)
+                        con.commit()
+            finally:
+                con.close()
+        except Exception as e:                              # noqa: BLE001 -- reported by close()
+            self.error = e
+
+    def close(self, abort=False):
+        self.q.put(('stop', abort, None))
+        self.thread.join()
+        if self.error is not None and not abort:
+            raise self.error
 
 
 class SubSpace(object):
@@ -692,21 +766,30 @@ class SubSpace(object):
                     self._adopt_sent_banks(stations, banks, sent)
             except Exception as e:                          # noqa: BLE001
                 failure = failure or '%s: %s' % (type(e).__name__, e)
-        todo = [] if failure is not None else [sta for sta in stations if sel[sta] is None or len(sel[sta])]
+        # A station's chunks are scanned in units: the whole record in one (ragged) launch while its DS tensor
+        # fits the budget, else day by day (_scan_units) -- the pipeline below keeps three UNITS in flight
+        todo = [] if failure is not None else self._scan_units(stations, bounds, sel, banks, fetcher)
         up = self._uploader(dev)
         up.reset()
+        parts = {}
+        # single process: the SQLite file is written by a thread of its own, fed as the units finish
+        # (detect.py:207-210 flushes every 500 rows); under a process group rank 0 writes after the gather
+        writer = _DbWriter(subspaceDB) if (subspaceDB is not None and not active) else None
 
         def collect(job):
-            """Second half of a station: triggers, trigger-time estimates, rows."""
+            """Second half of a unit: triggers, trigger-time estimates, rows."""
             try:
                 res = job.finish()
             finally:
                 job.close()
             if res is not None:
-                results[job.sta] = res
+                parts.setdefault(job.sta, []).append(res)
+                if writer is not None:
+                    writer.put('ss_df', res['ss'])
+                    writer.put('sg_df', res['sg'])
 
-        # Three stations are in flight on the one stream, in the order S0 S1 T0 S2 T1 S3 ... (S: a
-        # station's scans, T: its trigger-time kernel).  The host picks station i's triggers and
+        # Three units are in flight on the one stream, in the order S0 S1 T0 S2 T1 S3 ... (S: a
+        # unit's scans, T: its trigger-time kernel).  The host picks unit i's triggers and
         # enqueues T_i while S_{i+1} runs, enqueues S_{i+2} behind it, and only then waits for T_i:
         # whenever the host blocks or builds rows, a whole scan is still queued.  (With two in flight
         # the wait for T_i -- queued behind S_{i+1} -- drained the queue: 2.5 ms of idle GPU per
@@ -714,14 +797,14 @@ class SubSpace(object):
         queue = []                                          # jobs started, oldest first
         try:
             if todo:
-                up.start(fetcher, todo[0], bounds[todo[0]], sel[todo[0]])
-            for i, sta in enumerate(todo):
+                up.start(fetcher, todo[0][0], bounds[todo[0][0]], todo[0][1], key=0)
+            for i, (sta, chunks) in enumerate(todo):
                 if own_ctx:
                     ctx = self._station_ctx(device, sta)
                 stream = getattr(ctx, 'stream', None)
-                shard = up.get(sta, stream)
-                if i + 1 < len(todo):                       # next station's H2D under this scan
-                    up.start(fetcher, todo[i + 1], bounds[todo[i + 1]], sel[todo[i + 1]])
+                shard = up.get(i, stream)
+                if i + 1 < len(todo):                       # next unit's H2D under this scan
+                    up.start(fetcher, todo[i + 1][0], bounds[todo[i + 1][0]], todo[i + 1][1], key=i + 1)
                 job = StationScan(self, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist,
                                   useSubSpaces, useSingles, fillZeros, device, ctx, estimateMags,
                                   shard=shard, bank=banks[sta], fetcher=fetcher, utcSaves=utc)
@@ -731,23 +814,27 @@ class SubSpace(object):
                 queue.append(job)
                 if not own_ctx:
                     # a context handed in by the caller serves every station in turn: its basis and
-                    # training events are replaced by the next start(), so this station is finished first
+                    # training events are replaced by the next start(), so this unit is finished first
                     collect(queue.pop(0))
                     continue
                 if len(queue) >= 2:
                     queue[-2].pick()                        # T_{i-1} goes in behind S_i
                 if len(queue) >= 3:
-                    collect(queue.pop(0))                   # rows of station i - 2, S_i still queued
+                    collect(queue.pop(0))                   # rows of unit i - 2, S_i still queued
             while queue:
                 collect(queue.pop(0))
         except Exception as e:                              # noqa: BLE001
+            for job in queue:
+                job.close()
+            if writer is not None:
+                writer.close(abort=True)
             if not active:
                 raise
             # the other ranks are (or will be) waiting in the gather below: take part in it with an
             # error marker instead of leaving them hung, then fail on every rank
-            for job in queue:
-                job.close()
             failure = '%s: %s' % (type(e).__name__, e)
+        results = {sta: _merge_ranks(parts.get(sta, [])) for sta in stations}
+        results = {sta: r for sta, r in results.items() if r is not None}
         self.last_run = dict(rank=rank, world=world, uploaded_bytes=up.bytes_uploaded,
                              chunks={sta: (len(bounds.get(sta, ())) if sel[sta] is None else len(sel[sta]))
                                      for sta in stations})
@@ -771,7 +858,9 @@ class SubSpace(object):
                 'ProEnMag']
         for k in out:
             out[k] = pd.concat(out[k], ignore_index=True) if out[k] else pd.DataFrame(columns=cols)
-        if subspaceDB is not None and rank == 0:
+        if writer is not None:
+            self._write_db(None, out, writer)               # the info / histogram tables; joins the thread
+        elif subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         if classifyEvents is not None:
             out['event_cors'] = self._event_cors(fetcher, stations, results, banks, eventCorFile, rank)
@@ -855,6 +944,35 @@ class SubSpace(object):
             df.to_pickle('UTCsaves.pkl')
         return df
 
+    def _scan_units(self, stations, bounds, sel, banks, fetcher):
+        """[(station, chunk indices or None)] in scan order.  A station goes through the kernels in ONE
+        (ragged) launch -- None: its whole record is uploaded as it is -- while the DS tensor of that launch,
+        chunks x detectors x windows x 4 bytes, stays within DETEX_AMD_DS_BUDGET_MB (default 1024: a day of
+        hourly chunks x 25 detectors is 0.9 GB); a longer record is cut into day-sized runs of consecutive
+        chunks (the units parallel.deal_station_chunks deals), each uploaded, scanned and picked on its own.
+        The rows are merged per station by (chunk, detector, order found): the tables do not depend on the cut."""
+        budget = int(os.environ.get('DETEX_AMD_DS_BUDGET_MB', '1024')) << 20
+        per = max(1, int(round(86400.0 / fetcher.conDatDuration)))
+        Nc = len(fetcher.channels)
+        units = []
+        for sta in stations:
+            idx = list(range(len(bounds[sta]))) if sel[sta] is None else [int(i) for i in sel[sta]]
+            if not idx:
+                continue
+            names, U = banks[sta][0], banks[sta][2]
+            if not names or len(idx) <= per:
+                units.append((sta, sel[sta]))
+                continue
+            P = max(0, (max(int(bounds[sta][i][1]) for i in idx) * Nc - U.shape[1]) // Nc + 1)
+            if len(idx) * len(names) * P * 4 <= budget:
+                units.append((sta, sel[sta]))
+                continue
+            days = {}
+            for i in idx:
+                days.setdefault(i // per, []).append(i)
+            units += [(sta, days[d]) for d in sorted(days)]
+        return units
+
     def _adopt_sent_banks(self, stations, banks, sent):
         """Every rank (rank 0 too) scans with the numbers that were broadcast; a bank object is kept
         while they are the ones already resident (its basis images stay on the device)."""
@@ -914,46 +1032,51 @@ class SubSpace(object):
             d.pop(k, None)                                  # device contexts / buffers are not picklable
         return d
 
-    def _write_db(self, path, out):
+    def _write_db(self, path, out, writer=None):
         """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /
-        sg_hist, filt_params."""
-        con = sqlite3.connect(path)
-        try:
-            for k, df in out.items():
-                if len(df):
-                    df.to_sql(k, con, if_exists='append', index=False)
-            # subspace.py:1905-1953 _getInfoDF: ss_info / sg_info (events comma-separated)
-            def beta_of(fas):
-                bd = (fas or {}).get('betadist') if isinstance(fas, dict) else None
-                return (bd[0], bd[1]) if bd is not None and len(bd) > 1 else (np.nan, np.nan)
-            info = []
-            for sta in self.ssStations:
-                for _, r in self.subspaces[sta].iterrows():
-                    b1, b2 = beta_of(r.FAS)
-                    info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
-                                     Threshold=r.Threshold, NumBasisUsed=r.NumBasis,
-                                     beta1=b1, beta2=b2))
-            if info:
-                pd.DataFrame(info).to_sql('ss_info', con, if_exists='replace', index=False)
-            info = []
-            for sta in self.singStations:
-                for _, r in self.singles[sta].iterrows():
-                    b1, b2 = beta_of(r.FAS)
-                    info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
-                                     Threshold=r.Threshold, beta1=b1, beta2=b2))
-            if info:
-                pd.DataFrame(info).to_sql('sg_info', con, if_exists='replace', index=False)
-            for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
-                rows = [dict(Sta=sta, Name=name, Value=' '.join(str(int(v)) for v in h))
-                        for sta, d in hd.items() for name, h in (d or {}).items()]
-                if rows:
-                    pd.DataFrame(rows).to_sql(tab, con, if_exists='replace', index=False)
-            cl = self.clusters
-            fp = pd.DataFrame([[cl.filt[0], cl.filt[1], cl.filt[2], cl.filt[3], cl.decimate]],
-                              columns=['FREQMIN', 'FREQMAX', 'CORNERS', 'ZEROPHASE', 'DECIMATE'])
-            fp.to_sql('filt_params', con, if_exists='replace', index=False)
-        finally:
-            con.close()
+        sg_hist, filt_params.  writer: the call's _DbWriter -- the detection rows are in (or on their way
+        into) the file already, the small tables follow on its thread and the thread is joined."""
+        if writer is not None:
+            writer.call(self._write_info_tables)
+            writer.close()
+            return
+        w = _DbWriter(path)
+        for k, df in out.items():
+            w.put(k, df)
+        w.call(self._write_info_tables)
+        w.close()
+
+    def _write_info_tables(self, con):
+        # subspace.py:1905-1953 _getInfoDF: ss_info / sg_info (events comma-separated)
+        def beta_of(fas):
+            bd = (fas or {}).get('betadist') if isinstance(fas, dict) else None
+            return (bd[0], bd[1]) if bd is not None and len(bd) > 1 else (np.nan, np.nan)
+        info = []
+        for sta in self.ssStations:
+            for _, r in self.subspaces[sta].iterrows():
+                b1, b2 = beta_of(r.FAS)
+                info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
+                                 Threshold=r.Threshold, NumBasisUsed=r.NumBasis,
+                                 beta1=b1, beta2=b2))
+        if info:
+            pd.DataFrame(info).to_sql('ss_info', con, if_exists='replace', index=False)
+        info = []
+        for sta in self.singStations:
+            for _, r in self.singles[sta].iterrows():
+                b1, b2 = beta_of(r.FAS)
+                info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
+                                 Threshold=r.Threshold, beta1=b1, beta2=b2))
+        if info:
+            pd.DataFrame(info).to_sql('sg_info', con, if_exists='replace', index=False)
+        for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
+            rows = [dict(Sta=sta, Name=name, Value=' '.join(str(int(v)) for v in h))
+                    for sta, d in hd.items() for name, h in (d or {}).items()]
+            if rows:
+                pd.DataFrame(rows).to_sql(tab, con, if_exists='replace', index=False)
+        cl = self.clusters
+        fp = pd.DataFrame([[cl.filt[0], cl.filt[1], cl.filt[2], cl.filt[3], cl.decimate]],
+                          columns=['FREQMIN', 'FREQMAX', 'CORNERS', 'ZEROPHASE', 'DECIMATE'])
+        fp.to_sql('filt_params', con, if_exists='replace', index=False)
 
     def write(self, filename='subspace.pkl'):
         """subspace.py:2018-2026."""

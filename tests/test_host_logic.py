@@ -813,3 +813,37 @@ def test_classifyEvents_scans_the_template_events(tmp_path, monkeypatch):
     assert sorted(set(few['event_cors'].Event)) == ['ev01', 'ev05']
     # detections at the events' own times come out in the ordinary table too
     assert len(res['ss_df']) >= 8
+
+
+def test_long_records_are_scanned_in_day_units(tmp_path, monkeypatch):
+    """A record whose DS tensor exceeds the budget is scanned day by day (SubSpace._scan_units): the same tables,
+    histograms and SQLite rows as the one-launch run, row for row; the SQLite file is fed by the writer
+    thread while the units are scanned."""
+    import sqlite3
+    import pandas as pd
+    ctx = OracleCtx()
+    ss, cf, stas, _ = multi_station_workflow(ctx)
+    db1, db2 = str(tmp_path / 'one.db'), str(tmp_path / 'units.db')
+    ref = ss.detex(subspaceDB=db1, ctx=ctx)
+    n_scans = len([c for c in ctx.calls if c[0] == 'scan'])
+    hist = {sta: {k: v.copy() for k, v in ss.histSubSpaces[sta].items()} for sta in stas}
+    monkeypatch.setenv('DETEX_AMD_DS_BUDGET_MB', '0')
+    got = ss.detex(subspaceDB=db2, ctx=ctx)
+    # five chunks per station, two per day: three units per station instead of one launch
+    assert len([c for c in ctx.calls if c[0] == 'scan']) - n_scans == 3 * n_scans
+    assert got['ss_df'].values.tolist() == ref['ss_df'].values.tolist() and len(ref['ss_df']) >= 10
+    for sta in stas:
+        for nm, h in hist[sta].items():
+            assert np.array_equal(ss.histSubSpaces[sta][nm], h)
+    rows = []
+    for db in (db1, db2):
+        con = sqlite3.connect(db)
+        rows.append(pd.read_sql('select * from ss_df', con))
+        tabs = set(r[0] for r in con.execute("select name from sqlite_master where type='table'"))
+        assert {'ss_df', 'ss_info', 'ss_hist', 'filt_params'} <= tabs
+        con.close()
+    assert rows[0].values.tolist() == rows[1].values.tolist() == ref['ss_df'].values.tolist()
+    assert list(rows[0].columns) == list(ref['ss_df'].columns)
+    # the units overlap by the chunks' 120 s buffer: a little more goes over the host link than the record holds
+    total = sum(4 * 3 * cf.data[s][0].shape[1] for s in stas)
+    assert total < ss.last_run['uploaded_bytes'] < 1.01 * total
