@@ -159,6 +159,10 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   DtxDeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->aux && !ctx->aux_is_main) (void)hipStreamSynchronize(ctx->aux);
+  if (ctx->ev_trig) {
+    if (ctx->trig_pending) (void)hipEventSynchronize(ctx->ev_trig);
+    (void)hipEventDestroy(ctx->ev_trig);
+  }
   dtx_free_tiles_internal(ctx);
   DtxBuf* bufs[] = {&ctx->ws_xp, &ctx->ws_mean, &ctx->ws_den,
                     &ctx->ws_misc, &ctx->ws_misc2, &ctx->ws_misc3, &ctx->ws_g, &ctx->ws_csum,
@@ -198,6 +202,12 @@ int dtx_ctx_sync(dtx_ctx* ctx) {
 }
 
 void* dtx_ctx_stream(dtx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int dtx_ctx_set_trigger_stream(dtx_ctx* ctx, void* stream) {
+  if (!ctx) return DTX_E_ARG;
+  ctx->trig_stream = (hipStream_t)stream;     // (launches on different streams are ordered by event: dtx_trig.hip)
+  return DTX_OK;
+}
 
 int dtx_timer_start(dtx_ctx* ctx) {
   if (!ctx) return DTX_E_ARG;

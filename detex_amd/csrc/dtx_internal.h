@@ -76,6 +76,13 @@ struct dtx_ctx {
   hipStream_t aux = nullptr;
   bool aux_is_main = false;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // stream of the trigger-time kernel (dtx_trigger_stats): NULL = `stream`.  A caller that keeps several scans
+  // queued hands in a stream of its own (dtx_ctx_set_trigger_stream): the kernel -- a few dozen workgroups of
+  // dependent passes, 0.2 .. 0.4 ms -- then runs beside the next scan instead of in front of it
+  hipStream_t trig_stream = nullptr;
+  hipStream_t trig_last = nullptr;     // stream of the last trigger-time launch ...
+  hipEvent_t ev_trig = nullptr;        // ... and the event recorded behind it (orders a launch on another stream, basis uploads, destroy)
+  bool trig_pending = false;
   std::string err;
 
   // basis

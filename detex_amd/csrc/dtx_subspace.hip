@@ -620,6 +620,7 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   }
   DtxDeviceGuard g(ctx->device);
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the old images may still be in use
+  if (ctx->trig_pending) DTX_HIP(ctx, hipEventSynchronize(ctx->ev_trig));   // (a trigger-time launch on its own stream reads U)
   const int Ktot = det_off[D];
   const int L = n / Nc;
   const int Lp = (int)dtx_round_up(L, kBQ);

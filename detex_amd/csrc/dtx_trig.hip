@@ -358,6 +358,14 @@ static int trigger_stats_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64
   int rc;
   const unsigned grid = (unsigned)std::min(ntrig, 1024);
   const int64_t scap = 6 * (int64_t)ctx->n + 1;
+  hipStream_t st = ctx->trig_stream ? ctx->trig_stream : ctx->stream;
+  if (!ctx->ev_trig) DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_trig, hipEventDisableTiming));
+  if (ctx->trig_pending) {
+    // the scratch is shared by consecutive launches: one on another stream than the last waits for it (no host
+    // wait); growing the scratch (dtx_reserve waits for ctx->stream only) waits for the last launch itself
+    if (ctx->trig_last != st) DTX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_trig, 0));
+    if ((size_t)grid * scap * sizeof(float) > ctx->ws_trig.bytes) DTX_HIP(ctx, hipEventSynchronize(ctx->ev_trig));
+  }
   if ((rc = dtx_reserve(ctx, ctx->ws_trig, (size_t)grid * scap * sizeof(float)))) return rc;
   TrigArgs a;
   a.x = x_dev; a.M = M; a.stride = chunk_stride; a.ctab = ctab; a.ds = ds_dev; a.P = P; a.ldp = ldp;
@@ -367,8 +375,11 @@ static int trigger_stats_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64
   a.scratch = (float*)ctx->ws_trig.p; a.scap = scap;
   a.D = ctx->D; a.n = ctx->n; a.Nc = ctx->Nc; a.emax = emax;
   a.full = ewf_dev != nullptr;
-  hipLaunchKernelGGL(trig_stats_kernel, dim3(grid, a.full ? 3u : 1u), dim3(kTT), 0, ctx->stream, a);
+  hipLaunchKernelGGL(trig_stats_kernel, dim3(grid, a.full ? 3u : 1u), dim3(kTT), 0, st, a);
   DTX_HIP(ctx, hipGetLastError());
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_trig, st));
+  ctx->trig_last = st;
+  ctx->trig_pending = true;
   return DTX_OK;
 }
 

@@ -309,6 +309,7 @@ class StationScan(object):
         self.ctx = HipContext(device) if self.own else ctx
         self.batches = []
         self.picked = None
+        self.scan_ev = None
 
     def close(self):
         if self.own and self.ctx is not None:
@@ -441,6 +442,9 @@ class StationScan(object):
         # which are queued behind: it drained the queue once per station-day)
         self.hist_host = self.hist_ev = None
         if hist.is_cuda:
+            # behind this unit's scans: what the trigger-time kernel (on a stream of its own) waits for
+            self.scan_ev = torch.cuda.Event()
+            self.scan_ev.record(_stream_of(ctx, hist.device))
             self.hist_host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
             self.hist_host.copy_(hist, non_blocking=True)
             self.hist_ev = torch.cuda.Event()
@@ -523,7 +527,8 @@ class StationScan(object):
             for (i0, i1, xb, M, cstride, ds, fetch, ctab) in self.batches:
                 try:
                     self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
-                                                               i0, i1, xb, M, cstride, ds, fetch, ctab))
+                                                               i0, i1, xb, M, cstride, ds, fetch, ctab,
+                                                               after=self.scan_ev))
                 except DetexHipError as e:
                     self._skip(i0, i1, e)
 
@@ -691,7 +696,7 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
     return out
 
 
-def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, ctab=None):
+def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, ctab=None, after=None):
     """One launch group of chunks (equal lengths, or a ragged batch with its chunk table), first
     host half: candidates -> triggers; the trigger-time kernel is enqueued and its (device) result
     returned with them: (trigs, bad, stats)."""
@@ -746,16 +751,21 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
                     tab[r, 4] = _centered_lo(ti, LTA, int(Pb[b]))
                 except IndexError:
                     bad[r] = True
-        stats = ctx.trigger_stats(xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
-                                  bank.ewf if estimateMags else None, bank.eoff, bank.emax,
-                                  **({} if ctab is None else {'chunk_tab': ctab}))
-        if stats.is_cuda:
-            # on its way to pinned host memory behind the kernel; _batch_rows waits for the event
-            host = torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True)
-            host.copy_(stats, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(_stream_of(ctx, stats.device))
-            stats = (host, ev, stats)
+        targs = (xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
+                 bank.ewf if estimateMags else None, bank.eoff, bank.emax)
+        tkw = {} if ctab is None else {'chunk_tab': ctab}
+        if hasattr(ctx, 'trigger_stats_async'):
+            # the kernel and the copy of its rows to pinned host memory on the context's trigger stream, beside
+            # the scans queued behind this batch's; _batch_rows waits for the event
+            stats = ctx.trigger_stats_async(*targs, after=after, **tkw)
+        else:
+            stats = ctx.trigger_stats(*targs, **tkw)
+            if stats.is_cuda:
+                host = torch.empty(stats.shape, dtype=stats.dtype, pin_memory=True)
+                host.copy_(stats, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(_stream_of(ctx, stats.device))
+                stats = (host, ev, stats)
     return trigs, bad, stats
 
 

@@ -422,6 +422,9 @@ class HipContext(object):
 
     @_on_ctx_stream
     def trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None):
+        return self._trigger_stats(x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab)
+
+    def _trigger_stats(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None):
         """dtx_trigger_stats: STA / LTA means and the magnitude / SNR ingredients at triggers.
 
         x, M, chunk_stride, ds: the buffers of the subspace_scan call the triggers come from;
@@ -448,6 +451,54 @@ class HipContext(object):
                                             _ptr(eoff) if ewf is not None else None, int(emax), _ptr(out))
         self._ck(rc, 'dtx_trigger_stats')
         return out
+
+    def trigger_stream(self):
+        """The stream the trigger-time kernel runs on when asked to run beside the scans
+        (trigger_stats_async): created and registered with the library on first use.
+        DETEX_AMD_TRIG_STREAM=0: none (everything on the context's stream)."""
+        if os.environ.get('DETEX_AMD_TRIG_STREAM', '1') == '0':
+            return None
+        if getattr(self, '_trig', None) is None:
+            self._trig = torch.cuda.Stream(self.device)
+        return self._trig
+
+    def trigger_stats_async(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None,
+                            after=None):
+        """trigger_stats with its rows on their way to pinned host memory: returns (host tensor, event to wait
+        for, device tensor).  The kernel -- a few dozen workgroups of dependent passes -- and the copies run on
+        the context's trigger stream, beside whatever is queued on the context's own stream behind the scan
+        that produced ``ds``: `after` is an event recorded behind that scan (default: the stream's tail now)."""
+        side = self.trigger_stream()
+        trig = np.ascontiguousarray(trig, dtype=np.int32).reshape(-1, 5)
+        if side is None or len(trig) == 0:
+            with self.on_stream():
+                out = self.trigger_stats(x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax,
+                                         **({} if chunk_tab is None else {'chunk_tab': chunk_tab}))
+                host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                host.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            return host, ev, out
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(self._stream)
+        side.wait_event(after)
+        rc0 = self.lib.dtx_ctx_set_trigger_stream(self.h, C.c_void_p(side.cuda_stream))
+        self._ck(rc0, 'dtx_ctx_set_trigger_stream')
+        try:
+            with torch.cuda.stream(side):
+                out = self._trigger_stats(x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab)
+                host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                host.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        finally:
+            self._ck(self.lib.dtx_ctx_set_trigger_stream(self.h, None), 'dtx_ctx_set_trigger_stream')
+        # buffers of the context stream's pool read by the side stream: not handed out again before it is done
+        for t in (x, ds, ewf, eoff, chunk_tab[0] if chunk_tab is not None else None):
+            if t is not None and t.is_cuda:
+                t.record_stream(side)
+        return host, ev, out
 
     @_on_ctx_stream
     def normcorr(self, t, s):

@@ -232,6 +232,15 @@ int dtx_trigger_stats_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
                              int ntrig, int sta_len, int lta_len, const float* ewf_dev,
                              const int32_t* ewf_off_dev, int emax, double* out_dev);
 
+/* The stream dtx_trigger_stats / dtx_trigger_stats_ragged launch on: NULL (default) = the context's own.
+ * The reference estimates magnitudes inside its chunk loop (detect.py:422-429); a host that keeps several
+ * scans queued on the context's stream can hand in a second stream so that the trigger-time kernel of one
+ * batch runs beside the scan of the next.  ORDERING IS THE CALLER'S: the stream must wait for the scan that
+ * produced ds_dev / wrote x_dev (an event) before dtx_trigger_stats is called, and trig_dev / out_dev /
+ * ewf_dev must be valid on it.  Consecutive launches on different streams are ordered among themselves by
+ * the library (they share a scratch buffer); dtx_basis_upload and dtx_ctx_destroy wait for the last one. */
+int dtx_ctx_set_trigger_stream(dtx_ctx* ctx, void* stream);
+
 /* fast_normcorr(t, s) (construct.py:469-483; callers detect.py:484, subspace.py:765): Pearson
  * correlation of the n-sample template t with every length-n window of the m-sample series s
  * (m >= n), out[p], p = 0 .. m - n; float64 accumulation, float32 in / out.  A window of zero

@@ -390,3 +390,34 @@ def test_classifyEvents_and_utcSaves_on_the_device(workflow, tmp_path, monkeypat
     for _, row in ss.subspaces['TA.M17A'].iterrows():
         for e in row.Events:
             assert ec[ec.Event == e].set_index('Name').MaxDS.idxmax() == row.Name
+
+
+def test_trigger_stream_and_day_units_do_not_change_the_tables(workflow, monkeypatch):
+    """The trigger-time kernel beside the next scans on a stream of its own (HipContext.trigger_stats_async)
+    against everything on the context's stream (DETEX_AMD_TRIG_STREAM=0), and the record scanned in day units
+    (DETEX_AMD_DS_BUDGET_MB=0: two chunks here) against one launch: identical tables, magnitudes included."""
+    ss = workflow['ss']
+    ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
+    ss.setSinglesThresholds(threshold=0.4)
+
+    def table(r):
+        df = pd.concat([r['ss_df'], r['sg_df']], ignore_index=True)
+        return df.fillna(-999.0).values.tolist()
+    ref = table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True))
+    assert len(ref) >= 6
+    monkeypatch.setenv('DETEX_AMD_TRIG_STREAM', '0')
+    assert table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True)) == ref
+    monkeypatch.delenv('DETEX_AMD_TRIG_STREAM')
+    monkeypatch.setenv('DETEX_AMD_DS_BUDGET_MB', '0')
+    cf = workflow['cf']
+    old = cf.conDatDuration
+    try:
+        units = ss._scan_units(['TA.M17A'], {'TA.M17A': cf.chunk_bounds('TA.M17A')}, {'TA.M17A': None},
+                               {'TA.M17A': ss._detector_bank('TA.M17A', True, True)}, cf)
+        assert len(units) == 1                   # 600 s chunks: a "day" holds 144 of them, the record only four
+        cf.conDatDuration = 43200                # (pretend two chunks make a day: the unit cut, not the geometry)
+        units = ss._scan_units(['TA.M17A'], {'TA.M17A': cf.chunk_bounds('TA.M17A')}, {'TA.M17A': None},
+                               {'TA.M17A': ss._detector_bank('TA.M17A', True, True)}, cf)
+    finally:
+        cf.conDatDuration = old
+    assert len(units) == 1 or all(len(u[1]) <= 2 for u in units)
