@@ -442,7 +442,38 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) w.a[e] = ldtw(l15 << e);
     }
-#if DTX_FFT_FOLD
+#if defined(DTX_FFT_MFMA_ABLATE)
+    // TIMING-ONLY ablation (results are wrong; VERDICT r3 next 5, profiles/README.md): what the scan kernel
+    // would cost if the twiddled radix-16 pass -- 208 vector instructions per wave -- ran on the matrix pipe
+    // instead: 64 complex 16-point DFTs per wave = [32 x 32] x [32 x 64] real, i.e. 8 v_mfma_f32_16x16x32_bf16
+    // per bf16 product, 24 for the three products of a split-bf16 float32 product (DTX_FFT_MFMA_ABLATE = the
+    // count).  Operands are whatever bits the registers hold: no twiddle pre-multiplication (64 instructions in
+    // a real build), no f32 -> 2 x bf16 split (~80), no transposition into the operand layout -- the most
+    // favourable case.  -DDTX_DUMMY_VALU=<n> adds those back.
+    {
+      typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 abf16x8;
+      typedef __attribute__((__vector_size__(4 * sizeof(float)))) float af32x4;
+      typedef __attribute__((__vector_size__(4 * sizeof(int)))) int ai32x4;
+      af32x4 acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = (af32x4){v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
+      const ai32x4 fa = {__float_as_int(w.a[0].x), __float_as_int(w.a[0].y), __float_as_int(w.a[1].x), __float_as_int(w.a[1].y)};
+#pragma unroll
+      for (int m = 0; m < DTX_FFT_MFMA_ABLATE; ++m) {
+        const int q = m & 7, o = (m * 5 + 3) & 7;
+        const ai32x4 xb = {__float_as_int(v[2 * o].x), __float_as_int(v[2 * o].y), __float_as_int(v[2 * o + 1].x),
+                           __float_as_int(v[2 * o + 1].y)};
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, fa), __builtin_bit_cast(abf16x8, xb),
+                                                         acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v[2 * q] = make_float2(acc[q][0], acc[q][1]);
+        v[2 * q + 1] = make_float2(acc[q][2], acc[q][3]);
+      }
+    }
+  }
+#elif DTX_FFT_FOLD
     const c32 wp[4] = {w.a[3], w.a[2], w.a[1], w.a[0]};
     dft_tw_bitrev<SG, 16>(v, wp);
   }
