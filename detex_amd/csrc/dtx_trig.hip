@@ -52,37 +52,78 @@ __device__ inline double block_sum(double v, double* red) {
   return s;
 }
 
-// k-th smallest (0-based) of count non-negative floats: radix select on the bit patterns,
-// 8 bits per pass.  Returns the value to every thread.
+// k-th smallest (0-based) of count non-negative floats, and the (k + 1)-th if next != NULL (the two middle
+// values of an even count): radix select on the bit patterns, 4 bits per pass, counted in REGISTERS and reduced
+// over the workgroup -- no atomics.  (Rounds 1-3 counted 8 bits per pass with LDS atomics: the values are the
+// rolling standard deviations of one stretch of noise, they share their leading bytes, and 36 000 atomics onto
+// one or two LDS words serialise -- ~40 us a pass, eight passes for an even count: the trigger-time kernel's
+// longest chain.)  Returns the value(s) to every thread.  hist: 8 x 16 words of LDS, sh: 2.
 __device__ inline float select_rank(const float* __restrict__ v, int count, int k, unsigned* hist,
-                                    unsigned* sh) {
+                                    unsigned* sh, float* next = nullptr) {
   unsigned prefix = 0u, mask = 0u;
   int rank = k;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int b = threadIdx.x; b < 256; b += kTT) hist[b] = 0u;
-    __syncthreads();
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  for (int shift = 28; shift >= 0; shift -= 4) {
+    unsigned c[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) c[b] = 0u;
     for (int i = threadIdx.x; i < count; i += kTT) {
       const unsigned u = __float_as_uint(v[i]);
-      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+      const unsigned d = (u & mask) == prefix ? (u >> shift) & 15u : 16u;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) c[b] += d == (unsigned)b;
+    }
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c[b] += __shfl_xor(c[b], off, 64);
+    }
+    __syncthreads();                       // (the previous pass' readers of hist / sh are done)
+    if (ln == 0) {
+#pragma unroll
+      for (int b = 0; b < 16; ++b) hist[16 * wv + b] = c[b];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       int acc = 0, b = 0;
-      for (; b < 256; ++b) {
-        const int c = (int)hist[b];
-        if (acc + c > rank) break;
-        acc += c;
+      for (; b < 16; ++b) {
+        int cb = 0;
+        for (int w = 0; w < kTT / 64; ++w) cb += (int)hist[16 * w + b];
+        if (acc + cb > rank) break;
+        acc += cb;
       }
       sh[0] = (unsigned)b;
       sh[1] = (unsigned)(rank - acc);
     }
     __syncthreads();
     prefix |= sh[0] << shift;
-    mask |= 255u << shift;
+    mask |= 15u << shift;
     rank = (int)sh[1];
+  }
+  const float val = __uint_as_float(prefix);
+  if (next != nullptr) {
+    // the (k + 1)-th smallest: val again if more than k + 1 values are <= val, else the smallest value above it
+    unsigned le = 0u, mn = 0xffffffffu;
+    for (int i = threadIdx.x; i < count; i += kTT) {
+      const unsigned u = __float_as_uint(v[i]);
+      le += u <= prefix;
+      if (u > prefix) mn = min(mn, u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      le += __shfl_xor(le, off, 64);
+      mn = min(mn, (unsigned)__shfl_xor(mn, off, 64));
+    }
+    __syncthreads();
+    if (ln == 0) { hist[2 * wv] = le; hist[2 * wv + 1] = mn; }
+    __syncthreads();
+    unsigned tle = 0u, tmn = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < kTT / 64; ++w) { tle += hist[2 * w]; tmn = min(tmn, hist[2 * w + 1]); }
+    *next = (int)tle > k + 1 ? val : __uint_as_float(tmn);
     __syncthreads();
   }
-  return __uint_as_float(prefix);
+  return val;
 }
 
 // pre-event noise of one trigger (every thread of the workgroup calls it; thread 0's return value is stored)
@@ -167,9 +208,13 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
     }
     __threadfence_block();
     __syncthreads();
-    const float hi = select_rank(scr, count, count / 2, hist, sh);
-    noise = (double)hi;
-    if ((count & 1) == 0) noise = 0.5 * (noise + (double)select_rank(scr, count, count / 2 - 1, hist, sh));
+    if (count & 1) {
+      noise = (double)select_rank(scr, count, count / 2, hist, sh);
+    } else {                         // the mean of the two middle values
+      float hi;
+      const float lo = select_rank(scr, count, count / 2 - 1, hist, sh, &hi);
+      noise = 0.5 * ((double)hi + (double)lo);
+    }
   }
   return noise;
 }
@@ -188,6 +233,9 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
   // the training events, 2 the pre-event noise -- three workgroups per trigger instead of one (a
   // station-day has tens of triggers: one workgroup each left most of the chip idle for 0.5 ms)
   const int task = blockIdx.y;
+#ifdef DTX_TRIG_ONLY_TASK            // timing-only builds: one of the three tasks alone
+  if (task != DTX_TRIG_ONLY_TASK) return;
+#endif
   for (int t = blockIdx.x; t < a.ntrig; t += gridDim.x) {
     const int32_t* tr = a.trig + 5 * (int64_t)t;
     const int chunk = tr[0], det = tr[1], p = tr[2], sta_lo = tr[3], lta_lo = tr[4];
