@@ -54,12 +54,13 @@ __device__ inline double block_sum(double v, double* red) {
 
 // k-th smallest (0-based) of count non-negative floats, and the (k + 1)-th if next != NULL (the two middle
 // values of an even count): radix select on the bit patterns, 4 bits per pass, counted in REGISTERS and reduced
-// over the workgroup -- no atomics.  (Rounds 1-3 counted 8 bits per pass with LDS atomics: the values are the
-// rolling standard deviations of one stretch of noise, they share their leading bytes, and 36 000 atomics onto
-// one or two LDS words serialise -- ~40 us a pass, eight passes for an even count: the trigger-time kernel's
-// longest chain.)  Returns the value(s) to every thread.  hist: 8 x 16 words of LDS, sh: 2.
-__device__ inline float select_rank(const float* __restrict__ v, int count, int k, unsigned* hist,
-                                    unsigned* sh, float* next = nullptr) {
+// over the workgroup -- no atomics, no walk of the buckets by one thread, two barriers a pass.  (Rounds 1-3
+// counted 8 bits per pass with LDS atomics from values in a global scratch buffer: nine passes of L2 round trips
+// one behind the other.)  Returns the value(s) to every thread.  hist: 8 x 16 words of LDS.
+// each(f): calls f(bit pattern) for every value this thread contributes (any partition of the multiset over the
+// workgroup's threads will do)
+template <class Each>
+__device__ inline float select_rank_impl(Each each, int k, unsigned* hist, unsigned* sh, float* next) {
   unsigned prefix = 0u, mask = 0u;
   int rank = k;
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
@@ -67,48 +68,49 @@ __device__ inline float select_rank(const float* __restrict__ v, int count, int 
     unsigned c[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) c[b] = 0u;
-    for (int i = threadIdx.x; i < count; i += kTT) {
-      const unsigned u = __float_as_uint(v[i]);
+    each([&](unsigned u) {
       const unsigned d = (u & mask) == prefix ? (u >> shift) & 15u : 16u;
 #pragma unroll
       for (int b = 0; b < 16; ++b) c[b] += d == (unsigned)b;
-    }
+    });
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) c[b] += __shfl_xor(c[b], off, 64);
     }
-    __syncthreads();                       // (the previous pass' readers of hist / sh are done)
+    __syncthreads();                       // (the previous pass' readers of hist are done)
     if (ln == 0) {
 #pragma unroll
       for (int b = 0; b < 16; ++b) hist[16 * wv + b] = c[b];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, b = 0;
-      for (; b < 16; ++b) {
-        int cb = 0;
-        for (int w = 0; w < kTT / 64; ++w) cb += (int)hist[16 * w + b];
-        if (acc + cb > rank) break;
-        acc += cb;
-      }
-      sh[0] = (unsigned)b;
-      sh[1] = (unsigned)(rank - acc);
+    // every wave finds the digit for itself (no serial walk by one thread, no broadcast, no third barrier): lane b
+    // adds bucket b over the eight waves, an inclusive scan over the 16 buckets, the first bucket whose running
+    // total passes the rank
+    int cb = 0;
+#pragma unroll
+    for (int w = 0; w < kTT / 64; ++w) cb += (int)hist[16 * w + (ln & 15)];
+    int incl = cb;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int o = __shfl_up(incl, off, 16);
+      if ((ln & 15) >= off) incl += o;
     }
-    __syncthreads();
-    prefix |= sh[0] << shift;
+    const unsigned long long over = __ballot(incl > rank) & 0xffffull;
+    const int dg = over ? __ffsll((long long)over) - 1 : 15;
+    const int acc = __shfl(incl - cb, dg, 16);
+    prefix |= (unsigned)dg << shift;
     mask |= 15u << shift;
-    rank = (int)sh[1];
+    rank -= acc;
   }
   const float val = __uint_as_float(prefix);
   if (next != nullptr) {
     // the (k + 1)-th smallest: val again if more than k + 1 values are <= val, else the smallest value above it
     unsigned le = 0u, mn = 0xffffffffu;
-    for (int i = threadIdx.x; i < count; i += kTT) {
-      const unsigned u = __float_as_uint(v[i]);
+    each([&](unsigned u) {
       le += u <= prefix;
       if (u > prefix) mn = min(mn, u);
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       le += __shfl_xor(le, off, 64);
@@ -125,6 +127,37 @@ __device__ inline float select_rank(const float* __restrict__ v, int count, int 
   }
   return val;
 }
+// ... of count values in memory
+__device__ inline float select_rank(const float* __restrict__ v, int count, int k, unsigned* hist,
+                                    unsigned* sh, float* next = nullptr) {
+  return select_rank_impl([&](auto f) {
+    for (int i = threadIdx.x; i < count; i += kTT) f(__float_as_uint(v[i]));
+  }, k, hist, sh, next);
+}
+// ... of the values the threads hold in registers: r[j], j < NR, 0xffffffff (never a non-negative float's
+// pattern: it sorts behind everything and is never reached) where a thread has none
+template <int NR>
+__device__ inline float select_rank_regs(const unsigned (&r)[NR], int k, unsigned* hist, unsigned* sh,
+                                         float* next = nullptr) {
+  return select_rank_impl([&](auto f) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) f(r[j]);
+  }, k, hist, sh, next);
+}
+constexpr int kRegW = 96;
+// four consecutive floats at any 4-byte aligned address in ONE load (global memory takes dword-aligned
+// multi-dword loads): a thread that walks its own run of samples issues a quarter of the instructions -- its lanes
+// are 70 .. 90 samples apart, so every load instruction is 64 separate cache-line requests whatever its width
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void load4_guarded(const float* __restrict__ p, int idx, int limit, float (&o)[4]) {
+  if (idx + 4 <= limit) {
+    const f4u v = *reinterpret_cast<const f4u*>(p + idx);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = idx + e < limit ? p[idx + e] : 0.f;
+  }
+}     // rolling standard deviations a thread keeps in registers (fast path of trig_noise)
 
 // pre-event noise of one trigger (every thread of the workgroup calls it; thread 0's return value is stored)
 __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t Mc, int64_t a0, float* scr, double* red,
@@ -146,14 +179,23 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
     s = 0.0;
     for (int q = tid; q < npe; q += kTT) s += (double)pe[q];
     const double shift = block_sum(s, red) / npe;       // std is shift-invariant: kills the cancellation
+#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 1      // timing-only builds: how far the task runs
+    return shift;
+#endif
     // prefix sums of y = pe - shift and y^2: per-thread segment sums, scanned by thread 0 .. 511
     const int seglen = (npe + kTT - 1) / kTT;
     const int q0 = min(tid * seglen, npe), q1 = min(q0 + seglen, npe);
     double t1 = 0.0, t2 = 0.0;
-    for (int q = q0; q < q1; ++q) {
-      const double y = (double)pe[q] - shift;
-      t1 += y;
-      t2 += y * y;
+    for (int q = q0; q < q1; q += 4) {
+      float f[4];
+      load4_guarded(pe, q, q1, f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q + e < q1) {
+          const double y = (double)f[e] - shift;
+          t1 += y;
+          t2 += y * y;
+        }
     }
     __syncthreads();
     seg1[tid] = t1;
@@ -188,8 +230,61 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
       }
       o1 = b1; o2 = b2;
     };
+#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 2
+    return seg1[tid] + seg2[tid];
+#endif
     const int wper = (count + kTT - 1) / kTT;
     const int i0 = min(tid * wper, count), i1 = min(i0 + wper, count);
+    if (wper <= kRegW) {
+      // the thread's rolling standard deviations stay in its registers: the selection passes read them nine times,
+      // and from the scratch buffer (written by other waves: L2 round trips, one behind the other) those reads
+      // were the kernel's longest chain -- 0.3 ms for a station-day's triggers
+      unsigned r[kRegW];
+      double A1 = 0.0, A2 = 0.0, B1 = 0.0, B2 = 0.0;
+      if (i0 < i1) {
+        prefix(i0, A1, A2);
+        prefix(i0 + n, B1, B2);
+      }
+#pragma unroll
+      for (int g = 0; g < kRegW / 4; ++g) {
+        float fa[4], fb[4];
+        if (i0 + 4 * g < i1) {                 // (the leaving and the entering samples of four windows, 16 bytes each)
+          load4_guarded(pe, i0 + 4 * g, npe, fa);
+          load4_guarded(pe, i0 + n + 4 * g, npe, fb);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 4 * g + e, i = i0 + j;
+          if (i < i1) {
+            const double S1 = B1 - A1, S2 = B2 - A2;
+            const double var = (S2 - S1 * S1 / n) / (n - 1.0);
+            r[j] = __float_as_uint((float)sqrt(var > 0.0 ? var : 0.0));
+            const double ya = (double)fa[e] - shift;
+            A1 += ya; A2 += ya * ya;
+            if (i + n < npe) {
+              const double yb = (double)fb[e] - shift;
+              B1 += yb; B2 += yb * yb;
+            }
+          } else {
+            r[j] = 0xffffffffu;
+          }
+        }
+      }
+#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 3
+      { unsigned acc = 0u;
+#pragma unroll
+        for (int j = 0; j < kRegW; ++j) acc ^= r[j];
+        return (double)acc; }
+#endif
+      if (count & 1) {
+        noise = (double)select_rank_regs(r, count / 2, hist, sh);
+      } else {                         // the mean of the two middle values
+        float hi;
+        const float lo = select_rank_regs(r, count / 2 - 1, hist, sh, &hi);
+        noise = 0.5 * ((double)hi + (double)lo);
+      }
+      return noise;
+    }
     if (i0 < i1) {
       double A1, A2, B1, B2;
       prefix(i0, A1, A2);
