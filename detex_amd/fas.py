@@ -66,6 +66,12 @@ def beta_mle(n, sx, sxx, s1, s2):
     return (a, b, 0, 1), float(nnlf)
 
 
+def _log(msg):
+    """detex.log(..., pri=True)"""
+    import logging
+    logging.getLogger('detex_amd.fas').info(msg)
+
+
 def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces=True,
             useSingles=False, numBins=401, recalc=False, device=0, seed=None):
     """fas._initFAS for every station of a SubSpace; stores a dict with 'bins',
@@ -83,6 +89,16 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
         for sta in ss.Stations:
             names, kinds, U, det_off, _, _ = ss._detector_bank_nothr(sta, useSubSpaces, useSingles)
             if not names or sta not in fetcher.data:
+                continue
+            # subspace.py:1700-1708, 1722-1729: a FAS that is there already is kept unless recalc is passed
+
+            def have(d):
+                df = ss.subspaces[sta] if kinds[d] == 'ss' else ss.singles[sta]
+                return isinstance(df.loc[df.index[df.Name == names[d]][0], 'FAS'], dict)
+            todo = [d for d in range(len(names)) if recalc or not have(d)]
+            if not todo:
+                _log('FAS for station %s already calculated, to recalculate pass True to the parameter recalc'
+                     % sta)
                 continue
             Nc = len(fetcher.channels)
             sr = fetcher.sampling_rate
@@ -159,6 +175,8 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             h = hist.cpu().numpy()
             sm = sums.cpu().numpy()
             for d, name in enumerate(names):
+                if d not in todo:
+                    continue
                 params, nnlf = beta_mle(*sm[d])
                 rec = {'bins': bins, 'hist': h[d], 'betadist': params, 'nnlf': nnlf}
                 df = ss.subspaces[sta] if kinds[d] == 'ss' else ss.singles[sta]

@@ -150,7 +150,7 @@ def test_fas_matches_scipy(workflow):
     from detex_amd.hip import HipContext
     ss, cf = workflow['ss'], workflow['cf']
     ss.SVD(selectCriteria=2, selectValue=0.75, conDatNum=3, useSingles=False, staltalimit=None,
-           seed=3)
+           seed=3, recalc=True)
     df = ss.subspaces['TA.M17A']
     names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
     ctx = HipContext(0)
@@ -176,6 +176,13 @@ def test_fas_matches_scipy(workflow):
         want = scipy.stats.beta.isf(ss.Pf, ref[0], ref[1], 0, 1)
         assert np.isclose(th, want, rtol=1e-5) or want > .9
     ctx.close()
+    # subspace.py:1700-1708: a FAS that is there already is kept unless recalc is passed
+    before = [r.FAS for _, r in df.iterrows()]
+    ss.getFAS(3, staltalimit=None, seed=4)
+    assert all(a is b for a, b in zip(before, [r.FAS for _, r in ss.subspaces['TA.M17A'].iterrows()]))
+    ss.getFAS(3, staltalimit=None, seed=4, recalc=True)
+    after = [r.FAS for _, r in ss.subspaces['TA.M17A'].iterrows()]
+    assert all(a is not b for a, b in zip(before, after)) and all(isinstance(a, dict) for a in after)
 
 
 def test_trigger_stats_kernel():
