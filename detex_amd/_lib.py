@@ -19,7 +19,7 @@ SYMBOLS = [
     'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
     'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean', 'dtx_subspace_scan_ragged',
-    'dtx_trigger_stats_ragged', 'dtx_chunk_table_check', 'dtx_ctx_set_trigger_stream',
+    'dtx_trigger_stats_ragged', 'dtx_chunk_table_check', 'dtx_ctx_set_trigger_stream', 'dtx_stream_wait_scan_kernel',
 ]
 
 
@@ -57,6 +57,8 @@ def load():
     lib.dtx_ctx_sync.argtypes = [vp]
     lib.dtx_ctx_set_trigger_stream.restype = i32
     lib.dtx_ctx_set_trigger_stream.argtypes = [vp, vp]
+    lib.dtx_stream_wait_scan_kernel.restype = i32
+    lib.dtx_stream_wait_scan_kernel.argtypes = [vp, vp]
     lib.dtx_ctx_stream.restype = vp
     lib.dtx_ctx_stream.argtypes = [vp]
     lib.dtx_last_error.restype = C.c_char_p

@@ -209,6 +209,14 @@ int dtx_ctx_set_trigger_stream(dtx_ctx* ctx, void* stream) {
   return DTX_OK;
 }
 
+int dtx_stream_wait_scan_kernel(dtx_ctx* ctx, void* stream) {
+  if (!ctx) return DTX_E_ARG;
+  if (!ctx->kernel_timed || !ctx->ev_k1) return DTX_OK;
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_k1, 0));
+  return DTX_OK;
+}
+
 int dtx_timer_start(dtx_ctx* ctx) {
   if (!ctx) return DTX_E_ARG;
   DtxDeviceGuard g(ctx->device);

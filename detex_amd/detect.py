@@ -515,12 +515,14 @@ class StationScan(object):
         _warn('failing to run detector on %s from %s to %s: %s'
               % (self.sta, b[i0][2], b[i1 - 1][2] + b[i1 - 1][1] / self.st['sr'], e))
 
-    def pick(self):
+    def pick(self, behind=None):
         """First host half, once the scans' candidate lists are back: trigger picking, and the
-        trigger-time kernel enqueued (its results are not waited for)."""
+        trigger-time kernel enqueued (its results are not waited for).  behind: the StationScan whose scans
+        are queued next on the device -- the trigger-time kernel starts when ITS scan kernel has ended."""
         from ._lib import DetexHipError
         if self.empty or self.picked is not None:
             return
+        bctx = getattr(behind, 'ctx', None) if behind is not None and not behind.empty else None
         st = self.st
         self.picked = []
         with self._guard():
@@ -528,7 +530,7 @@ class StationScan(object):
                 try:
                     self.picked.append((i0,) + _batch_triggers(self.ctx, self.sta, st, self.args[5], self.args[6],
                                                                i0, i1, xb, M, cstride, ds, fetch, ctab,
-                                                               after=self.scan_ev))
+                                                               after=self.scan_ev, behind=bctx))
                 except DetexHipError as e:
                     self._skip(i0, i1, e)
 
@@ -696,7 +698,8 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
     return out
 
 
-def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, ctab=None, after=None):
+def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstride, ds, fetch, ctab=None, after=None,
+                    behind=None):
     """One launch group of chunks (equal lengths, or a ragged batch with its chunk table), first
     host half: candidates -> triggers; the trigger-time kernel is enqueued and its (device) result
     returned with them: (trigs, bad, stats)."""
@@ -757,7 +760,7 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
         if hasattr(ctx, 'trigger_stats_async'):
             # the kernel and the copy of its rows to pinned host memory on the context's trigger stream, beside
             # the scans queued behind this batch's; _batch_rows waits for the event
-            stats = ctx.trigger_stats_async(*targs, after=after, **tkw)
+            stats = ctx.trigger_stats_async(*targs, after=after, behind=behind, **tkw)
         else:
             stats = ctx.trigger_stats(*targs, **tkw)
             if stats.is_cuda:

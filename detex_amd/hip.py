@@ -462,12 +462,20 @@ class HipContext(object):
             self._trig = torch.cuda.Stream(self.device)
         return self._trig
 
+    def wait_scan_kernel(self, stream):
+        """`stream` waits for the end of this context's last scan KERNEL (dtx_stream_wait_scan_kernel)."""
+        self._ck(self.lib.dtx_stream_wait_scan_kernel(self.h, C.c_void_p(stream.cuda_stream)),
+                 'dtx_stream_wait_scan_kernel')
+
     def trigger_stats_async(self, x, M, chunk_stride, ds, trig, sta_len, lta_len, ewf, eoff, emax, chunk_tab=None,
-                            after=None):
+                            after=None, behind=None):
         """trigger_stats with its rows on their way to pinned host memory: returns (host tensor, event to wait
         for, device tensor).  The kernel -- a few dozen workgroups of dependent passes -- and the copies run on
-        the context's trigger stream, beside whatever is queued on the context's own stream behind the scan
-        that produced ``ds``: `after` is an event recorded behind that scan (default: the stream's tail now)."""
+        the context's trigger stream: `after` is an event recorded behind the scan that produced ``ds`` (default:
+        the stream's tail now); `behind` is the context whose scan is queued NEXT: the kernel then also waits for
+        that scan KERNEL to end and runs beside its post pass and the following preparation (small kernels that
+        leave room on the CUs) instead of beside a scan kernel, whose workgroups it would keep off every CU it
+        occupies (DETEX_AMD_TRIG_BEHIND=0: beside the scan, as in the first version)."""
         side = self.trigger_stream()
         trig = np.ascontiguousarray(trig, dtype=np.int32).reshape(-1, 5)
         if side is None or len(trig) == 0:
@@ -483,6 +491,8 @@ class HipContext(object):
             after = torch.cuda.Event()
             after.record(self._stream)
         side.wait_event(after)
+        if behind is not None and os.environ.get('DETEX_AMD_TRIG_BEHIND', '1') != '0':
+            behind.wait_scan_kernel(side)
         rc0 = self.lib.dtx_ctx_set_trigger_stream(self.h, C.c_void_p(side.cuda_stream))
         self._ck(rc0, 'dtx_ctx_set_trigger_stream')
         try:

@@ -818,7 +818,7 @@ class SubSpace(object):
                     collect(queue.pop(0))
                     continue
                 if len(queue) >= 2:
-                    queue[-2].pick()                        # T_{i-1} goes in behind S_i
+                    queue[-2].pick(behind=job)              # T_{i-1} goes in behind S_i's scan kernel
                 if len(queue) >= 3:
                     collect(queue.pop(0))                   # rows of unit i - 2, S_i still queued
             while queue:

@@ -240,6 +240,12 @@ int dtx_trigger_stats_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
  * ewf_dev must be valid on it.  Consecutive launches on different streams are ordered among themselves by
  * the library (they share a scratch buffer); dtx_basis_upload and dtx_ctx_destroy wait for the last one. */
 int dtx_ctx_set_trigger_stream(dtx_ctx* ctx, void* stream);
+/* Makes `stream` wait for the END OF THE SCAN KERNEL of the context's last dtx_subspace_ds / dtx_subspace_scan(_ragged)
+ * call (not for the post pass behind it): what a host uses to start one batch's trigger-time kernel when the NEXT
+ * batch's scan kernel has finished -- beside that batch's post pass and the preparation of the one after, which
+ * leave room on the CUs, instead of beside a scan kernel, which does not (its workgroups hold every vector register
+ * of a CU: a trigger-time workgroup on a CU keeps the scan off it for its whole run).  No-op before the first scan. */
+int dtx_stream_wait_scan_kernel(dtx_ctx* ctx, void* stream);
 
 /* fast_normcorr(t, s) (construct.py:469-483; callers detect.py:484, subspace.py:765): Pearson
  * correlation of the n-sample template t with every length-n window of the m-sample series s

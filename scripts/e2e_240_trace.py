@@ -49,7 +49,9 @@ from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubS
 
 NDAY = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 RAW = len(sys.argv) > 2 and sys.argv[2] == 'raw'
-SR, NC, L, NFAM, NPER, NSTA = 100.0, 3, 3300, 25, 8, 8
+SR, NC, L, NFAM, NPER, NSTA = 100.0, 3, 3300, 25, 8, int(os.environ.get('E2E_STATIONS', '8'))
+MAGS = os.environ.get('E2E_MAGS', '1') == '1'
+PIN = os.environ.get('E2E_PIN', '1') == '1'
 rs = np.random.RandomState(0)
 td = synth.event_families(1, NFAM, NPER, NC, L, maxshift=20, snr=8.0)
 stas = ['TA.S%02dA' % i for i in range(NSTA)]
@@ -69,7 +71,8 @@ for d in range(NDAY):
 cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'], raw=RAW)
 for sta in stas:
     cf.add(sta, rec.numpy(), starttime=1499997600.0)
-cf.pinned = {sta: rec for sta in stas}
+if PIN:
+    cf.pinned = {sta: rec for sta in stas}
 cl = createCluster(CCreq=0.5, fetch_arg=ef, device=0, saveclust=False)
 ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
 ss.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
@@ -78,10 +81,12 @@ os.environ.setdefault('DETEX_AMD_DS_BUDGET_MB', '1024')
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = ss.detex(subspaceDB=None, estimateMags=True, device=0)
+    res = ss.detex(subspaceDB=None, estimateMags=MAGS, device=0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print('call %d: %.1f ms, %.3f ms per station-day, %d detections' % (rep, 1e3 * dt, 1e3 * dt / (NSTA * NDAY), len(res['ss_df'])))
+    kms = [c.kernel_ms_mean(min(NDAY, 16)) for c in ss._hip_ctx.values()]
+    print('call %d: %.1f ms, %.3f ms per station-day, %d detections; scan kernel %.3f ms (mean of the contexts\' last launches)'
+          % (rep, 1e3 * dt, 1e3 * dt / (NSTA * NDAY), len(res['ss_df']), sum(kms) / len(kms)))
 if os.environ.get('E2E_CPROFILE') == '1':
     import cProfile
     import pstats

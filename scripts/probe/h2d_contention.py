@@ -53,8 +53,35 @@ def run(kind, mb, pieces=1):
           % (kind, mb, pieces, 1e3 * dt / steps, ctx.kernel_ms_mean(32)))
 
 
+# the DS tensor of every step in a buffer of its own, round robin over `nbuf` (SubSpace.detex has three units in flight)
+for nbuf in (1, 3, 6):
+    bufs = [torch.empty((chunks, D, (P + 63) // 64 * 64), dtype=torch.float32, device='cuda')[:, :, :P] for _ in range(nbuf)]
+    pend = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        f = ctx.subspace_scan(xt, out=bufs[i % nbuf], thr=thr, hist=hist, lazy=True)[1]
+        if pend is not None:
+            pend()
+        pend = f
+    pend()
+    torch.cuda.synchronize()
+    print('%d DS buffers: %.3f ms per step, scan kernel %.3f ms' % (nbuf, 1e3 * (time.perf_counter() - t0) / steps, ctx.kernel_ms_mean(32)))
+    del bufs
+# fresh DS tensor per step from the caching allocator (what StationScan does)
+pend = None
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    f = ctx.subspace_scan(xt, thr=thr, hist=hist, lazy=True)[1]
+    if pend is not None:
+        pend()
+    pend = f
+pend()
+torch.cuda.synchronize()
+print('fresh DS per step: %.3f ms per step, scan kernel %.3f ms' % (1e3 * (time.perf_counter() - t0) / steps, ctx.kernel_ms_mean(32)))
 run('none', 0)
-for rep in range(2):
+for rep in range(1):
     run('none', 0)
     run('h2d', 104)
     run('h2d', 52)
