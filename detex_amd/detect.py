@@ -276,11 +276,16 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     the three stages: SubSpace.detex keeps three stations in flight, one in each.)"""
     job = StationScan(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
                       useSingles, fillZeros, device, ctx, estimateMags, shard, bank)
+    import pandas as pd
     try:
         job.start()
-        return job.finish()
+        res = job.finish()
     finally:
         job.close()
+    if res is not None:
+        for k in ('ss', 'sg'):
+            res[k] = pd.DataFrame(res[k], columns=StationScan.COLS)
+    return res
 
 
 class StationScan(object):
@@ -536,7 +541,6 @@ class StationScan(object):
 
     def finish(self):
         """Second host half: trigger-time estimates back from the device -> rows."""
-        import pandas as pd
         if self.empty:
             return None
         self.pick()
@@ -553,7 +557,9 @@ class StationScan(object):
         else:
             h = st['hist'].cpu().numpy()
         names, kinds = st['names'], st['kinds']
-        out = {k: pd.DataFrame(v, columns=self.COLS) for k, v in rows.items()}
+        # rows as plain lists (column order COLS): SubSpace.detex makes ONE DataFrame per table at the end of the
+        # call (a DataFrame per unit and kind cost the host a millisecond per station-day)
+        out = dict(rows)
         # (chunk index in the station's chunk list, detector, order found) per row: a multi-process
         # run merges the ranks' tables by it into the single-process order
         for k, v in keys.items():

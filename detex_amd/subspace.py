@@ -141,6 +141,10 @@ class ClusterStream(object):
 # SubSpace                                         subspace.py:715-2037
 # --------------------------------------------------------------------------
 
+# units SubSpace.detex keeps in flight on the device (scans queued ahead of the host's picking / row building)
+INFLIGHT = max(3, int(os.environ.get('DETEX_AMD_INFLIGHT', '4')))
+
+
 class _StationUploader(object):
     """Station data to the device ahead of its scan.  Arrays the fetcher holds in pinned
     memory (ContinuousFetcher.pin) are copied on a second stream, under the kernels of the
@@ -155,7 +159,8 @@ class _StationUploader(object):
         self.device = device
         self.stream = torch.cuda.Stream(device) if device.type == 'cuda' else None
         self.pending = {}
-        self.slots = [None, None, None]   # [buffer, event recorded when its last reader was enqueued]
+        # one device buffer per unit in flight: [buffer, event recorded when its last reader was enqueued]
+        self.slots = [None] * INFLIGHT
         self.turn = 0
         self.cur = None
         self.bytes_uploaded = 0           # host -> device bytes of station data since reset()
@@ -259,16 +264,12 @@ def _merge_ranks(parts, names_order=None):
         return parts[0]
     out = {}
     for kind in ('ss', 'sg'):
-        dfs = [p[kind] for p in parts if len(p[kind])]
-        if not dfs:
-            out[kind] = parts[0][kind]
-            out['key_' + kind] = np.zeros((0, 3), dtype=np.int64)
-            continue
-        keys = np.concatenate([np.asarray(p['key_' + kind], dtype=np.int64).reshape(-1, 3)
-                               for p in parts if len(p[kind])])
-        order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
-        out[kind] = pd.concat(dfs, ignore_index=True).iloc[order].reset_index(drop=True)
-        out['key_' + kind] = keys[order]
+        rows = [r for p in parts for r in p[kind]]
+        keys = np.array([k for p in parts for k in np.asarray(p['key_' + kind], dtype=np.int64).reshape(-1, 3)],
+                        dtype=np.int64).reshape(-1, 3)
+        order = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0])) if len(rows) else []
+        out[kind] = [rows[i] for i in order]
+        out['key_' + kind] = keys[order] if len(rows) else keys
     for hk in ('hist_ss', 'hist_sg'):
         acc = {}
         for p in parts:
@@ -303,9 +304,12 @@ class _DbWriter(object):
         self.thread = threading.Thread(target=self._run, name='detex-db-writer', daemon=True)
         self.thread.start()
 
-    def put(self, table, df):
-        if df is not None and len(df):
-            self.q.put(('rows', table, df[self.COLS].values.tolist()))
+    def put(self, table, rows):
+        """rows: a list of row lists in COLS order, or a DataFrame with those columns"""
+        if rows is not None and len(rows):
+            if isinstance(rows, pd.DataFrame):
+                rows = rows[self.COLS].values.tolist()
+            self.q.put(('rows', table, list(rows)))
 
     def call(self, fn):
         """fn(connection) on the writer thread, behind everything queued so far."""
@@ -788,12 +792,13 @@ class SubSpace(object):
                     writer.put('ss_df', res['ss'])
                     writer.put('sg_df', res['sg'])
 
-        # Three units are in flight on the one stream, in the order S0 S1 T0 S2 T1 S3 ... (S: a
-        # unit's scans, T: its trigger-time kernel).  The host picks unit i's triggers and
-        # enqueues T_i while S_{i+1} runs, enqueues S_{i+2} behind it, and only then waits for T_i:
-        # whenever the host blocks or builds rows, a whole scan is still queued.  (With two in flight
-        # the wait for T_i -- queued behind S_{i+1} -- drained the queue: 2.5 ms of idle GPU per
-        # station-day.)
+        # INFLIGHT (four) units are in flight: S_i (a unit's scans) is enqueued on its station's stream, then the host
+        # picks unit i - 1's triggers and enqueues T_{i-1} (its trigger-time kernel) on that context's TRIGGER stream,
+        # behind S_i's scan kernel (beside S_i's post pass and the preparation of S_{i+1}: a trigger-time workgroup
+        # beside a scan kernel keeps the scan off its CU), and only then waits for the oldest unit's T and builds its
+        # rows: whenever the host blocks or builds rows, whole scans are still queued.  (With two in flight the wait
+        # for T_i drained the queue: 2.5 ms of idle GPU per station-day; with three a host shared with other jobs
+        # left the GPU waiting now and then: 3.7 - 4.7 ms per station-day from call to call.)
         queue = []                                          # jobs started, oldest first
         try:
             if todo:
@@ -819,8 +824,8 @@ class SubSpace(object):
                     continue
                 if len(queue) >= 2:
                     queue[-2].pick(behind=job)              # T_{i-1} goes in behind S_i's scan kernel
-                if len(queue) >= 3:
-                    collect(queue.pop(0))                   # rows of unit i - 2, S_i still queued
+                if len(queue) >= INFLIGHT:
+                    collect(queue.pop(0))                   # rows of the oldest unit, the younger ones' scans still queued
             while queue:
                 collect(queue.pop(0))
         except Exception as e:                              # noqa: BLE001
@@ -850,14 +855,13 @@ class SubSpace(object):
             if res is None:
                 continue
             for kind in ('ss', 'sg'):
-                if len(res[kind]):
-                    out[kind + '_df'].append(res[kind])
+                out[kind + '_df'] += res[kind]
             self.histSubSpaces[sta] = res['hist_ss']
             self.histSingles[sta] = res['hist_sg']
         cols = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR',
                 'ProEnMag']
-        for k in out:
-            out[k] = pd.concat(out[k], ignore_index=True) if out[k] else pd.DataFrame(columns=cols)
+        for k in out:                                       # one DataFrame per table (the units hand over row lists)
+            out[k] = pd.DataFrame(out[k], columns=cols)
         if writer is not None:
             self._write_db(None, out, writer)               # the info / histogram tables; joins the thread
         elif subspaceDB is not None and rank == 0:
