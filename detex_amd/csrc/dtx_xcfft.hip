@@ -110,6 +110,9 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
   for (int m = 0; m < 16; ++m) dst[w_slot(tid + 512 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
 }
 
+#ifndef DTX_XC_BLKLOOP
+#define DTX_XC_BLKLOOP 0     // 1: a workgroup walks ALL lag blocks of its (later event, unit) and keeps the rows' best
+#endif                       // candidate in registers (one atomicMax per row instead of three): 168 against 152 ms, not kept
 #ifndef DTX_XC_DUAL
 #define DTX_XC_DUAL 1        // the two transforms of an iteration taken together (fft8192_x2), the second on the X staging buffers
 #endif
@@ -144,21 +147,36 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   // (unit-major) work list so that the workgroups sharing an L2 share a unit's pair spectra
   const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
   if (logical >= a.nwork) return;
-  const int item = (int)(logical / a.nblk), blk = (int)(logical - (int64_t)item * a.nblk);
+#if DTX_XC_BLKLOOP
+  const int item = (int)logical, blk_lo = 0, blk_hi = a.nblk;
+#else
+  const int item = (int)(logical / a.nblk), blk_lo = (int)(logical - (int64_t)item * a.nblk), blk_hi = blk_lo + 1;
+#endif
   const int2 it = a.items[item];
   const int c = it.x, pr0 = it.y;
   const int npr = min(kUnitX, (c + 1) / 2 - pr0);          // pairs with at least one row < c
   const LdsBases lb = lds_bases(tid);
-  const int p0 = blk * a.V;
-
+  // state of the lag block being walked (set by load_block)
+  int p0 = 0, nse = 1, nsteps = 1;
+  const c32* xh = a.xh;
   float mu[VM], rw[VM];
+  auto load_block = [&](int blk) {
+    p0 = blk * a.V;
 #pragma unroll
-  for (int m = 0; m < VM; ++m) {
-    const int p = p0 + tid + 512 * m;
-    const bool ok = p < a.Pz;
-    mu[m] = ok ? a.mean_w[(int64_t)c * a.Ppad + p] : 0.f;
-    rw[m] = ok ? a.rsw[(int64_t)c * a.Ppad + p] : __builtin_nanf("");       // (see reduce_rows)
-  }
+    for (int m = 0; m < VM; ++m) {
+      const int p = p0 + tid + 512 * m;
+      const bool ok = p < a.Pz;
+      mu[m] = ok ? a.mean_w[(int64_t)c * a.Ppad + p] : 0.f;
+      rw[m] = ok ? a.rsw[(int64_t)c * a.Ppad + p] : __builtin_nanf("");       // (see reduce_rows)
+    }
+    // Segment s of the earlier events meets the later event's padded planes at samples blk V + s seglen ..:
+    // a (block, segment) whose 8192 samples lie wholly in the zero padding behind the data contributes
+    // nothing and is skipped (3 of 16 products at L = 13 000 with segments of 4096; 1 of 12 with the
+    // 3 x 4 layout the host picks).  nse: segments of this lag block that see data.
+    nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+    nsteps = a.Nc * nse;
+    xh = a.xh + ((int64_t)c * a.nblk + blk) * a.nseg * a.Nc * kXh;
+  };
   // the thread's 16 frequencies in a stored half spectrum (see ds_fft_kernel)
   const int wv = tid >> 6, ln = tid & 63;
   const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
@@ -171,13 +189,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
   const int wlo = 512 * wv + ln;              // pair spectra: w_slot order, float4 units
   const int nvc = a.Nc * a.nseg;
-  // Segment s of the earlier events meets the later event's padded planes at samples blk V + s seglen ..:
-  // a (block, segment) whose 8192 samples lie wholly in the zero padding behind the data contributes
-  // nothing and is skipped (3 of 16 products at L = 13 000 with segments of 4096; 1 of 12 with the
-  // 3 x 4 layout the host picks).  nse: segments of this lag block that see data.
-  const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
-  const int nsteps = a.Nc * nse;
-  const c32* xh = a.xh + ((int64_t)c * a.nblk + blk) * a.nseg * a.Nc * kXh;
   auto xsrc = [&](int i) {                    // block spectrum of step i = (channel, segment): uniform
     const int ch = i / nse, sg = i - ch * nse;
     return reinterpret_cast<const float4*>(xh + ((int64_t)sg * a.Nc + ch) * kXh) + tid;
@@ -258,10 +269,9 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       r1v[h] = rowok ? a.frs[b] : 0.f;
       s1v[h] = rowok ? a.fsum[b] * r1v[h] : 0.f;
     }
-    c32 z[16], zb[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
+    unsigned long long kacc = 0ull;          // threads 0 .. 3: the best candidate of their row over the lag blocks
     float4 wa[2][4], wb[2][4];
+    c32 z[16], zb[16];
     auto issue_w = [&](int i, auto hc) {
       constexpr int h = hc;
       const int64_t o = woff(i);
@@ -304,6 +314,11 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
         }
       }
     };
+#pragma nounroll
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+    load_block(blk);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) z[m] = zb[m] = make_float2(0.f, 0.f);
     {
       const float4* src = xsrc(0);
       const float4 x0 = src[0], x1 = src[512], x2 = src[1024], x3 = src[1536];
@@ -368,10 +383,16 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
       unsigned long long key = wred[tid][0];
 #pragma unroll
       for (int w = 1; w < kT / 64; ++w) key = max(key, wred[tid][w]);
+      kacc = max(kacc, key);
+    }
+#endif
+    }      // lag blocks
+#if !(DTX_XC_ABLATE & (4 | 16))
+    if (tid < (has2 ? 4 : 2)) {
       const int b = 2 * pr + tid;
-      if (key != 0ull && b < c) {
+      if (kacc != 0ull && b < c) {
         const int64_t idx = condensed_index_x(a.N, b, c);
-        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+        if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, kacc);
       }
     }
 #endif
@@ -413,7 +434,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   static_assert(sizeof(int2) == sizeof(dtxplan::I2), "work items are int2");
   const std::vector<dtxplan::I2> items = dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
-  const int64_t nwork = (int64_t)items.size() * nblk;
+  const int64_t nwork = (int64_t)items.size() * (DTX_XC_BLKLOOP ? 1 : nblk);
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
