@@ -226,7 +226,7 @@ def _makeDFcclags(eventList, row, ctx):
     return _frames_from_condensed(N, cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy())
 
 
-def fast_normcorr(t, s, ctx=None, device=0):
+def fast_normcorr(t, s, ctx=None, device=None):
     """detex/construct.py:469-483 on the GPU (dtx_normcorr): normalised correlation of the
     shorter array with every same-length window of the longer one; NumPy in, NumPy out
     (float32 arithmetic inputs, float64 accumulation)."""
@@ -234,7 +234,8 @@ def fast_normcorr(t, s, ctx=None, device=0):
     from .hip import HipContext
     own = ctx is None
     if own:
-        ctx = HipContext(device)
+        from . import parallel
+        ctx = HipContext(parallel.local_device() if device is None else device)
     try:
         tt = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(ctx.device)
         st = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).to(ctx.device)

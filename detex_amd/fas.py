@@ -73,7 +73,7 @@ def _log(msg):
 
 
 def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces=True,
-            useSingles=False, numBins=401, recalc=False, device=0, seed=None):
+            useSingles=False, numBins=401, recalc=False, device=None, seed=None):
     """fas._initFAS for every station of a SubSpace; stores a dict with 'bins',
     'hist', 'betadist', 'nnlf' in the FAS column of each subspace / single."""
     import torch
@@ -84,7 +84,8 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
     if fetcher is None:
         raise DetexHipError('no continuous-data fetcher attached (conDatFetcher)')
     bins = np.linspace(-.01, 1, num=numBins)                        # fas.py:31
-    ctx = HipContext(device)
+    from . import parallel
+    ctx = HipContext(parallel.local_device() if device is None else device)     # one process per GPU: LOCAL_RANK
     try:
         for sta in ss.Stations:
             names, kinds, U, det_off, _, _ = ss._detector_bank_nothr(sta, useSubSpaces, useSingles)

@@ -374,7 +374,7 @@ class SubSpace(object):
         self.histSingles = {}
 
     # ------------------------------------------------------------ validation
-    def validateClusters(self, device=0, ctx=None):
+    def validateClusters(self, device=None, ctx=None):
         """subspace.py:737-783: drop events whose aligned (and trimmed) waveform no longer
         correlates with any later event of its cluster at the cluster's ccReq (misaligned
         events, reference issue 25).  The correlations are fast_normcorr at lag 0
@@ -384,7 +384,8 @@ class SubSpace(object):
         from .hip import HipContext
         own = ctx is None
         if own:
-            ctx = HipContext(device)
+            from . import parallel
+            ctx = HipContext(parallel.local_device() if device is None else device)
         try:
             for sta in list(self.subspaces.keys()):
                 subs = self.subspaces[sta]
@@ -684,7 +685,7 @@ class SubSpace(object):
 
     # ------------------------------------------------------------ FAS
     def getFAS(self, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces=True,
-               useSingles=False, numBins=401, recalc=False, device=0, seed=None, **kwargs):
+               useSingles=False, numBins=401, recalc=False, device=None, seed=None, **kwargs):
         """subspace.py:1652-1743 -> fas._initFAS: empirical null distribution of
         the detection statistic over random continuous chunks, beta fit."""
         from . import fas

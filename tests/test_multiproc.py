@@ -349,4 +349,6 @@ def test_device_defaults_to_local_rank():
     from detex_amd import construct, parallel, subspace
     assert inspect.signature(subspace.SubSpace.detex).parameters['device'].default is None
     assert inspect.signature(construct.createCluster).parameters['device'].default is None
+    for fn in (subspace.SubSpace.getFAS, subspace.SubSpace.validateClusters, construct.fast_normcorr):
+        assert inspect.signature(fn).parameters['device'].default is None, fn
     assert parallel.local_device() == 0 and not parallel.dist_active()        # no process group here
