@@ -113,3 +113,19 @@ def test_c_example_runs(lib, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'planted at 1500' in r.stdout
+
+
+def test_chunk_table_check_on_the_host(lib):
+    """dtx_chunk_table_check: host-side validation of a ragged batch's table, no GPU involved (the library's
+    share of the planners that tests/test_plan_sanitizer.py sweeps under ASAN / UBSAN)."""
+    import numpy as np
+
+    def chk(rows, M, numel):
+        tab = np.ascontiguousarray(rows, dtype=np.int64)
+        return lib.dtx_chunk_table_check(tab.ctypes.data_as(ctypes.c_void_p), len(tab), M, numel)
+    assert chk([[0, 100], [50, 120], [170, 0]], 120, 170) == 0
+    assert chk([[0, 100], [80, 100]], 100, 170) == 2          # reaches past the buffer
+    assert chk([[-1, 10]], 100, 170) == 1
+    assert chk([[0, 101]], 100, 170) == 1                     # longer than M
+    assert chk([[2 ** 62, 2 ** 62]], 2 ** 62, 2 ** 63 - 1) == 1      # no overflow in the bound test
+    assert lib.dtx_chunk_table_check(None, 1, 10, 10) != 0
