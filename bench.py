@@ -588,9 +588,12 @@ def e2e_detex_240(local):
                 res = ss.detex(subspaceDB=db, estimateMags=True, device=local)
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
-            dt = sum(times) / len(times)
+            # the median of the three calls: the host is shared with the pod's other GPU jobs, and a call whose
+            # Python side lost its cores for a moment shows up as an outlier (all three calls are listed)
+            dt = sorted(times)[len(times) // 2]
             out[key] = {'value': windows / dt, 's_per_call': dt, 'ms_per_station_day': 1e3 * dt / (NSTA * NDAY),
                         'ms_per_station_day_calls': [1e3 * t / (NSTA * NDAY) for t in times],
+                        'ms_per_station_day_mean': 1e3 * sum(times) / len(times) / (NSTA * NDAY),
                         'detections': int(len(res['ss_df'])), 'units': NSTA * NDAY,
                         'uploaded_gb': ss.last_run['uploaded_bytes'] / 1e9}
             assert len(res['ss_df']) >= 0.9 * nplant * NDAY * NSTA, (key, len(res['ss_df']))

@@ -780,6 +780,8 @@ class SubSpace(object):
         # single process: the SQLite file is written by a thread of its own, fed as the units finish
         # (detect.py:207-210 flushes every 500 rows); under a process group rank 0 writes after the gather
         writer = _DbWriter(subspaceDB) if (subspaceDB is not None and not active) else None
+        if writer is not None:
+            writer.call(self._write_static_tables)      # (nothing in them depends on the scan: written under it)
 
         def collect(job):
             """Second half of a unit: triggers, trigger-time estimates, rows."""
@@ -1039,49 +1041,62 @@ class SubSpace(object):
 
     def _write_db(self, path, out, writer=None):
         """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /
-        sg_hist, filt_params.  writer: the call's _DbWriter -- the detection rows are in (or on their way
-        into) the file already, the small tables follow on its thread and the thread is joined."""
-        if writer is not None:
-            writer.call(self._write_info_tables)
-            writer.close()
-            return
-        w = _DbWriter(path)
-        for k, df in out.items():
-            w.put(k, df)
-        w.call(self._write_info_tables)
-        w.close()
+        sg_hist, filt_params.  writer: the call's _DbWriter -- the detection rows and the tables that do not
+        depend on the scan (info, filter parameters: queued when the call began) are in, or on their way into,
+        the file already; the histograms follow on its thread and the thread is joined."""
+        if writer is None:
+            writer = _DbWriter(path)
+            for k, df in out.items():
+                writer.put(k, df)
+            writer.call(self._write_static_tables)
+        writer.call(self._write_hist_tables)
+        writer.close()
 
-    def _write_info_tables(self, con):
-        # subspace.py:1905-1953 _getInfoDF: ss_info / sg_info (events comma-separated)
+    @staticmethod
+    def _replace_table(con, name, cols, rows):
+        """pandas' to_sql(if_exists='replace', index=False) for a small table, without pandas (3 - 4 ms a call):
+        cols = [(name, 'REAL' | 'TEXT' | 'INTEGER')]."""
+        con.execute('DROP TABLE IF EXISTS "%s"' % name)
+        con.execute('CREATE TABLE "%s" (%s)' % (name, ', '.join('"%s" %s' % c for c in cols)))
+        con.executemany('INSERT INTO "%s" VALUES (%s)' % (name, ','.join('?' * len(cols))), rows)
+
+    def _write_static_tables(self, con):
+        # subspace.py:1905-1953 _getInfoDF: ss_info / sg_info (events comma-separated); filt_params
         def beta_of(fas):
             bd = (fas or {}).get('betadist') if isinstance(fas, dict) else None
-            return (bd[0], bd[1]) if bd is not None and len(bd) > 1 else (np.nan, np.nan)
+            return (float(bd[0]), float(bd[1])) if bd is not None and len(bd) > 1 else (None, None)
+
+        def num(v):
+            v = float(v)
+            return None if v != v else v                     # NaN -> NULL, as to_sql writes it
         info = []
         for sta in self.ssStations:
             for _, r in self.subspaces[sta].iterrows():
-                b1, b2 = beta_of(r.FAS)
-                info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
-                                 Threshold=r.Threshold, NumBasisUsed=r.NumBasis,
-                                 beta1=b1, beta2=b2))
+                info.append((r.Name, sta, ','.join(r.Events), num(r.Threshold), int(r.NumBasis)) + beta_of(r.FAS))
         if info:
-            pd.DataFrame(info).to_sql('ss_info', con, if_exists='replace', index=False)
+            self._replace_table(con, 'ss_info', [('Name', 'TEXT'), ('Sta', 'TEXT'), ('Events', 'TEXT'),
+                                                 ('Threshold', 'REAL'), ('NumBasisUsed', 'INTEGER'),
+                                                 ('beta1', 'REAL'), ('beta2', 'REAL')], info)
         info = []
         for sta in self.singStations:
             for _, r in self.singles[sta].iterrows():
-                b1, b2 = beta_of(r.FAS)
-                info.append(dict(Name=r.Name, Sta=sta, Events=','.join(r.Events),
-                                 Threshold=r.Threshold, beta1=b1, beta2=b2))
+                info.append((r.Name, sta, ','.join(r.Events), num(r.Threshold)) + beta_of(r.FAS))
         if info:
-            pd.DataFrame(info).to_sql('sg_info', con, if_exists='replace', index=False)
+            self._replace_table(con, 'sg_info', [('Name', 'TEXT'), ('Sta', 'TEXT'), ('Events', 'TEXT'),
+                                                 ('Threshold', 'REAL'), ('beta1', 'REAL'), ('beta2', 'REAL')], info)
+        cl = self.clusters
+        self._replace_table(con, 'filt_params', [('FREQMIN', 'REAL'), ('FREQMAX', 'REAL'), ('CORNERS', 'INTEGER'),
+                                                 ('ZEROPHASE', 'INTEGER'), ('DECIMATE', 'INTEGER')],
+                            [(cl.filt[0], cl.filt[1], int(cl.filt[2]), int(bool(cl.filt[3])),
+                              None if cl.decimate is None else int(cl.decimate))])
+
+    def _write_hist_tables(self, con):
+        # subspace.py:1956-1995: one row per detector, the 400 counts as a blank-separated string
         for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
-            rows = [dict(Sta=sta, Name=name, Value=' '.join(str(int(v)) for v in h))
+            rows = [(sta, name, ' '.join(map(str, np.asarray(h, dtype=np.int64).tolist())))
                     for sta, d in hd.items() for name, h in (d or {}).items()]
             if rows:
-                pd.DataFrame(rows).to_sql(tab, con, if_exists='replace', index=False)
-        cl = self.clusters
-        fp = pd.DataFrame([[cl.filt[0], cl.filt[1], cl.filt[2], cl.filt[3], cl.decimate]],
-                          columns=['FREQMIN', 'FREQMAX', 'CORNERS', 'ZEROPHASE', 'DECIMATE'])
-        fp.to_sql('filt_params', con, if_exists='replace', index=False)
+                self._replace_table(con, tab, [('Sta', 'TEXT'), ('Name', 'TEXT'), ('Value', 'TEXT')], rows)
 
     def write(self, filename='subspace.pkl'):
         """subspace.py:2018-2026."""
