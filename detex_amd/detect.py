@@ -273,7 +273,7 @@ def scan_station(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calc
     chunks, packed; bank: the station's detector bank if the
     caller already built (or received) it; a failing batch is logged and skipped like a
     failing chunk of the reference (detect.py:160-174).  (StationScan.start / .pick / .finish are
-    the three stages: SubSpace.detex keeps three stations in flight, one in each.)"""
+    the three stages: SubSpace.detex keeps several units in flight, one or more in each.)"""
     job = StationScan(ss, sta, utcStart, utcEnd, triggerLTATime, triggerSTATime, calcHist, useSubSpaces,
                       useSingles, fillZeros, device, ctx, estimateMags, shard, bank)
     import pandas as pd
