@@ -205,6 +205,13 @@ def _configs3_worker(rank, world, port, q):
     # the group is still usable afterwards: same tables as before
     again = ss.detex(subspaceDB=None, ctx=ctx)
     assert again['ss_df'].values.tolist() == res['ss_df'].values.tolist()
+    # ... also with every rank's chunks scanned in day units (SubSpace._scan_units): the cut does not show
+    os.environ['DETEX_AMD_DS_BUDGET_MB'] = '0'
+    nscan = len([c for c in ctx.calls if c[0] == 'scan'])
+    units = ss.detex(subspaceDB=None, ctx=ctx)
+    os.environ.pop('DETEX_AMD_DS_BUDGET_MB')
+    assert units['ss_df'].values.tolist() == res['ss_df'].values.tolist()
+    assert len([c for c in ctx.calls if c[0] == 'scan']) - nscan > len(stas)      # more launches than stations
     q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed, early))
     dist.barrier()
     dist.destroy_process_group()
