@@ -373,3 +373,11 @@ def test_raw_templates_and_raw_continuous_equal_prefiltered_run(ctx, dec):
     assert len(got) == len(want) >= len(plants)
     for (_, g), w in zip(got.iterrows(), want):
         assert abs(g.STMP - w[0]) < 1e-6 and g.Name == w[1] and abs(g.DS - w[2]) <= 1e-5, (g.STMP, g.Name, g.DS, w)
+    # classifyEvents on RAW records: the events are cut / decimated / filtered on the device like the templates
+    # were (SubSpace._event_chunks), every member of a cluster is best matched by its own subspace
+    ec = ssa.detex(subspaceDB=None, ctx=ctx, estimateMags=False, classifyEvents=True, eventCorFile=None)['event_cors']
+    assert set(ec.Event) == set(ra.Events)
+    for _, row in ssa.subspaces['XX.RAW'].iterrows():
+        for e in row.Events:
+            mine = ec[ec.Event == e].set_index('Name').MaxDS
+            assert mine.idxmax() == row.Name and mine[row.Name] > 0.6, (e, dict(mine))

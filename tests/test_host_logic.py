@@ -847,3 +847,39 @@ def test_long_records_are_scanned_in_day_units(tmp_path, monkeypatch):
     # the units overlap by the chunks' 120 s buffer: a little more goes over the host link than the record holds
     total = sum(4 * 3 * cf.data[s][0].shape[1] for s in stas)
     assert total < ss.last_run['uploaded_bytes'] < 1.01 * total
+
+
+def test_raw_template_fragments_with_fillZeros():
+    """createCluster(fillZeros=True) on fragmented raw records: the gap is filled with zeros (_mergeChannelsFill,
+    construct.py:1069-1071) and the event keeps its whole window, where the default cuts it to its longest
+    gap-free stretch."""
+    recs, sr, Nc = raw_event_records(nev=6)
+    filt, trim = [1, 8, 2, True], [5, 20]
+    T = recs[0]['data'].shape[1]
+    g0 = int((30 - 5) * sr) + 300
+
+    def fetcher():
+        ef = EventFetcher(sr, ['E', 'N', 'Z'])
+        for i, r in enumerate(recs):
+            cnt = r['data'].astype(np.int32)
+            frs = [(c, 0, cnt[c]) for c in range(Nc)]
+            if i == 2:          # a 30-sample gap in the middle of the window, on one channel
+                frs = [(0, 0, cnt[0, :g0]), (0, g0 + 30, cnt[0, g0 + 30:])] + [(c, 0, cnt[c]) for c in (1, 2)]
+            ef.add_counts('XX.RAW', r['name'], frs, T, r['starttime'], r['origintime'], r['magnitude'])
+        return ef
+    full = Nc * (int(round(25 * sr)) + 1)
+    filled = createCluster(CCreq=0.4, fetch_arg=fetcher(), filt=filt, trim=trim, fillZeros=True, ctx=OracleCtx(),
+                           saveclust=False)
+    assert 'ev02' in filled.trdf.iloc[0].Events and len(filled._mptd['XX.RAW']['ev02']) == full
+    cut = createCluster(CCreq=0.4, fetch_arg=fetcher(), filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
+    # without fillZeros the longest gap-free stretch of ev02 (671 of 1001 samples, behind the gap) is all that is
+    # left of it: below 90 % of the median length, _testStreamLengths drops the event (construct.py:679-694)
+    assert 'ev02' not in cut.trdf.iloc[0].Events and len(cut._mptd['XX.RAW']['ev00']) == full
+    # zero fill: the filtered waveform equals the one of the record with the gap samples set to zero
+    rec = recs[2]['data'].copy()
+    rec[0, g0:g0 + 30] = 0
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    for i, r in enumerate(recs):
+        ef.add_raw('XX.RAW', r['name'], rec if i == 2 else r['data'], r['starttime'], r['origintime'], r['magnitude'])
+    ref = createCluster(CCreq=0.4, fetch_arg=ef, filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
+    assert np.allclose(filled._mptd['XX.RAW']['ev02'], ref._mptd['XX.RAW']['ev02'], atol=1e-6)
