@@ -708,7 +708,12 @@ class SubSpace(object):
         ``estimateMags`` (detect.py:447-499) fills Mag, SNR and ProEnMag at every
         trigger (dtx_trigger_stats + detect.mags_from_stats); they are NaN with estimateMags=False as in the
         reference.  A raw ContinuousFetcher is decimated (clusters.decimate),
-        detrended and band-passed (clusters.filt) chunk by chunk on the device."""
+        detrended and band-passed (clusters.filt) chunk by chunk on the device.
+        ``classifyEvents`` (a template key, a list of event names, or True; detect.py:51-55, 151-152): the detectors
+        run over the event waveforms of the cluster's event fetcher instead; the result also holds 'event_cors'
+        (highest detection statistic per event, station and detector), pickled to ``eventCorFile_<station>.pkl``.
+        ``utcSaves`` (epoch seconds; detect.py:63-75, 297-318): 'utc_saves' holds, per detector, the data and the
+        whole detection-statistic vector of every chunk that covers a listed time, appended to UTCsaves.pkl."""
         import torch
         from . import parallel
         from .detect import StationScan
@@ -772,7 +777,7 @@ class SubSpace(object):
             except Exception as e:                          # noqa: BLE001
                 failure = failure or '%s: %s' % (type(e).__name__, e)
         # A station's chunks are scanned in units: the whole record in one (ragged) launch while its DS tensor
-        # fits the budget, else day by day (_scan_units) -- the pipeline below keeps three UNITS in flight
+        # fits the budget, else day by day (_scan_units) -- the pipeline below keeps INFLIGHT units in flight
         todo = [] if failure is not None else self._scan_units(stations, bounds, sel, banks, fetcher)
         up = self._uploader(dev)
         up.reset()
