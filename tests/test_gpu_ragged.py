@@ -2,6 +2,8 @@
 arbitrary positions of one buffer in ONE launch give, chunk by chunk, what dtx_subspace_scan gives
 for that chunk alone -- the reference scans every chunk on its own (detex/detect.py:154-218), whatever
 its length (getdata.py:494-524: the first and the last chunk of a request are shorter)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -116,8 +118,11 @@ def test_ragged_trigger_stats_equal_chunk_by_chunk():
         one = ctx.subspace_ds(xc)
         want = ctx.trigger_stats(xc, m, m, one, np.array(per[b], np.int32), 5, 40, ewf, eoff, 2).cpu().numpy()
         for w in want:
-            # (the detection statistic of a chunk shorter than 64 x 256 samples differs by its rounding)
-            assert np.allclose(got[r], w, rtol=5e-6, atol=1e-9, equal_nan=True), (b, got[r], w)
+            # (the detection statistic of a chunk shorter than 64 x 256 samples differs by its rounding; under a
+            # contraction engine forced by DETEX_AMD_ENGINE the tiles of the ragged launch and of the chunk alone
+            # differ too: the STA / LTA means of a 3e-3 statistic then agree to 1e-5 instead of 5e-6)
+            rtol = 2e-5 if os.environ.get('DETEX_AMD_ENGINE') else 5e-6
+            assert np.allclose(got[r], w, rtol=rtol, atol=1e-9, equal_nan=True), (b, got[r], w)
             r += 1
     ctx.close()
 
