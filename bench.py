@@ -290,7 +290,8 @@ def dist_overhead(local, timed_loop, steps, ms_plain, Uh, det_off, n):
     os.environ['MASTER_PORT'] = str(port)
     dev = torch.device('cuda', local)
     t0 = time.perf_counter()
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    import datetime
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
     try:
         dist.barrier()
         torch.cuda.synchronize()
