@@ -212,7 +212,12 @@ def _configs3_worker(rank, world, port, q):
     os.environ.pop('DETEX_AMD_DS_BUDGET_MB')
     assert units['ss_df'].values.tolist() == res['ss_df'].values.tolist()
     assert len([c for c in ctx.calls if c[0] == 'scan']) - nscan > len(stas)      # more launches than stations
-    q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed, early))
+    # utcSaves under a process group: the rows of the chunks the ranks scanned come together in chunk order
+    t_in = [cf.chunk_bounds(stas[0])[1][2] + 100.0, cf.chunk_bounds(stas[0])[3][2] + 100.0]
+    os.chdir(os.environ.get('DTX_TEST_TMP', '.'))
+    usv = ss.detex(subspaceDB=None, ctx=ctx, utcSaves=t_in)['utc_saves']
+    utc = [(r.Station, r.Name, float(r.TS1), float(np.max(r.SSdetect))) for _, r in usv.iterrows()]
+    q.put((rank, coll, last, scans, res['ss_df'].values.tolist(), hist, failed, early, utc))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -234,6 +239,7 @@ def test_configs3_sharding_world2():
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     port = _free_port()
+    os.environ['DTX_TEST_TMP'] = os.getcwd()             # (UTCsaves.pkl of the workers goes to the test's scratch directory)
     procs = [mpc.Process(target=_configs3_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -242,7 +248,8 @@ def test_configs3_sharding_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     up = []
-    for rank, coll, last, scans, rows, hist, failed, early in res:
+    want_utc = None
+    for rank, coll, last, scans, rows, hist, failed, early, utc in res:
         # three collectives per call: shapes / thresholds (object), the bases (tensor), the rows
         assert coll == {'broadcast': 1, 'broadcast_object': 1, 'all_gather_object': 1, 'all_gather': 0}, coll
         want_bytes, dealt = _expected_upload(cf, stas, rank, world)
@@ -263,6 +270,17 @@ def test_configs3_sharding_world2():
                 assert hist[sta][nm] == h.tolist()
         assert failed is not None and 'rank' in failed and 'injected fault' in failed
         assert len(early) == 2 and all(e is not None and 'no bank on rank' in e for e in early), early
+        # utcSaves rows: the same on every rank as in a single process (chunks 1 and 3 of every station cover a time)
+        if want_utc is None:
+            t_in = [cf.chunk_bounds(stas[0])[1][2] + 100.0, cf.chunk_bounds(stas[0])[3][2] + 100.0]
+            if os.path.exists('UTCsaves.pkl'):           # (rank 0's file: a new run appends what it finds, detect.py:101-105)
+                os.remove('UTCsaves.pkl')
+            u1 = ss1.detex(subspaceDB=None, ctx=c1, utcSaves=t_in)['utc_saves']
+            want_utc = [(r.Station, r.Name, float(r.TS1), float(np.max(r.SSdetect))) for _, r in u1.iterrows()]
+            assert len(want_utc) >= 2 * len(stas)
+        assert len(utc) == len(want_utc)
+        for g, w in zip(utc, want_utc):
+            assert g[:3] == w[:3] and abs(g[3] - w[3]) < 1e-6      # (every rank scans with the float32 basis that was broadcast)
     # each rank moved about half of the data over the host link (plus the 120 s chunk overlap)
     assert max(up) < 0.52 * total and sum(up) < 1.01 * total
 
