@@ -883,3 +883,48 @@ def test_raw_template_fragments_with_fillZeros():
         ef.add_raw('XX.RAW', r['name'], rec if i == 2 else r['data'], r['starttime'], r['origintime'], r['magnitude'])
     ref = createCluster(CCreq=0.4, fetch_arg=ef, filt=filt, trim=trim, ctx=OracleCtx(), saveclust=False)
     assert np.allclose(filled._mptd['XX.RAW']['ev02'], ref._mptd['XX.RAW']['ev02'], atol=1e-6)
+
+
+def _updateReqCC_by_sets(link, key, ccReq):
+    """The reference's dendrogram cut (subspace.py:305-346, 385-412) restated with its member lists and subset
+    tests -- the O(N^2) form detex_amd.subspace.Cluster.updateReqCC replaces; kept here as the yardstick."""
+    N = len(link)
+    members = {i: [i] for i in range(N + 1)}
+    rows = []
+    for a in range(N):
+        i1, i2 = int(link[a, 0]), int(link[a, 1])
+        members[N + 1 + a] = members[i1] + members[i2]
+        rows.append(dict(disSim=link[a, 2], clust=N + 1 + a, II=members[i1] + members[i2]))
+    rest = [r for r in rows if r['disSim'] <= 1 - ccReq]
+    rest.sort(key=lambda r: -r['disSim'])
+    clustlinks, clusts = {}, []
+    while rest:
+        top = rest[0]
+        inside = [r for r in rest if set(r['II']).issubset(top['II'])]
+        clustlinks[len(clusts)] = [r['clust'] for r in inside]
+        clusts.append([key[y] for y in sorted(set(y for r in inside for y in r['II']))])
+        rest = [r for r in rest if r not in inside]
+    cs = set(y for x in clusts for y in x)
+    return clusts, [k for k in key if k not in cs], clustlinks
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_dendrogram_cut_equals_the_subset_form(seed):
+    """Cluster.updateReqCC (one depth-first walk per cluster) against the reference's subset form on random
+    single linkages, ties between merge heights included, at several ccReq."""
+    from scipy.cluster.hierarchy import linkage
+    from detex_amd.subspace import Cluster
+    rs = np.random.RandomState(seed)
+    N = int(rs.randint(3, 60))
+    npair = N * (N - 1) // 2
+    cc = rs.uniform(0, 1, npair)
+    if seed % 3 == 0:
+        cc = np.round(cc, 1)                           # many equal dissimilarities: ties between merges
+    link = linkage(1.0000001 - cc)
+    key = ['ev%02d' % i for i in range(N)]
+    for ccReq in (0.0, 0.2, 0.5, 0.8, 0.95, 1.0):
+        c = Cluster(None, 'XX.STA', None, key, link, ccReq, None, None, None, None)
+        clusts, singles, clustlinks = _updateReqCC_by_sets(link, key, ccReq)
+        assert c.clusts == clusts and c.singles == singles and c.clustlinks == clustlinks, (seed, ccReq)
+        assert c.clustcount == sum(len(x) for x in clusts)
+    assert sorted(c.members(2 * len(link))) == list(range(N))          # the root holds every leaf
