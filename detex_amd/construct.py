@@ -189,11 +189,13 @@ def _frames_from_condensed(N, cc, lag, ss):
     (construct.py:373-378)."""
     cols = np.arange(1, N)
     idx = np.arange(0, N - 1)
-    iu = np.triu_indices(N, 1)
+    # pair (b, c), b < c, sits at [b, c - 1]: the upper triangle (diagonal included) of the frame in row-major
+    # order IS the condensed order -- one masked assignment (a fancy-indexed one took 0.2 s per frame at 2000 events)
+    upper = np.triu(np.ones((N - 1, N - 1), dtype=bool))
     out = []
     for v in (cc, lag, ss):
         m = np.full((N - 1, N - 1), np.nan, dtype=np.float64)
-        m[iu[0], iu[1] - 1] = np.asarray(v, dtype=np.float64)
+        m[upper] = np.asarray(v, dtype=np.float64)
         out.append(pd.DataFrame(m, columns=cols, index=idx))
     return out[0], out[1], out[2]
 
@@ -208,8 +210,10 @@ def _makeDFcclags(eventList, row, ctx):
         _error('Lengths not equal on multiplexed data, cannot correlate')       # 433-436
     from . import parallel
     Nc = len(row.Channels[eventList[0]])
-    td = np.ascontiguousarray([row.MPtd[e] for e in eventList], dtype=np.float32)
     N = len(eventList)
+    td = np.empty((N, len(row.MPtd[eventList[0]])), dtype=np.float32)      # (row by row: a list of 2000 float64
+    for i, e in enumerate(eventList):                                       # arrays through ascontiguousarray: 1.2 s)
+        td[i] = row.MPtd[e]
     rank, world = parallel.dist_info()
     if parallel.dist_active():
         # one process per GPU: every rank correlates a contiguous range of the condensed pair
