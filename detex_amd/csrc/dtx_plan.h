@@ -208,6 +208,29 @@ inline std::vector<I2> plan_xc_items(int N, int64_t b_begin, int64_t b_end, int 
   return items;
 }
 
+// Work items of the 2 x 2 workgroup {later event c (and c + 1 when bit 30 of .y is set), first of TWO pair spectra}:
+// the same walk -- groups of `group` units, `ctile` (even) later events at a time --, the later events taken in
+// twos inside a tile.  A unit is listed for the two when it holds a row below the larger of them.
+inline std::vector<I2> plan_xc_items22(int N, int64_t b_begin, int64_t b_end, int group, int ctile) {
+  std::vector<I2> items;
+  const int unit = 2, npr = (N + 1) / 2;
+  for (int g0 = 0; g0 < npr; g0 += unit * group) {
+    const int64_t g_lo = 2 * (int64_t)g0, g_hi = 2 * (int64_t)(g0 + unit * group) - 1;
+    if (g_hi < b_begin || g_lo > b_end) continue;
+    for (int c0 = (int)std::max<int64_t>(g_lo + 1, 1); c0 < N; c0 += ctile)
+      for (int pr0 = g0; pr0 < std::min(npr, g0 + unit * group); pr0 += unit) {
+        const int64_t r_lo = 2 * (int64_t)pr0, r_hi = 2 * (int64_t)(pr0 + unit) - 1;
+        if (r_hi < b_begin || r_lo > b_end) continue;
+        const int c_end = std::min(N, c0 + ctile);
+        for (int c = c0; c < c_end; c += 2) {
+          const int has1 = c + 1 < c_end ? 1 : 0;
+          if (c + has1 > r_lo) items.push_back(I2{c, pr0 | (has1 << 30)});
+        }
+      }
+  }
+  return items;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Rings of the context  (dtx_ctx.hip)
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 // (max, first argmax) over lags as a 64-bit atomicMax key per pair; the winning lag is then
 // re-evaluated in float64 by xc_finish_kernel exactly as before, so the float32 transforms
 // only have to pick the lag.
+#include <cstdlib>
 #include "dtx_fftcore.h"
 #include "dtx_plan.h"
 
@@ -399,6 +400,219 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
   }
 }
 
+// ---- the 2 x 2 workgroup ------------------------------------------------------------------------------------
+// What bounds xc_fft_kernel is the sum of its phases under two waves per SIMD, and 80 KB through a CU's L1 per
+// product (a pair spectrum to registers + half of a staged block spectrum).  Here a workgroup of 1024 threads takes
+// TWO later events x TWO pair spectra of one lag block: half h (512 threads, the transform's own layout) holds pair
+// spectrum pr0 + h in registers and multiplies it with BOTH later events' block spectra, which the halves stage
+// together through LDS (each loads one): 2 x 64 + 2 x 32 = 192 KB per four products = 48 KB each, sixteen waves
+// of 128 registers instead of eight of 198.  The staging buffers (4 x 32 KB: two events, double-buffered) and the
+// halves' two transform images (2 x 64 KB) are the same 128 KB of LDS, used one phase after the other.
+#ifndef DTX_XC_T22
+#define DTX_XC_T22 1         // the 2 x 2 workgroup is the lag search's kernel (0: xc_fft_kernel)
+#endif
+#ifndef DTX_XC_NW
+#define DTX_XC_NW 2          // pair-spectrum batches (2 x 16 bytes per thread) in flight: 4 = a whole step ahead, 2 = half a step
+#endif
+constexpr int kT2 = 2 * kT;
+template <int VM>
+__global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
+  __shared__ c32 lds[2 * kLdsC];
+  __shared__ unsigned long long wred[8][kT / 64];   // [(half, later event, row)][wave of the half]
+  const int tid = threadIdx.x, hf = tid >> 9, ht = tid & 511;
+  const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if (logical >= a.nwork) return;
+  const int item = (int)(logical / a.nblk), blk = (int)(logical - (int64_t)item * a.nblk);
+  const int2 it = a.items[item];
+  const int c0 = it.x, has1 = (it.y >> 30) & 1, pr0 = it.y & 0x3fffffff;
+  const int c1 = has1 ? c0 + 1 : c0;                       // (without a second event: the first again, its rows dead)
+  const int nprt = (a.N + 1) / 2;
+  const bool prok = pr0 + hf < nprt;                        // uniform per half
+  const int pr = prok ? pr0 + hf : pr0;
+  const LdsBases lb = lds_bases(ht);
+  const int p0 = blk * a.V;
+  const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+  const int nsteps = a.Nc * nse;
+  const int64_t xstride = (int64_t)a.nblk * a.nseg * a.Nc * kXh;
+  const c32* xhh = a.xh + (hf ? c1 : c0) * xstride + (int64_t)blk * a.nseg * a.Nc * kXh;   // the event this half stages
+  const int wv = ht >> 6, ln = ht & 63;
+  const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
+  auto fix_x = [&](c32 xx, int r) {
+    if (r == 0 && ht == 0) xx.y = 0.f;
+    if (r == 8 && ht == 0) return make_float2(xx.y, 0.f);
+    if (r >= 8) xx.y = -xx.y;
+    return xx;
+  };
+  auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && ht == 0) ? 0 : xhi - 64 * r); };
+  const int nvc = a.Nc * a.nseg;
+  auto xsrc = [&](int i) {
+    const int ch = i / nse, sg = i - ch * nse;
+    return reinterpret_cast<const float4*>(xhh + ((int64_t)sg * a.Nc + ch) * kXh) + ht;
+  };
+  const float4* wq = reinterpret_cast<const float4*>(a.W + (int64_t)pr * nvc * kN) + (512 * wv + ln);
+  auto woff = [&](int i) {
+    const int ch = i / nse, sg = i - ch * nse;
+    return (int64_t)(ch * a.nseg + sg) * (kN / 2);
+  };
+  // rows 2 pr, 2 pr + 1 against the two later events: 1 / sqrt(ssd) and sum x_b / sqrt(ssd), 0 for a dead row
+  float r1v[2][2], s1v[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = 2 * pr + h;
+      const bool rowok = prok && b < (k ? c1 : c0) && (k == 0 || has1);
+      r1v[k][h] = rowok ? a.frs[b] : 0.f;
+      s1v[k][h] = rowok ? a.fsum[b] * r1v[k][h] : 0.f;
+    }
+  c32 z0[16], z1[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) z0[m] = z1[m] = make_float2(0.f, 0.f);
+  float4 w[DTX_XC_NW][2];
+  auto issue_w = [&](int i, auto qc, auto sc) {       // batch q of step i (frequencies 4 q .. 4 q + 3) into slot s
+    constexpr int q = qc, sl = sc;
+    const float4* src = wq + woff(i);
+    w[sl][0] = src[64 * (2 * q)];
+    w[sl][1] = src[64 * (2 * q + 1)];
+  };
+  auto mac_q = [&](const c32* x0, const c32* x1, auto qc, auto sc) {
+    constexpr int q = qc, sl = sc;
+    c32 pa[4], pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      pa[e] = fix_x(x0[x_slot(r)], r);
+      pb[e] = fix_x(x1[x_slot(r)], r);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = 4 * q + e;
+      const float4 t = w[sl][e >> 1];
+      const c32 pw = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+      z0[m].x = __fmaf_rn(-pw.y, pa[e].y, __fmaf_rn(pw.x, pa[e].x, z0[m].x));
+      z0[m].y = __fmaf_rn(pw.y, pa[e].x, __fmaf_rn(pw.x, pa[e].y, z0[m].y));
+      z1[m].x = __fmaf_rn(-pw.y, pb[e].y, __fmaf_rn(pw.x, pb[e].x, z1[m].x));
+      z1[m].y = __fmaf_rn(pw.y, pb[e].x, __fmaf_rn(pw.x, pb[e].y, z1[m].y));
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2c = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  {
+    const float4* src = xsrc(0);
+    const float4 x0 = src[0], x1 = src[512], x2 = src[1024], x3 = src[1536];
+    issue_w(0, I0{}, I0{});
+    issue_w(0, I1{}, I1{});
+    if constexpr (DTX_XC_NW == 4) { issue_w(0, I2c{}, I2c{}); issue_w(0, I3{}, I3{}); }
+    float4* dst = reinterpret_cast<float4*>(lds + hf * kXh) + ht;
+    dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int i = 0; i < nsteps; ++i) {
+    const int nx = min(i + 1, nsteps - 1);    // (the last step fetches its own operands again: straight-line steps)
+    const float4* src = xsrc(nx);
+    const c32* x0 = lds + (2 * (i & 1)) * kXh;
+    const c32* x1 = x0 + kXh;
+    float4* dst = reinterpret_cast<float4*>(lds + (2 * ((i + 1) & 1) + hf) * kXh) + ht;
+    float4 xa0 = src[0], xa1 = src[512];
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) issue_w(nx, I0{}, I0{}); else issue_w(i, I2c{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) issue_w(nx, I1{}, I1{}); else issue_w(i, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    dst[0] = xa0; dst[512] = xa1;
+    xa0 = src[1024]; xa1 = src[1536];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) mac_q(x0, x1, I2c{}, I2c{}); else mac_q(x0, x1, I2c{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) issue_w(nx, I2c{}, I2c{}); else issue_w(nx, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) mac_q(x0, x1, I3{}, I3{}); else mac_q(x0, x1, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DTX_XC_NW == 4) issue_w(nx, I3{}, I3{}); else issue_w(nx, I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    dst[1024] = xa0; dst[1536] = xa1;
+    __syncthreads();
+  }
+  // the transforms: each half on its own image (the staging buffers' memory; the loop's last barrier is
+  // behind every read of them), one later event after the other
+  c32* img = lds + hf * kLdsC;
+  auto finish = [&](c32 (&z)[16], auto kc) {
+    constexpr int k = kc;
+    const int c = k ? c1 : c0;
+    fft8192<1>(z, img, lb, a.tab, ht);
+    // (the lags' window statistics are fetched behind the transform: held across it they spill -- the other
+    // later event's accumulators are live --, and sixteen waves cover the loads)
+    __builtin_amdgcn_sched_barrier(0);
+    float best[2] = {-INFINITY, -INFINITY};
+    int bm[2] = {0, 0};
+    constexpr int kCh = 5;                               // lags per thread whose statistics are in flight together
+    dtx::static_for<0, (VM + kCh - 1) / kCh>([&](auto cc_) {
+      constexpr int m0 = cc_ * kCh, m1 = m0 + kCh < VM ? m0 + kCh : VM;
+      float mu[m1 - m0], rw[m1 - m0];
+#pragma unroll
+      for (int m = m0; m < m1; ++m) {
+        // (loads at a clamped index, then a select: predicated loads became a branch per lag)
+        const int p = p0 + ht + 512 * m, pc = min(p, a.Pz - 1);
+        const float mv = a.mean_w[(int64_t)c * a.Ppad + pc], rv = a.rsw[(int64_t)c * a.Ppad + pc];
+        mu[m - m0] = mv;
+        rw[m - m0] = p < a.Pz ? rv : __builtin_nanf("");      // NaN: never wins a comparison
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+          const float y = h ? z[m].y : z[m].x;
+          float cc = (y - s1v[k][h] * mu[m - m0]) * rw[m - m0];
+          cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+          const bool gt = cc > best[h];
+          best[h] = gt ? cc : best[h];
+          bm[h] = gt ? m : bm[h];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float r1 = r1v[k][h];
+      const float wmax = wave_max_f32(best[h]);
+      const unsigned pcand = (best[h] == wmax) ? (unsigned)(p0 + ht + 512 * bm[h]) : 0xFFFFFFFFu;
+      const unsigned pmin = wave_min_u32(pcand);
+      if ((tid & 63) == 0) {
+        unsigned long long key = 0ull;
+        if (r1 > 0.f && wmax > -INFINITY) {
+          const unsigned bits = __float_as_uint(wmax);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
+        }
+        wred[4 * hf + 2 * k + h][wv] = key;
+      }
+    }
+  };
+  finish(z0, I0{});
+  finish(z1, I1{});
+  __syncthreads();
+  if (tid < 8) {
+    unsigned long long key = wred[tid][0];
+#pragma unroll
+    for (int q = 1; q < kT / 64; ++q) key = max(key, wred[tid][q]);
+    const int h2 = tid >> 2, k = (tid >> 1) & 1, h = tid & 1;
+    const int b = 2 * (pr0 + h2) + h, c = k ? c1 : c0;
+    if (key != 0ull && b < c && (k == 0 || has1)) {
+      const int64_t idx = condensed_index_x(a.N, b, c);
+      if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+    }
+  }
+}
+
+template <int VM>
+void launch_xc22(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
+  hipLaunchKernelGGL((xc_fft22_kernel<VM>), dim3(grid), dim3(kT2), 0, ctx->stream, a);
+}
+
 template <int VM>
 void launch_xc(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
   hipLaunchKernelGGL((xc_fft_kernel<VM>), dim3(grid), dim3(kT), 0, ctx->stream, a);
@@ -432,9 +646,13 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // (one per unit of the group) share its block spectra in L2, those of one unit (one per later event of
   // the tile and lag block) its pair spectra
   static_assert(sizeof(int2) == sizeof(dtxplan::I2), "work items are int2");
-  const std::vector<dtxplan::I2> items = dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
+  // (DETEX_AMD_XC22=0 / 1 overrides the build's choice of kernel: A/B runs and the tests of both)
+  bool t22 = DTX_XC_T22 != 0;
+  if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = e[0] == '1';
+  const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
+                                             : dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
-  const int64_t nwork = (int64_t)items.size() * (DTX_XC_BLKLOOP ? 1 : nblk);
+  const int64_t nwork = (int64_t)items.size() * ((DTX_XC_BLKLOOP && !t22) ? 1 : nblk);
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
@@ -476,7 +694,22 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   a.per_xcd = per_xcd; a.nwork = nwork;
   { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-  switch (V / 512) {
+  if (t22) switch (V / 512) {
+    case 4: launch_xc22<4>(ctx, a, (unsigned)grid); break;
+    case 5: launch_xc22<5>(ctx, a, (unsigned)grid); break;
+    case 6: launch_xc22<6>(ctx, a, (unsigned)grid); break;
+    case 7: launch_xc22<7>(ctx, a, (unsigned)grid); break;
+    case 8: launch_xc22<8>(ctx, a, (unsigned)grid); break;
+    case 9: launch_xc22<9>(ctx, a, (unsigned)grid); break;
+    case 10: launch_xc22<10>(ctx, a, (unsigned)grid); break;
+    case 11: launch_xc22<11>(ctx, a, (unsigned)grid); break;
+    case 12: launch_xc22<12>(ctx, a, (unsigned)grid); break;
+    case 13: launch_xc22<13>(ctx, a, (unsigned)grid); break;
+    case 14: launch_xc22<14>(ctx, a, (unsigned)grid); break;
+    case 15: launch_xc22<15>(ctx, a, (unsigned)grid); break;
+    default: return dtx_fail(ctx, DTX_E_STATE, "xcorr (FFT): bad block advance %d", V);
+  }
+  else switch (V / 512) {
     case 4: launch_xc<4>(ctx, a, (unsigned)grid); break;
     case 5: launch_xc<5>(ctx, a, (unsigned)grid); break;
     case 6: launch_xc<6>(ctx, a, (unsigned)grid); break;

@@ -140,6 +140,22 @@ static void check_xc(int N, int L, int Nc) {
       for (int64_t b = bb; b <= be; ++b)
         for (int c = (int)b + 1; c < N; ++c) CHECK(uniq.count({c, (int)(b / 2 / un * un)}) == 1);
     }
+    // the 2 x 2 workgroup's list: units of two pair spectra against one or two later events; every
+    // (later event, unit) of the range exactly once, nothing listed that holds no pair
+    for (int ct : {ctile, 2, 6}) {
+      std::vector<I2> items = plan_xc_items22(N, bb, be, group, ct);
+      std::set<std::pair<int, int>> seen;
+      const int npr = (N + 1) / 2;
+      for (const I2& it : items) {
+        const int has1 = (it.y >> 30) & 1, pr0 = it.y & 0x3fffffff;
+        CHECK(it.x >= 1 && it.x + has1 < N && pr0 >= 0 && pr0 < npr && pr0 % 2 == 0);
+        CHECK(it.x + has1 > 2 * pr0);
+        CHECK(seen.insert({it.x, pr0}).second);
+        if (has1) CHECK(seen.insert({it.x + 1, pr0}).second);
+      }
+      for (int64_t b = bb; b <= be; ++b)
+        for (int c = (int)b + 1; c < N; ++c) CHECK(seen.count({c, (int)(b / 4 * 4 / 2)}) == 1);
+    }
   }
 }
 
