@@ -347,7 +347,8 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     nblk, nprod = 3, 11
     nfft = (npairs / 2.0) * nblk
     flop_fft = nfft * 5.0 * 8192 * 13 + (npairs / 2.0) * nprod * Nc * 8.0 * 8192
-    l2_bytes = (npairs / 2.0) * nprod * Nc * (8192 * 8 + 4096 * 8 / 2.0)   # pair spectrum + half of a shared block spectrum
+    # per product: half a pair spectrum (one serves two later events) + half of a staged block spectrum (the 2 x 2 workgroup)
+    l2_bytes = (npairs / 2.0) * nprod * Nc * (8192 * 8 / 2.0 + 4096 * 8 / 2.0)
     bytes_alg = 4.0 * N * n + 12.0 * npairs                        # events once + 12 B per pair
     # counters of the committed rocprofv3 --pmc passes of scripts/bench_xcorr.py (scripts/profile_xc.sh), newest tag
     import glob
@@ -362,8 +363,9 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     def cnt(kern, name):
         v = pmc.get(kern, {}).get(name)
         return v['mean_per_launch'] if isinstance(v, dict) else v
-    hbm = cnt('xc_fft_kernel', 'hbm_bytes_per_launch_corrected')
-    l2req = cnt('xc_fft_kernel', 'TCC_REQ_sum')
+    xk = 'xc_fft22_kernel' if pmc.get('xc_fft22_kernel') else 'xc_fft_kernel'      # (summaries up to x8: the round-3 kernel)
+    hbm = cnt(xk, 'hbm_bytes_per_launch_corrected')
+    l2req = cnt(xk, 'TCC_REQ_sum')
     cpu_leg = None
     if cpu:
         # the reference's _CCX2 (construct.py:425-466) on this host: one core (the reference is
@@ -378,20 +380,21 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,
             'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs),
             'cc_mean': ccm, 'cpu_baseline': cpu_leg,
-            'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
+            'roofline': {'bound': 'hbm', 'kernel': 'xc_fft22_kernel', 'kernel_ms': kms,
                          'achieved': bytes_alg / (kms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0,
                          'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False,
                                       'same_kernel_source': pmc_same} if hbm else None),
                          'bytes_per_launch': bytes_alg,
-                         'bound_actual': 'the sum of its two phases, run one after the other by one workgroup per CU: '
-                                         'products (L2 -> L1 stream of the pair spectra, ~0.85 of the L1 fill rate) '
-                                         'and transforms (counters: %s; DESIGN 4.3) -- the algorithmic HBM bytes the '
+                         'bound_actual': 'the sum of its phases, run one after the other by one workgroup of sixteen '
+                                         'waves per CU: products (L2 -> L1 stream of pair and block spectra, 48 KB per '
+                                         'product, ~0.8 of the L1 fill rate), transforms, lag search '
+                                         '(counters: %s; DESIGN 4.3) -- the algorithmic HBM bytes the '
                                          'schema prices are 3 orders of magnitude below what the frequency-domain '
                                          'search moves on chip' % pmc_src,
                          'l2_counters': ({'TCC_REQ_sum': l2req, 'bytes_at_128B': 128.0 * l2req,
                                           'TBps': 128.0 * l2req / (kms * 1e-3) / 1e12,
-                                          'hit_rate': cnt('xc_fft_kernel', 'TCC_HIT_sum') / l2req,
+                                          'hit_rate': cnt(xk, 'TCC_HIT_sum') / l2req,
                                           'source': pmc_src, 'live': False} if l2req else None),
                          'compute': {'unit': 'TFLOP/s', 'issued': flop_fft / (kms * 1e-3) / 1e12,
                                      'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,

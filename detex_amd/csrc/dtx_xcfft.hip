@@ -472,8 +472,13 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   auto issue_w = [&](int i, auto qc, auto sc) {       // batch q of step i (frequencies 4 q .. 4 q + 3) into slot s
     constexpr int q = qc, sl = sc;
     const float4* src = wq + woff(i);
+#if DTX_XC_ABLATE & 1     // timing only: no pair-spectrum loads
+    w[sl][0] = w[sl][1] = make_float4(1.f, 0.5f, 1.f, 0.5f);
+    if (src == nullptr) w[sl][0].x = 2.f;
+#else
     w[sl][0] = src[64 * (2 * q)];
     w[sl][1] = src[64 * (2 * q + 1)];
+#endif
   };
   auto mac_q = [&](const c32* x0, const c32* x1, auto qc, auto sc) {
     constexpr int q = qc, sl = sc;
@@ -481,8 +486,12 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int r = 4 * q + e;
+#if DTX_XC_ABLATE & 2     // timing only: no block-spectrum reads from LDS
+      pa[e] = make_float2(0.25f, 1.f); pb[e] = make_float2(0.5f, 1.f);
+#else
       pa[e] = fix_x(x0[x_slot(r)], r);
       pb[e] = fix_x(x1[x_slot(r)], r);
+#endif
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -497,6 +506,45 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2c = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // One step = one (channel, segment): four batches of four frequencies.  Behind the products of a batch the
+  // batch DTX_XC_NW further on is fetched into the slot that fell free (NW = 2: half a step ahead, 4: a whole step).
+  auto issue_ahead = [&](int i, int nx, auto qc, auto slc) {     // batch q + NW, counted from step i's batch 0
+    constexpr int q = qc, g = q + DTX_XC_NW;
+    issue_w(g < 4 ? i : nx, std::integral_constant<int, (g & 3)>{}, slc);
+  };
+  auto step = [&](int i, auto phc) {
+    constexpr int ph = phc;
+    const int nx = min(i + 1, nsteps - 1);    // (the last step fetches its own operands again: straight-line steps)
+    const float4* src = xsrc(nx);
+    const c32* x0 = lds + (2 * (i & 1)) * kXh;
+    const c32* x1 = x0 + kXh;
+    float4* dst = reinterpret_cast<float4*>(lds + (2 * ((i + 1) & 1) + hf) * kXh) + ht;
+    float4 xa0 = src[0], xa1 = src[512];
+    using S0 = std::integral_constant<int, (ph + 0) % DTX_XC_NW>; using S1 = std::integral_constant<int, (ph + 1) % DTX_XC_NW>;
+    using S2 = std::integral_constant<int, (ph + 2) % DTX_XC_NW>; using S3 = std::integral_constant<int, (ph + 3) % DTX_XC_NW>;
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I0{}, S0{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ahead(i, nx, I0{}, S0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I1{}, S1{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ahead(i, nx, I1{}, S1{});
+    __builtin_amdgcn_sched_barrier(0);
+    dst[0] = xa0; dst[512] = xa1;
+    xa0 = src[1024]; xa1 = src[1536];
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I2c{}, S2{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ahead(i, nx, I2c{}, S2{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(x0, x1, I3{}, S3{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ahead(i, nx, I3{}, S3{});
+    __builtin_amdgcn_sched_barrier(0);
+    dst[1024] = xa0; dst[1536] = xa1;
+    __syncthreads();
+  };
   {
     const float4* src = xsrc(0);
     const float4 x0 = src[0], x1 = src[512], x2 = src[1024], x3 = src[1536];
@@ -507,79 +555,68 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
     dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
   }
   __syncthreads();
+  // (NW = 3 -- the slots rotate, three compiled phases of the step -- spills 239 registers; 4 spills 17: 162 ms)
+  static_assert(DTX_XC_NW == 2 || DTX_XC_NW == 4, "slots that do not rotate");
 #pragma nounroll
-  for (int i = 0; i < nsteps; ++i) {
-    const int nx = min(i + 1, nsteps - 1);    // (the last step fetches its own operands again: straight-line steps)
-    const float4* src = xsrc(nx);
-    const c32* x0 = lds + (2 * (i & 1)) * kXh;
-    const c32* x1 = x0 + kXh;
-    float4* dst = reinterpret_cast<float4*>(lds + (2 * ((i + 1) & 1) + hf) * kXh) + ht;
-    float4 xa0 = src[0], xa1 = src[512];
-    __builtin_amdgcn_sched_barrier(0);
-    mac_q(x0, x1, I0{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) issue_w(nx, I0{}, I0{}); else issue_w(i, I2c{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    mac_q(x0, x1, I1{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) issue_w(nx, I1{}, I1{}); else issue_w(i, I3{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    dst[0] = xa0; dst[512] = xa1;
-    xa0 = src[1024]; xa1 = src[1536];
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) mac_q(x0, x1, I2c{}, I2c{}); else mac_q(x0, x1, I2c{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) issue_w(nx, I2c{}, I2c{}); else issue_w(nx, I0{}, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) mac_q(x0, x1, I3{}, I3{}); else mac_q(x0, x1, I3{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DTX_XC_NW == 4) issue_w(nx, I3{}, I3{}); else issue_w(nx, I1{}, I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    dst[1024] = xa0; dst[1536] = xa1;
-    __syncthreads();
-  }
+  for (int i = 0; i < nsteps; ++i) step(i, I0{});
   // the transforms: each half on its own image (the staging buffers' memory; the loop's last barrier is
   // behind every read of them), one later event after the other
   c32* img = lds + hf * kLdsC;
+#ifndef DTX_XC_STATS_EARLY
+#define DTX_XC_STATS_EARLY 0   // the lags' window statistics fetched in front of the transform (0: behind it: 127 against 133 ms, the transform spills)
+#endif
+#ifndef DTX_XC_LEAN
+#define DTX_XC_LEAN 0          // the transform's twiddles loaded pass by pass
+#endif
   auto finish = [&](c32 (&z)[16], auto kc) {
     constexpr int k = kc;
     const int c = k ? c1 : c0;
-    fft8192<1>(z, img, lb, a.tab, ht);
-    // (the lags' window statistics are fetched behind the transform: held across it they spill -- the other
-    // later event's accumulators are live --, and sixteen waves cover the loads)
-    __builtin_amdgcn_sched_barrier(0);
-    float best[2] = {-INFINITY, -INFINITY};
-    int bm[2] = {0, 0};
-    constexpr int kCh = 5;                               // lags per thread whose statistics are in flight together
-    dtx::static_for<0, (VM + kCh - 1) / kCh>([&](auto cc_) {
-      constexpr int m0 = cc_ * kCh, m1 = m0 + kCh < VM ? m0 + kCh : VM;
-      float mu[m1 - m0], rw[m1 - m0];
+    // cc = (Y' - (sum x_b) rs_b mu_w) rs_w at the thread's VM lags (loads at a clamped index, then a select:
+    // predicated loads became a branch per lag).  Fetched in front of the transform, which covers them: behind
+    // it all sixteen waves stood waiting for them together (30 of the kernel's 139 ms).
+    float mu[VM], rw[VM];
+    auto load_stats = [&]() {
+      // (uniform row base + a 32-bit lane offset: eighteen 64-bit lane addresses cost the transform its registers)
+      const char* mwc = reinterpret_cast<const char*>(a.mean_w + (int64_t)c * a.Ppad);
+      const char* rwc = reinterpret_cast<const char*>(a.rsw + (int64_t)c * a.Ppad);
+      const unsigned last = 4u * (unsigned)(a.Pz - 1);
 #pragma unroll
-      for (int m = m0; m < m1; ++m) {
-        // (loads at a clamped index, then a select: predicated loads became a branch per lag)
-        const int p = p0 + ht + 512 * m, pc = min(p, a.Pz - 1);
-        const float mv = a.mean_w[(int64_t)c * a.Ppad + pc], rv = a.rsw[(int64_t)c * a.Ppad + pc];
-        mu[m - m0] = mv;
-        rw[m - m0] = p < a.Pz ? rv : __builtin_nanf("");      // NaN: never wins a comparison
+      for (int m = 0; m < VM; ++m) {
+        const unsigned p4 = 4u * (unsigned)(p0 + ht + 512 * m), o = min(p4, last);
+        mu[m] = *reinterpret_cast<const float*>(mwc + o);
+        const float rv = *reinterpret_cast<const float*>(rwc + o);
+        rw[m] = p4 <= last ? rv : __builtin_nanf("");      // NaN: never wins a comparison
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int m = m0; m < m1; ++m) {
-          const float y = h ? z[m].y : z[m].x;
-          float cc = (y - s1v[k][h] * mu[m - m0]) * rw[m - m0];
-          cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
-          const bool gt = cc > best[h];
-          best[h] = gt ? cc : best[h];
-          bm[h] = gt ? m : bm[h];
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    });
+    };
+    constexpr bool early = DTX_XC_STATS_EARLY && VM <= 10;      // (more lags per thread: the registers are not there)
+    if (early) load_stats();
+#if DTX_XC_ABLATE & 8     // timing only: no transforms
+    if (z[0].x == 1.2345f && z[3].y == 5.4321f) a.keys[1] = 1ull;
+#else
+    fft8192<1, DTX_XC_LEAN != 0>(z, img, lb, a.tab, ht);
+#endif
+    if (!early) { __builtin_amdgcn_sched_barrier(0); load_stats(); }
+#if DTX_XC_ABLATE & 4     // timing only: no epilogue
+    if (z[0].x == 1.2345f && z[5].y == 5.4321f && mu[0] == 0.5f && rw[VM - 1] == 1.f) a.keys[1] = 1ull;
+    if ((tid & 63) == 0) { wred[4 * hf + 2 * k][wv] = 0ull; wred[4 * hf + 2 * k + 1][wv] = 0ull; }
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float r1 = r1v[k][h];
-      const float wmax = wave_max_f32(best[h]);
-      const unsigned pcand = (best[h] == wmax) ? (unsigned)(p0 + ht + 512 * bm[h]) : 0xFFFFFFFFu;
+      const float r1 = r1v[k][h], s1 = s1v[k][h];
+      float best = -INFINITY;
+      int bm = 0;
+#pragma unroll
+      for (int m = 0; m < VM; ++m) {
+        const float y = h ? z[m].y : z[m].x;
+        float cc = (y - s1 * mu[m]) * rw[m];
+        cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+        const bool gt = cc > best;
+        best = gt ? cc : best;
+        bm = gt ? m : bm;
+      }
+      const float wmax = wave_max_f32(best);
+      const unsigned pcand = (best == wmax) ? (unsigned)(p0 + ht + 512 * bm) : 0xFFFFFFFFu;
       const unsigned pmin = wave_min_u32(pcand);
       if ((tid & 63) == 0) {
         unsigned long long key = 0ull;

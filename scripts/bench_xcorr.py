@@ -50,7 +50,7 @@ out = {'metric': 'pairs/sec (all-pairs normalised xcorr)', 'value': npairs / dt,
                      'frac': flops / (kms * 1e-3) / 1e12 / (157.3 if a.engine == 'fp32' else 2500.0), 'kernel_ms': kms,
                      'flop_per_pair': 2.0 * mac}
                     if a.engine in ('fp32', 'bf16x3') or L < 1024 else
-                    {'kernel': 'xc_fft_kernel', 'kernel_ms': kms,
+                    {'kernel': 'xc_fft22_kernel', 'kernel_ms': kms,
                      'contraction_equivalent_tflops': flops / (kms * 1e-3) / 1e12,
                      'note': 'frequency-domain lag search (dtx_xcfft.hip); the direct contraction it replaces is %.3g flop per pair' % (2.0 * mac)}),
        'cc_mean': float(cc.mean()), 'cc_max': float(cc.max())}

@@ -2,7 +2,7 @@
 """Copy the judged summaries of gpurun_out/prof_<tag>/ (scripts/profile_xc.sh) into profiles/:
    python scripts/summarize_xc.py <tag>
 Writes profiles/<tag>_xcorr_kernel_stats.csv and profiles/<tag>_xcorr_pmc.json (mean per launch of
-every counter for xc_fft_kernel and xc_finish_kernel; FETCH_SIZE doubled per the gfx950 note of
+every counter for the lag-search kernel (xc_fft22_kernel; xc_fft_kernel when DETEX_AMD_XC22=0) and xc_finish_kernel; FETCH_SIZE doubled per the gfx950 note of
 MI355X_MICROARCH.md)."""
 import collections
 import csv
@@ -19,7 +19,7 @@ st = glob.glob(src + '/trace/**/*_kernel_stats.csv', recursive=True)
 if st:
     shutil.copy(st[0], 'profiles/%s_xcorr_kernel_stats.csv' % tag)
 res = {}
-for kern in ("xc_fft_kernel", "xc_finish"):
+for kern in ("xc_fft22_kernel", "xc_fft_kernel", "xc_finish"):
     out = {}
     for d in ['pmc_fetch', 'pmc_write', 'pmc_tcc', 'pmc_sq', 'pmc_sq2']:
         for f in glob.glob('%s/%s/**/*counter_collection.csv' % (src, d), recursive=True):
@@ -35,7 +35,8 @@ for kern in ("xc_fft_kernel", "xc_finish"):
     if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
         out['hbm_bytes_per_launch_corrected'] = (2 * out['FETCH_SIZE']['mean_per_launch'] +
                                                  out['WRITE_SIZE']['mean_per_launch']) * 1024
-    res[kern] = out
+    if out:
+        res[kern] = out
 h = hashlib.sha1()          # the kernel sources the counters belong to (bench.py flags a stale summary)
 for fn in sorted(glob.glob('detex_amd/csrc/*.hip') + glob.glob('detex_amd/csrc/*.h')):
     h.update(os.path.basename(fn).encode())

@@ -226,6 +226,37 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
     assert nchecked >= N
 
 
+@pytest.mark.parametrize('Nc,L,N', [(3, 3000, 23), (1, 2500, 12), (3, 13000, 9), (2, 7777, 5), (6, 6000, 6), (3, 1024, 2)])
+def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
+    """The frequency-domain lag search has two kernels: the 2 x 2 workgroup (two later events x two pair spectra,
+    the default) and the round-3 one (DETEX_AMD_XC22=0).  The same products summed in the same order and the same
+    transform: identical answers, on the whole matrix and on disjoint pair ranges (odd and even event counts: a
+    last later event without a partner, a last pair spectrum with one row)."""
+    from detex_amd import synth
+    td = synth.event_families(L + 1, 2, (N + 1) // 2, Nc, L, maxshift=max(1, L // 40))[:N]
+    if N >= 8:
+        td[5] = td[2]
+        td[7] = 0.0
+    npairs = N * (N - 1) // 2
+    res = {}
+    for v in ('1', '0'):
+        monkeypatch.setenv('DETEX_AMD_XC22', v)
+        full = _gpu(ctx, td, Nc)
+        cuts = sorted({0, 1, npairs // 3, npairs // 3 + 1, (2 * npairs) // 3, npairs})
+        acc = [np.zeros(npairs, np.float32), np.zeros(npairs, np.int32), np.zeros(npairs, np.float32)]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = _gpu(ctx, td, Nc, pair_begin=lo, pair_end=hi)
+            for a, p_ in zip(acc, part):
+                assert not p_[:lo].any() and not p_[hi:].any()
+                a[lo:hi] = p_[lo:hi]
+        for a, f in zip(acc, full):
+            assert np.array_equal(a, f)
+        res[v] = full
+    for a, b in zip(res['1'], res['0']):
+        assert np.array_equal(a, b)
+
+
+
 def test_fast_normcorr_golden(ctx):
     """fast_normcorr (construct.py:469-483) on the device against the reference's own outputs
     (tests/golden/normcorr.npz), through the context method and the NumPy-facing function."""
