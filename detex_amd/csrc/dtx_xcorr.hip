@@ -490,16 +490,36 @@ __global__ __launch_bounds__(256) void xc_prefix_kernel(const float* __restrict_
 //   * the window sums sum(w), sum(w^2) of the zero-padded shifted x_c come from the prefix sums
 //     (xc_prefix_kernel) instead of two more accumulations per element;
 //   * a wave walks only the samples its pair's shift leaves inside both events.
-constexpr int kFinCh = 2048;         // x_b samples per staged chunk
+//   * round 4 (NC = the channel count at compile time, 1 .. 6): a lane takes kFinE CONSECUTIVE samples of a step
+//     instead of every 64th.  The three lags pair sample e with x_b[e + 2 Nc], x_b[e + Nc], x_b[e]: one window
+//     of kFinE + 2 Nc doubles per lane, fetched by 16-byte LDS reads, serves all 3 kFinE products (at Nc = 3:
+//     one LDS instruction per sample instead of 3), and the lane's x_c samples come by 16- and 8-byte loads
+//     (dword aligned: the pair's shift is arbitrary).  kFinE = 6: the lanes' windows start 48 bytes apart, an
+//     odd number of 16-byte units, which is what keeps ds_read_b128's lane groups on distinct banks
+//     (MI355X_MICROARCH.md, LDS; 8 doubles apart = 64 bytes would be a 4-way conflict).  What is left is the
+//     stream of the later events from L2: 156 KB per pair, 0.31 TB per launch at configs[2] = 14 TB/s.
+#ifndef DTX_XCFIN_WINDOW
+#define DTX_XCFIN_WINDOW 1
+#endif
+#ifndef DTX_XCFIN_E
+#define DTX_XCFIN_E 6          // configs[2], scripts/ab_xcfin.sh: 6 -> 21.7 ms, 10 -> 25.2, 14 -> 21.9, 18 -> 22.1; every 64th sample: 28.3
+#endif
+constexpr int kFinE = DTX_XCFIN_E;   // samples per lane and step of the window form (2 x an odd number)
+constexpr int kFinStep = 64 * kFinE; // samples per wave and step
+constexpr int kFinCh = 4 * kFinStep; // x_b samples per staged chunk (2560)
 constexpr int kFinPad = 64;
 constexpr int kFinWaves = 8;
+typedef float fin_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float fin_f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef double fin_d2 __attribute__((ext_vector_type(2)));
+template <int NC>
 __global__ __launch_bounds__(64 * kFinWaves) void xc_finish2_kernel(
     const float* __restrict__ td, const unsigned long long* __restrict__ keys,
     const double* __restrict__ esum, const double* __restrict__ essd,
     const double* __restrict__ esq, const double* __restrict__ ps, const double* __restrict__ pq,
     int N, int n, int Nc, int S, int Pz, int trunc, int64_t pair_begin, int64_t pair_end,
     float* __restrict__ cc_out, int32_t* __restrict__ lag_out, float* __restrict__ ss_out, int T) {
-  __shared__ double x1s[2][kFinCh + 2 * kFinPad];
+  __shared__ __attribute__((aligned(16))) double x1s[2][kFinCh + 2 * kFinPad];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // tile walk as in xc_finish_kernel: T x T events per tile, upper triangle of tiles, inside a tile an
   // XCD owns whole groups of 16 later events and walks every earlier event against them
@@ -577,7 +597,49 @@ __global__ __launch_bounds__(64 * kFinWaves) void xc_finish2_kernel(
     const double* xs = x1s[buf];
     // this wave's share of the chunk, in steps of 64 samples from the chunk's start
     const int c0 = max(J0, jlo), c1 = min(J0 + kFinCh, jhi);
-    if (c0 < c1) {
+    // samples lo .. hi - 1, 64 at a time from a multiple of 64 behind the chunk's start
+    auto walk64 = [&](int lo, int hi) {
+      for (int jb = J0 + (lo - J0) / 64 * 64; jb < hi; jb += 64) {
+        const int jm = jb + lane;
+        const bool ok = jm >= lo && jm < hi;
+        const double v = ok ? (double)x2[min(max(jm + sh1, 0), n - 1)] : 0.0;
+        const int i = jm - J0 + Nc;
+        dot[0] += xs[i + Nc] * v;
+        dot[1] += xs[i] * v;
+        dot[2] += xs[i - Nc] * v;
+      }
+    };
+    if (NC > 0 && c0 < c1) {
+      for (int jb = J0; jb < J0 + kFinCh; jb += kFinStep) {
+        if (jb + kFinStep <= c0 || jb >= c1) continue;            // (uniform)
+        if (jb < c0 || jb + kFinStep > c1) { walk64(max(jb, c0), min(jb + kFinStep, c1)); continue; }
+        const int jm0 = jb + kFinE * lane;
+        const float* src = x2 + jm0 + sh1;
+        float v[kFinE];
+        static_assert(kFinE % 4 == 2, "16-byte loads and one of 8 bytes; an odd number of 16-byte units of doubles");
+#pragma unroll
+        for (int q = 0; q < kFinE / 4; ++q) {
+          const fin_f4u t = *reinterpret_cast<const fin_f4u*>(src + 4 * q);
+          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        {
+          const fin_f2u t = *reinterpret_cast<const fin_f2u*>(src + kFinE - 2);
+          v[kFinE - 2] = t.x; v[kFinE - 1] = t.y;
+        }
+        constexpr int kW = kFinE + 2 * (NC > 0 ? NC : 1);
+        double w[kW];
+        const fin_d2* wp = reinterpret_cast<const fin_d2*>(xs + (jm0 - J0));
+#pragma unroll
+        for (int q = 0; q < kW / 2; ++q) { const fin_d2 t = wp[q]; w[2 * q] = t.x; w[2 * q + 1] = t.y; }
+#pragma unroll
+        for (int e = 0; e < kFinE; ++e) {
+          const double dv = (double)v[e];
+          dot[0] += w[e + 2 * NC] * dv;
+          dot[1] += w[e + NC] * dv;
+          dot[2] += w[e] * dv;
+        }
+      }
+    } else if (c0 < c1) {
       int jb = J0 + (c0 - J0) / 64 * 64;
       constexpr int kB = 4;
       for (; jb < c1; jb += 64) {
@@ -888,10 +950,21 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
     const int64_t ntile = (N + T - 1) / T;
     const int64_t fgrid = ntile * (ntile + 1) / 2 * ((int64_t)T * T / kFinWaves);
     if (fgrid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "too many events");
-    hipLaunchKernelGGL(xc_finish2_kernel, dim3((unsigned)fgrid), dim3(64 * kFinWaves), 0, ctx->stream,
-                       td_dev, (const unsigned long long*)keys, (const double*)esum,
-                       (const double*)essd, (const double*)esq, (const double*)ps, (const double*)pq, N, n,
-                       Nc, S, Pz, trunc, pair_begin, pair_end, cc_dev, lag_dev, subsamp_dev, T);
+    auto fin = [&](auto ncc) {
+      constexpr int NC = ncc;
+      hipLaunchKernelGGL((xc_finish2_kernel<NC>), dim3((unsigned)fgrid), dim3(64 * kFinWaves), 0, ctx->stream,
+                         td_dev, (const unsigned long long*)keys, (const double*)esum,
+                         (const double*)essd, (const double*)esq, (const double*)ps, (const double*)pq, N, n,
+                         Nc, S, Pz, trunc, pair_begin, pair_end, cc_dev, lag_dev, subsamp_dev, T);
+    };
+    switch (DTX_XCFIN_WINDOW ? Nc : 0) {              // (the window form: channel count at compile time)
+      case 1: fin(std::integral_constant<int, 1>{}); break;
+      case 2: fin(std::integral_constant<int, 2>{}); break;
+      case 3: fin(std::integral_constant<int, 3>{}); break;
+      case 4: fin(std::integral_constant<int, 4>{}); break;
+      case 6: fin(std::integral_constant<int, 6>{}); break;
+      default: fin(std::integral_constant<int, 0>{}); break;
+    }
   } else {
     const int T = std::min(512, (N + 3) / 4 * 4);
     const int64_t ntile = (N + T - 1) / T;
