@@ -886,6 +886,16 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   }
 
   // ---- prep kernels
+  // the finishing kernel's prefix sums depend on the events only: on the side stream, beside the preparation and
+  // the head of the lag search (joined in front of the finishing kernel)
+  if (fin2) {
+    if ((rc = dtx_aux_fork(ctx))) return rc;
+    hipLaunchKernelGGL(xc_prefix_kernel, dim3((unsigned)N), dim3(256), 0, ctx->aux, td_dev, n,
+                       (double*)(base + o_ps), (double*)(base + o_pq));
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  // (an error return below leaves nothing running on the side stream that the next call does not wait for)
+  auto bail = [&](int r) { if (fin2) dtx_aux_join(ctx); return r; };
   if (!use_fft) {
     dim3 grid((unsigned)std::min<int64_t>(((int64_t)Nc * Lp + 3) / 4, 8192), 1, (unsigned)nkt);
     hipLaunchKernelGGL(xc_transpose_kernel, grid, dim3(256), 0, ctx->stream, td_dev, N, n, Nc, L,
@@ -902,7 +912,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
     hipLaunchKernelGGL(xc_transpose16_kernel, grid, dim3(256), 0, ctx->stream, td_dev, N, n, Nc, L,
                        Lp, xt16);
     DTX_HIP(ctx, hipGetLastError());
-    if ((rc = dtx_launch_demux16(ctx, z, Tz, N * Nc, g16))) return rc;
+    if ((rc = dtx_launch_demux16(ctx, z, Tz, N * Nc, g16))) return bail(rc);
   }
   hipLaunchKernelGGL(xc_event_stats_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, td_dev, n,
                      esum, essd, esq, fsum, frs);
@@ -924,9 +934,9 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   if (use_fft) {
     if ((rc = dtx_xcfft_run(ctx, td_dev, N, n, Nc, L, Pz, Ppad, Tz, z, fsum, frs, mean_w, rsw, keys,
                             pair_begin, pair_end, b_begin, b_end)))
-      return rc;
+      return bail(rc);
   } else {
-  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
+  { const int rck = dtx_kev_next(ctx); if (rck) return bail(rck); }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   {
     const int2* p = (const int2*)ctx->ws_misc2.p;
@@ -934,7 +944,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
       size_t skip = 0;
       for (int q = 0; q < rm; ++q) skip += items[q].size();
       if (items[rm].empty()) continue;
-      if ((rc = launch_items_rm(ctx, rm, a, p + skip, (int)items[rm].size()))) return rc;
+      if ((rc = launch_items_rm(ctx, rm, a, p + skip, (int)items[rm].size()))) return bail(rc);
     }
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
@@ -944,8 +954,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   if (fin2) {
     double* ps = (double*)(base + o_ps);
     double* pq = (double*)(base + o_pq);
-    hipLaunchKernelGGL(xc_prefix_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, td_dev, n, ps, pq);
-    DTX_HIP(ctx, hipGetLastError());
+    if ((rc = dtx_aux_join(ctx))) return rc;
     const int T = std::min(512, (N + 7) / 8 * 8);
     const int64_t ntile = (N + T - 1) / T;
     const int64_t fgrid = ntile * (ntile + 1) / 2 * ((int64_t)T * T / kFinWaves);
