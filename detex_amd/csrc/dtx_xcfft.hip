@@ -684,7 +684,11 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // the tile and lag block) its pair spectra
   static_assert(sizeof(int2) == sizeof(dtxplan::I2), "work items are int2");
   // (DETEX_AMD_XC22=0 / 1 overrides the build's choice of kernel: A/B runs and the tests of both)
-  bool t22 = DTX_XC_T22 != 0;
+  // The 2 x 2 workgroup pays where the products' traffic counts: with more than nine lags per thread (events up
+  // to ~3000 samples: one segment, three products per transform) its epilogue runs out of registers and the
+  // round-3 kernel is as fast or faster (configs[2]'s N = 1000, scripts/xc_sweep_L.sh: L = 1024 9.8 against 7.2 ms,
+  // 2500 7.3 / 7.0, 3000 7.2 / 7.0; 4000 6.2 / 7.1, 5633 16.0 / 19.3, 13 000 127 / 152 at N = 2000, 20 000 77 / 95).
+  bool t22 = DTX_XC_T22 != 0 && V / 512 <= 9;
   if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = e[0] == '1';
   const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
                                              : dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
