@@ -562,61 +562,60 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   // the transforms: each half on its own image (the staging buffers' memory; the loop's last barrier is
   // behind every read of them), one later event after the other
   c32* img = lds + hf * kLdsC;
-#ifndef DTX_XC_STATS_EARLY
-#define DTX_XC_STATS_EARLY 0   // the lags' window statistics fetched in front of the transform (0: behind it: 127 against 133 ms, the transform spills)
-#endif
-#ifndef DTX_XC_LEAN
-#define DTX_XC_LEAN 0          // the transform's twiddles loaded pass by pass
-#endif
   auto finish = [&](c32 (&z)[16], auto kc) {
     constexpr int k = kc;
     const int c = k ? c1 : c0;
-    // cc = (Y' - (sum x_b) rs_b mu_w) rs_w at the thread's VM lags (loads at a clamped index, then a select:
-    // predicated loads became a branch per lag).  Fetched in front of the transform, which covers them: behind
-    // it all sixteen waves stood waiting for them together (30 of the kernel's 139 ms).
-    float mu[VM], rw[VM];
-    auto load_stats = [&]() {
-      // (uniform row base + a 32-bit lane offset: eighteen 64-bit lane addresses cost the transform its registers)
-      const char* mwc = reinterpret_cast<const char*>(a.mean_w + (int64_t)c * a.Ppad);
-      const char* rwc = reinterpret_cast<const char*>(a.rsw + (int64_t)c * a.Ppad);
-      const unsigned last = 4u * (unsigned)(a.Pz - 1);
-#pragma unroll
-      for (int m = 0; m < VM; ++m) {
-        const unsigned p4 = 4u * (unsigned)(p0 + ht + 512 * m), o = min(p4, last);
-        mu[m] = *reinterpret_cast<const float*>(mwc + o);
-        const float rv = *reinterpret_cast<const float*>(rwc + o);
-        rw[m] = p4 <= last ? rv : __builtin_nanf("");      // NaN: never wins a comparison
-      }
-    };
-    constexpr bool early = DTX_XC_STATS_EARLY && VM <= 10;      // (more lags per thread: the registers are not there)
-    if (early) load_stats();
 #if DTX_XC_ABLATE & 8     // timing only: no transforms
     if (z[0].x == 1.2345f && z[3].y == 5.4321f) a.keys[1] = 1ull;
 #else
-    fft8192<1, DTX_XC_LEAN != 0>(z, img, lb, a.tab, ht);
+    fft8192<1>(z, img, lb, a.tab, ht);
 #endif
-    if (!early) { __builtin_amdgcn_sched_barrier(0); load_stats(); }
+    __builtin_amdgcn_sched_barrier(0);
 #if DTX_XC_ABLATE & 4     // timing only: no epilogue
-    if (z[0].x == 1.2345f && z[5].y == 5.4321f && mu[0] == 0.5f && rw[VM - 1] == 1.f) a.keys[1] = 1ull;
+    if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
     if ((tid & 63) == 0) { wred[4 * hf + 2 * k][wv] = 0ull; wred[4 * hf + 2 * k + 1][wv] = 0ull; }
     return;
 #endif
+    // cc = (Y' - (sum x_b) rs_b mu_w) rs_w at the thread's VM lags, max / first argmax of both rows.  The lags'
+    // window statistics are fetched behind the transform (in front of it they cost the transform its registers:
+    // 133 against 127 ms) by a uniform row base + a 32-bit lane offset at a clamped index, then a select
+    // (predicated loads became a branch per lag, eighteen 64-bit lane addresses spilled: 139 ms), kStat lags at a
+    // time: with all of them in flight at once the epilogue of more than nine lags per thread ran out of registers
+    // beside the other later event's accumulators.
+    const char* mwc = reinterpret_cast<const char*>(a.mean_w + (int64_t)c * a.Ppad);
+    const char* rwc = reinterpret_cast<const char*>(a.rsw + (int64_t)c * a.Ppad);
+    const unsigned last = 4u * (unsigned)(a.Pz - 1);
+    float best[2] = {-INFINITY, -INFINITY};
+    int bm[2] = {0, 0};
+    constexpr int kStat = VM <= 9 ? VM : (VM + 1) / 2;
+    dtx::static_for<0, (VM + kStat - 1) / kStat>([&](auto chc) {
+      constexpr int m0 = chc * kStat, m1 = m0 + kStat < VM ? m0 + kStat : VM;
+      float mu[m1 - m0], rw[m1 - m0];
+#pragma unroll
+      for (int m = m0; m < m1; ++m) {
+        const unsigned p4 = 4u * (unsigned)(p0 + ht + 512 * m), o = min(p4, last);
+        mu[m - m0] = *reinterpret_cast<const float*>(mwc + o);
+        const float rv = *reinterpret_cast<const float*>(rwc + o);
+        rw[m - m0] = p4 <= last ? rv : __builtin_nanf("");      // NaN (a lag past Pz) never wins a comparison
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+          const float y = h ? z[m].y : z[m].x;
+          float cc = (y - s1v[k][h] * mu[m - m0]) * rw[m - m0];
+          cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+          const bool gt = cc > best[h];
+          best[h] = gt ? cc : best[h];
+          bm[h] = gt ? m : bm[h];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    });
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float r1 = r1v[k][h], s1 = s1v[k][h];
-      float best = -INFINITY;
-      int bm = 0;
-#pragma unroll
-      for (int m = 0; m < VM; ++m) {
-        const float y = h ? z[m].y : z[m].x;
-        float cc = (y - s1 * mu[m]) * rw[m];
-        cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
-        const bool gt = cc > best;
-        best = gt ? cc : best;
-        bm = gt ? m : bm;
-      }
-      const float wmax = wave_max_f32(best);
-      const unsigned pcand = (best == wmax) ? (unsigned)(p0 + ht + 512 * bm) : 0xFFFFFFFFu;
+      const float r1 = r1v[k][h];
+      const float wmax = wave_max_f32(best[h]);
+      const unsigned pcand = (best[h] == wmax) ? (unsigned)(p0 + ht + 512 * bm[h]) : 0xFFFFFFFFu;
       const unsigned pmin = wave_min_u32(pcand);
       if ((tid & 63) == 0) {
         unsigned long long key = 0ull;
@@ -685,9 +684,11 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   static_assert(sizeof(int2) == sizeof(dtxplan::I2), "work items are int2");
   // (DETEX_AMD_XC22=0 / 1 overrides the build's choice of kernel: A/B runs and the tests of both)
   // The 2 x 2 workgroup pays where the products' traffic counts: with more than nine lags per thread (events up
-  // to ~3000 samples: one segment, three products per transform) its epilogue runs out of registers and the
-  // round-3 kernel is as fast or faster (configs[2]'s N = 1000, scripts/xc_sweep_L.sh: L = 1024 9.8 against 7.2 ms,
-  // 2500 7.3 / 7.0, 3000 7.2 / 7.0; 4000 6.2 / 7.1, 5633 16.0 / 19.3, 13 000 127 / 152 at N = 2000, 20 000 77 / 95).
+  // to ~3000 samples: one segment, three products per transform, a workgroup's fixed costs on top) the transform
+  // of the first later event spills beside the second one's accumulators and the round-3 kernel is as fast or
+  // faster (N = 1000 events, scripts/xc_sweep_L.sh, kernel ms: L = 1024 7.9 against 7.3, 2000 7.2 / 7.1,
+  // 3000 7.1 / 7.0; 3500 6.4 / 7.0, 4000 6.2 / 7.1, 5633 16.0 / 19.3, 9000 23.4 / 23.8, 20 000 77 / 95;
+  // 13 000 at N = 2000: 127 / 152).
   bool t22 = DTX_XC_T22 != 0 && V / 512 <= 9;
   if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = e[0] == '1';
   const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
