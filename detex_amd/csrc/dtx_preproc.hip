@@ -116,6 +116,9 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 #ifndef DTX_PP_SCAN
 #define DTX_PP_SCAN 1        // entry states by pp_scan_kernel (0: pp_chain_kernel)
 #endif
+#ifndef DTX_PP_LOCAL
+#define DTX_PP_LOCAL 1       // pass 1 as dot products with the impulse table (pp_local_kernel; 0: the tiled filter run)
+#endif
 constexpr int kSub = 32;
 template <bool FIRST, bool RUN, bool LAST>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
@@ -339,6 +342,140 @@ __global__ __launch_bounds__(kScanT) void pp_scan_kernel(double* __restrict__ fs
   }
 }
 
+// Pass 1 without a recurrence.  The state a block leaves behind when it starts from zero is LINEAR in its samples:
+// sample j of a block of m is followed by m - 1 - j others, so it contributes x_j A^(m-1-j) B = x_j tab[m - 1 - j]
+// (A the sections' one-sample state transition, B their input vector; tab is built on the host by running the
+// sections over a unit sample).  A dot product per state instead of kPB dependent filter steps per thread: one wave
+// per block, four coalesced samples per lane against four table rows held in registers, a wave reduction per state.
+// The same pass adds up the series' trend sums (pp_trend_kernel's); the trend is not known yet, so the states are
+// those of the RAW samples and pp_detrend_states_kernel takes the line's own response off them afterwards
+// (126 + 51 us of pass 1 and the trend pass per station-day -> one pass over the samples).
+// values left per lane after the halving steps of wave_reduce_scatter
+__host__ __device__ constexpr int reduce_left(int cnt) {
+  int off = 32;
+  while (cnt % 2 == 0 && off >= 1) { cnt /= 2; off /= 2; }
+  return cnt;
+}
+// acc[0 .. CNT) of every lane -> sums over the wave.  On return acc[0 .. reduce_left) of a lane hold the totals of
+// states kbase .., the same in every lane of its group of 64 / (NS / reduce_left) consecutive lanes.
+template <int CNT, int OFF, int N>
+__device__ __forceinline__ void wave_reduce_scatter(double (&acc)[N], int lane, int& kbase) {
+  if constexpr (OFF >= 1 && CNT % 2 == 0) {
+    const bool upper = (lane & OFF) != 0;
+#pragma unroll
+    for (int i = 0; i < CNT / 2; ++i) {
+      const double send = upper ? acc[i] : acc[i + CNT / 2];
+      const double keep = upper ? acc[i + CNT / 2] : acc[i];
+      acc[i] = keep + __shfl_xor(send, OFF, 64);
+    }
+    if (upper) kbase += CNT / 2;
+    wave_reduce_scatter<CNT / 2, OFF / 2>(acc, lane, kbase);
+  } else if constexpr (OFF >= 1) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) acc[i] += __shfl_xor(acc[i], OFF, 64);
+    wave_reduce_scatter<CNT, OFF / 2>(acc, lane, kbase);
+  }
+}
+
+template <int NS, bool TREND>
+__global__ __launch_bounds__(256) void pp_local_kernel(const float* __restrict__ raw, int64_t ser_stride, int64_t T,
+                                                       int nblk, const double* __restrict__ tab,
+                                                       double* __restrict__ fstate, double* __restrict__ tsum) {
+  __shared__ double sh[8];
+  const int ser = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = raw + (int64_t)ser * ser_stride;
+  double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
+  double tw[4][NS];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tw[r][k] = tab[(kPB - 1 - (lane + 64 * r)) * NS + k];
+  const double tc = 0.5 * (double)(T - 1);
+  double s0 = 0.0, s1 = 0.0;
+  const int per = (nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int b_lo = (int)blockIdx.x * per, b_hi = min(b_lo + per, nblk);
+  for (int b = b_lo + wave; b < b_hi; b += 4) {
+    const int64_t t0 = (int64_t)b * kPB;
+    const int m = (int)min((int64_t)kPB, T - t0);
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    if (m == kPB) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = x[t0 + lane + 64 * r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double d = (double)v[r];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += tw[r][k] * d;
+        if (TREND) { s0 += d; s1 += d * ((double)(t0 + lane + 64 * r) - tc); }
+      }
+    } else {
+      for (int r = 0; r < 4; ++r) {
+        const int j = lane + 64 * r;
+        if (j < m) {
+          const double d = (double)x[t0 + j];
+#pragma unroll
+          for (int k = 0; k < NS; ++k) acc[k] += tab[(m - 1 - j) * NS + k] * d;
+          if (TREND) { s0 += d; s1 += d * ((double)(t0 + j) - tc); }
+        }
+      }
+    }
+    // the wave's sums: while the count of values is even the two halves of the lanes trade halves of them (each
+    // keeps the half it goes on summing), the rest by plain butterfly steps -- 7 exchanges for four states, not 24
+    int kbase = 0;
+    wave_reduce_scatter<NS, 32>(acc, lane, kbase);
+    constexpr int kLeft = reduce_left(NS), kFree = 64 / (NS / kLeft);      // values a lane ends with; lanes per group
+    if ((lane & (kFree - 1)) == 0) {
+#pragma unroll
+      for (int k = 0; k < kLeft; ++k) fs[(int64_t)b * (2 * kMaxSec) + kbase + k] = acc[k];
+    }
+  }
+  if (TREND) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s0 += __shfl_down(s0, off, 64);
+      s1 += __shfl_down(s1, off, 64);
+    }
+    if (lane == 0) { sh[wave] = s0; sh[4 + wave] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(&tsum[2 * ser], sh[0] + sh[1] + sh[2] + sh[3]);
+      atomicAdd(&tsum[2 * ser + 1], sh[4] + sh[5] + sh[6] + sh[7]);
+    }
+  }
+}
+
+// fstate[b] -= the zero-state response of the trend line a + s t over block b: a C1 + s (t0 C1 + C2), with the
+// block sums of the impulse table (cfull for whole blocks; the series' last block adds its own up)
+__global__ __launch_bounds__(256) void pp_detrend_states_kernel(double* __restrict__ fstate,
+                                                                const double* __restrict__ tsum,
+                                                                const double* __restrict__ tab,
+                                                                const double* __restrict__ cfull, int64_t T,
+                                                                int nblk, int ns) {
+  const int ser = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int b = idx / ns, k = idx - b * ns;
+  if (b >= nblk) return;
+  double a, sl;
+  trend_of(tsum + 2 * ser, T, &a, &sl);
+  const int64_t t0 = (int64_t)b * kPB;
+  const int m = (int)min((int64_t)kPB, T - t0);
+  double c1, c2;
+  if (m == kPB) {
+    c1 = cfull[k]; c2 = cfull[ns + k];
+  } else {
+    c1 = c2 = 0.0;
+    for (int j = 0; j < m; ++j) {
+      const double w = tab[(m - 1 - j) * ns + k];
+      c1 += w;
+      c2 += (double)j * w;
+    }
+  }
+  fstate[((int64_t)ser * nblk + b) * (2 * kMaxSec) + k] -= a * c1 + sl * ((double)t0 * c1 + c2);
+}
+
 // no filter: detrend (optional) + multiplex
 __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ raw,
                                                       int64_t ser_stride,
@@ -395,6 +532,10 @@ struct PpPlan {
   Sos f;
   int nser, nblk, ns, seg;
   double *trend, *fstate, *Mdev, *mid;
+  // impulse table of the sections (pp_local_kernel): tab[q][k] = state k, q samples after a unit sample entered a
+  // zero state; behind it its sums over a full block, C1[k] = sum_q tab[q][k], C2[k] = sum_j j tab[kPB - 1 - j][k]
+  const double* tab() const { return Mdev + (size_t)(2 + kScanSteps) * ns * ns; }
+  const double* cfull() const { return tab() + (size_t)kPB * ns; }
 };
 
 int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser, int64_t T,
@@ -487,10 +628,35 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
       P.swap(Q);
     }
   }
+  {  // the impulse table and its block sums
+    std::vector<double> tab((size_t)kPB * ns), c1(ns, 0.0), c2(ns, 0.0);
+    double z[2 * kMaxSec] = {0};
+    for (int q = 0; q < kPB; ++q) {
+      double x = q == 0 ? 1.0 : 0.0;
+      for (int sct = 0; sct < nsec; ++sct) {
+        const double y = f.b0[sct] * x + z[2 * sct];
+        z[2 * sct] = f.b1[sct] * x - f.a1[sct] * y + z[2 * sct + 1];
+        z[2 * sct + 1] = f.b2[sct] * x - f.a2[sct] * y;
+        x = y;
+      }
+      for (int k = 0; k < ns; ++k) tab[(size_t)q * ns + k] = z[k];
+    }
+    for (int j = 0; j < kPB; ++j)
+      for (int k = 0; k < ns; ++k) {
+        const double w = tab[(size_t)(kPB - 1 - j) * ns + k];
+        c1[k] += w;
+        c2[k] += (double)j * w;
+      }
+    M.insert(M.end(), tab.begin(), tab.end());
+    M.insert(M.end(), c1.begin(), c1.end());
+    M.insert(M.end(), c2.begin(), c2.end());
+  }
   Mkey.clear();
   // (kernels of earlier calls may still read the old matrices: wait for them before overwriting)
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if ((rc = dtx_reserve(ctx, Mbuf, (size_t)2 * kMaxSec * 2 * kMaxSec * (2 + kScanSteps) * sizeof(double)))) return rc;
+  if ((rc = dtx_reserve(ctx, Mbuf, ((size_t)2 * kMaxSec * 2 * kMaxSec * (2 + kScanSteps) + (size_t)(kPB + 2) * 2 * kMaxSec) *
+                                       sizeof(double))))
+    return rc;
   DTX_HIP(ctx, hipMemcpy(Mbuf.p, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
   Mkey = key;
   pl->Mdev = (double*)Mbuf.p;
@@ -512,6 +678,34 @@ static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int n
   }
 #endif
   hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, Mdev, Mdev + ns * ns, nblk, seg, ns);
+}
+
+// pass 1 (+ the trend sums when tsum is given): zero-state exit states of every block of every series
+static int launch_local(dtx_ctx* ctx, const float* raw, int64_t ser_stride, int64_t T, const PpPlan& pl, double* tsum) {
+  // ~2000 workgroups whatever the series count; a wave takes every fourth block of its workgroup's run
+  const int slices = std::max(1, std::min((pl.nblk + 7) / 8, (2048 + pl.nser - 1) / pl.nser));
+  const dim3 grid((unsigned)slices, (unsigned)pl.nser);
+#define DTX_LOCAL_CASE(NS)                                                                                          \
+  case NS:                                                                                                          \
+    if (tsum) hipLaunchKernelGGL((pp_local_kernel<NS, true>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, T,  \
+                                 pl.nblk, pl.tab(), pl.fstate, tsum);                                               \
+    else hipLaunchKernelGGL((pp_local_kernel<NS, false>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, T,      \
+                            pl.nblk, pl.tab(), pl.fstate, tsum);                                                    \
+    break
+  switch (pl.ns) {
+    DTX_LOCAL_CASE(2); DTX_LOCAL_CASE(4); DTX_LOCAL_CASE(6); DTX_LOCAL_CASE(8);
+    DTX_LOCAL_CASE(10); DTX_LOCAL_CASE(12); DTX_LOCAL_CASE(14); DTX_LOCAL_CASE(16);
+    default: return dtx_fail(ctx, DTX_E_ARG, "pre-processing: %d filter states", pl.ns);
+  }
+#undef DTX_LOCAL_CASE
+  DTX_HIP(ctx, hipGetLastError());
+  if (tsum) {
+    const dim3 g2((unsigned)(((int64_t)pl.nblk * pl.ns + 255) / 256), (unsigned)pl.nser);
+    hipLaunchKernelGGL(pp_detrend_states_kernel, g2, dim3(256), 0, ctx->stream, pl.fstate, (const double*)tsum,
+                       pl.tab(), pl.cfull(), T, pl.nblk, pl.ns);
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  return DTX_OK;
 }
 
 // ---------------------------------------------------------------- raw-count ingest
@@ -643,9 +837,11 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
 
   if (detrend) {
     DTX_HIP(ctx, hipMemsetAsync(trend, 0, (size_t)nser * 2 * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(pp_trend_kernel, dim3(kTrendSlices, (unsigned)nser), dim3(256), 0,
-                       ctx->stream, raw_dev, T, ser_stride, trend);
-    DTX_HIP(ctx, hipGetLastError());
+    if (nsec == 0 || !DTX_PP_LOCAL) {          // (with a filter the trend sums come out of pass 1)
+      hipLaunchKernelGGL(pp_trend_kernel, dim3(kTrendSlices, (unsigned)nser), dim3(256), 0,
+                         ctx->stream, raw_dev, T, ser_stride, trend);
+      DTX_HIP(ctx, hipGetLastError());
+    }
   }
   if (nsec == 0) {
     // no trend, 16-byte aligned planes and output: the vector kernel
@@ -677,9 +873,13 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   const double* nod = nullptr;
   const float* nof = nullptr;
   // forward pass: raw - trend -> (mid | output)
-  hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                     ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
-                     (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+  if (DTX_PP_LOCAL) {
+    if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, trend))) return rc;
+  } else {
+    hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
+                       (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+  }
   auto chain = [&]() { launch_chain(ctx, fstate, (const double*)Mdev, nser, nblk, seg, ns); };
   chain();
   if (zerophase) {
@@ -719,9 +919,13 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   if ((rc = pp_plan(ctx, "dtx_decimate", sos, nsec, nser, T, false, &pl))) return rc;
   dim3 grid((unsigned)((pl.nblk + 255) / 256), (unsigned)nser);
   const double* nod = nullptr;
-  hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                     ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
-                     (float*)nullptr, 1, out_stride, 0);
+  if (DTX_PP_LOCAL) {
+    if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, nullptr))) return rc;
+  } else {
+    hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
+                       ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
+                       (float*)nullptr, 1, out_stride, 0);
+  }
   launch_chain(ctx, pl.fstate, (const double*)pl.Mdev, nser, pl.nblk, pl.seg, pl.ns);
   // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
   hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from detex_amd import EventFetcher, createCluster, synth  # noqa: E402
 from detex_amd.hip import HipContext  # noqa: E402
 
-SR, NC, L = 100.0, 3, 3000
+SR, NC, L = 100.0, 3, int(os.environ.get('CL_L', '3000'))      # (CL_L=13000: configs[2]'s events)
 ctx = HipContext(0)
 for N in [int(a) for a in sys.argv[1:]] or [200, 1000, 2000]:
     td = synth.event_families(1, N // 20, 20, NC, L, maxshift=20, snr=8.0)
