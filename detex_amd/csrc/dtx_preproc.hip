@@ -377,13 +377,15 @@ __device__ __forceinline__ void wave_reduce_scatter(double (&acc)[N], int lane, 
   }
 }
 
-template <int NS, bool TREND>
-__global__ __launch_bounds__(256) void pp_local_kernel(const float* __restrict__ raw, int64_t ser_stride, int64_t T,
+// (TIN = double, REV: the same for the backward pass of a zero-phase filter -- the forward output walked from its end)
+template <int NS, bool TREND, typename TIN = float, bool REV = false>
+__global__ __launch_bounds__(256) void pp_local_kernel(const TIN* __restrict__ raw, int64_t ser_stride, int64_t T,
                                                        int nblk, const double* __restrict__ tab,
                                                        double* __restrict__ fstate, double* __restrict__ tsum) {
   __shared__ double sh[8];
   const int ser = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* x = raw + (int64_t)ser * ser_stride;
+  const TIN* x = raw + (int64_t)ser * ser_stride;
+  auto at = [&](int64_t i) { return REV ? x[T - 1 - i] : x[i]; };      // sample i in filter order
   double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
   double tw[4][NS];
 #pragma unroll
@@ -401,9 +403,9 @@ __global__ __launch_bounds__(256) void pp_local_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     if (m == kPB) {
-      float v[4];
+      TIN v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = x[t0 + lane + 64 * r];
+      for (int r = 0; r < 4; ++r) v[r] = at(t0 + lane + 64 * r);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double d = (double)v[r];
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void pp_local_kernel(const float* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int j = lane + 64 * r;
         if (j < m) {
-          const double d = (double)x[t0 + j];
+          const double d = (double)at(t0 + j);
 #pragma unroll
           for (int k = 0; k < NS; ++k) acc[k] += tab[(m - 1 - j) * NS + k] * d;
           if (TREND) { s0 += d; s1 += d * ((double)(t0 + j) - tc); }
@@ -708,6 +710,25 @@ static int launch_local(dtx_ctx* ctx, const float* raw, int64_t ser_stride, int6
   return DTX_OK;
 }
 
+// the same for the backward pass over the forward output (float64, walked from its end)
+static int launch_local_back(dtx_ctx* ctx, const double* mid, int64_t T, const PpPlan& pl) {
+  const int slices = std::max(1, std::min((pl.nblk + 7) / 8, (2048 + pl.nser - 1) / pl.nser));
+  const dim3 grid((unsigned)slices, (unsigned)pl.nser);
+#define DTX_LOCALB_CASE(NS)                                                                                        \
+  case NS:                                                                                                         \
+    hipLaunchKernelGGL((pp_local_kernel<NS, false, double, true>), grid, dim3(256), 0, ctx->stream, mid, T, T,     \
+                       pl.nblk, pl.tab(), pl.fstate, (double*)nullptr);                                            \
+    break
+  switch (pl.ns) {
+    DTX_LOCALB_CASE(2); DTX_LOCALB_CASE(4); DTX_LOCALB_CASE(6); DTX_LOCALB_CASE(8);
+    DTX_LOCALB_CASE(10); DTX_LOCALB_CASE(12); DTX_LOCALB_CASE(14); DTX_LOCALB_CASE(16);
+    default: return dtx_fail(ctx, DTX_E_ARG, "pre-processing: %d filter states", pl.ns);
+  }
+#undef DTX_LOCALB_CASE
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}
+
 // ---------------------------------------------------------------- raw-count ingest
 // The front half of _applyFilter (detex/construct.py:1005-1022): a chunk arrives as FRAGMENTS of
 // raw int32 digitiser counts (ObsPy traces of one channel each, with gaps between them).
@@ -887,9 +908,13 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
                        ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate, mid,
                        (float*)nullptr, Nc, mp_stride, 0);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
-    hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
-                       ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
-                       (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+    if (DTX_PP_LOCAL) {
+      if ((rc = launch_local_back(ctx, mid, T, pl))) return rc;
+    } else {
+      hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
+                         ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
+                         (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+    }
     chain();
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
     hipLaunchKernelGGL((pp_tiled_kernel<false, true, true>), grid, dim3(256), 0, ctx->stream, nof,
