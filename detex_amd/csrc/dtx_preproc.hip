@@ -116,18 +116,36 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 #ifndef DTX_PP_SCAN
 #define DTX_PP_SCAN 1        // entry states by pp_scan_kernel (0: pp_chain_kernel)
 #endif
+#ifndef DTX_PP_TILED_ABLATE
+#define DTX_PP_TILED_ABLATE 0
+#endif
 #ifndef DTX_PP_LOCAL
 #define DTX_PP_LOCAL 1       // pass 1 as dot products with the impulse table (pp_local_kernel; 0: the tiled filter run)
 #endif
 constexpr int kSub = 32;
-template <bool FIRST, bool RUN, bool LAST>
+// NSEC (the section count) is a template parameter and the coefficients come from device memory into per-thread
+// registers: as a by-value struct of eight-section arrays behind a switch they lived in scalar registers that did
+// not fit -- every use inside the sample loop re-read a 16-register tuple from a spill lane by lane (~100
+// v_readlane per sample: the filter run was 99 of the forward pass's 167 us per station-day).
+template <bool FIRST, bool RUN, bool LAST, int NSEC>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
     const float* __restrict__ raw, int64_t ser_stride, const double* __restrict__ mid,
-    const double* __restrict__ trend, int64_t T, int nblk, Sos f, bool rev,
+    const double* __restrict__ trend, int64_t T, int nblk, const double* __restrict__ coef, bool rev,
     double* __restrict__ fstate, double* __restrict__ out_mid, float* __restrict__ out_mp, int Nc,
     int64_t mp_stride, int dec) {
   __shared__ double tile[256][kSub + 1];
   const int tid = threadIdx.x;
+  double cb0[NSEC], cb1[NSEC], cb2[NSEC], ca1[NSEC], ca2[NSEC];
+  {
+    int opaque;                                   // (keeps the loads per lane: vector registers, not scalar ones)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+    const double* cv = coef + opaque;
+#pragma unroll
+    for (int sct = 0; sct < NSEC; ++sct) {
+      cb0[sct] = cv[sct]; cb1[sct] = cv[kMaxSec + sct]; cb2[sct] = cv[2 * kMaxSec + sct];
+      ca1[sct] = cv[3 * kMaxSec + sct]; ca2[sct] = cv[4 * kMaxSec + sct];
+    }
+  }
   const int ser = blockIdx.y;
   const int g0 = blockIdx.x * 256;
   const int g = g0 + tid;
@@ -140,7 +158,8 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
   const int chunk = ser / Nc, c = ser - chunk * Nc;
   double z[2 * kMaxSec];
   double* st = fstate + ((int64_t)ser * nblk + (valid ? g : 0)) * (2 * kMaxSec);
-  for (int k = 0; k < 2 * f.nsec; ++k) z[k] = (RUN && valid) ? st[k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 2 * NSEC; ++k) z[k] = (RUN && valid) ? st[k] : 0.0;
 
   for (int jj = 0; jj < kPB; jj += kSub) {
     // (DTX_PP_LOADS loads in flight: four at a time the 32 of a sub-tile were eight exposed latencies)
@@ -152,7 +171,14 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
         const int idx = (m0 + q) * 256 + tid;
         const int b = idx / kSub, j = idx - b * kSub;
         const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
-        v[q] = (g0 + b < nblk && i < T) ? pp_input<FIRST>(r, m, tr, T, i, rev) : 0.0;
+        // (the load at a clamped index, then a select: as "in range ? load : 0" every load sat in a branch of
+        // its own with its wait inside -- sixteen "loads in flight" were sixteen exposed latencies)
+#if DTX_PP_TILED_ABLATE & 1      // timing only: no loads
+        const double val = (double)i;
+#else
+        const double val = pp_input<FIRST>(r, m, tr, T, min(i, T - 1), rev);
+#endif
+        v[q] = (g0 + b < nblk && i < T) ? val : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < DTX_PP_LOADS; ++q) {
@@ -162,27 +188,21 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
       }
     }
     __syncthreads();
-    if (valid) {
+    if (valid && !(DTX_PP_TILED_ABLATE & 2)) {      // (2: timing only, no filter run)
       const int64_t i0 = (int64_t)g * kPB + jj;
-      auto run = [&](auto nc) {
-        constexpr int NSEC = decltype(nc)::value;
 #pragma unroll 4
-        for (int j = 0; j < kSub; ++j) {
-          if (i0 + j < T) {
-            const double y = sos_step_t<NSEC>(f, tile[tid][j], z);
-            if (RUN) tile[tid][j] = y;
+      for (int j = 0; j < kSub; ++j) {
+        if (i0 + j < T) {
+          double x = tile[tid][j];
+#pragma unroll
+          for (int sct = 0; sct < NSEC; ++sct) {         // scipy.signal.sosfilt's step (direct form II transposed)
+            const double y = cb0[sct] * x + z[2 * sct];
+            z[2 * sct] = cb1[sct] * x - ca1[sct] * y + z[2 * sct + 1];
+            z[2 * sct + 1] = cb2[sct] * x - ca2[sct] * y;
+            x = y;
           }
+          if (RUN) tile[tid][j] = x;
         }
-      };
-      switch (f.nsec) {                       // (uniform)
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 3: run(std::integral_constant<int, 3>{}); break;
-        case 4: run(std::integral_constant<int, 4>{}); break;
-        case 5: run(std::integral_constant<int, 5>{}); break;
-        case 6: run(std::integral_constant<int, 6>{}); break;
-        case 7: run(std::integral_constant<int, 7>{}); break;
-        default: run(std::integral_constant<int, 8>{}); break;
       }
     }
     if (RUN) {
@@ -192,21 +212,24 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
         const int idx = mm * 256 + tid;
         const int b = idx / kSub, j = idx - b * kSub;
         const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
-        if (g0 + b < nblk && i < T) {
+        const double yv = tile[b][j];
+        if (g0 + b < nblk && i < T && !((DTX_PP_TILED_ABLATE & 4) && yv != 1.2345)) {      // (4: timing only, no stores)
           const int64_t t = rev ? (T - 1 - i) : i;
           if (LAST) {
-            if (dec <= 1) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)tile[b][j];
-            else if (t % dec == 0) out_mp[(int64_t)ser * mp_stride + t / dec] = (float)tile[b][j];
+            if (dec <= 1) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)yv;
+            else if (t % dec == 0) out_mp[(int64_t)ser * mp_stride + t / dec] = (float)yv;
           } else {
-            out_mid[(int64_t)ser * T + t] = tile[b][j];
+            out_mid[(int64_t)ser * T + t] = yv;
           }
         }
       }
     }
     __syncthreads();
   }
-  if (!RUN && valid)
-    for (int k = 0; k < 2 * f.nsec; ++k) st[k] = z[k];
+  if (!RUN && valid) {
+#pragma unroll
+    for (int k = 0; k < 2 * NSEC; ++k) st[k] = z[k];
+  }
 }
 
 // pass 2: true entry state of every block, S_b = M S_{b-1} + f_{b-1}, by the same
@@ -538,6 +561,8 @@ struct PpPlan {
   // zero state; behind it its sums over a full block, C1[k] = sum_q tab[q][k], C2[k] = sum_j j tab[kPB - 1 - j][k]
   const double* tab() const { return Mdev + (size_t)(2 + kScanSteps) * ns * ns; }
   const double* cfull() const { return tab() + (size_t)kPB * ns; }
+  // the normalised sections [b0 | b1 | b2 | a1 | a2][kMaxSec] (pp_tiled_kernel reads them into registers)
+  const double* coef() const { return cfull() + 2 * (size_t)ns; }
 };
 
 int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser, int64_t T,
@@ -652,11 +677,13 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
     M.insert(M.end(), tab.begin(), tab.end());
     M.insert(M.end(), c1.begin(), c1.end());
     M.insert(M.end(), c2.begin(), c2.end());
+    for (const double* arr : {f.b0, f.b1, f.b2, f.a1, f.a2})
+      for (int sct = 0; sct < kMaxSec; ++sct) M.push_back(sct < nsec ? arr[sct] : 0.0);
   }
   Mkey.clear();
   // (kernels of earlier calls may still read the old matrices: wait for them before overwriting)
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if ((rc = dtx_reserve(ctx, Mbuf, ((size_t)2 * kMaxSec * 2 * kMaxSec * (2 + kScanSteps) + (size_t)(kPB + 2) * 2 * kMaxSec) *
+  if ((rc = dtx_reserve(ctx, Mbuf, ((size_t)2 * kMaxSec * 2 * kMaxSec * (2 + kScanSteps) + (size_t)(kPB + 2) * 2 * kMaxSec + 5 * kMaxSec) *
                                        sizeof(double))))
     return rc;
   DTX_HIP(ctx, hipMemcpy(Mbuf.p, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -680,6 +707,24 @@ static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int n
   }
 #endif
   hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, Mdev, Mdev + ns * ns, nblk, seg, ns);
+}
+
+// pp_tiled_kernel for the plan's section count
+template <bool FIRST, bool RUN, bool LAST>
+static void launch_tiled(dtx_ctx* ctx, dim3 grid, const PpPlan& pl, const float* raw, int64_t ser_stride, const double* mid,
+                         const double* trend, int64_t T, bool rev, double* out_mid, float* out_mp, int Nc,
+                         int64_t mp_stride, int dec) {
+#define DTX_TILED_CASE(NSEC)                                                                                      \
+  case NSEC:                                                                                                      \
+    hipLaunchKernelGGL((pp_tiled_kernel<FIRST, RUN, LAST, NSEC>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, \
+                       mid, trend, T, pl.nblk, pl.coef(), rev, pl.fstate, out_mid, out_mp, Nc, mp_stride, dec);    \
+    break
+  switch (pl.f.nsec) {
+    DTX_TILED_CASE(1); DTX_TILED_CASE(2); DTX_TILED_CASE(3); DTX_TILED_CASE(4);
+    DTX_TILED_CASE(5); DTX_TILED_CASE(6); DTX_TILED_CASE(7); DTX_TILED_CASE(8);
+    default: break;
+  }
+#undef DTX_TILED_CASE
 }
 
 // pass 1 (+ the trend sums when tsum is given): zero-state exit states of every block of every series
@@ -851,7 +896,6 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   PpPlan pl;
   int rc;
   if ((rc = pp_plan(ctx, "dtx_preprocess", sos, nsec, nser, T, zerophase && nsec, &pl))) return rc;
-  const Sos& f = pl.f;
   const int nblk = pl.nblk, ns = pl.ns, seg = pl.seg;
   double* trend = detrend ? pl.trend : nullptr;
   double *fstate = pl.fstate, *Mdev = pl.Mdev, *mid = pl.mid;
@@ -897,33 +941,28 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   if (DTX_PP_LOCAL) {
     if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, trend))) return rc;
   } else {
-    hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
-                       (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+    launch_tiled<true, false, false>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false,
+                                     (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
   }
   auto chain = [&]() { launch_chain(ctx, fstate, (const double*)Mdev, nser, nblk, seg, ns); };
   chain();
   if (zerophase) {
-    hipLaunchKernelGGL((pp_tiled_kernel<true, true, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate, mid,
-                       (float*)nullptr, Nc, mp_stride, 0);
+    launch_tiled<true, true, false>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false, mid,
+                                    (float*)nullptr, Nc, mp_stride, 0);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
     if (DTX_PP_LOCAL) {
       if ((rc = launch_local_back(ctx, mid, T, pl))) return rc;
     } else {
-      hipLaunchKernelGGL((pp_tiled_kernel<false, false, false>), grid, dim3(256), 0, ctx->stream, nof,
-                         ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
-                         (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
+      launch_tiled<false, false, false>(ctx, grid, pl, nof, ser_stride, (const double*)mid, nod, T, true,
+                                        (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
     }
     chain();
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
-    hipLaunchKernelGGL((pp_tiled_kernel<false, true, true>), grid, dim3(256), 0, ctx->stream, nof,
-                       ser_stride, (const double*)mid, nod, T, nblk, f, true, fstate,
-                       (double*)nullptr, mp_dev, Nc, mp_stride, 0);
+    launch_tiled<false, true, true>(ctx, grid, pl, nof, ser_stride, (const double*)mid, nod, T, true,
+                                    (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   } else {
-    hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, nod, (const double*)trend, T, nblk, f, false, fstate,
-                       (double*)nullptr, mp_dev, Nc, mp_stride, 0);
+    launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false,
+                                   (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   }
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
@@ -947,15 +986,13 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   if (DTX_PP_LOCAL) {
     if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, nullptr))) return rc;
   } else {
-    hipLaunchKernelGGL((pp_tiled_kernel<true, false, false>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                       ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
-                       (float*)nullptr, 1, out_stride, 0);
+    launch_tiled<true, false, false>(ctx, grid, pl, raw_dev, ser_stride, nod, nod, T, false, (double*)nullptr,
+                                     (float*)nullptr, 1, out_stride, 0);
   }
   launch_chain(ctx, pl.fstate, (const double*)pl.Mdev, nser, pl.nblk, pl.seg, pl.ns);
   // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
-  hipLaunchKernelGGL((pp_tiled_kernel<true, true, true>), grid, dim3(256), 0, ctx->stream, raw_dev,
-                     ser_stride, nod, nod, T, pl.nblk, pl.f, false, pl.fstate, (double*)nullptr,
-                     out_dev, 1, out_stride, factor);
+  launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_stride, nod, nod, T, false, (double*)nullptr, out_dev, 1,
+                                 out_stride, factor);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }
