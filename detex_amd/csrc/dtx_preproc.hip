@@ -20,7 +20,11 @@
 namespace {
 
 constexpr int kMaxSec = 8;    // biquad sections (bandpass corners <= 8)
-constexpr int kPB = 256;      // samples per block (short blocks: more workgroups in flight)
+#ifndef DTX_PP_PB
+#define DTX_PP_PB 256
+#endif
+constexpr int kPB = DTX_PP_PB;   // samples per block (short blocks: more workgroups in flight)
+constexpr int kLR = kPB / 64;     // samples per lane of a block in pp_local_kernel
 constexpr int kTrendSlices = 16;
 
 struct Sos {
@@ -410,9 +414,9 @@ __global__ __launch_bounds__(256) void pp_local_kernel(const TIN* __restrict__ r
   const TIN* x = raw + (int64_t)ser * ser_stride;
   auto at = [&](int64_t i) { return REV ? x[T - 1 - i] : x[i]; };      // sample i in filter order
   double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
-  double tw[4][NS];
+  double tw[kLR][NS];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < kLR; ++r)
 #pragma unroll
     for (int k = 0; k < NS; ++k) tw[r][k] = tab[(kPB - 1 - (lane + 64 * r)) * NS + k];
   const double tc = 0.5 * (double)(T - 1);
@@ -426,18 +430,18 @@ __global__ __launch_bounds__(256) void pp_local_kernel(const TIN* __restrict__ r
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
     if (m == kPB) {
-      TIN v[4];
+      TIN v[kLR];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = at(t0 + lane + 64 * r);
+      for (int r = 0; r < kLR; ++r) v[r] = at(t0 + lane + 64 * r);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < kLR; ++r) {
         const double d = (double)v[r];
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] += tw[r][k] * d;
         if (TREND) { s0 += d; s1 += d * ((double)(t0 + lane + 64 * r) - tc); }
       }
     } else {
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < kLR; ++r) {
         const int j = lane + 64 * r;
         if (j < m) {
           const double d = (double)at(t0 + j);
