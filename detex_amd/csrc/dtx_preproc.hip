@@ -165,32 +165,40 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
 #pragma unroll
   for (int k = 0; k < 2 * NSEC; ++k) z[k] = (RUN && valid) ? st[k] : 0.0;
 
-  for (int jj = 0; jj < kPB; jj += kSub) {
-    // (DTX_PP_LOADS loads in flight: four at a time the 32 of a sub-tile were eight exposed latencies)
-#pragma unroll 1
-    for (int m0 = 0; m0 < kSub; m0 += DTX_PP_LOADS) {
-      double v[DTX_PP_LOADS];
+  // The sub-tile's samples are fetched a sub-tile AHEAD, into registers (raw float32 / the float64 intermediate as
+  // loaded; trend and conversion when they go to the tile): the loads of sub-tile jj + 1 fly under the filter run
+  // and the stores of sub-tile jj.  (Fetched at the top of their own sub-tile, sixteen at a time, their two
+  // latencies stood in front of every run: 110 + 134 us for the two runs.)  Loads at a clamped index, then a
+  // select: as "in range ? load : 0" every load sat in a branch of its own with its wait inside.
+  typedef typename std::conditional<FIRST, float, double>::type tin_t;
+  tin_t pre[kSub];
+  auto fetch = [&](int jj) {
 #pragma unroll
-      for (int q = 0; q < DTX_PP_LOADS; ++q) {
-        const int idx = (m0 + q) * 256 + tid;
-        const int b = idx / kSub, j = idx - b * kSub;
-        const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
-        // (the load at a clamped index, then a select: as "in range ? load : 0" every load sat in a branch of
-        // its own with its wait inside -- sixteen "loads in flight" were sixteen exposed latencies)
+    for (int q = 0; q < kSub; ++q) {
+      const int b = q * (256 / kSub) + tid / kSub, j = tid % kSub;
+      const int64_t i = min((int64_t)(g0 + b) * kPB + jj + j, T - 1);
+      const int64_t t = rev ? (T - 1 - i) : i;
 #if DTX_PP_TILED_ABLATE & 1      // timing only: no loads
-        const double val = (double)i;
+      pre[q] = (tin_t)i;
 #else
-        const double val = pp_input<FIRST>(r, m, tr, T, min(i, T - 1), rev);
+      if constexpr (FIRST) pre[q] = r[t]; else pre[q] = m[t];
 #endif
-        v[q] = (g0 + b < nblk && i < T) ? val : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < DTX_PP_LOADS; ++q) {
-        const int idx = (m0 + q) * 256 + tid;
-        const int b = idx / kSub, j = idx - b * kSub;
-        tile[b][j] = v[q];
-      }
     }
+  };
+  fetch(0);
+  for (int jj = 0; jj < kPB; jj += kSub) {
+#pragma unroll
+    for (int q = 0; q < kSub; ++q) {
+      const int b = q * (256 / kSub) + tid / kSub, j = tid % kSub;
+      const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
+      double val = (double)pre[q];
+      if (FIRST) {
+        const int64_t t = rev ? (T - 1 - i) : i;
+        val -= tr[0] + tr[1] * (double)t;
+      }
+      tile[b][j] = (g0 + b < nblk && i < T) ? val : 0.0;
+    }
+    if (jj + kSub < kPB) fetch(jj + kSub);
     __syncthreads();
     if (valid && !(DTX_PP_TILED_ABLATE & 2)) {      // (2: timing only, no filter run)
       const int64_t i0 = (int64_t)g * kPB + jj;
