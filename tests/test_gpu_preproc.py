@@ -43,6 +43,39 @@ def test_preprocess_matches_scipy(ctx, T, Nc, nchunk, filt, sr, detrend):
         assert np.max(np.abs(got[b] - want)) <= 2e-6 * scale + 1e-7 * 400, (b, scale)
 
 
+@pytest.mark.parametrize('seed', range(16))
+def test_preprocess_random_shapes(ctx, seed):
+    """Seeded random lengths around the block structure of the filter kernels (blocks of 256 samples: shorter than
+    one, whole multiples, one sample off), channel / chunk counts, band-pass orders 1 .. 4 (two to eight filter
+    states), causal and zero-phase, with and without the trend: the scipy restatement within 2e-6 of the output's
+    scale -- the zero-state block states are dot products with an impulse table here, a filter run there."""
+    rs = np.random.RandomState(1000 + seed)
+    base = int(rs.choice([1, 2, 3, 5, 9, 40]))
+    T = max(40, base * 256 + int(rs.choice([-1, 0, 1, 17, 128, 255])))
+    if seed == 0:
+        T = 200                                         # shorter than one block
+    Nc = int(rs.choice([1, 2, 3, 6]))
+    nchunk = int(rs.choice([1, 2, 5]))
+    corners = int(rs.choice([1, 2, 3, 4]))
+    sr = float(rs.choice([40.0, 100.0, 500.0]))
+    lo = sr * rs.uniform(0.01, 0.05)
+    hi = sr * rs.uniform(0.1, 0.4)
+    zerophase = bool(rs.randint(2))
+    detrend = bool(rs.randint(2))
+    filt = [lo, hi, corners, zerophase]
+    t = np.arange(T)
+    raw = (rs.standard_normal((nchunk, Nc, T)) * 50 + rs.uniform(-500, 500, (nchunk, Nc, 1)) +
+           0.05 * t[None, None, :] * rs.uniform(-1, 1, (nchunk, Nc, 1))).astype(np.float32)
+    out = ctx.preprocess(torch.from_numpy(raw).cuda(), filt=filt, sampling_rate=sr, detrend=detrend)
+    ctx.sync()
+    got = out.cpu().numpy()
+    assert got.shape == (nchunk, Nc * T)
+    for b in range(nchunk):
+        want = orc.multiplex(orc.apply_filter(list(raw[b]), filt, sr, detrend=detrend))
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(got[b] - want)) <= 2e-6 * scale + 1e-7 * 1000, (seed, T, Nc, filt, detrend, b)
+
+
 def test_preprocess_feeds_the_scan(ctx):
     """Raw counts -> device pre-processing -> detection statistic, against the
     oracle pipeline on the same raw data."""

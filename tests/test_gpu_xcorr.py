@@ -262,6 +262,52 @@ def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
 
 
 
+@pytest.mark.parametrize('seed', range(10))
+def test_lag_search_random_shapes(ctx, monkeypatch, seed):
+    """Seeded random event counts, channel counts and lengths across the frequency-domain lag search's layouts (one
+    segment / several, four to fifteen lags per thread, odd and even counts): both kernels and a random split of the
+    pair range give one answer, and a sample of pairs agrees with the float64 oracle (cc 1e-5, lag exact away from
+    ties)."""
+    from detex_amd import synth
+    rs = np.random.RandomState(500 + seed)
+    N = int(rs.randint(2, 12))
+    Nc = int(rs.choice([1, 2, 3, 4, 6]))
+    L = int(rs.choice([1024, 1300, 2049, 3100, 4000, 5633, 5634, 7000, 9001, 14000]))
+    td = synth.event_families(seed + 3, 2, (N + 1) // 2, Nc, L, maxshift=max(1, L // 50))[:N]
+    td = td * (10.0 ** rs.choice([-2, 0, 2], size=N)).astype(np.float32)[:, None]
+    npairs = N * (N - 1) // 2
+    cut = int(rs.randint(0, npairs + 1))
+    res = {}
+    for v in ('1', '0'):
+        monkeypatch.setenv('DETEX_AMD_XC22', v)
+        full = _gpu(ctx, td, Nc)
+        acc = [np.zeros(npairs, np.float32), np.zeros(npairs, np.int32), np.zeros(npairs, np.float32)]
+        for lo, hi in ((0, cut), (cut, npairs)):
+            if lo == hi:
+                continue
+            part = _gpu(ctx, td, Nc, pair_begin=lo, pair_end=hi)
+            for a, p_ in zip(acc, part):
+                a[lo:hi] = p_[lo:hi]
+        for a, f in zip(acc, full):
+            assert np.array_equal(a, f)
+        res[v] = full
+    for a, b in zip(res['1'], res['0']):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv('DETEX_AMD_XC22')
+    cc, lag, ss = res['1']
+    n = Nc * L
+    trunc = n // (2 * Nc) - 1
+    pairs = [(b, c) for b in range(N) for c in range(b + 1, N)]
+    for (b, c) in [pairs[i] for i in rs.choice(len(pairs), min(4, len(pairs)), replace=False)]:
+        k = N * b - b * (b + 1) // 2 + (c - b - 1)
+        raw = orc.ccx2_raw_fft(td[b].astype(np.float64), td[c].astype(np.float64), Nc)
+        rc, rl, rss, rr = orc.ccx2_reduce(raw, n, Nc, trunc, SCRUB)
+        assert abs(cc[k] - rc) <= 1e-5, (seed, b, c, cc[k], rc)
+        fin = np.sort(rr[np.isfinite(rr)])
+        if len(fin) > 1 and fin[-1] - fin[-2] > 5e-6 and abs(abs(rc) - 1) > 2e-5:
+            assert lag[k] == rl, (seed, b, c, lag[k], rl)
+
+
 def test_fast_normcorr_golden(ctx):
     """fast_normcorr (construct.py:469-483) on the device against the reference's own outputs
     (tests/golden/normcorr.npz), through the context method and the NumPy-facing function."""
