@@ -49,8 +49,11 @@ def parse():
                          "else bf16x3; fft: frequency-domain overlap-save engine (float32 transforms in "
                          "LDS); bf16x3: split-bfloat16 MFMA contraction (3 bf16 products per float32 "
                          "product, float32 accumulate); fp32: exact float32 MFMA contraction")
-    ap.add_argument('--prewarm', type=float, default=0.5,
-                    help='seconds of untimed scanning before the warm-up steps (GPU clocks settle)')
+    ap.add_argument('--prewarm', type=float, default=5.0,
+                    help='cap (seconds) of the untimed scanning before the warm-up steps: the same step is '
+                         'repeated until the scan kernel\'s duration has settled (mean of the last 10 launches '
+                         'within 1 %% of the 10 before), at least --prewarm-min seconds, at most this; 0 = none')
+    ap.add_argument('--prewarm-min', type=float, default=0.5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary fields (other engines, configs[2] / configs[4], PCIe-inclusive '
@@ -832,11 +835,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the clocks of an idle GPU take a few hundred milliseconds of load to settle (20 steps are 70 ms): spin
-    # the same step, untimed, for half a second before the W warm-up steps the contract asks for
+    # The clocks of an idle GPU take time under load to settle, and how long differs from box to box (round 4's
+    # driver run: 2.88 ms per kernel after a fixed half second, 2.72 on the builder's boxes; 20 steps are 70 ms).
+    # A criterion instead of a constant: repeat the same step, untimed, until the scan kernel's duration (HIP
+    # events around it) has stopped moving -- mean of the last 10 launches within 1 % of the 10 before -- for
+    # at least --prewarm-min and at most --prewarm seconds; what was spent is in the line (config.prewarm).
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < a.prewarm:
+    pre_k, settled = [], False
+    while a.prewarm > 0:
         step()()
+        pre_k.append(ctx.last_kernel_ms())
+        el = time.perf_counter() - t_pre
+        if len(pre_k) >= 20 and el >= min(a.prewarm_min, a.prewarm):
+            m1, m0 = sum(pre_k[-10:]) / 10.0, sum(pre_k[-20:-10]) / 10.0
+            settled = abs(m1 - m0) <= 0.01 * m0
+        if settled or el >= a.prewarm:
+            break
+    prewarm = {'seconds': time.perf_counter() - t_pre, 'steps': len(pre_k), 'settled': settled,
+               'cap_s': a.prewarm, 'min_s': a.prewarm_min,
+               'kernel_ms_first10': (sum(pre_k[:10]) / len(pre_k[:10])) if pre_k else None,
+               'kernel_ms_last10': (sum(pre_k[-10:]) / len(pre_k[-10:])) if pre_k else None}
     for _ in range(a.warmup):
         res = step()()
 
@@ -847,16 +865,33 @@ def main():
         barrier()
         t0 = time.perf_counter()
         pending = res = None
+        stamps.clear()
         for _ in range(steps):
             fetch = step()
             if pending is not None:
                 res = pending()
+                stamps.append(time.perf_counter())
             pending = fetch
         res = pending()
+        stamps.append(time.perf_counter())
         barrier()
         return time.perf_counter() - t0, res
 
+    def spread(steps):
+        """Per-step spread of the loop that just ran: the scan kernel's durations one by one (HIP events, the
+        last <= 64 launches) and the host's step-to-step intervals (a step's results arrive while the next one
+        runs, so an interval is one step of the pipeline)."""
+        ks = sorted(ctx.kernel_ms_list(min(steps, 64)))
+        iv = sorted(1e3 * (b - a_) for a_, b in zip(stamps[:-1], stamps[1:]))
+        o = {'kernel_ms_min': ks[0], 'kernel_ms_median': ks[len(ks) // 2], 'kernel_ms_max': ks[-1],
+             'kernel_ms_launches': len(ks)}
+        if iv:
+            o.update({'step_ms_min': iv[0], 'step_ms_median': iv[len(iv) // 2], 'step_ms_max': iv[-1]})
+        return o
+
+    stamps = []
     dt, res = timed_loop(a.steps, barrier)
+    step_spread = spread(a.steps)
     # dominant-kernel time: HIP events the library records around the scan kernel of every call on the
     # context's stream (a ring of 64 pairs), read here, after the timed region: average launch duration
     # over its (last 64) steps
@@ -901,15 +936,28 @@ def main():
                                % ('configs[1]: ' if default_cfg else 'custom: ', K, D, k, a.chunks,
                                   a.chunk_seconds, Nc, a.sr, n),
                    'engine': eng if a.engine == eng else '%s -> %s' % (a.engine, eng),
-                   'prewarm_s': a.prewarm, 'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants)),
+                   'prewarm_s': prewarm['seconds'], 'prewarm': prewarm,
+                   **step_spread, 'windows_per_step_per_gpu': a.chunks * P, 'planted_found': '%d/%d' % (found, len(plants)),
                    # digest of the last step's candidate list: equal between launch modes (plain / torchrun) on one box
                    'candidates': {'n': int(len(cp)), 'index_sum': int(cp.sum()), 'value_sum': float(np.sum(cv, dtype=np.float64))},
                    'results': 'maxima and candidate lists of every step fetched to the host inside the timed '
                               'region, each while the next step runs (pinned buffers, side stream)'},
         'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
     }
+    tr = out['roofline'].get('traffic') if out['roofline'] else None
+    if tr and tr.get('bytes') and out['roofline'].get('bytes_per_launch'):
+        # flat copies of the nested `traffic` object (a consumer that keeps only scalars keeps these)
+        out['roofline']['traffic_bytes'] = tr['bytes']
+        out['roofline']['traffic_ratio'] = tr['bytes'] / out['roofline']['bytes_per_launch']
     extras = rank == 0 and world == 1 and default_cfg and not a.no_extras
     if extras:
+        # the same loop again, 200 steps, right behind the timed region: what this box sustains once nothing is
+        # cold.  The headline within a few per cent of this = the K timed steps were not taken on a cold lease.
+        sdt, _ = timed_loop(200, barrier)
+        sk = ctx.kernel_ms_mean(64)
+        out['steady'] = {'value': a.chunks * P * 200 / sdt, 'unit': 'windows/s', 'steps': 200,
+                         'ms_per_step': 1e3 * sdt / 200, 'kernel_ms': sk, **spread(200),
+                         'headline_over_steady': value / (a.chunks * P * 200 / sdt)}
         # the other engines on the same input (same step: scan + post pass)
         for other, key in (('bf16x3', 'mfma_engine'), ('fp32', 'fp32_engine'), ('fft', 'fft_engine')):
             if other == eng:

@@ -253,6 +253,21 @@ int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms) {
   return DTX_OK;
 }
 
+int dtx_kernel_ms_list(dtx_ctx* ctx, int n, float* ms) {
+  if (!ctx || !ms || n <= 0) return DTX_E_ARG;
+  if (!ctx->kernel_timed) return dtx_fail(ctx, DTX_E_STATE, "no timed kernel has run yet");
+  int slots[dtx_ctx::kKev];
+  if (!dtxplan::ring_last_slots(ctx->kev_count, dtx_ctx::kKev, n, slots))
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_kernel_ms_list: only the last %d launches are kept (%lld timed so far)",
+                    dtx_ctx::kKev, ctx->kev_count);
+  DtxDeviceGuard g(ctx->device);
+  for (int q = 0; q < n; ++q) {
+    DTX_HIP(ctx, hipEventSynchronize(ctx->kev1[slots[q]]));
+    DTX_HIP(ctx, hipEventElapsedTime(&ms[q], ctx->kev0[slots[q]], ctx->kev1[slots[q]]));
+  }
+  return DTX_OK;
+}
+
 int dtx_last_kernel_ms(dtx_ctx* ctx, float* ms) {
   if (!ctx || !ms) return DTX_E_ARG;
   if (!ctx->kernel_timed) return dtx_fail(ctx, DTX_E_STATE, "no timed kernel has run yet");

@@ -855,6 +855,10 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
 
   i32x4* g16 = nullptr;
   const int64_t V = Tpad / 8;
+  // the timed region (dtx_last_kernel_ms, dtx_stream_wait_scan_kernel) of the split engine holds ALL of its passes:
+  // the guard's pass over xp / den, the split image, the contraction and the float32 repair of the guard's list
+  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
+  if (split) DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   if (split) {
     hipLaunchKernelGGL(split_guard_kernel, dim3((unsigned)(nchunk * gnblk)), dim3(256), 0, ctx->stream,
                        (const float*)xp, Tpad, Nc, ctx->L, (const float*)den, Ppad, P, kSplitGuardV, gnblk,
@@ -867,8 +871,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
   }
 
-  { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
-  DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  if (!split) DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   for (const DtxKTile& t : ctx->tiles) {
     DsArgs a;
     a.ut16 = g16 ? t.ut16_dev : nullptr; a.g16 = g16; a.V = V;
@@ -879,8 +882,6 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     a.list = nullptr; a.lV = 0; a.lnblk = 0; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
-  DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  dtx_kev_commit(ctx);
   if (split)      // the guard's blocks again, on the float32 engine (a 256-workgroup launch that finds an empty list on ordinary data)
     for (const DtxKTile& t : ctx->tiles) {
       DsArgs a;
@@ -892,6 +893,8 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
       a.list = list; a.lV = kSplitGuardV; a.lnblk = gnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
       if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
     }
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  dtx_kev_commit(ctx);
   if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
   return DTX_OK;
 }

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
   xc_epilogue<RM, TN>(acc, a, c, kt, p0);
 }
 
-#ifndef DTX_XCFIN2
 static constexpr size_t kFin2PrefixBudget = (size_t)4 << 30;   // bytes of float64 prefix sums xc_finish2 may carve
+#ifndef DTX_XCFIN2
 #define DTX_XCFIN2 1        // 1: xc_finish2_kernel for Nc <= 64, 0: xc_finish_kernel always
 #endif
 #ifndef DTX_XCFIN_ABLATE

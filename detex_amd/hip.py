@@ -637,6 +637,12 @@ class HipContext(object):
         self._ck(self.lib.dtx_kernel_ms_mean(self.h, int(n), C.byref(ms)), 'dtx_kernel_ms_mean')
         return float(ms.value)
 
+    def kernel_ms_list(self, n):
+        """Durations of the dominant kernel of the last n scan / cross-correlation calls, oldest first (n <= 64)."""
+        ms = (C.c_float * int(n))()
+        self._ck(self.lib.dtx_kernel_ms_list(self.h, int(n), ms), 'dtx_kernel_ms_list')
+        return [float(v) for v in ms][::-1]
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._ck(self.lib.dtx_last_kernel_ms(self.h, C.byref(ms)), 'dtx_last_kernel_ms')

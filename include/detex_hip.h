@@ -364,6 +364,9 @@ int dtx_last_kernel_ms(dtx_ctx* ctx, float* ms);
 /* Mean of that over the last n such calls (1 <= n <= 64; waits for the newest): a caller that runs several
  * calls ahead of the device reads the durations afterwards instead of synchronising after each. */
 int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms);
+/* The same n durations one by one (ms[0 .. n), in the order dtxplan::ring_last_slots lists them: newest first):
+ * bench.py's per-step spread (kernel_ms_min / median / max) and its settled-clock pre-warm criterion. */
+int dtx_kernel_ms_list(dtx_ctx* ctx, int n, float* ms);
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,9 @@ def gen_ccx2():
     names = []
     try:
         case = 0
-        for (Nc, L) in [(1, 64), (3, 50), (3, 400), (6, 33), (2, 7)]:
+        # (5, 40) and (9, 30): round 5 -- channel counts outside {1, 2, 3, 4, 6}, for which the build has
+        # no compile-time specialisation (appended: the first 70 cases keep their keys and bytes)
+        for (Nc, L) in [(1, 64), (3, 50), (3, 400), (6, 33), (2, 7), (5, 40), (9, 30)]:
             for seed in range(4):
                 rs = np.random.RandomState(100 * Nc + L + seed)
                 kinds = ['random', 'shifted', 'identical', 'zeroed_chan',
@@ -212,7 +214,10 @@ def gen_mpxds():
             (3, 1, 40, 600, 2, 'single'), (3, 4, 100, 1500, 3, 'subspace'),
             (3, 8, 300, 2000, 4, 'subspace'), (6, 4, 50, 800, 5, 'subspace'),
             (6, 1, 33, 500, 6, 'single'), (3, 4, 100, 1500, 7, 'f32'),
-            (3, 2, 60, 900, 8, 'zero_gap'), (2, 3, 45, 701, 9, 'ragged')]:
+            (3, 2, 60, 900, 8, 'zero_gap'), (2, 3, 45, 701, 9, 'ragged'),
+            # round 5: channel counts without a specialised kernel form
+            (5, 3, 40, 700, 10, 'subspace'), (9, 2, 30, 600, 11, 'subspace'),
+            (5, 1, 40, 650, 12, 'single'), (9, 4, 30, 555, 13, 'ragged')]:
         rs = np.random.RandomState(1000 + seed)
         n = Nc * L
         if kind == 'single':

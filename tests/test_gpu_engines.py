@@ -51,6 +51,8 @@ def test_golden_mpxds(ctx):
 @pytest.mark.parametrize('Nc,L,ks', [
     (3, 100, [8]), (3, 100, [1] * 5), (1, 128, [16]), (3, 64, [7, 9, 16, 1]), (3, 100, [8] * 25),
     (6, 50, [64]), (2, 90, [3] * 30), (3, 33, [40, 60, 108]), (3, 47, [1] * 230), (1, 31, [5, 11]),
+    # channel counts without a specialised kernel form (round 5)
+    (5, 40, [8, 3]), (7, 33, [4]), (8, 64, [16, 1]), (9, 30, [5, 11]), (12, 25, [6]), (5, 300, [8, 1]), (9, 280, [4]),
 ])
 def test_ds_vs_oracle_shapes(ctx, Nc, L, ks):
     rs = np.random.RandomState(sum(ks) + L)

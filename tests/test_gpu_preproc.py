@@ -43,7 +43,7 @@ def test_preprocess_matches_scipy(ctx, T, Nc, nchunk, filt, sr, detrend):
         assert np.max(np.abs(got[b] - want)) <= 2e-6 * scale + 1e-7 * 400, (b, scale)
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(26))
 def test_preprocess_random_shapes(ctx, seed):
     """Seeded random lengths around the block structure of the filter kernels (blocks of 256 samples: shorter than
     one, whole multiples, one sample off), channel / chunk counts, band-pass orders 1 .. 4 (two to eight filter
@@ -55,6 +55,8 @@ def test_preprocess_random_shapes(ctx, seed):
     if seed == 0:
         T = 200                                         # shorter than one block
     Nc = int(rs.choice([1, 2, 3, 6]))
+    if seed >= 16:                                      # channel counts the multiplex has no vector form for
+        Nc = [5, 7, 8, 9, 12][(seed - 16) % 5]
     nchunk = int(rs.choice([1, 2, 5]))
     corners = int(rs.choice([1, 2, 3, 4]))
     sr = float(rs.choice([40.0, 100.0, 500.0]))
@@ -207,7 +209,9 @@ def _random_fragments(rs, Nc, T, holes, dead_channel=False):
 
 
 @pytest.mark.parametrize('Nc,T,holes,seed', [(3, 5000, 0, 0), (3, 5000, 2, 1), (1, 777, 3, 2),
-                                             (6, 20000, 4, 3), (3, 372000, 1, 4), (2, 1500, 0, 5)])
+                                             (6, 20000, 4, 3), (3, 372000, 1, 4), (2, 1500, 0, 5),
+                                             (5, 3000, 2, 6), (7, 1500, 1, 7), (8, 4097, 3, 8), (9, 2500, 2, 9),
+                                             (12, 1000, 1, 10)])
 def test_ingest_counts_matches_merge_restatement(ctx, Nc, T, holes, seed):
     """dtx_ingest_counts / dtx_gapfree_run against the NumPy restatement of the merge with zero
     fill (construct.py:1038 / 1070) and of _mergeChannels' longest-run rule (construct.py:1033-1066),

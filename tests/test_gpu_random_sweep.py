@@ -9,6 +9,10 @@ pytestmark = pytest.mark.gpu
 
 from oracle import detex_oracle as orc  # noqa: E402
 
+# channel counts for which the library has no compile-time form (the reference takes any Nc:
+# construct.py:428-439, detect.py:577): the seeds past each test's original range draw from these
+NC_EXTRA = [5, 7, 8, 9, 12]
+
 
 @pytest.fixture(scope='module')
 def ctx():
@@ -19,7 +23,7 @@ def ctx():
 
 
 @pytest.mark.parametrize('engine', ['mfma', 'fft', 'auto'])
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(34))
 def test_random_scan(ctx, seed, engine):
     """engine 'mfma': the two contraction engines alternate over the seeds; 'fft': the
     frequency-domain engine forced on the same shapes (dead stretches, spikes, offsets);
@@ -28,6 +32,8 @@ def test_random_scan(ctx, seed, engine):
     1e-5 -- the windows that hold the 10^4 sigma spike included."""
     rs = np.random.RandomState(1000 + seed)
     Nc = int(rs.choice([1, 2, 3, 4, 6]))
+    if seed >= 24:
+        Nc = NC_EXTRA[(seed - 24) % 5]
     L = int(rs.randint(4, 260))
     n = Nc * L
     nd = int(rs.randint(1, 7))
@@ -84,7 +90,7 @@ def test_random_scan(ctx, seed, engine):
     ctx.set_engine('auto')
 
 
-@pytest.mark.parametrize('seed', range(17))
+@pytest.mark.parametrize('seed', range(24))
 def test_random_scan_long(ctx, seed):
     """Default engine on templates long enough for the frequency-domain engine: every block
     advance V = 2048 .. 7680, several blocks per chunk with a ragged last one, overlapping
@@ -92,11 +98,12 @@ def test_random_scan_long(ctx, seed):
     detectors sharing a pair, a 300-sigma event (guard), and templates past 5633 samples that
     are cut into 2 .. 4 segments of 4096 (virtual channels)."""
     rs = np.random.RandomState(3000 + seed)
-    Nc = int([3, 1, 2, 3, 6, 3, 4, 1, 3, 2, 3, 3, 6, 3, 1, 3, 2][seed])
-    L = int([256, 300, 700, 1100, 1500, 2100, 2600, 3000, 3700, 4200, 5000, 5633, 5634, 7681, 9000, 13000, 16384][seed])
+    Nc = int([3, 1, 2, 3, 6, 3, 4, 1, 3, 2, 3, 3, 6, 3, 1, 3, 2, 5, 7, 8, 9, 12, 5, 9][seed])
+    L = int([256, 300, 700, 1100, 1500, 2100, 2600, 3000, 3700, 4200, 5000, 5633, 5634, 7681, 9000, 13000, 16384,
+             256, 900, 2100, 3000, 1500, 5634, 9000][seed])
     n = Nc * L
     ks = [[8, 3], [1, 1, 1, 2], [5], [16, 1], [2, 2], [7], [1], [8] * 3, [4, 1, 1], [3], [9], [2, 5], [4], [2],
-          [3, 1, 1], [4], [2]][seed]
+          [3, 1, 1], [4], [2], [8, 3], [1, 1, 2], [5], [2, 2], [7], [3], [1, 4]][seed]
     off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
     U = rs.standard_normal((off[-1], n))
     U -= U.mean(axis=1, keepdims=True) * (seed % 2)
@@ -129,11 +136,13 @@ def test_random_scan_long(ctx, seed):
         assert abs(int(np.argmax(ds[0, 0])) - p_ev) <= 0
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(14))
 def test_random_xcorr(ctx, seed):
     from detex_amd import synth
     rs = np.random.RandomState(2000 + seed)
     Nc = int(rs.choice([1, 2, 3, 6]))
+    if seed >= 8:
+        Nc = (NC_EXTRA + [65])[seed - 8]      # 65: past the finishing kernel's 64-channel window (xc_finish_kernel)
     L = int(rs.randint(8, 400))
     N = int(rs.choice([2, 3, 7, 20, 64, 209, 215]))
     nfam = max(1, N // 5)

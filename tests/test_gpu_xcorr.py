@@ -63,24 +63,25 @@ def _check_pair(x1, x2, Nc, got, what):
     return 'ok'
 
 
-# The 14 golden cases on which the build deliberately differs from the reference.  The two
+# The 15 golden cases on which the build deliberately differs from the reference.  The two
 # events are identical (or identical up to a constant offset): the true maximum is cc = 1 at lag 0, but the
 # reference's float64 round-off lands a hair ABOVE 1 there, its scrub (construct.py:458-462: every value > 1 or
 # < -1 is set to 0 and the maximum taken again) removes the true peak and a side lobe wins.  The build scrubs at
 # |cc| > 1 + 1e-5 and keeps the peak.  name: (reference cc, reference lag) -- read from the fixture and asserted
-# below -- against the build's (1.0, 0).  Every OTHER case (56, the 20 zero_tail / zeroed_chan ones included) must
+# below -- against the build's (1.0, 0).  Every OTHER case (83, the 20 zero_tail / zeroed_chan ones included) must
 # equal the reference's own output.
 KNIFE = {
     'c008': (0.7901441, -1), 'c010': (0.5618626, -1), 'c016': (0.8101324, 3), 'c018': (0.5822324, 3),
     'c024': (0.5824542, 3), 'c030': (0.8168820, -3), 'c032': (0.8192597, -3), 'c036': (0.8231192, 3),
     'c038': (0.7938896, 3), 'c052': (0.6192905, 6), 'c058': (0.4627540, -2), 'c060': (0.2692443, -8),
     'c064': (0.4729424, -2), 'c066': (0.3145494, -8),
+    'c080': (0.6002927, 5),                 # round 5's (Nc, L) = (5, 40) family
 }
 
 
 def test_golden_ccx2_pairs(ctx):
     """Every golden _CCX2 case as a 2-event problem against the REFERENCE's output (cc 1e-5, lag exact,
-    subsamp 1e-4), except the 14 listed knife-edge cases, which are held to the build's documented answer
+    subsamp 1e-4), except the 15 listed knife-edge cases, which are held to the build's documented answer
     with the reference's value beside it."""
     z = np.load(os.path.join(G, 'ccx2.npz'))
     seen = set()
@@ -100,7 +101,7 @@ def test_golden_ccx2_pairs(ctx):
         if abs(ref[2]) <= .5:
             assert abs(got[2] - ref[2]) <= 1e-4, (nm, got, ref)
         _check_pair(x1, x2, Nc, got, nm)                    # and the oracle agrees
-    assert seen == set(KNIFE) and len(z['names']) == 70
+    assert seen == set(KNIFE) and len(z['names']) == 98
 
 
 def test_golden_cclags_matrix(ctx):
@@ -121,7 +122,10 @@ def test_golden_cclags_matrix(ctx):
 
 
 @pytest.mark.parametrize('N,Nc,L', [(5, 3, 64), (17, 1, 100), (40, 3, 37), (9, 6, 50),
-                                    (230, 2, 24), (12, 3, 333)])
+                                    (230, 2, 24), (12, 3, 333),
+                                    # channel counts without a specialised form; 65 > the finishing kernel's window
+                                    (9, 5, 40), (12, 7, 33), (20, 8, 64), (6, 9, 30), (7, 12, 50), (5, 65, 12),
+                                    (215, 5, 24), (6, 9, 300)])
 def test_allpairs_vs_oracle(ctx, N, Nc, L):
     """Row tiles of every size (N > 208 spans two tiles), odd lengths."""
     from detex_amd import synth
@@ -182,7 +186,10 @@ def test_dead_and_degenerate_events(ctx):
                                     # round 3: the host picks segment count / length / lag-block advance by cost
                                     # (dtx_xcfft_run): just past the single-segment limit, odd step counts, the
                                     # longest events (16 segments), many channels
-                                    (3, 5700, 6), (2, 7777, 5), (1, 20000, 5), (1, 32768, 4), (6, 6000, 5)])
+                                    (3, 5700, 6), (2, 7777, 5), (1, 20000, 5), (1, 32768, 4), (6, 6000, 5),
+                                    # round 5: channel counts without a specialised form (one segment / several)
+                                    (5, 1024, 8), (7, 2000, 5), (8, 3000, 4), (9, 1500, 9), (12, 1100, 5), (5, 6000, 4),
+                                    (65, 1024, 3)])
 def test_long_events_frequency_domain(ctx, Nc, L, N):
     """Events of >= 1024 samples per channel take the frequency-domain lag search under the
     default engine (dtx_xcfft.hip; past 5633 samples cut into segments): same answers as the
@@ -226,7 +233,8 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
     assert nchecked >= N
 
 
-@pytest.mark.parametrize('Nc,L,N', [(3, 3000, 23), (1, 2500, 12), (3, 13000, 9), (2, 7777, 5), (6, 6000, 6), (3, 1024, 2)])
+@pytest.mark.parametrize('Nc,L,N', [(3, 3000, 23), (1, 2500, 12), (3, 13000, 9), (2, 7777, 5), (6, 6000, 6), (3, 1024, 2),
+                                    (5, 2000, 9), (9, 1024, 8)])
 def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
     """The frequency-domain lag search has two kernels: the 2 x 2 workgroup (two later events x two pair spectra,
     the default) and the round-3 one (DETEX_AMD_XC22=0).  The same products summed in the same order and the same
@@ -262,7 +270,7 @@ def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
 
 
 
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', range(16))
 def test_lag_search_random_shapes(ctx, monkeypatch, seed):
     """Seeded random event counts, channel counts and lengths across the frequency-domain lag search's layouts (one
     segment / several, four to fifteen lags per thread, odd and even counts): both kernels and a random split of the
@@ -272,6 +280,8 @@ def test_lag_search_random_shapes(ctx, monkeypatch, seed):
     rs = np.random.RandomState(500 + seed)
     N = int(rs.randint(2, 12))
     Nc = int(rs.choice([1, 2, 3, 4, 6]))
+    if seed >= 10:
+        Nc = [5, 7, 8, 9, 12, 5][seed - 10]
     L = int(rs.choice([1024, 1300, 2049, 3100, 4000, 5633, 5634, 7000, 9001, 14000]))
     td = synth.event_families(seed + 3, 2, (N + 1) // 2, Nc, L, maxshift=max(1, L // 50))[:N]
     td = td * (10.0 ** rs.choice([-2, 0, 2], size=N)).astype(np.float32)[:, None]

@@ -36,7 +36,7 @@ def test_ccx2_matches_reference(form):
     decisions."""
     z = _load('ccx2.npz')
     names = list(z['names'])
-    assert len(names) == 70
+    assert len(names) == 98     # 70 + the (Nc, L) = (5, 40), (9, 30) families of round 5
     raw_fn = orc.ccx2_raw_fft if form == 'fft' else orc.ccx2_raw_direct
     nvec = nknife = 0
     for nm in names:
