@@ -12,7 +12,7 @@ import pandas as pd
 from scipy.cluster.hierarchy import linkage
 
 from ._lib import DetexHipError
-from .getdata import EventFetcher, multiplex, trim_window
+from .getdata import EventFetcher, clip_fragments, multiplex, trim_window
 
 
 def _error(msg, exc=DetexHipError):
@@ -60,11 +60,7 @@ def _preprocess_events(ctx, fetcher, sta, filt, trim, decimate, fillZeros=False)
             cut.append((name, np.asarray(rec['data'][:, i0:i0 + cnt], dtype=np.float32), t0 + i0 / sr))
             continue
         # the traces that reach into the window, clipped to it and re-based to its first sample
-        frs = []
-        for (c, f0, x) in rec['counts']:
-            lo, hi = max(f0, i0), min(f0 + len(x), i0 + cnt)
-            if hi > lo:
-                frs.append((c, lo - i0, x[lo - f0:hi - f0]))
+        frs = clip_fragments(rec['counts'], [(i0, i0 + cnt, 0)])
         off, tab = 0, []
         for (c, f0, x) in frs:
             tab.append((c, off, f0, len(x)))

@@ -640,9 +640,10 @@ def chunk_traces(counts, s0, cnt):
     """The traces a chunk [s0, s0 + cnt) of a fragmented record consists of, per channel: the
     fragments that reach into it, clipped to it -- what the reference's fetcher hands to
     _applyFilter as ``st`` (one ObsPy trace per fragment).  {channel: [(first, end), ...]}"""
+    from .getdata import trace_extents
     per = {}
-    for (c, t0, x) in counts:
-        lo, hi = max(int(t0), s0), min(int(t0) + len(x), s0 + cnt)
+    for (c, t0, m) in trace_extents(counts):
+        lo, hi = max(int(t0), s0), min(int(t0) + m, s0 + cnt)
         if hi > lo:
             per.setdefault(c, []).append((lo, hi))
     return per
@@ -693,7 +694,12 @@ def _trim_to_gapfree(ctx, planes, counts, bounds, sr, sta):
             if rl <= 0:
                 _warn('no gap-free data on %s from %s' % (sta, ts))
                 continue
-            if (r0, rl) != (0, cnt):
+            # _mergeChannels looks for zeros inside the span ALL merged channels cover (construct.py:1039-1050);
+            # without one the merged stream itself goes on (1065-1066): no fracture check, trimmed to that span
+            whole = chunk_traces(counts, s0, cnt)
+            A = max(min(lo for lo, _ in v) for v in whole.values())
+            B = min(max(hi for _, hi in v) for v in whole.values())
+            if (s0 + r0, rl) != (A, B - A):
                 per = chunk_traces(counts, s0 + r0, rl)       # traces that reach into the kept window
                 if any(len(v) > 1 for v in per.values()):     # len(st) != len(nc)
                     _warn('Stream is too fractured around %s on %s' % (ts, sta))

@@ -38,6 +38,106 @@ def trim_window(t0, T, sr, start, end):
     return lo, max(T - hi - lo, 0)
 
 
+class Fragments(list):
+    """[(channel, first sample, int32 counts)], non-overlapping -- what the device merges.  ``traces``: the
+    extents [(channel, first sample, number of samples)] of the ObsPy traces the record ARRIVED in, when they
+    differ from the fragments (overlaps were resolved): the reference decides 'is this chunk fragmented' and
+    'too fractured' on the unmerged stream (construct.py:1005, 1009-1014, 1064), so those decisions keep
+    reading the original traces (trace_extents)."""
+    traces = None
+
+
+def trace_extents(counts):
+    tr = getattr(counts, 'traces', None)
+    return tr if tr is not None else [(c, t0, len(x)) for (c, t0, x) in counts]
+
+
+def clip_fragments(counts, spans):
+    """Fragments (and their trace extents) clipped to spans [(first, end, new offset of first)], re-based."""
+    out = Fragments()
+    for (c, t0, x) in counts:
+        for (a, b, off) in spans:
+            lo, hi = max(t0, a), min(t0 + len(x), b)
+            if hi > lo:
+                out.append((c, off + lo - a, x[lo - t0:hi - t0]))
+    out.sort(key=lambda f: (f[0], f[1]))
+    if getattr(counts, 'traces', None) is not None:
+        out.traces = sorted((c, off + max(t0, a) - a, min(t0 + m, b) - max(t0, a))
+                            for (c, t0, m) in counts.traces for (a, b, off) in spans
+                            if min(t0 + m, b) > max(t0, a))
+    return out
+
+
+def resolve_overlaps(fragments):
+    """Overlapping count fragments of a channel resolved the way ObsPy's default merge does it, so that what goes
+    to the device (dtx_ingest_counts: non-overlapping fragments, zero fill) is what ``st.merge(fill_value=0.0)``
+    (detex/construct.py:1038, 1070) would have produced.  Third-party behaviour, restated from ObsPy 1.0.2
+    ``Stream.merge(method=0)`` -> ``Trace.__add__`` (ObsPy is not installable here: parity vs ObsPy unpinned):
+    the traces of a channel are taken in (start, end) order and added one by one to the running trace;
+
+    * partial overlap (the next trace starts inside the running one and ends past it): if ALL samples of the
+      overlap are identical the data are kept once, else the WHOLE overlap becomes the fill value (0);
+    * contained trace (ends inside the running one): identical -> dropped, else its whole extent in the running
+      trace becomes the fill value;
+    * the filled zeros are data for every later comparison (fill_value is applied in each addition).
+
+    fragments: [(channel, first sample, int32 array)], any order.  Returns the same triples (a ``Fragments``
+    list), sorted by (channel, first sample), non-overlapping; without any overlap every input trace comes
+    back as it is (abutting traces stay separate: a seam is a seam for 'too fractured').
+    Re-sent telemetry packets -- the ordinary case -- cost one comparison and no copy of anything else."""
+    by_ch = {}
+    for c, t0, x in fragments:
+        by_ch.setdefault(int(c), []).append((int(t0), np.asarray(x)))
+    out = Fragments()
+    overlapped = False
+    for c, frs in by_ch.items():
+        end = None
+        for t0, n in sorted((t0, len(x)) for t0, x in frs if len(x)):
+            overlapped = overlapped or (end is not None and t0 < end)
+            end = t0 + n if end is None else max(end, t0 + n)
+    if not overlapped:                                    # the ordinary record: every trace as it came
+        out.extend(sorted(((int(c), int(t0), x) for c, t0, x in fragments if len(x)), key=lambda f: (f[0], f[1])))
+        return out
+    for c in sorted(by_ch):
+        frs = sorted(by_ch[c], key=lambda f: (f[0], f[0] + len(f[1])))
+        cur_t0, parts, cur_end = None, [], None           # the running trace: pieces end to end
+        own = False                                       # parts[-1] is a private copy (may be written)
+
+        def flush():
+            if parts:
+                out.append((c, cur_t0, parts[0] if len(parts) == 1 else np.concatenate(parts)))
+
+        for t0, x in frs:
+            if len(x) == 0:
+                continue
+            if cur_t0 is None or t0 >= cur_end:           # gap or exact fit: a new piece
+                if cur_t0 is not None and t0 > cur_end:
+                    flush()
+                    cur_t0, parts = None, []
+                if cur_t0 is None:
+                    cur_t0 = t0
+                parts.append(x)
+                cur_end, own = t0 + len(x), False
+                continue
+            # overlap with the running trace: make it one private array (only traces that overlap are copied)
+            run = parts[0] if len(parts) == 1 and own else np.concatenate(parts)
+            a = t0 - cur_t0
+            if t0 + len(x) > cur_end:                     # partial overlap
+                d = cur_end - t0
+                if not np.array_equal(run[a:], x[:d]):
+                    run[a:] = 0
+                parts, own = [run, x[d:]], False
+                cur_end = t0 + len(x)
+            else:                                         # contained
+                b = a + len(x)
+                if not np.array_equal(run[a:b], x):
+                    run[a:b] = 0
+                parts, own = [run], True
+        flush()
+    out.traces = sorted((int(c), int(t0), len(x)) for c, t0, x in fragments if len(x))
+    return out
+
+
 class EventFetcher(object):
     """Template-event waveforms of one or more stations.
 
@@ -80,11 +180,12 @@ class EventFetcher(object):
         """The record as int32 count fragments [(channel index, first sample, counts), ...] -- one entry
         per ObsPy trace, gaps between them -- of a record of ``nsamples`` samples starting at
         ``starttime`` (cf. ContinuousFetcher.add_counts)."""
-        frs = sorted(((int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments),
-                     key=lambda f: (f[0], f[1]))
+        frs = [(int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments]
         for c, t0, x in frs:
             if not (0 <= c < len(self.channels)) or t0 < 0 or t0 + len(x) > nsamples:
                 raise ValueError('fragment of channel %d at sample %d does not fit the record' % (c, t0))
+        # overlapping traces (re-sent packets): ObsPy's merge rule, on the host, before the device sees them
+        frs = resolve_overlaps(frs)
         self.events.setdefault(station, {})[name] = dict(
             data=None, starttime=float(starttime), origintime=float(origintime), magnitude=float(magnitude),
             raw=True, counts=frs, nsamples=int(nsamples))
@@ -171,11 +272,12 @@ class ContinuousFetcher(object):
         detrends and band-passes on the device (construct.py:990-1030, _applyFilter)."""
         self.raw = True
         self.counts = getattr(self, 'counts', {})
-        frs = sorted(((int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments),
-                     key=lambda f: (f[0], f[1]))
+        frs = [(int(c), int(t0), np.ascontiguousarray(x, dtype=np.int32)) for c, t0, x in fragments]
         for c, t0, x in frs:
             if not (0 <= c < len(self.channels)) or t0 < 0 or t0 + len(x) > nsamples:
                 raise ValueError('fragment of channel %d at sample %d does not fit the record' % (c, t0))
+        # overlapping traces (re-sent packets): ObsPy's merge rule, on the host, before the device sees them
+        frs = resolve_overlaps(frs)
         self.counts[station] = frs
         # chunk geometry only needs the extent: a zero-stride placeholder, no memory
         self.data[station] = (np.broadcast_to(np.float32(0), (len(self.channels), int(nsamples))),

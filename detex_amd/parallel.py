@@ -115,14 +115,8 @@ def plan_shard(bounds, sel):
 def rebase_fragments(frags, runs):
     """Fragments (channel, first sample, samples) of a station clipped to the runs of
     plan_shard and moved to compact-buffer coordinates."""
-    out = []
-    for (c, t0, x) in frags:
-        for (a, b, off) in runs:
-            lo, hi = max(t0, a), min(t0 + len(x), b)
-            if hi > lo:
-                out.append((c, off + lo - a, x[lo - t0:hi - t0]))
-    out.sort(key=lambda f: (f[0], f[1]))
-    return out
+    from .getdata import clip_fragments
+    return clip_fragments(frags, runs)
 
 
 def gather_rows(rows):

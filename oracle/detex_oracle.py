@@ -594,6 +594,33 @@ def merge_fill(frags, Nc, T):
     return planes
 
 
+def merge_fill_overlaps(frags, Nc, T):
+    """The same merge with OVERLAPPING traces, as ObsPy 1.0.2 resolves them (Stream.merge(method=0,
+    fill_value=0) -> Trace.__add__; third-party behaviour restated, ObsPy is not installable here): per
+    channel the traces in (start, end) order are added to a running trace; an overlap (partial, or a contained
+    trace) whose samples are all identical is kept once, otherwise the whole overlap is set to the fill value
+    0 -- and stays data for later additions.  Dense and sample-wise on purpose: the checker of
+    detex_amd.getdata.resolve_overlaps, which works on fragment lists."""
+    planes = np.zeros((Nc, T))
+    for c in range(Nc):
+        trs = sorted([(int(t0), np.asarray(x, dtype=np.float64)) for (cc, t0, x) in frags if cc == c and len(x)],
+                     key=lambda f: (f[0], f[0] + len(f[1])))
+        end = None                                       # one past the last sample of the running trace
+        for t0, x in trs:
+            e = t0 + len(x)
+            if end is None or t0 >= end:                 # first trace, gap (zeros between) or exact fit
+                planes[c, t0:e] = x
+                end = e
+                continue
+            lo, hi = t0, min(e, end)                     # the overlap with the running trace
+            if not np.array_equal(planes[c, lo:hi], x[:hi - lo]):
+                planes[c, lo:hi] = 0.0
+            if e > end:
+                planes[c, end:e] = x[end - t0:]
+                end = e
+    return planes
+
+
 def merge_channels_run(planes):
     """_mergeChannels (construct.py:1033-1066) on the merged planes: the product of the channels
     (1047-1049) masked where it is zero (1050), split into its contiguous unmasked pieces (1056),
@@ -615,8 +642,9 @@ def chunk_span(frags, Nc, s0, cnt):
     (first sample, length) of what is filtered and scanned, or None if the chunk is dropped.
 
     * ``len(st) > len(nc)`` (1005) -- some channel has several traces in the chunk: _mergeChannels
-      (1033-1066) on the zero-filled merge, longest run without a zero in any channel; if the kept
-      stretch still holds several traces of a channel: 'too fractured' (1009-1014) -> None.
+      (1033-1066) on the zero-filled merge (overlapping traces: merge_fill_overlaps), longest run without
+      a zero in any channel; if the kept stretch still holds several of the ORIGINAL traces of a channel:
+      'too fractured' (1009-1014) -> None; no zero inside the common span: the merged stream, whole.
     * otherwise the traces are NOT merged and zeros are ordinary samples: only the trim to
       [max start, min end] of 1019-1023.
     * a channel without any trace in the chunk: None (the build drops it; the reference would
@@ -632,13 +660,17 @@ def chunk_span(frags, Nc, s0, cnt):
         a = max(v[0][0] for v in per.values())
         b = min(v[0][1] for v in per.values())
         return (a, b - a) if b > a else None
-    merged = merge_fill([(c, t0 - s0, x) for (c, t0, x) in
+    merged = merge_fill_overlaps([(c, t0 - s0, x) for (c, t0, x) in
                          [(c, max(t0, s0), np.asarray(x)[max(t0, s0) - t0:min(t0 + len(x), s0 + cnt) - t0])
                           for (c, t0, x) in frags if min(t0 + len(x), s0 + cnt) > max(t0, s0)]], Nc, cnt)
     r0, rl = merge_channels_run(merged)
     if rl <= 0:
         return None
-    if (r0, rl) != (0, cnt):
+    # zeros are looked for inside the span all merged channels cover (construct.py:1039-1050); without one the
+    # merged stream goes on whole (1065-1066) and is trimmed to that span by 1019-1023
+    A = max(min(lo for lo, _ in v) for v in per.values())
+    B = min(max(hi for _, hi in v) for v in per.values())
+    if (s0 + r0, rl) != (A, B - A):
         a, b = s0 + r0, s0 + r0 + rl
         pieces = {}
         for (c, t0, x) in frags:

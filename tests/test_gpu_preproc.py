@@ -335,6 +335,73 @@ def test_detex_on_raw_counts_with_gaps(ctx):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and g.DS_STALTA == 0.0
 
 
+def test_detex_on_raw_counts_with_resent_packets(ctx):
+    """Overlapping (re-sent) packets in ContinuousFetcher.add_counts through the device path: resolved on the host
+    by ObsPy's merge rule (getdata.resolve_overlaps; restated, parity vs ObsPy unpinned), merged / trimmed /
+    filtered / scanned on the device -- against the oracle chain on the ORIGINAL traces, and the same detections
+    as a record that was delivered clean wherever the duplicates were identical."""
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
+    from detex_amd.getdata import multiplex
+    rs = np.random.RandomState(34)
+    sr, Nc, L = 20.0, 3, 160
+    filt = [1, 8, 2, True]
+    wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
+           for _ in range(Nc)]
+    wavf = orc.apply_filter([w.astype(np.float32) for w in wav], filt, sr)
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    for i in range(4):
+        ef.add('XX.STA', 'ev%d' % i, np.array([rs.uniform(.5, 2) * w + 0.02 * rs.standard_normal(L)
+                                                for w in wavf]), starttime=100. * i)
+    T = 36000                                            # chunks of 600 s (no buffer): 0, 12000, 24000
+    con = rs.standard_normal((Nc, T)) * 300
+    for t in (4000, 9000, 14000, 22000, 27000, 33000):
+        for c in range(Nc):
+            con[c, t:t + L] += 3000.0 * wav[c]
+    cnt = np.rint(con).astype(np.int32)
+    cnt[cnt == 0] = 1
+    bad = cnt[1, 18000:18400].copy()
+    bad[7] += 3
+    clean = [(0, 0, cnt[0, :12000]), (0, 12000, cnt[0, 12000:24000]), (0, 24000, cnt[0, 24000:]),
+             (1, 0, cnt[1, :12000]), (1, 12000, cnt[1, 12000:24000]), (1, 24000, cnt[1, 24000:]),
+             (2, 0, cnt[2, :12000]), (2, 12000, cnt[2, 12000:24000]),
+             (2, 24000, cnt[2, 24000:25000]), (2, 25100, cnt[2, 25100:])]
+    frags = clean + [(0, 5000, cnt[0, 5000:5600]),       # chunk 0: identical duplicate -> merged, scanned whole
+                     (1, 18000, bad),                    # chunk 1: differs -> overlap zero-filled -> longest stretch
+                     (1, 30000, cnt[1, 30000:30500])]    # chunk 2: hole + duplicate in the kept stretch -> too fractured
+
+    def run(fr):
+        cf = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=0)
+        cf.add_counts('XX.STA', fr, T, starttime=6.0e5)
+        cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, ctx=ctx)
+        ss = createSubSpace(clust=cl, conDatFetcher=cf)
+        ss.attachPickTimes(0.0, 6.0)
+        ss.SVD(selectCriteria=4, selectValue=0, threshold=0.35, useSingles=False)
+        return cf, ss, ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)['ss_df'].sort_values('STMP')
+
+    cf, ss, got = run(frags)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('XX.STA', useSingles=False)
+    merged = orc.merge_fill_overlaps(frags, Nc, T)
+    spans, want = [], []
+    for (s0, n, ts) in cf.chunk_bounds('XX.STA'):
+        sp = orc.chunk_span(frags, Nc, s0, n)
+        spans.append(sp)
+        if sp is None:
+            continue
+        a, m = sp
+        x = multiplex(orc.apply_filter([p.astype(np.float32) for p in merged[:, a:a + m]], filt, sr))
+        ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
+            want += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, ts + (a - s0) / sr)]
+    assert spans[:3] == [(0, 12000), (12000, 6000), None]
+    assert len(got) == len(want) >= 3
+    for (_, g), w in zip(got.iterrows(), sorted(want)):
+        assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5
+    # chunk 0 with its identical duplicate = chunk 0 of the clean record, bit for bit
+    _, _, ref = run(clean)
+    t1 = 6.0e5 + 600
+    assert got[got.STMP < t1][['STMP', 'DS']].values.tolist() == ref[ref.STMP < t1][['STMP', 'DS']].values.tolist()
+
+
 @pytest.mark.parametrize('dec', [None, 2])
 def test_raw_templates_and_raw_continuous_equal_prefiltered_run(ctx, dec):
     """f4 end to end: RAW template records + RAW continuous data through

@@ -620,6 +620,142 @@ def test_raw_counts_trimming_is_gated_like_applyFilter():
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5
 
 
+def test_resolve_overlaps_rule():
+    """Overlapping count fragments (re-sent telemetry packets) are resolved on the host as ObsPy's default merge
+    resolves them (construct.py:1038 / 1070 st.merge(fill_value=0.0) -> Trace.__add__, method 0): an overlap whose
+    samples are all identical is kept once, otherwise the whole overlap becomes the fill value 0.  ObsPy is not
+    installable here (parity vs ObsPy unpinned): the fragment-list implementation (getdata.resolve_overlaps) is
+    held to an independent dense restatement (oracle.merge_fill_overlaps) and to hand-written cases."""
+    from detex_amd.getdata import resolve_overlaps, trace_extents
+    a = np.arange(1, 21, dtype=np.int32)
+
+    def dense(frs, T=30):
+        out = np.zeros(T)
+        for (_, t0, x) in frs:
+            assert not out[t0:t0 + len(x)].any() or not np.any(x)      # non-overlapping
+            out[t0:t0 + len(x)] = x
+        return out
+    # identical partial overlap: AAAAAAAA + ....AAAAAAAA -> one trace
+    got = resolve_overlaps([(0, 0, a[:12]), (0, 8, a[8:20])])
+    assert np.array_equal(dense(got)[:20], a) and got.traces == [(0, 0, 12), (0, 8, 12)]
+    # differing partial overlap: the whole overlap (8..11) is zeroed, not just the sample that differs
+    b = a[8:20].copy()
+    b[1] += 5
+    want = a.astype(float).copy()
+    want[8:12] = 0
+    assert np.array_equal(dense(resolve_overlaps([(0, 0, a[:12]), (0, 8, b)]))[:20], want)
+    # contained trace: identical -> dropped; differing -> its extent zeroed
+    assert np.array_equal(dense(resolve_overlaps([(0, 0, a), (0, 5, a[5:9])]))[:20], a)
+    c = a[5:9].copy()
+    c[0] = 99
+    want = a.astype(float).copy()
+    want[5:9] = 0
+    assert np.array_equal(dense(resolve_overlaps([(0, 0, a), (0, 5, c)]))[:20], want)
+    # a third packet identical to the ORIGINAL data over a zeroed overlap now differs from the running trace
+    want[5:9] = 0
+    assert np.array_equal(dense(resolve_overlaps([(0, 0, a), (0, 5, c), (0, 5, a[5:9])]))[:20], want)
+    # no overlap: every trace comes back as it is -- abutting traces stay two traces (a seam is a seam)
+    got = resolve_overlaps([(1, 10, a[10:]), (1, 0, a[:10]), (0, 3, a[:4])])
+    assert [(c_, t0, len(x)) for c_, t0, x in got] == [(0, 3, 4), (1, 0, 10), (1, 10, 10)] and got.traces is None
+    assert trace_extents(got) == [(0, 3, 4), (1, 0, 10), (1, 10, 10)]
+    # random records against the dense restatement
+    rs = np.random.RandomState(0)
+    nover = 0
+    for trial in range(400):
+        Nc, T = int(rs.randint(1, 4)), int(rs.randint(30, 200))
+        base = rs.randint(1, 50, size=(Nc, T)).astype(np.int32)
+        frags = []
+        for ch in range(Nc):
+            for _ in range(int(rs.randint(1, 6))):
+                lo = int(rs.randint(0, T - 1))
+                hi = int(rs.randint(lo + 1, min(T, lo + 60) + 1))
+                x = base[ch, lo:hi].copy()
+                r = rs.rand()
+                if r < 0.3:
+                    x[rs.randint(len(x))] += 1
+                elif r < 0.4:
+                    x[:] = 0
+                frags.append((ch, lo, x))
+        got = resolve_overlaps(frags)
+        planes = np.zeros((Nc, T))
+        cover = np.zeros((Nc, T), int)
+        for (ch, t0, x) in got:
+            planes[ch, t0:t0 + len(x)] = x
+            cover[ch, t0:t0 + len(x)] += 1
+        assert cover.max() <= 1
+        assert np.array_equal(planes, orc.merge_fill_overlaps(frags, Nc, T)), trial
+        nover += got.traces is not None
+    assert nover > 200
+
+
+def test_raw_counts_with_resent_packets():
+    """A record with re-sent (overlapping) packets through ContinuousFetcher.add_counts -> SubSpace.detex on the
+    CPU stand-in, against the oracle's chunk_span -> filter -> DS chain on the ORIGINAL traces:
+    chunk 0: a duplicate packet, identical, no zero anywhere -> the merged chunk is scanned whole
+             (_mergeChannels finds no zero: `st = st1`, construct.py:1065-1066);
+    chunk 1: a packet that DIFFERS from the data it overlaps -> the overlap is zero-filled -> the longest
+             stretch beside it is kept;
+    chunk 2: a hole on one channel AND a duplicate packet inside the kept stretch -> the unmerged stream,
+             trimmed (construct.py:1064), still has two traces there -> 'Stream is too fractured' -> dropped."""
+    from detex_amd.getdata import multiplex
+    rs = np.random.RandomState(34)
+    sr, Nc, L = 20.0, 3, 160
+    filt = [1, 8, 2, True]
+    wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
+           for _ in range(Nc)]
+    wavf = orc.apply_filter([w.astype(np.float32) for w in wav], filt, sr)
+    ef = EventFetcher(sr, ['E', 'N', 'Z'])
+    for i in range(4):
+        ef.add('XX.STA', 'ev%d' % i, np.array([rs.uniform(.5, 2) * w + 0.02 * rs.standard_normal(L)
+                                                for w in wavf]), starttime=100. * i)
+    T = 36000                                            # chunks of 600 s (no buffer): 0, 12000, 24000
+    con = rs.standard_normal((Nc, T)) * 300
+    for t in (4000, 9000, 14000, 22000, 27000, 33000):
+        for c in range(Nc):
+            con[c, t:t + L] += 3000.0 * wav[c]
+    cnt = np.rint(con).astype(np.int32)
+    cnt[cnt == 0] = 1
+    bad = cnt[1, 18000:18400].copy()
+    bad[7] += 3
+    frags = [(0, 0, cnt[0, :12000]), (0, 12000, cnt[0, 12000:24000]), (0, 24000, cnt[0, 24000:]),
+             (1, 0, cnt[1, :12000]), (1, 12000, cnt[1, 12000:24000]), (1, 24000, cnt[1, 24000:]),
+             (2, 0, cnt[2, :12000]), (2, 12000, cnt[2, 12000:24000]),
+             (2, 24000, cnt[2, 24000:25000]), (2, 25100, cnt[2, 25100:]),          # chunk 2: a hole ...
+             (0, 5000, cnt[0, 5000:5600]),                                         # chunk 0: re-sent, identical
+             (1, 18000, bad),                                                      # chunk 1: re-sent, differs
+             (1, 30000, cnt[1, 30000:30500])]                                      # chunk 2: ... and a duplicate
+    cf = ContinuousFetcher(sr, ['E', 'N', 'Z'], conDatDuration=600, conBuff=0)
+    cf.add_counts('XX.STA', frags, T, starttime=6.0e5)
+    assert cf.counts['XX.STA'].traces is not None
+    ctx = OracleCtx()
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, filt=filt, ctx=ctx)
+    ss = createSubSpace(clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(0.0, 6.0)
+    ss.SVD(selectCriteria=4, selectValue=0, threshold=0.35, useSingles=False)
+    res = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False)
+    names, kinds, U, off, offsets, thr = ss._detector_bank('XX.STA', useSingles=False)
+    merged = orc.merge_fill_overlaps(frags, Nc, T)
+    spans, want = [], []
+    for (s0, n, ts) in cf.chunk_bounds('XX.STA'):
+        sp = orc.chunk_span(frags, Nc, s0, n)
+        spans.append(sp)
+        if sp is None:
+            continue
+        a, m = sp
+        x = multiplex(orc.apply_filter([p.astype(np.float32) for p in merged[:, a:a + m]], filt, sr))
+        ds = orc.mpxds_fft(x, U.astype(np.float32), Nc)
+        if orc.eval_trig_con(ds.max(), np.float32(thr['SS0'])):
+            want += [(t['STMP'], t['DS']) for t in orc.pick_triggers(ds, np.float32(thr['SS0']), sr, ts + (a - s0) / sr)]
+    assert spans[:3] == [(0, 12000), (12000, 6000), None], spans     # (chunk 1: 12000..17999 beats 18400..23999)
+    got = res['ss_df'].sort_values('STMP')
+    assert len(got) == len(want) >= 3
+    for (_, g), w in zip(got.iterrows(), sorted(want)):
+        assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5
+    # fillZeros: merged only (_mergeChannelsFill, construct.py:1069-1071) -- every chunk is scanned whole
+    resz = ss.detex(subspaceDB=None, ctx=ctx, estimateMags=False, fillZeros=True)
+    assert len(resz['ss_df']) >= 6
+
+
 def raw_event_records(seed=5, sr=40.0, Nc=3, nev=7, pre=30.0, post=50.0):
     """Unprocessed records around template events (two families + a loner): drifting offsets, a slow trend
     and noise on top of band-limited wavelets; origin `pre` seconds into each record."""
