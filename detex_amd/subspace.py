@@ -41,11 +41,11 @@ class Cluster(object):
     def _makeDFLINK(self):
         """subspace.py:385-412: the merges as rows {i1, i2, disSim, num, clust} (clust = the node a merge
         creates).  The member lists the reference keeps with every row ('II') are not materialised: for a
-        single-linkage chain of N events they hold N^2 / 2 indices (98 ms at 2000 events); ``members(node)``
-        walks the tree on demand."""
+        single-linkage chain of N events they hold N^2 / 2 indices (98 ms at 2000 events); ``row['II']`` (and
+        ``members(node)``) walk the tree when asked."""
         N = len(self.link)
-        return [dict(i1=int(self.link[a, 0]), i2=int(self.link[a, 1]), disSim=self.link[a, 2],
-                     num=self.link[a, 3], clust=N + 1 + a) for a in range(N)]
+        return [_LinkRow(self, i1=int(self.link[a, 0]), i2=int(self.link[a, 1]), disSim=self.link[a, 2],
+                         num=self.link[a, 3], clust=N + 1 + a) for a in range(N)]
 
     def members(self, node):
         """Leaves (positions in ``key``) under a dendrogram node: the reference's dflink.II of that merge."""
@@ -316,6 +316,21 @@ def _merge_ranks(parts, names_order=None):
     return out
 
 
+class _LinkRow(dict):
+    """One merge of Cluster.dflink.  'II' -- the member list the reference stores with every row
+    (subspace.py:392-406) -- is computed on first access instead of for all rows up front."""
+
+    def __init__(self, cluster, **kw):
+        dict.__init__(self, **kw)
+        self._cluster = cluster
+
+    def __missing__(self, key):
+        if key != 'II':
+            raise KeyError(key)
+        self['II'] = self._cluster.members(self['clust'])
+        return self['II']
+
+
 class _DbWriter(object):
     """The SQLite file of a SubSpace.detex call, written by a thread of its own: the detection rows of
     every finished unit are queued and appended there while the next units are scanned (the reference
@@ -337,6 +352,8 @@ class _DbWriter(object):
 
     def put(self, table, rows):
         """rows: a list of row lists in COLS order, or a DataFrame with those columns"""
+        if self.error is not None:                          # the writer thread has died: say so now, not at close()
+            raise self.error
         if rows is not None and len(rows):
             if isinstance(rows, pd.DataFrame):
                 rows = rows[self.COLS].values.tolist()
@@ -755,7 +772,9 @@ class SubSpace(object):
             if isinstance(utcSaves, (str, bytes)) or not hasattr(utcSaves, '__iter__'):
                 _error('UTCSaves must be a list or tupple')
             try:
-                utc = np.array([float(getattr(x, 'timestamp', x)) for x in utcSaves], dtype=np.float64)
+                # epoch seconds, ObsPy UTCDateTime (.timestamp is a property) or datetime (.timestamp() a method)
+                stamps = [getattr(x, 'timestamp', x) for x in utcSaves]
+                utc = np.array([float(t() if callable(t) else t) for t in stamps], dtype=np.float64)
             except (TypeError, ValueError):
                 _error('Not all elements in utcSaves are readable as epoch seconds')
         if classifyEvents is None and self.cfetcher is None:
@@ -779,7 +798,7 @@ class SubSpace(object):
             if classifyEvents is not None:
                 # detect.py:51-55, 151-152: the detectors run over the event waveforms of the cluster's
                 # own event fetcher instead of over continuous data
-                fetcher = self._event_chunks(classifyEvents, device if own_ctx else None, ctx)
+                fetcher = self._event_chunks(classifyEvents, device if own_ctx else None, ctx, fillZeros)
             stations = [sta for sta in self.Stations if sta in fetcher.data]
             bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
             banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
@@ -911,12 +930,15 @@ class SubSpace(object):
             out['utc_saves'] = self._utc_saves(stations, results, rank)
         return out
 
-    def _event_chunks(self, classifyEvents, device, ctx):
+    def _event_chunks(self, classifyEvents, device, ctx, fillZeros=False):
         """The events a classifyEvents run scans, as one chunk each (getdata.EventChunks).  classifyEvents:
         a template key -- DataFrame with a NAME column or the path of such a csv -- or a list of event names,
         or True for every event of the cluster's event fetcher (the reference reads the key and asks that
-        fetcher for the events in it, detect.py:51-55).  Raw records are cut / decimated / filtered like the
-        templates were (clusters.trim / decimate / filt)."""
+        fetcher for the events in it, detect.py:51-55).  Raw records are cut to the cluster's trim window and go
+        through what the reference applies to every chunk it scans, events included (detect.py:231:
+        _applyFilter(st, filt, decimate, dtype, fillZeros=<the detex call's>)) -- NOT through createCluster's
+        template rules (enforceOrigin, the short / all-zero waveform drops of construct.py:884-922): the
+        reference does not apply those here either."""
         from . import construct
         from .getdata import EventChunks
         ef = self.clusters.fetcher
@@ -932,14 +954,17 @@ class SubSpace(object):
             wanted = set(str(v) for v in classifyEvents)
         cl = self.clusters
         dec = int(cl.decimate or 1)
-        out = EventChunks(ef.sampling_rate / (dec if ef.has_raw() else 1), ef.channels)
-        for sta in ef.stations():
-            if sta not in self.Stations:
-                continue
+        stas = [sta for sta in ef.stations() if sta in self.Stations]
+        rawness = set(bool(ef.has_raw(sta)) for sta in stas)
+        if dec > 1 and len(rawness) > 1:
+            # (EventChunks runs at ONE rate: a decimated raw station beside a pre-processed one would get the wrong one)
+            _error('classifyEvents: the event fetcher mixes raw and pre-processed stations under decimate=%d' % dec)
+        out = EventChunks(ef.sampling_rate / (dec if True in rawness else 1), ef.channels)
+        for sta in stas:
             if ef.has_raw(sta):
                 own = ctx is None
                 c = self._station_ctx(device, sta) if own else ctx
-                done = construct._preprocess_events(c, ef, sta, cl.filt, cl.trim, cl.decimate)
+                done = construct._preprocess_events(c, ef, sta, cl.filt, cl.trim, cl.decimate, fillZeros)
             else:
                 done = [(nm, rec['data'], rec['starttime']) for nm, rec in ef.getTemData(sta)]
             out.add(sta, [(nm, d, t) for (nm, d, t) in done if wanted is None or nm in wanted])

@@ -908,6 +908,15 @@ def test_utcSaves_rows_match_the_reference_layout(tmp_path, monkeypatch):
     assert plain['ss_df'].values.tolist() == res['ss_df'].values.tolist() and 'utc_saves' not in plain
     with pytest.raises(Exception):
         ss.detex(subspaceDB=None, ctx=ctx, utcSaves='2015-01-01')
+    # a datetime (timestamp() is a method) and an ObsPy-style object (timestamp is a property) read alike
+    import datetime
+
+    class _UTC(object):
+        timestamp = t_in
+    dt = datetime.datetime.fromtimestamp(t_in, tz=datetime.timezone.utc)
+    for form in (dt, _UTC()):
+        r2 = ss.detex(subspaceDB=None, useSingles=True, ctx=ctx, utcSaves=[form])
+        assert len(r2['utc_saves']) % len(df) == 0 and len(r2['utc_saves']) > 2 * len(df)
 
 
 def pd_read(path):
@@ -1064,3 +1073,15 @@ def test_dendrogram_cut_equals_the_subset_form(seed):
         assert c.clusts == clusts and c.singles == singles and c.clustlinks == clustlinks, (seed, ccReq)
         assert c.clustcount == sum(len(x) for x in clusts)
     assert sorted(c.members(2 * len(link))) == list(range(N))          # the root holds every leaf
+    # dflink rows answer 'II' like the reference's frame (subspace.py:392-411: members of i1, then of i2), lazily;
+    # a pickled cluster keeps them
+    import pickle
+    mem = {i: [i] for i in range(N)}
+    for a in range(len(link)):
+        mem[N + a] = mem[int(link[a, 0])] + mem[int(link[a, 1])]
+    c2 = pickle.loads(pickle.dumps(c))
+    for a in (0, len(link) // 2, len(link) - 1):
+        assert 'II' not in dict.keys(c.dflink[a])
+        assert c.dflink[a]['II'] == mem[N + a] == c2.dflink[a]['II']
+    with pytest.raises(KeyError):
+        c.dflink[0]['nope']
