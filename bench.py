@@ -352,8 +352,29 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
         t1 = time.perf_counter()
         ctx.xcorr_allpairs(tds, Nc)
         ctx.sync()
-        short = {'seconds': time.perf_counter() - t1, 'kernel_ms': ctx.last_kernel_ms(),
-                 'workload': 'configs[2] short variant: %d events, Nc=%d, L=3000 (n=%d)' % (N, Nc, 3000 * Nc)}
+        ks = ctx.last_kernel_ms()
+        Ls = 3000
+        Ss = Ls - Ls // 2
+        b_s = 4.0 * N * Nc * Ls + 12.0 * npairs
+        short = {'seconds': time.perf_counter() - t1, 'kernel_ms': ks, 'value': npairs / (time.perf_counter() - t1),
+                 'unit': 'pairs/s',
+                 'workload': 'configs[2] short variant: %d events, Nc=%d, L=3000 (n=%d)' % (N, Nc, 3000 * Nc),
+                 # one segment, one lag block (3001 lags in a block of 8192): one transform and Nc products per event pair;
+                 # outside the lag search: the float64 finish (xc_finish2_kernel) + preparation, seconds - kernel_ms
+                 'outside_lag_search_ms': 1e3 * (time.perf_counter() - t1) - ks,
+                 'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel<6>', 'kernel_ms': ks, 'bytes_per_launch': b_s,
+                              'achieved': b_s / (ks * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                              'frac': b_s / (ks * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                              'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
+                                          'issued': (npairs / 2.0) * (5.0 * 8192 * 13 + Nc * 8.0 * 8192) / (ks * 1e-3) / 1e12,
+                                          'contraction_equivalent': 2.0 * Nc * ((2 * Ss + 1) * Ls - Ss * (Ss + 1)) * npairs
+                                          / (ks * 1e-3) / 1e12}}}
+        if cpu:
+            from oracle import cpu_bench
+            try:
+                short['cpu_baseline'] = cpu_bench.xcorr_onecore(tds.cpu().numpy(), Nc, npairs=2000)
+            except Exception as e:                      # noqa: BLE001
+                short['cpu_baseline'] = dict(value=None, unit='pairs/s', error=repr(e))
         del tds
     except Exception as e:                              # noqa: BLE001 -- an extra never takes the line down
         short = {'error': repr(e)}
@@ -458,13 +479,190 @@ def config5(ctx, synth):
     ctx.set_engine('auto')
     P = T - L + 1
     flops = 2.0 * K * n * P
+    # a DAY per call, the way configs[1] hands its 24 chunks over: 24 hourly chunks (views of one buffer would do; here
+    # the hour repeated) in ONE dtx_subspace_scan -- preparation kernels and launch boundaries are paid once per day
+    day = None
+    try:
+        ctx.upload_basis(U, off, Nc)
+        xd = xt.reshape(1, -1).expand(24, -1).contiguous()
+        dsd, rd = ctx.subspace_scan(xd, thr=thr)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dsd, rd = ctx.subspace_scan(xd, out=dsd, thr=thr)
+        ctx.sync()
+        dtd = (time.perf_counter() - t1) / 3
+        kd = ctx.last_kernel_ms()
+        day = {'value': 24 * P / dtd, 'unit': 'windows/s', 'ms_per_hour_of_data': 1e3 * dtd / 24, 'kernel_ms_per_hour': kd / 24,
+               'step_over_kernel': 1e3 * dtd / kd, 'hours_per_call': 24}
+        del xd, dsd, rd
+    except Exception as e:                              # noqa: BLE001 -- an extra never takes the line down
+        day = {'error': repr(e)}
+    ka = res['auto'][1]
+    b_alg = (4.0 * Nc + 4.0) * P                        # the stream once + one detector's DS once
+    nblk5 = -(-P // ((8192 - L + 1) // 512 * 512))
+    flop_fft = (K / 2) * nblk5 * (5.0 * 8192 * 13 + 8.0 * Nc * 8192)
     return {'value': P / res['auto'][0], 'unit': 'windows/s', 'ms_per_hour_of_data': 1e3 * res['auto'][0],
-            'kernel_ms': res['auto'][1],
+            'kernel_ms': res['auto'][1], 'step_over_kernel': 1e3 * res['auto'][0] / res['auto'][1],
+            'day_per_call': day,
+            'roofline': {'bound': 'hbm', 'kernel': 'ds_fft_kernel<14,false,6>', 'kernel_ms': ka, 'bytes_per_launch': b_alg,
+                         'achieved': b_alg / (ka * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': b_alg / (ka * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                         'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
+                                     'issued': flop_fft / (ka * 1e-3) / 1e12,
+                                     'frac': flop_fft / (ka * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                     'contraction_equivalent': flops / (ka * 1e-3) / 1e12},
+                         'note': 'frequency-domain engine, block spectra streamed (6 channels do not fit beside the image): '
+                                 '%d transforms of 8192 points per launch; 28 algorithmic bytes per window' % ((K // 2) * nblk5)},
             'workload': 'configs[4]: 500 Hz, 6 channels, K=64, n=6000, 1 h (%d windows)' % P,
             'fp32_mfma_engine': {'value': P / res['fp32'][0], 'unit': 'windows/s', 'kernel_ms': res['fp32'][1],
                                  'roofline': {'bound': 'mfma', 'achieved': flops / (res['fp32'][1] * 1e-3) / 1e12,
                                               'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                               'frac': flops / (res['fp32'][1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}}
+
+
+def config2_singles(ctx, synth, a, xt, M, Nc, n, cpu_rate=None):
+    """SURVEY 8d's variant of configs[1]: the same 200 vectors as 200 single-vector detectors (useSingles,
+    detect.py:319-388, subspace.py:1871-1880) -- 200 DS rows per window instead of 25.  Here the DS tensor is real HBM
+    traffic: 812 B per window, 7.2 GB per station-day written by the scan and read once more by the post pass."""
+    D = a.detectors * a.basis_per_detector
+    U, off = synth.detector_bank(1, D, 1, n)
+    ctx.upload_basis(U, off, Nc)
+    P = ctx.num_windows(M)
+    ldp = (P + 63) // 64 * 64
+    ds = torch.empty((a.chunks, D, ldp), dtype=torch.float32, device='cuda')[:, :, :P]
+    thr = torch.full((D,), 0.3, dtype=torch.float32, device='cuda')
+    hist = torch.zeros((D, 400), dtype=torch.int32, device='cuda')
+    for _ in range(3):
+        ctx.subspace_scan(xt, out=ds, thr=thr, hist=hist, lazy=True)[1]()
+    torch.cuda.synchronize()
+    steps = 10
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(steps):
+        f = ctx.subspace_scan(xt, out=ds, thr=thr, hist=hist, lazy=True)[1]
+        if pending is not None:
+            pending()
+        pending = f
+    pending()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kms = ctx.kernel_ms_mean(steps)
+    # the post pass alone (histogram / maxima / candidates over the finished tensor): timed apart, HIP events
+    ctx.timer_start()
+    for _ in range(3):
+        ctx.ds_post(ds, thr=thr, hist=hist)
+    post_ms = ctx.timer_stop() / 3
+    W = a.chunks * P
+    b_scan = (4.0 * Nc + 4.0 * D) * W                 # stream once + DS written once (SURVEY 8d: 812 B per window)
+    b_post = 4.0 * D * W                              # DS read once more
+    out = {'value': W / dt, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt, 'kernel_ms': kms, 'post_ms': post_ms,
+           'workload': 'configs[1] as singles: %d detectors x 1 vector x %d chunks, n=%d; DS tensor %.2f GB'
+                       % (D, a.chunks, n, 4.0 * D * W / 1e9),
+           'roofline': {'bound': 'hbm', 'kernel': 'ds_fft_pp_kernel<10,false,3> + ds_post_kernel',
+                        'bytes_per_launch': b_scan + b_post, 'kernel_ms': kms + post_ms,
+                        'achieved': (b_scan + b_post) / ((kms + post_ms) * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': (b_scan + b_post) / ((kms + post_ms) * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                        'scan': {'bytes': b_scan, 'ms': kms, 'GBps': b_scan / (kms * 1e-3) / 1e9,
+                                 'frac': b_scan / (kms * 1e-3) / 1e9 / 8000.0},
+                        'post': {'bytes': b_post, 'ms': post_ms, 'GBps': b_post / (post_ms * 1e-3) / 1e9,
+                                 'frac': b_post / (post_ms * 1e-3) / 1e9 / 8000.0},
+                        'step': {'bytes': b_scan + b_post, 'ms': 1e3 * dt, 'GBps': (b_scan + b_post) / dt / 1e9,
+                                 'frac': (b_scan + b_post) / dt / 1e9 / 8000.0}}}
+    if cpu_rate:
+        # the reference's cost per (basis vector, chunk) does not depend on how the vectors are grouped into
+        # detectors (one IFFT per vector, detect.py:559-578): the configs[1] CPU figure applies as it is
+        out['cpu_baseline'] = {'value': cpu_rate, 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'the configs[1] sample (same 200 vectors, one IFFT per vector and chunk)'}
+    del ds
+    return out
+
+
+def e2e_createcluster(local, cpu=True):
+    """BASELINE configs[2] through the PRODUCT API: createCluster on an EventFetcher of 2000 events x 3 x 13000
+    samples (one station) -- event matrix, upload, kernels, download, the three 1999 x 1999 frames, SciPy single
+    linkage of 1 999 000 dissimilarities, Cluster.updateReqCC -- with the seconds of every phase
+    (ClusterStream.timings)."""
+    from detex_amd import EventFetcher, createCluster, synth
+    N, Nc, L = 2000, 3, 13000
+    td = synth.event_families(2, 100, 20, Nc, L)
+    out = {'workload': 'configs[2] through createCluster: %d events, Nc=%d, L=%d, one station, saveclust=False'
+                       % (N, Nc, L), 'unit': 'pairs/s'}
+    npairs = N * (N - 1) // 2
+    for dtype in ('single', 'double'):
+        ef = EventFetcher(100.0, ['HHE', 'HHN', 'HHZ'])
+        for e in range(N):
+            ef.add('TA.M17A', 'ev%04d' % e, td[e].reshape(L, Nc).T, starttime=1000.0 + 200.0 * e,
+                   origintime=990.0 + 200.0 * e, magnitude=1.0)
+        createCluster(CCreq=0.5, fetch_arg=ef, device=local, saveclust=False, dtype=dtype)      # warm: workspaces
+        times, last = [], None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            last = createCluster(CCreq=0.5, fetch_arg=ef, device=local, saveclust=False, dtype=dtype)
+            times.append(time.perf_counter() - t0)
+        dt = min(times)
+        out[dtype] = {'seconds': dt, 'value': npairs / dt, 'calls_s': times,
+                      'phases_s': {k: round(v, 4) for k, v in last.timings.items()},
+                      'clusters': len(last[0].clusts), 'singles': len(last[0].singles)}
+        del ef, last
+    out['value'] = out['double']['value']                  # the reference's default dtype
+    out['seconds'] = out['double']['seconds']
+    if cpu:
+        from oracle import cpu_bench
+        try:
+            out['cpu_baseline'] = cpu_bench.xcorr_onecore(td, Nc, npairs=200)
+            out['cpu_baseline']['note'] = ('the reference spends its time in _CCX2 (32 ms per pair measured in the build '
+                                           'container, SURVEY 8a): pairs/s of the kernel leg is the comparable figure')
+        except Exception as e:                              # noqa: BLE001
+            out['cpu_baseline'] = dict(value=None, unit='pairs/s', error=repr(e))
+    return out
+
+
+def e2e_fas(local, cpu_rate=None):
+    """SubSpace.getFAS(conDatNum=100) (subspace.py:1652-1743 -> fas._initFAS, fas.py:23-117) for the 25 detectors of
+    one station over a 5-day record (120 hourly chunks, 100 of them sampled): STA/LTA screen of every candidate
+    chunk on the host, the detection statistic of every detector on every chosen chunk (the scan's kernel),
+    histogram + beta-fit moments on the device, 25 beta fits (SciPy) on the host."""
+    from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace, synth
+    SR, NC, L, NFAM, NPER, NDAY = 100.0, 3, 3300, 25, 8, 5
+    rs = np.random.RandomState(3)
+    td = synth.event_families(1, NFAM, NPER, NC, L, maxshift=20, snr=8.0)
+    ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    for e in range(len(td)):
+        ef.add('TA.M17A', 'ev%03d' % e, td[e].reshape(L, NC).T, starttime=1000.0 + 100 * e,
+               origintime=990.0 + 100 * e, magnitude=1.0)
+    T = int(NDAY * 24 * 3600 * SR)
+    con = rs.standard_normal((NC, T)).astype(np.float32)
+    cf = ContinuousFetcher(SR, ['HHE', 'HHN', 'HHZ'])
+    cf.add('TA.M17A', con, starttime=1.5e9 - 1.5e9 % 3600)
+    cl = createCluster(CCreq=0.5, fetch_arg=ef, device=local, saveclust=False)
+    ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
+    ss.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
+    ss.SVD(selectCriteria=4, selectValue=7, threshold=0.3, useSingles=False)
+    ss.getFAS(100, recalc=True, device=local, seed=0)                  # warm
+    torch.cuda.synchronize()
+    times = []
+    for k in range(3):
+        t0 = time.perf_counter()
+        ss.getFAS(100, recalc=True, device=local, seed=k)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
+    n = U.shape[1]
+    P = (int(round(3720.0 * SR)) * NC - n) // NC + 1
+    fas0 = ss.subspaces['TA.M17A'].FAS.iloc[0]
+    out = {'seconds': dt, 'calls_s': times, 'value': 100 * P / dt, 'unit': 'windows/s',
+           'workload': 'getFAS(conDatNum=100): %d detectors (%d vectors, n=%d) x 100 chunks of 3720 s drawn from %d, '
+                       'one station' % (len(names), U.shape[0], n, len(cf.chunk_bounds('TA.M17A'))),
+           'ms_per_chunk': 1e3 * dt / 100, 'beta_first_detector': [float(v) for v in fas0['betadist'][:2]],
+           'windows_in_histogram': int(np.sum(fas0['hist']))}
+    if cpu_rate:
+        # fas._MPXSSCorr is the bit-equal twin of _MPXDS (fas.py:120-134): the reference's cost is the scan's
+        out['cpu_baseline'] = {'value': cpu_rate * 200.0 / U.shape[0], 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'the configs[1] sample scaled to %d vectors (one IFFT per vector and chunk)'
+                                         % U.shape[0]}
+    return out
 
 
 def e2e_detex(local):
@@ -981,6 +1179,14 @@ def main():
         out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, min(a.steps, 50))
         out['xcorr_full'] = xcorr_full(ctx, synth, Nc, cpu=not a.no_cpu_baseline)
         out['config5'] = config5(ctx, synth)
+        try:
+            del ds
+            torch.cuda.empty_cache()
+            out['config2_singles'] = config2_singles(ctx, synth, a, xt, M, Nc, n)
+        except Exception as e:                         # noqa: BLE001 -- a secondary field never takes the line down
+            out['config2_singles'] = {'value': None, 'error': repr(e)}
+        torch.cuda.empty_cache()
+        ds = None
         ctx.upload_basis(Ut, det_off, Nc)
         # BASELINE configs[3] at its real size on this one GPU: the N = 1 anchor of the strong-scaling curve
         # (the driver measures N = 2, 4, 8 with --config 4 --gpus N)
@@ -988,7 +1194,6 @@ def main():
             import copy
             a4 = copy.copy(a)
             a4.config, a4.steps, a4.warmup, a4.stations, a4.days = 4, 2, 1, 8, 30
-            del ds
             torch.cuda.empty_cache()
             c4 = run_config4(a4, 0, 1, local, False)
             out['config4_n1'] = {'value': c4['value'], 'unit': c4['unit'], 'ms_per_step': c4['ms_per_step'],
@@ -996,6 +1201,15 @@ def main():
                                  'ms_per_station_day': c4['ms_per_step'] / 240.0, 'config': c4['config']}
         except Exception as e:                         # noqa: BLE001 -- a secondary field never takes the line down
             out['config4_n1'] = {'value': None, 'error': repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            out['e2e_createCluster_2000'] = e2e_createcluster(local, cpu=not a.no_cpu_baseline)
+        except Exception as e:                         # noqa: BLE001
+            out['e2e_createCluster_2000'] = {'value': None, 'error': repr(e)}
+        try:
+            out['e2e_fas'] = e2e_fas(local)
+        except Exception as e:                         # noqa: BLE001
+            out['e2e_fas'] = {'value': None, 'error': repr(e)}
         torch.cuda.empty_cache()
         try:
             out['e2e_detex'] = e2e_detex(local)
@@ -1011,6 +1225,18 @@ def main():
         if default_cfg and not a.no_extras:
             out['cpu_baseline']['all_cores'] = cpu_baseline_allcores(Uh, det_off, x, Nc,
                                                                      onecore_rate=out['cpu_baseline']['value'])
+            # the same reference arithmetic prices the singles variant and the FAS (one IFFT per vector and chunk)
+            rate = out['cpu_baseline']['value']
+            if isinstance(out.get('config2_singles'), dict) and out['config2_singles'].get('value'):
+                out['config2_singles']['cpu_baseline'] = {
+                    'value': rate, 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+                    'sample': 'the configs[1] sample: the same 200 vectors, one IFFT per vector and chunk however they '
+                              'are grouped into detectors (detect.py:559-578)'}
+            if isinstance(out.get('e2e_fas'), dict) and out['e2e_fas'].get('value'):
+                out['e2e_fas']['cpu_baseline'] = {
+                    'value': rate, 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+                    'sample': 'the configs[1] sample: fas._MPXSSCorr is the bit-equal twin of _MPXDS (fas.py:120-134), '
+                              '200 vectors per chunk here too'}
     else:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -196,6 +196,33 @@ def _frames_from_condensed(N, cc, lag, ss):
     return out[0], out[1], out[2]
 
 
+# seconds per phase of the last createCluster call in this process (ClusterStream.timings; bench.py's
+# e2e_createCluster_2000 leg): plain perf_counter stamps around the phases, device work synchronised at their ends
+_PHASES = {}
+
+
+class _phase(object):
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        _PHASES[self.name] = _PHASES.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
+def _sync_copy(ctx):
+    """Wait for the copies torch queued on its current stream of the context's device (phase timing only)."""
+    import torch
+    dev = getattr(ctx, 'device', None)
+    if dev is not None and str(dev).startswith('cuda') and torch.cuda.is_available():
+        torch.cuda.current_stream(dev).synchronize()
+
+
 def _makeDFcclags(eventList, row, ctx):
     """construct.py:369-394 on the GPU: all pairs b < c of ``eventList`` in one
     dtx_xcorr_allpairs call.  Returns (DFcc, DFlag, DFsubsamp)."""
@@ -207,9 +234,18 @@ def _makeDFcclags(eventList, row, ctx):
     from . import parallel
     Nc = len(row.Channels[eventList[0]])
     N = len(eventList)
-    td = np.empty((N, len(row.MPtd[eventList[0]])), dtype=np.float32)      # (row by row: a list of 2000 float64
-    for i, e in enumerate(eventList):                                       # arrays through ascontiguousarray: 1.2 s)
-        td[i] = row.MPtd[e]
+    with _phase('fill'):
+        # the event matrix, assembled in page-locked memory (row by row: a list of 2000 float64 arrays through
+        # ascontiguousarray took 1.2 s); its upload then runs at the link's rate instead of through a pageable
+        # staging copy
+        n = len(row.MPtd[eventList[0]])
+        try:
+            tdt = torch.empty((N, n), dtype=torch.float32, pin_memory=True)
+        except RuntimeError:                                                # (no GPU runtime: the CPU stand-in of the tests)
+            tdt = torch.empty((N, n), dtype=torch.float32)
+        td = tdt.numpy()
+        for i, e in enumerate(eventList):
+            td[i] = row.MPtd[e]
     rank, world = parallel.dist_info()
     if parallel.dist_active():
         # one process per GPU: every rank correlates a contiguous range of the condensed pair
@@ -217,13 +253,24 @@ def _makeDFcclags(eventList, row, ctx):
         npairs = N * (N - 1) // 2
         ranges = [parallel.shard_pairs(npairs, r, world) for r in range(world)]
         b, e = ranges[rank]
-        cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc, b, e)
-        ctx.sync()
+        with _phase('h2d'):
+            tdev = tdt.to(ctx.device, non_blocking=True)
+            _sync_copy(ctx)
+        with _phase('kernels'):
+            cc, lag, ss = ctx.xcorr_allpairs(tdev, Nc, b, e)
+            ctx.sync()
         cc, lag, ss = (parallel.gather_condensed(v, ranges, npairs, ctx.device) for v in (cc, lag, ss))
     else:
-        cc, lag, ss = ctx.xcorr_allpairs(torch.from_numpy(td).to(ctx.device), Nc)
-        ctx.sync()
-    return _frames_from_condensed(N, cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy())
+        with _phase('h2d'):
+            tdev = tdt.to(ctx.device, non_blocking=True)
+            _sync_copy(ctx)
+        with _phase('kernels'):
+            cc, lag, ss = ctx.xcorr_allpairs(tdev, Nc)
+            ctx.sync()
+    with _phase('d2h'):
+        cc, lag, ss = cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy()
+    with _phase('frames'):
+        return _frames_from_condensed(N, cc, lag, ss)
 
 
 def fast_normcorr(t, s, ctx=None, device=None):
@@ -310,8 +357,12 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
             from . import parallel
             device = parallel.local_device()
         ctx = HipContext(device)
+    import time
+    _PHASES.clear()
+    t_all = time.perf_counter()
     try:
-        TRDF = _loadEvents(fetch_arg, dtype, filt, trim, decimate, enforceOrigin, fillZeros, ctx)
+        with _phase('load_events'):
+            TRDF = _loadEvents(fetch_arg, dtype, filt, trim, decimate, enforceOrigin, fillZeros, ctx)
         if len(TRDF) < 1:
             _error('No events survived pre-processing, check DataFetcher and event quality')
         if eventsOnAllStations:
@@ -327,8 +378,9 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
             TRDF.at[ind, 'Lags'] = DFlag
             TRDF.at[ind, 'CCs'] = DFcc
             TRDF.at[ind, 'Subsamp'] = DFsubsamp
-            cx = _flatNoNan(1.0000001 - DFcc)                  # construct.py:153-156
-            TRDF.at[ind, 'Link'] = linkage(cx)                 # default: single
+            with _phase('linkage'):
+                cx = _flatNoNan(1.0000001 - DFcc)              # construct.py:153-156
+                TRDF.at[ind, 'Link'] = linkage(cx)             # default: single
     finally:
         if own:
             ctx.close()
@@ -337,15 +389,18 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
     if len(keep) < 1:
         _error('Less than 2 valid events on every station')
     eventListAll = sorted(set.union(*[set(x) for x in keep.Events]))
-    clust = ClusterStream(keep[colstk], templateKey, stationKey, fetch_arg, eventListAll,
-                          CCreq, filt, decimate, trim, fileName, eventsOnAllStations,
-                          enforceOrigin)
+    with _phase('cluster_stream'):                             # Cluster objects: updateReqCC on every station
+        clust = ClusterStream(keep[colstk], templateKey, stationKey, fetch_arg, eventListAll,
+                              CCreq, filt, decimate, trim, fileName, eventsOnAllStations,
+                              enforceOrigin)
     clust._mptd = {r.Station: r.MPtd for _, r in TRDF.iterrows()}
     clust._channels = {r.Station: r.Channels for _, r in TRDF.iterrows()}
     if saveclust:
         from . import parallel
         if parallel.dist_info()[0] == 0:       # one process per GPU: rank 0 writes the pickle
-            clust.write()
+            with _phase('write_pickle'):
+                clust.write()
+    clust.timings = dict(_PHASES, total=time.perf_counter() - t_all)
     return clust
 
 

@@ -119,7 +119,15 @@ __global__ __launch_bounds__(kT) void xc_wspec_kernel(const float* __restrict__ 
 #endif
 #ifndef DTX_XC_ABLATE
 #define DTX_XC_ABLATE 0      // timing-only ablations (results are wrong): 1 no pair-spectrum loads, 2 no block-spectrum loads,
-                             // 4 no epilogue (normalise / max / atomics), 8 no transforms, 16 epilogue without the atomics
+                             // 4 no epilogue (normalise / max / atomics), 8 no transforms, 16 epilogue without the atomics,
+                             // 32 (2 x 2 kernel): what ONE lag block on a 16 384-point transform would cost --
+                             //    only lag block 0 is launched, its product loop runs DTX_XC_A16_STEPS steps (24 = the MACs of
+                             //    12 double-length steps, 32 = their L1 traffic: 256 KB per 32 768 MACs against 192 KB here),
+                             //    every finish runs TWO transforms (2 x 14 / 13 of one is priced on top by hand) and searches
+                             //    three blocks' worth of lags
+#endif
+#ifndef DTX_XC_A16_STEPS
+#define DTX_XC_A16_STEPS 24
 #endif
 struct XcFftArgs {
   const c32* xh;        // [N][nblk][nseg][Nc][kXh] block spectra of the padded planes of every event
@@ -422,7 +430,11 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   const int tid = threadIdx.x, hf = tid >> 9, ht = tid & 511;
   const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
   if (logical >= a.nwork) return;
+#if DTX_XC_ABLATE & 32
+  const int item = (int)logical, blk = 0;
+#else
   const int item = (int)(logical / a.nblk), blk = (int)(logical - (int64_t)item * a.nblk);
+#endif
   const int2 it = a.items[item];
   const int c0 = it.x, has1 = (it.y >> 30) & 1, pr0 = it.y & 0x3fffffff;
   const int c1 = has1 ? c0 + 1 : c0;                       // (without a second event: the first again, its rows dead)
@@ -432,7 +444,11 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   const LdsBases lb = lds_bases(ht);
   const int p0 = blk * a.V;
   const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+#if DTX_XC_ABLATE & 32
+  const int nsteps_real = a.Nc * nse, nsteps = DTX_XC_A16_STEPS;
+#else
   const int nsteps = a.Nc * nse;
+#endif
   const int64_t xstride = (int64_t)a.nblk * a.nseg * a.Nc * kXh;
   const c32* xhh = a.xh + (hf ? c1 : c0) * xstride + (int64_t)blk * a.nseg * a.Nc * kXh;   // the event this half stages
   const int wv = ht >> 6, ln = ht & 63;
@@ -446,11 +462,17 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && ht == 0) ? 0 : xhi - 64 * r); };
   const int nvc = a.Nc * a.nseg;
   auto xsrc = [&](int i) {
+#if DTX_XC_ABLATE & 32
+    i %= nsteps_real;
+#endif
     const int ch = i / nse, sg = i - ch * nse;
     return reinterpret_cast<const float4*>(xhh + ((int64_t)sg * a.Nc + ch) * kXh) + ht;
   };
   const float4* wq = reinterpret_cast<const float4*>(a.W + (int64_t)pr * nvc * kN) + (512 * wv + ln);
   auto woff = [&](int i) {
+#if DTX_XC_ABLATE & 32
+    i %= nsteps_real;
+#endif
     const int ch = i / nse, sg = i - ch * nse;
     return (int64_t)(ch * a.nseg + sg) * (kN / 2);
   };
@@ -569,6 +591,9 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
     if (z[0].x == 1.2345f && z[3].y == 5.4321f) a.keys[1] = 1ull;
 #else
     fft8192<1>(z, img, lb, a.tab, ht);
+#if DTX_XC_ABLATE & 32
+    fft8192<1>(z, img, lb, a.tab, ht);
+#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if DTX_XC_ABLATE & 4     // timing only: no epilogue
@@ -588,6 +613,10 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
     float best[2] = {-INFINITY, -INFINITY};
     int bm[2] = {0, 0};
     constexpr int kStat = VM <= 9 ? VM : (VM + 1) / 2;
+#if DTX_XC_ABLATE & 32
+#pragma nounroll
+    for (int rep = 0, p0 = 0; rep < 3; ++rep, p0 += a.V)       // (shadows the block's p0: three blocks' lags)
+#endif
     dtx::static_for<0, (VM + kStat - 1) / kStat>([&](auto chc) {
       constexpr int m0 = chc * kStat, m1 = m0 + kStat < VM ? m0 + kStat : VM;
       float mu[m1 - m0], rw[m1 - m0];
@@ -694,7 +723,7 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
                                              : dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
-  const int64_t nwork = (int64_t)items.size() * ((DTX_XC_BLKLOOP && !t22) ? 1 : nblk);
+  const int64_t nwork = (int64_t)items.size() * ((DTX_XC_BLKLOOP && !t22) || (DTX_XC_ABLATE & 32) ? 1 : nblk);
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
