@@ -592,7 +592,8 @@ def e2e_createcluster(local, cpu=True):
     for dtype in ('single', 'double'):
         ef = EventFetcher(100.0, ['HHE', 'HHN', 'HHZ'])
         for e in range(N):
-            ef.add('TA.M17A', 'ev%04d' % e, td[e].reshape(L, Nc).T, starttime=1000.0 + 200.0 * e,
+            # ([Nc, L] contiguous rows: what an ObsPy stream's traces are)
+            ef.add('TA.M17A', 'ev%04d' % e, np.ascontiguousarray(td[e].reshape(L, Nc).T), starttime=1000.0 + 200.0 * e,
                    origintime=990.0 + 200.0 * e, magnitude=1.0)
         createCluster(CCreq=0.5, fetch_arg=ef, device=local, saveclust=False, dtype=dtype)      # warm: workspaces
         times, last = [], None

@@ -7,6 +7,8 @@ reference's Python pair loop is replaced by ONE call into the HIP library
 dendrogram cut, alignment by accumulated lags, Harris 2006 App. B) is host logic
 on tiny arrays and follows the reference line by line.
 """
+from collections.abc import Mapping
+
 import numpy as np
 import pandas as pd
 from scipy.cluster.hierarchy import linkage
@@ -102,6 +104,38 @@ def _preprocess_events(ctx, fetcher, sta, filt, trim, decimate, fillZeros=False)
     return [(name, out[name][0], out[name][1]) for (name, _, _) in cut]
 
 
+class _LazyMPtd(Mapping):
+    """{event: multiplexed array} of a station (the reference's ``MPtd`` column, construct.py:639-655), multiplexed
+    when an event is ASKED for: createCluster itself only needs the event matrix on the device, which is
+    assembled from the channel planes (``planes_f32``) and interleaved there -- at 2000 events the host-side
+    multiplex of every event cost more than the correlation kernels.  ``le``: the common length the station's
+    events are trimmed to (_testStreamLengths, construct.py:679-694), in multiplexed samples."""
+
+    def __init__(self, planes, le, dtype):
+        self._planes, self._le, self._dtype, self._done = planes, int(le), dtype, {}
+
+    def __getitem__(self, ev):
+        if ev not in self._done:
+            self._done[ev] = multiplex(list(self._planes[ev]), dtype=self._dtype)[:self._le]
+        return self._done[ev]
+
+    def __iter__(self):
+        return iter(self._planes)
+
+    def __len__(self):
+        return len(self._planes)
+
+    def length(self, ev):
+        """len(self[ev]) without building it"""
+        p = self._planes[ev]
+        return min(self._le, int(p.shape[0]) * int(p.shape[1]))
+
+    def planes_f32(self, ev, out):
+        """The event's channel planes, trimmed like the multiplexed array, into out [Nc, le / Nc] float32."""
+        p = self._planes[ev]
+        np.copyto(out, p[:, :out.shape[1]], casting='unsafe')
+
+
 def _loadEvents(fetcher, dtype, filt=None, trim=None, decimate=None, enforceOrigin=False, fillZeros=False,
                 ctx=None):
     """construct.py:615-655 (+ _loadStream 852-925) on an EventFetcher: one row per station with
@@ -124,47 +158,48 @@ def _loadEvents(fetcher, dtype, filt=None, trim=None, decimate=None, enforceOrig
         else:
             done = [(name, rec['data'], rec['starttime']) for name, rec in fetcher.getTemData(sta)]
             sr = fetcher.sampling_rate
-        allzeros, lens = [], {}
+        allzeros, lens, planes = [], {}, {}
         for name, data, start in done:
             rec = fetcher.events[sta][name]
-            data = np.asarray(data, dtype=np_dtype)
+            data = np.asarray(data)
             if enforceOrigin and raw:
                 # construct.py:884-885: st.trim(starttime=originTime, pad=True, fill_value=0.0)
                 k = int(round((rec['origintime'] - start) * sr))
                 data = data[:, k:] if k >= 0 else np.concatenate(
-                    [np.zeros((data.shape[0], -k), dtype=np_dtype), data], axis=1)
+                    [np.zeros((data.shape[0], -k), dtype=data.dtype), data], axis=1)
                 start = start + k / sr
             if data.shape[1] == 0:
                 continue
             if any(not np.any(c) for c in data):                  # construct.py:896-897
                 allzeros.append(name)
-            mptd[name] = multiplex(list(data))
+            planes[name] = data                                   # [Nc, L]: multiplexed when asked for (_LazyMPtd)
             lens[name] = data.size                                # STlens: total samples of the stream
             stats[name] = dict(Nc=Nc, sampling_rate=sr, starttime=start, origintime=rec['origintime'],
                                magnitude=rec['magnitude'], offset=start - rec['origintime'])
             chans[name] = list(fetcher.channels)
-        if raw and mptd:
+        if raw and planes:
             # construct.py:901-916: fractured / very short waveforms (< 20 % of the median length) and
             # waveforms with an all-zero channel are removed
             mlen = np.median(list(lens.values()))
-            for key in [k for k in mptd if lens[k] < mlen * .2]:
+            for key in [k for k in planes if lens[k] < mlen * .2]:
                 _warn('%s is fractured or missing data, removing' % key)
-                mptd.pop(key), stats.pop(key), chans.pop(key)
+                planes.pop(key), stats.pop(key), chans.pop(key)
             for key in set(allzeros):
-                if key in mptd:
+                if key in planes:
                     _warn('%s has at least one channel that is all zeros, deleting' % key)
-                    mptd.pop(key), stats.pop(key), chans.pop(key)
-            if len(mptd) < 2:                                     # construct.py:918-922
+                    planes.pop(key), stats.pop(key), chans.pop(key)
+            if len(planes) < 2:                                   # construct.py:918-922
                 _warn('Less than 2 events survived preprocessing for station %s' % sta)
                 continue
-        if not mptd:
+        if not planes:
             continue
         # construct.py:679-694 _testStreamLengths: trim to the smallest length that is
-        # within 90 % of the median, drop shorter events
-        lens = np.array([len(v) for v in mptd.values()])
-        le = int(np.min(lens[lens > np.median(lens) * .9]))
-        events = sorted(k for k, v in mptd.items() if len(v) >= le)
-        mptd = {k: mptd[k][:le] for k in events}
+        # within 90 % of the median, drop shorter events (lengths of the multiplexed arrays)
+        mlens = {k: int(v.shape[0]) * int(v.shape[1]) for k, v in planes.items()}
+        lv = np.array(list(mlens.values()))
+        le = int(np.min(lv[lv > np.median(lv) * .9]))
+        events = sorted(k for k in planes if mlens[k] >= le)
+        mptd = _LazyMPtd({k: planes[k] for k in events}, le, np_dtype)
         rows.append(dict(Station=sta, Events=events, MPtd=mptd,
                          Channels={k: chans[k] for k in events},
                          Stats={k: stats[k] for k in events},
@@ -229,7 +264,8 @@ def _makeDFcclags(eventList, row, ctx):
     import torch
     if len(set(len(row.Channels[e]) for e in eventList)) != 1:
         _error('Number of Channels not equal, cannot perform correlation')      # 429-431
-    if len(set(len(row.MPtd[e]) for e in eventList)) != 1:
+    lazy = isinstance(row.MPtd, _LazyMPtd)
+    if len(set((row.MPtd.length(e) if lazy else len(row.MPtd[e])) for e in eventList)) != 1:
         _error('Lengths not equal on multiplexed data, cannot correlate')       # 433-436
     from . import parallel
     Nc = len(row.Channels[eventList[0]])
@@ -238,14 +274,22 @@ def _makeDFcclags(eventList, row, ctx):
         # the event matrix, assembled in page-locked memory (row by row: a list of 2000 float64 arrays through
         # ascontiguousarray took 1.2 s); its upload then runs at the link's rate instead of through a pageable
         # staging copy
-        n = len(row.MPtd[eventList[0]])
+        n = row.MPtd.length(eventList[0]) if lazy else len(row.MPtd[eventList[0]])
+        lazy = lazy and n % Nc == 0
         try:
             tdt = torch.empty((N, n), dtype=torch.float32, pin_memory=True)
         except RuntimeError:                                                # (no GPU runtime: the CPU stand-in of the tests)
             tdt = torch.empty((N, n), dtype=torch.float32)
         td = tdt.numpy()
-        for i, e in enumerate(eventList):
-            td[i] = row.MPtd[e]
+        if lazy:
+            # channel planes [N][Nc][n / Nc]: one contiguous copy per channel; interleaved on the device below
+            # (construct.py:977-978; dtx_preprocess without filter or detrend)
+            td3 = td.reshape(N, Nc, n // Nc)
+            for i, e in enumerate(eventList):
+                row.MPtd.planes_f32(e, td3[i])
+        else:
+            for i, e in enumerate(eventList):
+                td[i] = row.MPtd[e]
     rank, world = parallel.dist_info()
     if parallel.dist_active():
         # one process per GPU: every rank correlates a contiguous range of the condensed pair
@@ -257,6 +301,8 @@ def _makeDFcclags(eventList, row, ctx):
             tdev = tdt.to(ctx.device, non_blocking=True)
             _sync_copy(ctx)
         with _phase('kernels'):
+            if lazy:
+                tdev = ctx.preprocess(tdev.reshape(N, Nc, n // Nc), filt=None, detrend=False)
             cc, lag, ss = ctx.xcorr_allpairs(tdev, Nc, b, e)
             ctx.sync()
         cc, lag, ss = (parallel.gather_condensed(v, ranges, npairs, ctx.device) for v in (cc, lag, ss))
@@ -265,6 +311,8 @@ def _makeDFcclags(eventList, row, ctx):
             tdev = tdt.to(ctx.device, non_blocking=True)
             _sync_copy(ctx)
         with _phase('kernels'):
+            if lazy:
+                tdev = ctx.preprocess(tdev.reshape(N, Nc, n // Nc), filt=None, detrend=False)
             cc, lag, ss = ctx.xcorr_allpairs(tdev, Nc)
             ctx.sync()
     with _phase('d2h'):
@@ -480,6 +528,18 @@ def _sub_condensed(df, sel):
     return np.array(out)
 
 
+class _CastView(object):
+    """mptd[ev] -> np.asarray(source[ev], dtype), remembered"""
+
+    def __init__(self, src, dtype):
+        self.src, self.dtype, self.done = src, dtype, {}
+
+    def __getitem__(self, ev):
+        if ev not in self.done:
+            self.done[ev] = np.asarray(self.src[ev], dtype=self.dtype)
+        return self.done[ev]
+
+
 def createSubSpace(Pf=10 ** -12, clust=None, minEvents=2, dtype='double', conDatFetcher=None):
     """Create a SubSpace from a ClusterStream (detex/construct.py:177-301): for
     every cluster with >= minEvents events re-use the stored CC / lag values (no
@@ -495,7 +555,8 @@ def createSubSpace(Pf=10 ** -12, clust=None, minEvents=2, dtype='double', conDat
     for _, trow in cl.trdf.iterrows():
         sta = trow.Station
         events_all = list(trow.Events)
-        mptd = {k: np.asarray(v, dtype=np_dtype) for k, v in cl._mptd[sta].items()}
+        src = cl._mptd[sta]
+        mptd = _CastView(src, np_dtype)                             # (cast on access: only what the clusters use)
         stats_all = trow.Stats
         c = cl[sta]
         rows = []

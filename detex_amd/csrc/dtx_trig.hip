@@ -545,3 +545,63 @@ extern "C" int dtx_trigger_stats_ragged(dtx_ctx* ctx, const float* x_dev, const 
   return trigger_stats_impl(ctx, x_dev, M, 0, chunk_tab_dev, ds_dev, P, ldp, trig_dev, ntrig, sta_len,
                             lta_len, ewf_dev, ewf_off_dev, emax, out_dev);
 }
+
+// ---------------------------------------------------------------- FAS screen
+// max_i classic_sta_lta(a, nsta, nlta)[i] of a batch of traces (fas.py:175-205 of the reference screens the random
+// chunks of _initFAS with obspy.signal.trigger.classic_sta_lta on the Z channel; its documented form:
+// sta[i], lta[i] = trailing sums of a^2 over nsta / nlta samples (clipped at the trace start) / nsta, nlta;
+// sta[: nlta - 1] = 0; lta floored at the smallest normal double; ratio sta / lta).  A thread takes kStaG
+// consecutive samples: the two window sums at its first sample by direct summation in float64 (nlta loads, the
+// anchor), then sliding -- no prefix over the trace, no error growing along it.  Trace k: x[tab[2 k] + j stride],
+// j < tab[2 k + 1].  out[k] (float64 bits, pre-zeroed) takes an atomicMax: ratios are >= 0, their bit patterns ordered.
+constexpr int kStaG = 64;
+__global__ __launch_bounds__(256) void stalta_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ tab,
+                                                         int stride, int nsta, int nlta,
+                                                         unsigned long long* __restrict__ out) {
+  const int k = blockIdx.y;
+  const int64_t len = tab[2 * k + 1];
+  const float* a = x + tab[2 * k];
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * kStaG;
+  double best = 0.0;
+  if (i0 < len && i0 + kStaG > nlta - 1) {
+    auto sq = [&](int64_t j) { const double v = (double)a[j * stride]; return v * v; };
+    double ss = 0.0, sl = 0.0;
+    for (int64_t j = max((int64_t)0, i0 - nlta + 1); j <= i0; ++j) {
+      const double q = sq(j);
+      sl += q;
+      if (j > i0 - nsta) ss += q;
+    }
+    const double rs = 1.0 / nsta, rl = 1.0 / nlta, tiny = 2.2250738585072014e-308;
+    const int64_t i1 = min(len, i0 + kStaG);
+    for (int64_t i = i0;;) {
+      if (i >= nlta - 1) best = fmax(best, (ss * rs) / fmax(sl * rl, tiny));
+      if (++i >= i1) break;
+      const double q = sq(i);
+      ss += q - (i - nsta >= 0 ? sq(i - nsta) : 0.0);
+      sl += q - (i - nlta >= 0 ? sq(i - nlta) : 0.0);
+    }
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = best;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + h]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(out + k, (unsigned long long)__double_as_longlong(red[0]));
+}
+
+extern "C" int dtx_stalta_max(dtx_ctx* ctx, const float* x_dev, const int64_t* tab_dev, int ntrace, int64_t maxlen,
+                              int stride, int nsta, int nlta, double* out_dev) {
+  if (!ctx) return DTX_E_ARG;
+  if (!x_dev || !tab_dev || !out_dev || ntrace <= 0 || maxlen <= 0 || stride <= 0 || nsta <= 0 || nlta < nsta)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_stalta_max: bad arguments (need 0 < nsta <= nlta)");
+  if (ntrace > 65535) return dtx_fail(ctx, DTX_E_ARG, "dtx_stalta_max: more than 65535 traces");
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)ntrace * sizeof(double), ctx->stream));
+  const int64_t gx = (maxlen + 256 * kStaG - 1) / (256 * kStaG);
+  hipLaunchKernelGGL(stalta_max_kernel, dim3((unsigned)gx, (unsigned)ntrace), dim3(256), 0, ctx->stream, x_dev, tab_dev,
+                     stride, nsta, nlta, (unsigned long long*)out_dev);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
+}

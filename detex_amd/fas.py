@@ -66,6 +66,10 @@ def beta_mle(n, sx, sxx, s1, s2):
     return (a, b, 0, 1), float(nnlf)
 
 
+def _declen(cnt, dec):
+    return (int(cnt) + dec - 1) // dec
+
+
 def _log(msg):
     """detex.log(..., pri=True)"""
     import logging
@@ -109,43 +113,57 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
             sr_raw, sr = sr, sr / dec                              # detect.py:239
 
-            def declen(cnt):
-                return (cnt + dec - 1) // dec
-            bounds = [b for b in fetcher.chunk_bounds(sta) if declen(b[1]) * Nc > n]
+            bounds = [b for b in fetcher.chunk_bounds(sta) if _declen(b[1], dec) * Nc > n]
             if not bounds:
                 raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
             # fas.py:92-93: ask for 4x more chunks than needed, in random order
-            order = rs.permutation(len(bounds))[:conDatNum * 4]
+            order = [int(k) for k in rs.permutation(len(bounds))[:conDatNum * 4]]
+            zs = [i for i, c in enumerate(fetcher.channels) if str(c).upper().endswith('Z')]
+            zi = zs[0] if zs else 0                                   # fas.py:175-205: the Z (else first) channel
+            nsta, nlta = int(STATime * sr), int(LTATime * sr)
+            pinned = getattr(fetcher, 'pinned', {}).get(sta)
+            planes = (pinned if pinned is not None else
+                      torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))).to(ctx.device, non_blocking=True)
+            T = int(planes.shape[1])
+            # candidate chunks on the device, multiplexed, grouped by length: rows[M] = (tensor [G, M], [chunk ids])
+            groups = {}
             if raw:
-                rawdev = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(ctx.device)
+                # every candidate is decimated / detrended / band-passed like a scanned chunk (fas.py:101 ->
+                # _applyFilter); chunks of one length go through the kernels as one batch
+                bylen = {}
+                for k in order:
+                    bylen.setdefault(int(bounds[k][1]), []).append(k)
+                for cnt, ks in bylen.items():
+                    pl = torch.stack([planes[:, bounds[k][0]:bounds[k][0] + cnt] for k in ks])
+                    if dec > 1:
+                        pl = ctx.decimate(pl, dec, sr_raw)
+                    mp = ctx.preprocess(pl, filt=ss.clusters.filt, sampling_rate=sr)
+                    groups.setdefault(int(mp.shape[1]), []).append((mp, ks))
+                ratio = {}
+                for M, lst in groups.items():
+                    for mp, ks in lst:
+                        r = ctx.stalta_max(mp, [g * M + zi for g in range(len(ks))], [M // Nc] * len(ks), nsta, nlta,
+                                           stride=Nc)
+                        ratio.update(zip(ks, r.cpu().numpy()))
+                lens = {k: _declen(bounds[k][1], dec) for k in order}
             else:
-                xdev = torch.from_numpy(np.ascontiguousarray(multiplex(list(data)),
-                                                             dtype=np.float32)).to(ctx.device)
-            cache = {}
+                # the screen reads the Z plane where it lies; the scan takes the interleaved record
+                # (construct.py:977-978; dtx_preprocess without filter or detrend)
+                r = ctx.stalta_max(planes, [zi * T + bounds[k][0] for k in order], [bounds[k][1] for k in order],
+                                   nsta, nlta)
+                xdev = ctx.preprocess(planes[None], filt=None, detrend=False)[0]
+                ratio = dict(zip(order, r.cpu().numpy()))
+                lens = {k: int(bounds[k][1]) for k in order}
 
-            def chunk_mp(k):
-                """multiplexed, pre-processed chunk k on the device (fas.py:101) + its
-                channels on the host for the STA/LTA screen"""
-                if k not in cache:
-                    s, cnt, _ = bounds[k]
-                    if raw:
-                        planes = rawdev[None, :, s:s + cnt]
-                        if dec > 1:
-                            planes = ctx.decimate(planes, dec, sr_raw)
-                        mp = ctx.preprocess(planes, filt=ss.clusters.filt, sampling_rate=sr)
-                        chans = mp[0].reshape(-1, Nc).t().cpu().numpy()
-                    else:
-                        mp = xdev[None, s * Nc:(s + cnt) * Nc]
-                        chans = data[:, s:s + cnt]
-                    cache[k] = (mp, chans)
-                return cache[k]
+            def ok(k, limit):
+                # fas._checkSTALTA: a chunk not longer than the LTA window is rejected, else max(cft) <= limit
+                return lens[k] > LTATime * sr and ratio[k] <= limit
 
             def pick(limit):
                 chosen, count = [], 0
                 for k in order:
                     count += 1
-                    if limit is not None and not _checkSTALTA(chunk_mp(k)[1], fetcher.channels, sr,
-                                                              STATime, LTATime, limit):
+                    if limit is not None and not ok(k, limit):
                         continue
                     if len(chosen) >= conDatNum:
                         break
@@ -160,16 +178,26 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             sums = torch.zeros((D, 5), dtype=torch.float64, device=ctx.device)
             # chunks of equal length go through the scan together (one launch fills the chip
             # better than one launch per chunk); batches bounded to ~4 GB of DS
-            bylen = {}
-            for k in chosen:
-                bylen.setdefault(int(chunk_mp(k)[0].shape[1]), []).append(k)
-            for M, ks in sorted(bylen.items()):
+            sel = set(chosen)
+            batches = []                                             # (tensor [G, M] multiplexed chunks)
+            if raw:
+                for M, lst in groups.items():
+                    for mp, ks in lst:
+                        idx = [g for g, k in enumerate(ks) if k in sel]
+                        if idx:
+                            batches.append(mp if len(idx) == len(ks) else
+                                           mp[torch.tensor(idx, device=mp.device)])
+            else:
+                bylen = {}
+                for k in chosen:
+                    bylen.setdefault(int(bounds[k][1]), []).append(k)
+                for cnt, ks in sorted(bylen.items()):
+                    batches.append(torch.stack([xdev[bounds[k][0] * Nc:(bounds[k][0] + cnt) * Nc] for k in ks]))
+            for mp in batches:
+                M = int(mp.shape[1])
                 per = max(1, int(4e9 // (4.0 * D * max(1, (M - n) // Nc + 1))))
-                for i in range(0, len(ks), per):
-                    grp = ks[i:i + per]
-                    mp = chunk_mp(grp[0])[0] if len(grp) == 1 else \
-                        torch.cat([chunk_mp(k)[0] for k in grp], dim=0)
-                    ds = ctx.subspace_ds(mp)
+                for i in range(0, int(mp.shape[0]), per):
+                    ds = ctx.subspace_ds(mp[i:i + per])
                     ctx.ds_moments(ds, lo=-.01, hi=1.0, nbins=numBins - 1, hist=hist, sums=sums)
                     del ds
             ctx.sync()

@@ -523,6 +523,24 @@ class HipContext(object):
         self._ck(rc, 'dtx_normcorr')
         return out
 
+    @_on_ctx_stream
+    def stalta_max(self, x, starts, lengths, nsta, nlta, stride=1):
+        """max of obspy's classic_sta_lta over each trace x.flat[starts[k] + j * stride], j < lengths[k]
+        (fas.py:175-205: the screen of the FAS chunks) -> float64 CUDA tensor [len(starts)] (asynchronous)."""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError('x must be a float32 CUDA tensor')
+        x = x.contiguous()
+        tab = np.empty((len(starts), 2), dtype=np.int64)
+        tab[:, 0], tab[:, 1] = starts, lengths
+        if len(tab) == 0 or tab.min() < 0 or int((tab[:, 0] + (tab[:, 1] - 1).clip(0) * stride).max()) >= x.numel():
+            raise ValueError('traces do not fit the buffer')
+        out = torch.empty((len(tab),), dtype=torch.float64, device=x.device)
+        tdev = h2d_async(tab.reshape(-1), x.device)
+        rc = self.lib.dtx_stalta_max(self.h, _ptr(x), _ptr(tdev), len(tab), int(tab[:, 1].max()), int(stride),
+                                     int(nsta), int(nlta), _ptr(out))
+        self._ck(rc, 'dtx_stalta_max')
+        return out
+
     # ------------------------------------------------------------ xcorr
     @_on_ctx_stream
     def xcorr_allpairs(self, td, Nc, pair_begin=0, pair_end=None):

@@ -254,6 +254,13 @@ int dtx_stream_wait_scan_kernel(dtx_ctx* ctx, void* stream);
 int dtx_normcorr(dtx_ctx* ctx, const float* t_dev, int n, const float* s_dev, int64_t m,
                  float* out_dev);
 
+/* The screen of fas._checkSTALTA (fas.py:175-205): out[k] = max_i obspy.signal.trigger.classic_sta_lta(a_k, nsta, nlta)[i]
+ * for ntrace traces a_k[j] = x[tab[2 k] + j * stride], j < tab[2 k + 1] (device table; stride 1: channel planes,
+ * stride Nc: one channel of a multiplexed chunk); maxlen = the longest trace.  float64 window sums, out float64.
+ * Asynchronous.  The caller applies the reference's length rule (len <= nlta: rejected) and the limit. */
+int dtx_stalta_max(dtx_ctx* ctx, const float* x_dev, const int64_t* tab_dev, int ntrace, int64_t maxlen,
+                   int stride, int nsta, int nlta, double* out_dev);
+
 static inline uint64_t dtx_cand_pack(uint32_t chunk, uint32_t det, uint32_t p) {
   return ((uint64_t)chunk << 48) | ((uint64_t)det << 32) | (uint64_t)p;
 }

@@ -185,6 +185,33 @@ def test_fas_matches_scipy(workflow):
     assert all(a is not b for a, b in zip(before, after)) and all(isinstance(a, dict) for a in after)
 
 
+def test_stalta_screen_kernel():
+    """dtx_stalta_max (the device form of fas._checkSTALTA's screen, fas.py:175-205 of the reference) against the
+    host restatement of obspy's classic_sta_lta: traces at arbitrary offsets of one buffer, contiguous and strided
+    (one channel of a multiplexed chunk), shorter than the LTA window (no value: 0), a burst at the very start / end,
+    a dead trace; and getFAS choosing the same chunks as the host screen would."""
+    from detex_amd import fas
+    from detex_amd.hip import HipContext
+    rs = np.random.RandomState(11)
+    ctx = HipContext(0)
+    buf = (rs.standard_normal(400000) * rs.uniform(0.5, 2.0)).astype(np.float32)
+    buf[1000:1040] *= 30.0
+    buf[399000:399020] *= 50.0
+    buf[200000:205000] = 0.0
+    x = torch.from_numpy(buf).cuda()
+    for (nsta, nlta, stride) in ((50, 500, 1), (10, 100, 3), (1, 7, 1), (25, 2500, 6)):
+        starts = [0, 990, 123457, 398000, 200500, 77, 300001]
+        lens = [372000, 20000, 5000, 2000 // stride, 4000 // stride, nlta - 1, nlta]
+        lens = [min(m, (len(buf) - a - 1) // stride + 1) for a, m in zip(starts, lens)]
+        got = ctx.stalta_max(x, starts, lens, nsta, nlta, stride=stride).cpu().numpy()
+        for a, m, g in zip(starts, lens, got):
+            tr = buf[a:a + (m - 1) * stride + 1:stride]
+            assert len(tr) == m
+            want = float(np.max(fas.classic_sta_lta(tr, nsta, nlta))) if m >= nlta else 0.0
+            assert abs(g - want) <= 1e-9 * max(1.0, want), (nsta, nlta, stride, a, m, g, want)
+    ctx.close()
+
+
 def test_trigger_stats_kernel():
     """dtx_trigger_stats against the oracle's NumPy restatement of every number it writes,
     and the magnitudes built from it against the reference's own _estMag outputs
