@@ -27,6 +27,7 @@ constexpr float kT1 = 0x1.47ae16p-9f, kT2 = 0x1.47ae16p-8f, kT3 = 0x1.eb852p-8f,
 #ifndef DTX_POST_WAVES
 #define DTX_POST_WAVES 8      // waves per SIMD the pass is compiled for (<= 64 registers: 154.7 -> 143.8 us; 7: 148.3)
 #endif
+template <int ITEMS>
 __global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
     float* __restrict__ maxds, const float* __restrict__ thr, uint64_t* __restrict__ cand_key,
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
   const int det = blockIdx.y, chunk = blockIdx.z;
   if (pb != nullptr) {        // ragged batch: the chunk's own windows only
     P = min(P, (int64_t)pb[chunk]);
-    if ((int64_t)blockIdx.x * (kPostThreads * kPostItems) >= P) return;
+    if ((int64_t)blockIdx.x * (kPostThreads * ITEMS) >= P) return;
   }
   const float* row = ds + ((int64_t)chunk * D + det) * ldp;
   if (hist) {
@@ -73,10 +74,10 @@ __global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
   // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
   const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
   constexpr int kBatch = DTX_POST_BATCH;      // 16-byte loads in flight per thread
-  static_assert(kPostItems / 4 % kBatch == 0, "whole batches");
+  static_assert(ITEMS / 4 % kBatch == 0, "whole batches");
   const unsigned t4bits = __float_as_uint(kT4);
-  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * kPostItems);
-  for (int it0 = 0; it0 < kPostItems / 4; it0 += kBatch) {
+  const int64_t base = (int64_t)blockIdx.x * (kPostThreads * ITEMS);
+  for (int it0 = 0; it0 < ITEMS / 4; it0 += kBatch) {
   float vb[kBatch][4];
   bool whole = vec;                       // every load of this lane's batch is a 16-byte load inside the row
 #pragma unroll
@@ -252,10 +253,22 @@ __global__ __launch_bounds__(kPostThreads) void ds_moments_kernel(
 
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
                     const DtxPost& po, const int* pb) {
+  // 64 values per thread (64 KB of a row per workgroup) when the launch fills the chip several times over anyway;
+  // a small launch (configs[4]: ONE detector x one hour = 110 such workgroups on 256 CUs, 45 us for 7 MB) is cut
+  // four times finer
   const int64_t per_block = (int64_t)kPostThreads * kPostItems;
-  dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
-  hipLaunchKernelGGL(ds_post_kernel, grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
-                     po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
+  const int64_t nwg = (P + per_block - 1) / per_block * D * nchunk;
+  if (nwg >= 8 * ctx->ncu) {
+    dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
+    hipLaunchKernelGGL((ds_post_kernel<kPostItems>), grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+                       po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
+  } else {
+    constexpr int kSmall = 16;
+    const int64_t pbs = (int64_t)kPostThreads * kSmall;
+    dim3 grid((unsigned)((P + pbs - 1) / pbs), (unsigned)D, (unsigned)nchunk);
+    hipLaunchKernelGGL((ds_post_kernel<kSmall>), grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+                       po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
+  }
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
 }

@@ -1039,6 +1039,22 @@ class SubSpace(object):
             for i in idx:
                 days.setdefault(i // per, []).append(i)
             units += [(sta, days[d]) for d in sorted(days)]
+        # Ramp: nothing hides the FIRST unit's upload (a day is 104 MB: ~3 ms before the first kernel can start) nor
+        # the LAST unit's host half (picks, trigger-time kernel, rows).  A quarter of the first unit goes ahead as a
+        # unit of its own and the last quarter of the last one comes behind as one: both ends of the pipeline are
+        # short units (the tables do not depend on the cut).  ~13 ms of fixed cost per call was a third of an
+        # 8-station-day call.
+        if os.environ.get('DETEX_AMD_RAMP', '1') != '0' and units:
+            def chunks_of(u):
+                return list(range(len(bounds[u[0]]))) if u[1] is None else [int(i) for i in u[1]]
+            head = chunks_of(units[0])
+            if banks[units[0][0]][0] and len(head) >= 8:
+                k = max(2, len(head) // 4)
+                units[0:1] = [(units[0][0], head[:k]), (units[0][0], head[k:])]
+            tail = chunks_of(units[-1])
+            if banks[units[-1][0]][0] and len(tail) >= 8:
+                k = max(2, len(tail) // 4)
+                units[-1:] = [(units[-1][0], tail[:-k]), (units[-1][0], tail[-k:])]
         return units
 
     def _adopt_sent_banks(self, stations, banks, sent):
