@@ -669,6 +669,156 @@ __device__ __forceinline__ void fft8192_x2(c32 (&va)[16], c32 (&vb)[16], c32* ld
   fft8192_back_compute<SG>(vb, w.p4);
 }
 
+// z += w p and z += w conj(p) in two packed fused multiply-adds each, the operand selection and the signs in the
+// instruction's modifiers.  Written out: the compiler's own packing of the four-fma form builds (-w.y, w.y) and
+// swapped copies in registers first -- a quarter of the scan kernel's vector instructions were v_mov.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cmac(f2& z, f2 w, f2 p) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+      : "+v"(z) : "v"(w), "v"(p));
+}
+__device__ __forceinline__ void cmac_conj(f2& z, f2 w, f2 p) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+      : "+v"(z) : "v"(w), "v"(p));
+}
+// z = w p / z = w conj(p): the first product of a sum (no zero fill of z)
+__device__ __forceinline__ f2 cmul2(f2 w, f2 p) {
+  f2 z;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+      : "=&v"(z) : "v"(w), "v"(p));
+  return z;
+}
+__device__ __forceinline__ f2 cmul2_conj(f2 w, f2 p) {
+  f2 z;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+      : "=&v"(z) : "v"(w), "v"(p));
+  return z;
+}
+
+constexpr int kN16 = 16384;
+constexpr int kT16 = 1024;
+constexpr int kXh16 = kN16 / 2;
+#if defined(DTX_XC16) && DTX_XC16
+// ---------------------------------------------------------------- the 16 384-point transform
+// The same construction one size up, for a workgroup of SIXTEEN waves (1024 threads, 16 points each) on a 128 KB image:
+// n = 16 n2 + w.  Phase A is the 8192-point transform's, wave for wave (a 1024-point Stockham transform of the wave's
+// own subsequence in its own 8 KB region: radices 16 x 16 x 4, one LDS exchange + one by lane swaps, no workgroup
+// barrier); phase B is ONE twiddled radix-16 butterfly per thread across the sixteen waves instead of two radix-8
+// ones across eight: thread tid combines Y_0..15[k2 = tid] -> X[tid + 1024 k1] in register k1.  The image's swizzle
+// is per 1024-slot region, so every address formula of fft8192 carries over (lds_bases: region = wave * 1024; the
+// phase-B read of region w' at slot tid ^ g(tid) is a permutation of 64 consecutive slots per wave: conflict-free).
+// tab: e^{2 pi i m / 16384}, m < 16384.  Used by the all-pairs lag search when one lag block of 16 384 replaces
+// several of 8192 (dtx_xcfft.hip: xc_fft16_kernel).
+template <int SG>
+__device__ __forceinline__ void fft16384(c32 (&v)[16], c32* lds, const LdsBases& lb0,
+                                         const c32* __restrict__ tab, int tid) {
+  int opaque;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+  auto ldtw = [&](int idx) {
+    c32 t = tab[idx];
+    if (SG < 0) t.y = -t.y;
+    return t;
+  };
+  c32 wa[4], wb[2];
+  {
+    const int l = (tid + opaque) & 63;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wa[e] = ldtw(((l & 15) * (kN16 / 256)) << e);
+    wb[0] = ldtw(l * (kN16 / 1024));
+    wb[1] = ldtw(l * (kN16 / 512));
+  }
+  LdsBases lb;   // in bytes
+  lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
+  lb.f = (lb0.f + opaque) << 3;
+  // ---- phase A, pass 1: radix 16 over r, no twiddles
+  dft16_plain<SG>(v);
+  __syncthreads();   // every wave has finished its reads of the image (the previous transform's phase B, a caller's staging)
+  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
+  wave_sync();
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
+  wave_sync();
+  // ---- pass 2: radix 16, sub-transforms of 16 -> 256
+  {
+    const c32 wp[4] = {wa[3], wa[2], wa[1], wa[0]};
+    dft_tw_bitrev<SG, 16>(v, wp);
+  }
+  {
+    c32 y[16];
+    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; y[s] = v[rev4(s)]; });
+    dtx::static_for<0, 16>([&](auto sc) {
+      constexpr int s = sc;
+      if constexpr ((s & 1) == 0) lane_swap16(y[s], y[s + 1]);
+    });
+    dtx::static_for<0, 16>([&](auto sc) {
+      constexpr int s = sc;
+      if constexpr ((s & 2) == 0) lane_swap32(y[s], y[s + 2]);
+    });
+    dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = y[(r >> 2) + 4 * (r & 3)]; });
+  }
+  // ---- pass 3: radix 4, sub-transforms of 256 -> 1024
+  dtx::static_for<0, 4>([&](auto bc) {
+    constexpr int b = bc;
+    const c32 w1 = mul_root<SG, 16, b>(wb[0]), w2 = mul_root<SG, 8, b>(wb[1]);
+    c32 u[4];
+    u[0] = v[b]; u[1] = v[b + 4]; u[2] = v[b + 8]; u[3] = v[b + 12];
+    const c32 wp[2] = {w2, w1};
+    dft_tw_bitrev<SG, 4>(u, wp);
+    dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
+  });
+  // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 16 across the waves
+  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
+  // the cross-wave twiddles w, w^2, w^4, w^8, w = e^{SG 2 pi i tid / 16384}: issued in front of the barrier (v is dead)
+  c32 p4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p4[e] = ldtw((tid + opaque) << e);
+  __syncthreads();
+  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds_at(lds, lb.f + 8 * 1024 * m); });
+  {
+    const c32 wp[4] = {p4[3], p4[2], p4[1], p4[0]};
+    dft_tw_bitrev<SG, 16>(v, wp);
+    c32 y[16];
+    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; y[s] = v[rev4(s)]; });
+    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; v[s] = y[s]; });
+  }
+}
+
+// pair spectra of the 16 384-point transform in memory: thread (wave w of 16, lane l) holds f = 16 (l + 64 r) + w
+__host__ __device__ constexpr int w_slot16(int f) {
+  const int w = f & 15, n2 = f >> 4, l = n2 & 63, r = n2 >> 6;
+  return w * 1024 + (r >> 1) * 128 + 2 * l + (r & 1);
+}
+
+// Block spectra for the 16 384-point lag search: as xhat_kernel, one transform of 16 384 REAL samples per
+// (stored block, channel, event), half spectrum kept: slot(f) = (f & 15) * 512 + (f >> 4), f < 8192; X[8192] rides
+// in the imaginary part of slot 0.  Stored block j = blk * nsub + s starts at sample blk V + s sub_stride.
+__global__ __launch_bounds__(kT16) void xhat16_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc, int V,
+                                                      int nblk, const c32* __restrict__ tab, c32* __restrict__ xh,
+                                                      int nsub, int sub_stride) {
+  __shared__ c32 lds[kN16];
+  const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
+  const LdsBases lb = lds_bases(tid);
+  const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
+  const int tb = 16 * (tid & 63) + (tid >> 6);          // sample within the block
+  const int64_t t0 = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride + tb;
+  c32 v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t t = t0 + 1024 * r;
+    v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
+  }
+  fft16384<-1>(v, lds, lb, tab, tid);
+  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh16 + (tid & 15) * 512 + (tid >> 4);
+  if (tid == 0) v[0].y = v[8].x;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
+}
+
+#endif   // DTX_XC16
+
 // Basis pair spectra in memory: thread (wave w, lane l) of a MAC holds frequencies
 // f = 8 (l + 64 r) + w, r = 0 .. 15.  Registers r = 2 j, 2 j + 1 of one lane are adjacent, so a
 // lane fetches its 16 values of a channel with eight 16-byte loads (eight 1 KiB wave

@@ -419,6 +419,12 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void xc_fft_kernel(const XcFftAr
 #ifndef DTX_XC_T22
 #define DTX_XC_T22 1         // the 2 x 2 workgroup is the lag search's kernel (0: xc_fft_kernel)
 #endif
+#ifndef DTX_XC16_ABLATE
+#define DTX_XC16_ABLATE 0    // timing only (results wrong): 1 no pair-spectrum loads, 2 no block-spectrum staging, 4 no lag search, 8 no transforms
+#endif
+#ifndef DTX_XC16_DMA
+#define DTX_XC16_DMA 1       // xc_fft16_kernel: the later events' block spectra staged by LDS-DMA (0: through registers)
+#endif
 #ifndef DTX_XC_NW
 #define DTX_XC_NW 2          // pair-spectrum batches (2 x 16 bytes per thread) in flight: 4 = a whole step ahead, 2 = half a step
 #endif
@@ -673,6 +679,340 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   }
 }
 
+#ifndef DTX_XC16
+#define DTX_XC16 0           // the 16 384-point lag search: built, parity-green, measured SLOWER than the 2 x 2 kernel at configs[2]
+#endif                       // (157 against 126 ms: profiles/x11_xc16_ablations.txt, profiles/README.md); make EXTRA=-DDTX_XC16=1 builds it
+#if DTX_XC16
+// ---- one lag block of 16 384 -------------------------------------------------------------------------------------
+// At configs[2] (L = 13 000: 13 001 lags) the 8192-point kernels search three lag blocks of 4608 -- 0.56 of every
+// transform's outputs are used, and the (block, segment) products that see data add up to 11 per pair spectrum and
+// later event.  On a 16 384-point transform the lags are ONE block (13 per thread of a 1024-thread workgroup, 0.79 of
+// the outputs) and the products 4: -27 % of the multiply-adds, -28 % of the transform work (two 16 384-point
+// transforms = 2 x 14 / 13 of four 8192-point ones, against six), measured beforehand by a timing-only build of
+// the 2 x 2 kernel (profiles/x10_ablate16k.txt: 126 -> 86 .. 103 ms predicted).
+//
+// A workgroup = ONE pair spectrum x TWO later events x one lag block, sixteen waves, a thread's 16 frequencies
+// f = 16 (l + 64 r) + w.  The pair spectrum streams through registers (128 KB per step, half a step ahead), the two
+// later events' block half-spectra (2 x 64 KB per step) through LDS -- in HALVES, so that the double-buffered
+// staging is the same 128 KB the transform image needs afterwards: the thread's frequency registers r = 0..3 and
+// 12..15 (own + mirrored) read the LOWER 256 slots of the sixteen 512-slot rows of a stored half spectrum, r = 4..11
+// the upper ones; a step is phase L (batches r 0..3, 12..15) then phase U (r 4..7, 8..11), one workgroup barrier
+// each.  Two mirrored reads of thread 0 fall outside their half (X[4096]: slot 256, wanted in phase L; the
+// (X[0], X[8192]) pair of slot 0, wanted in phase U): those two values per event and step come through the scalar
+// path (a uniform address: s_load into scalar registers in front of the previous barrier) and replace what thread 0
+// read from LDS by a select -- a branch here cut the half-step into basic blocks and cost 200 spilled registers.
+constexpr int kHalfX = 4096;                  // slots of one staged half
+template <int VM>
+__global__ __launch_bounds__(kT16, 1) void xc_fft16_kernel(const XcFftArgs a) {
+  __shared__ c32 lds[4 * kHalfX];               // [phase L / U buffer][later event][kHalfX]; then the 128 KB image
+  static_assert(4 * kHalfX >= kN16, "the staging buffers hold the transform image");
+  __shared__ unsigned long long wred[4][kT16 / 64];   // [(later event, row)][wave]
+  // (wave-uniform values are SAID to be: the compiler then keeps them, and every address built from them, in scalar
+  // registers -- the vector registers are all spoken for)
+  const int tid = threadIdx.x, hf = __builtin_amdgcn_readfirstlane(tid >> 9), ht = tid & 511;
+  const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if (logical >= a.nwork) return;
+  // (item, which of its two pair spectra, lag block): the two pair spectra of an item side by side
+  const int blk = (int)(logical % a.nblk);
+  const int64_t ip = logical / a.nblk;
+  const int item = (int)(ip >> 1), hp = (int)(ip & 1);
+  const int2 it = a.items[item];
+  const int ity = __builtin_amdgcn_readfirstlane(it.y);
+  const int c0 = __builtin_amdgcn_readfirstlane(it.x), has1 = (ity >> 30) & 1, pr = (ity & 0x3fffffff) + hp;
+  const int c1 = has1 ? c0 + 1 : c0;
+  if (pr >= (a.N + 1) / 2 || 2 * pr >= c1) return;          // no such pair spectrum / no row below the later events
+  const LdsBases lb = lds_bases(tid);
+  const int p0 = blk * a.V;
+  const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+  const int nsteps = a.Nc * nse;
+  const int64_t xstride = (int64_t)a.nblk * a.nseg * a.Nc * kXh16;
+  const c32* xhh = a.xh + (hf ? c1 : c0) * xstride + (int64_t)blk * a.nseg * a.Nc * kXh16;   // the event this half stages
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+  // the thread's reads of a staged half spectrum (positions inside an event's half-buffer)
+  const int xlo = 256 * wv + ln;                                        // r < 8: + 64 r (phase U: - 256)
+  const int xhi = wv ? 256 * (16 - wv) + 1023 - ln : 1024 - ln;         // r >= 8: - 64 r (phase U: - 256)
+  auto x_slot = [&](int r) {                     // (thread 0 at r = 8, 12: a valid slot whose value is replaced)
+    if (r < 4) return xlo + 64 * r;
+    if (r < 8) return xlo + 64 * r - 256;
+    if (r < 12) return xhi - 256 - 64 * r;
+    return xhi - 64 * r;
+  };
+  const int nvc = a.Nc * a.nseg;
+  // staging: half hf loads event hf; float4 q = ht + 512 k of a half = row (ht >> 7) + 4 k, float4 (ht & 127) of its 128
+  const unsigned sthr = 16u * (unsigned)((ht >> 7) * 256 + (ht & 127));      // bytes inside a stored half spectrum
+  auto xsrc = [&](int i, int ph) {              // uniform
+    const int ch = i / nse, sg = i - ch * nse;
+    return reinterpret_cast<const char*>(xhh + ((int64_t)sg * a.Nc + ch) * kXh16) + 16 * 128 * ph;
+  };
+  const c32* xh0 = a.xh + c0 * xstride + (int64_t)blk * a.nseg * a.Nc * kXh16;     // (uniform: the scalar path)
+  const c32* xh1 = a.xh + c1 * xstride + (int64_t)blk * a.nseg * a.Nc * kXh16;
+  f2 st0 = {0.f, 0.f}, st1 = st0;               // thread 0's stray values of the CURRENT half-step, both later events
+  auto load_stray = [&](int i, int ph) {        // slot 256 for phase L, slot 0 for phase U
+    const int ch = i / nse, sg = i - ch * nse;
+    const int64_t o = ((int64_t)sg * a.Nc + ch) * kXh16 + (ph ? 0 : 256);
+    const c32 a0 = xh0[o], a1 = xh1[o];
+    st0 = ph ? (f2){a0.y, 0.f} : (f2){a0.x, a0.y};      // phase U wants X[8192] = the imaginary part of slot 0
+    st1 = ph ? (f2){a1.y, 0.f} : (f2){a1.x, a1.y};
+  };
+  const char* wq = reinterpret_cast<const char*>(a.W + (int64_t)pr * nvc * kN16);      // uniform
+  const unsigned wlane = 16u * (unsigned)(512 * wv + ln);                              // the thread's float4 inside a [kN16]
+  auto woff = [&](int i) {
+    const int ch = i / nse, sg = i - ch * nse;
+    return (int64_t)(ch * a.nseg + sg) * (kN16 * 8);                                   // bytes, uniform
+  };
+  float r1v[2][2], s1v[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = 2 * pr + h;
+      const bool rowok = b < (k ? c1 : c0) && (k == 0 || has1);
+      r1v[k][h] = rowok ? a.frs[b] : 0.f;
+      s1v[k][h] = rowok ? a.fsum[b] * r1v[k][h] : 0.f;
+    }
+  f2 z0[16], z1[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) z0[m] = z1[m] = (f2){0.f, 0.f};
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 w[2][2];
+  auto issue_w = [&](int i, auto qc, auto sc) {       // batch q of step i (frequency registers 4 q .. 4 q + 3) into slot s
+    constexpr int q = qc, sl = sc;
+    const char* src = wq + woff(i);                   // scalar base + 32-bit lane offset + immediate
+#if DTX_XC16_ABLATE & 1
+    w[sl][0] = w[sl][1] = (f4){1.f, 0.5f, 1.f, 0.5f};
+    if (src == nullptr) w[sl][0].x = 2.f;
+#else
+    w[sl][0] = *reinterpret_cast<const f4*>(src + wlane + 16 * 64 * (2 * q));
+    w[sl][1] = *reinterpret_cast<const f4*>(src + wlane + 16 * 64 * (2 * q + 1));
+#endif
+  };
+  const bool t0 = tid == 0;
+  auto mac_q = [&](const c32* x0, const c32* x1, auto qc, auto sc) {
+    constexpr int q = qc, sl = sc;
+    f2 pa[4], pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      pa[e] = *reinterpret_cast<const f2*>(x0 + x_slot(r));
+      pb[e] = *reinterpret_cast<const f2*>(x1 + x_slot(r));
+      if (r == 0) {                             // X[0] is real: slot 0's imaginary part is X[8192]
+        pa[e].y = t0 ? 0.f : pa[e].y;
+        pb[e].y = t0 ? 0.f : pb[e].y;
+      }
+      if (r == 8 || r == 12) {                  // thread 0's mirrored reads outside the staged half
+        pa[e] = t0 ? st0 : pa[e];
+        pb[e] = t0 ? st1 : pb[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = 4 * q + e;
+      const f4 t = w[sl][e >> 1];
+      const f2 pw = (e & 1) ? (f2){t.z, t.w} : (f2){t.x, t.y};
+      if constexpr (q < 2) {                    // own frequencies / mirrored ones: X[kN16 - f] = conj X[f]
+        cmac(z0[m], pw, pa[e]);
+        cmac(z1[m], pw, pb[e]);
+      } else {
+        cmac_conj(z0[m], pw, pa[e]);
+        cmac_conj(z1[m], pw, pb[e]);
+      }
+    }
+  };
+  const int wvh = wv & 7;                                        // wave of the half: 0 .. 7 (uniform)
+  auto stage_dma = [&](const char* src, c32* dbuf) {
+    float4* d = reinterpret_cast<float4*>(dbuf) + 64 * wvh;
+#if DTX_XC16_ABLATE & 2
+    if (src == nullptr)
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + sthr + 16 * 1024 * k),
+                                       (__attribute__((address_space(3))) void*)(d + 512 * k), 16, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2c = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // batch order in time: (i, 0) (i, 3) | (i, 1) (i, 2) | (i + 1, 0) ...; pair-spectrum slot = position in that order & 1,
+  // the batch two further on is fetched into a slot as soon as its products are done
+  auto half = [&](int i, auto phc) {
+    constexpr int ph = phc;
+    const int nx = min(i + 1, nsteps - 1);      // (the last step fetches its own operands again: straight-line steps)
+    // the NEXT half-step's block spectra: phase U of this step, or phase L of the next
+    const char* src = ph ? xsrc(nx, 0) : xsrc(i, 1);
+    const c32* x0 = lds + (2 * ph) * kHalfX;
+    const c32* x1 = x0 + kHalfX;
+    c32* dbuf = lds + (2 * (1 - ph) + hf) * kHalfX;
+#if DTX_XC16_DMA
+    // the next half-step's block spectra straight into the other buffer (LDS-DMA: no staging registers, no
+    // ds_write): a wave's 64 lanes x 16 bytes land side by side at a wave-uniform LDS address
+    stage_dma(src, dbuf);
+#else
+    float4* dst = reinterpret_cast<float4*>(dbuf) + ht;
+    auto ldx = [&](int k) { return *reinterpret_cast<const float4*>(src + sthr + 16 * 1024 * k); };
+    float4 xa0 = ldx(0), xa1 = ldx(1);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ph == 0) mac_q(x0, x1, I0{}, I0{}); else mac_q(x0, x1, I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ph == 0) issue_w(i, I1{}, I0{}); else issue_w(nx, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+#if !DTX_XC16_DMA
+    dst[0] = xa0; dst[512] = xa1;
+    xa0 = ldx(2); xa1 = ldx(3);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if constexpr (ph == 0) mac_q(x0, x1, I3{}, I1{}); else mac_q(x0, x1, I2c{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ph == 0) issue_w(i, I2c{}, I1{}); else issue_w(nx, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+#if !DTX_XC16_DMA
+    dst[1024] = xa0; dst[1536] = xa1;
+#endif
+    if constexpr (ph == 0) load_stray(i, 1); else load_stray(nx, 0);     // the next half-step's, in front of the barrier
+#if DTX_XC16_DMA
+    // the four DMA loads are older than the four pair-spectrum loads issued behind them (loads return in order):
+    // wait for all but those, leave them in flight across the barrier
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+  };
+  {
+    const float4* src = reinterpret_cast<const float4*>(xsrc(0, 0) + sthr);
+    const float4 x0 = src[0], x1 = src[1024], x2 = src[2048], x3 = src[3072];
+    issue_w(0, I0{}, I0{});
+    issue_w(0, I3{}, I1{});
+    c32* dbuf = lds + hf * kHalfX;
+    float4* dst = reinterpret_cast<float4*>(dbuf) + ht;
+    dst[0] = x0; dst[512] = x1; dst[1024] = x2; dst[1536] = x3;
+    load_stray(0, 0);
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int i = 0; i < nsteps; ++i) {
+    half(i, I0{});
+    half(i, I1{});
+  }
+  // the transforms: all sixteen waves on one image (the staging buffers' memory; the loop's last barrier is behind
+  // every read of them), one later event after the other
+  auto finish = [&](f2 (&zz)[16], auto kc) {
+    constexpr int k = kc;
+    const int c = k ? c1 : c0;
+    c32 z[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) z[m] = make_float2(zz[m].x, zz[m].y);
+#if DTX_XC16_ABLATE & 8
+    if (z[0].x == 1.2345f && z[3].y == 5.4321f) a.keys[1] = 1ull;
+#else
+    fft16384<1>(z, lds, lb, a.tab, tid);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#if DTX_XC16_ABLATE & 4
+    if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
+    if ((tid & 63) == 0) { wred[2 * k][wv] = 0ull; wred[2 * k + 1][wv] = 0ull; }
+    return;
+#endif
+    // cc = (Y' - (sum x_b) rs_b mu_w) rs_w at the thread's VM lags p0 + tid + 1024 m (see xc_fft22_kernel)
+    const char* mwc = reinterpret_cast<const char*>(a.mean_w + (int64_t)c * a.Ppad);
+    const char* rwc = reinterpret_cast<const char*>(a.rsw + (int64_t)c * a.Ppad);
+    const unsigned last = 4u * (unsigned)(a.Pz - 1);
+    float best[2] = {-INFINITY, -INFINITY};
+    int bm[2] = {0, 0};
+    constexpr int kStat = VM <= 9 ? VM : (VM + 1) / 2;
+    dtx::static_for<0, (VM + kStat - 1) / kStat>([&](auto chc) {
+      constexpr int m0 = chc * kStat, m1 = m0 + kStat < VM ? m0 + kStat : VM;
+      float mu[m1 - m0], rw[m1 - m0];
+#pragma unroll
+      for (int m = m0; m < m1; ++m) {
+        const unsigned p4 = 4u * (unsigned)(p0 + tid + 1024 * m), o = min(p4, last);
+        mu[m - m0] = *reinterpret_cast<const float*>(mwc + o);
+        const float rv = *reinterpret_cast<const float*>(rwc + o);
+        rw[m - m0] = p4 <= last ? rv : __builtin_nanf("");      // NaN (a lag past Pz) never wins a comparison
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+          const float y = h ? z[m].y : z[m].x;
+          float cc = (y - s1v[k][h] * mu[m - m0]) * rw[m - m0];
+          cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+          const bool gt = cc > best[h];
+          best[h] = gt ? cc : best[h];
+          bm[h] = gt ? m : bm[h];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float r1 = r1v[k][h];
+      const float wmax = wave_max_f32(best[h]);
+      const unsigned pcand = (best[h] == wmax) ? (unsigned)(p0 + tid + 1024 * bm[h]) : 0xFFFFFFFFu;
+      const unsigned pmin = wave_min_u32(pcand);
+      if ((tid & 63) == 0) {
+        unsigned long long key = 0ull;
+        if (r1 > 0.f && wmax > -INFINITY) {
+          const unsigned bits = __float_as_uint(wmax);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
+        }
+        wred[2 * k + h][wv] = key;
+      }
+    }
+  };
+  finish(z0, I0{});
+  finish(z1, I1{});
+  __syncthreads();
+  if (tid < 4) {
+    unsigned long long key = wred[tid][0];
+#pragma unroll
+    for (int q = 1; q < kT16 / 64; ++q) key = max(key, wred[tid][q]);
+    const int k = tid >> 1, h = tid & 1;
+    const int b = 2 * pr + h, c = k ? c1 : c0;
+    if (key != 0ull && b < c && (k == 0 || has1)) {
+      const int64_t idx = condensed_index_x(a.N, b, c);
+      if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+    }
+  }
+}
+
+// pair spectra for the 16 384-point lag search (xc_wspec_kernel one size up): W[pair][vc][w_slot16 order]
+__global__ __launch_bounds__(kT16) void xc_wspec16_kernel(const float* __restrict__ td, int N, int n, int Nc, int L,
+                                                          int nseg, int seglen, const float* __restrict__ frs,
+                                                          const c32* __restrict__ tab, c32* __restrict__ W) {
+  __shared__ c32 lds[kN16];
+  const int tid = threadIdx.x;
+  const int nvc = Nc * nseg;
+  const int pr = blockIdx.x / nvc, vc = blockIdx.x - pr * nvc;
+  const int ch = vc / nseg, sg = vc - ch * nseg;
+  const int a = 2 * pr, b = a + 1;
+  const int j0 = sg * seglen;
+  const float ra = frs[a], rb = b < N ? frs[b] : 0.f;
+  const LdsBases lb = lds_bases(tid);
+  c32 v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = 16 * ((tid & 63) + 64 * r) + (tid >> 6);    // point index the transform expects
+    float re = 0.f, im = 0.f;
+    if (j < seglen && j0 + j < L) {
+      const int64_t q = (int64_t)(j0 + j) * Nc + ch;
+      re = td[(int64_t)a * n + q] * ra;
+      if (b < N) im = td[(int64_t)b * n + q] * rb;
+    }
+    v[r] = make_float2(re, im);
+  }
+  fft16384<1>(v, lds, lb, tab, tid);
+  c32* dst = W + ((int64_t)pr * nvc + vc) * kN16;     // register m holds frequency tid + 1024 m
+  const float sc = 1.0f / (float)kN16;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) dst[w_slot16(tid + 1024 * m)] = make_float2(v[m].x * sc, v[m].y * sc);
+}
+
+template <int VM>
+void launch_xc16(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
+  hipLaunchKernelGGL((xc_fft16_kernel<VM>), dim3(grid), dim3(kT16), 0, ctx->stream, a);
+}
+
+#endif   // DTX_XC16
+
 template <int VM>
 void launch_xc22(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
   hipLaunchKernelGGL((xc_fft22_kernel<VM>), dim3(grid), dim3(kT2), 0, ctx->stream, a);
@@ -700,10 +1040,24 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // V = 4608, 3 blocks, 11 products -- a quarter fewer transforms and a sixth fewer MAC steps.
   // (host arithmetic: dtxplan::plan_xc_segments / plan_xc_items, dtx_plan.h -- covered by the CPU sanitizer build)
   const int S = (Pz - 1) / 2;
-  const dtxplan::XcSegPlan sp = dtxplan::plan_xc_segments(L, Pz, Nc, kN, kFftMaxL);
+  dtxplan::XcSegPlan sp = dtxplan::plan_xc_segments(L, Pz, Nc, kN, kFftMaxL);
+  // One size up (round 5): a 16 384-point kernel searches configs[2]'s 13 001 lags in ONE block
+  // (42 against 58 steps' worth per two pair spectra and two later events in the planner's cost model).  Built and
+  // parity-green, it ran 157 ms against the 2 x 2 kernel's 126: a workgroup holds one pair spectrum where the 2 x 2
+  // kernel holds two, so the bytes through the L1 per multiply-add rise by a third and the products -- bound by
+  // that traffic, ~20 TB/s either way -- take as long as before, while the sixteen-wave transforms came out no
+  // cheaper (profiles/x11_xc16_ablations.txt).  Not the default anywhere.
+  bool t16 = false;
+#if DTX_XC16
+  // (opt-in build; never the default: measured slower.  DETEX_AMD_XC16=1 selects it where a plan exists)
+  const dtxplan::XcSegPlan16 sp16 = dtxplan::plan_xc_segments16(L, Pz, Nc, kN16);
+  if (const char* e = std::getenv("DETEX_AMD_XC16")) t16 = sp16.ok && e[0] == '1';
+  if (t16) { sp.nseg = sp16.nseg; sp.seglen = sp16.seglen; sp.V = sp16.V; sp.nblk = sp16.nblk; }
+#endif
   const int nseg = sp.nseg, seglen = sp.seglen, V = sp.V;
   const int nblk = sp.nblk, nblkx = nblk * nseg;
   const int nvc = Nc * nseg, npr = (N + 1) / 2;
+  const int kNx = t16 ? kN16 : kN;                  // transform length of the kernel chosen
 
   // work items (c, first pair of a unit), unit-major so that concurrent workgroups share the
   // unit's pair spectra in L2.
@@ -718,20 +1072,20 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // faster (N = 1000 events, scripts/xc_sweep_L.sh, kernel ms: L = 1024 7.9 against 7.3, 2000 7.2 / 7.1,
   // 3000 7.1 / 7.0; 3500 6.4 / 7.0, 4000 6.2 / 7.1, 5633 16.0 / 19.3, 9000 23.4 / 23.8, 20 000 77 / 95;
   // 13 000 at N = 2000: 127 / 152).
-  bool t22 = DTX_XC_T22 != 0 && V / 512 <= 9;
-  if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = e[0] == '1';
+  bool t22 = t16 || (DTX_XC_T22 != 0 && V / 512 <= 9);       // (the 16 384-point kernel walks the 2 x 2 kernel's items)
+  if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = t16 || e[0] == '1';
   const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
                                              : dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
-  const int64_t nwork = (int64_t)items.size() * ((DTX_XC_BLKLOOP && !t22) || (DTX_XC_ABLATE & 32) ? 1 : nblk);
+  const int64_t nwork = (int64_t)items.size() * (t16 ? 2 * nblk : ((DTX_XC_BLKLOOP && !t22) || (DTX_XC_ABLATE & 32) ? 1 : nblk));
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_w = carve((size_t)npr * nvc * kN * sizeof(float2));
-  const size_t o_x = carve((size_t)N * nblkx * Nc * kXh * sizeof(float2));
-  const size_t o_t = carve((size_t)kN * sizeof(float2));
+  const size_t o_w = carve((size_t)npr * nvc * kNx * sizeof(float2));
+  const size_t o_x = carve((size_t)N * nblkx * Nc * (kNx / 2) * sizeof(float2));
+  const size_t o_t = carve((size_t)kNx * sizeof(float2));
   const size_t o_i = carve(items.size() * sizeof(int2));
   int rc;
   if ((rc = dtx_reserve(ctx, ctx->ws_xhat, off))) return rc;
@@ -740,21 +1094,33 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   c32* xh = (c32*)(base + o_x);
   c32* tab = (c32*)(base + o_t);
   {
-    std::vector<float2> htab(kN);
+    std::vector<float2> htab(kNx);
     const double pi = 3.14159265358979323846264338327950288;
-    for (int m = 0; m < kN; ++m)
-      htab[m] = make_float2((float)std::cos(2 * pi * m / kN), (float)std::sin(2 * pi * m / kN));
+    for (int m = 0; m < kNx; ++m)
+      htab[m] = make_float2((float)std::cos(2 * pi * m / kNx), (float)std::sin(2 * pi * m / kNx));
     DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the arena may be in use by queued work
     DTX_HIP(ctx, hipMemcpy(tab, htab.data(), htab.size() * sizeof(float2), hipMemcpyHostToDevice));
     DTX_HIP(ctx, hipMemcpy(base + o_i, items.data(), items.size() * sizeof(int2),
                            hipMemcpyHostToDevice));
   }
+#if DTX_XC16
+  if (t16) {
+    hipLaunchKernelGGL(xc_wspec16_kernel, dim3((unsigned)(npr * nvc)), dim3(kT16), 0, ctx->stream, td_dev,
+                       N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
+    DTX_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(xhat16_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT16), 0,
+                       ctx->stream, z, Tz, Nc, V, nblkx, (const c32*)tab, xh, nseg, nseg == 1 ? 0 : seglen);
+    DTX_HIP(ctx, hipGetLastError());
+  } else
+#endif
+  {
   hipLaunchKernelGGL(xc_wspec_kernel, dim3((unsigned)(npr * nvc)), dim3(kT), 0, ctx->stream, td_dev,
                      N, n, Nc, L, nseg, seglen, frs, (const c32*)tab, W);
   DTX_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)N), dim3(kT), 0,
                      ctx->stream, z, Tz, Nc, V, nblkx, kN, (const c32*)tab, xh, nseg, nseg == 1 ? 0 : seglen);
   DTX_HIP(ctx, hipGetLastError());
+  }
 
   XcFftArgs a;
   a.xh = xh; a.W = W; a.tab = tab; a.items = (const int2*)(base + o_i);
@@ -765,6 +1131,32 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   a.per_xcd = per_xcd; a.nwork = nwork;
   { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+#if DTX_XC16
+#ifdef DTX_XC16_ONLY       // (quick builds while tuning: one instantiation)
+  if (t16) switch (V / 1024) {
+    case DTX_XC16_ONLY: launch_xc16<DTX_XC16_ONLY>(ctx, a, (unsigned)grid); break;
+    default: return dtx_fail(ctx, DTX_E_STATE, "xcorr (FFT 16384): built for one block advance only");
+  }
+  else
+#endif
+  if (t16) switch (V / 1024) {
+    case 4: launch_xc16<4>(ctx, a, (unsigned)grid); break;
+    case 5: launch_xc16<5>(ctx, a, (unsigned)grid); break;
+    case 6: launch_xc16<6>(ctx, a, (unsigned)grid); break;
+    case 7: launch_xc16<7>(ctx, a, (unsigned)grid); break;
+    case 8: launch_xc16<8>(ctx, a, (unsigned)grid); break;
+    case 9: launch_xc16<9>(ctx, a, (unsigned)grid); break;
+    case 10: launch_xc16<10>(ctx, a, (unsigned)grid); break;
+    case 11: launch_xc16<11>(ctx, a, (unsigned)grid); break;
+    case 12: launch_xc16<12>(ctx, a, (unsigned)grid); break;
+    case 13: launch_xc16<13>(ctx, a, (unsigned)grid); break;
+    case 14: launch_xc16<14>(ctx, a, (unsigned)grid); break;
+    case 15: launch_xc16<15>(ctx, a, (unsigned)grid); break;
+    case 16: launch_xc16<16>(ctx, a, (unsigned)grid); break;
+    default: return dtx_fail(ctx, DTX_E_STATE, "xcorr (FFT 16384): bad block advance %d", V);
+  }
+  else
+#endif
   if (t22) switch (V / 512) {
     case 4: launch_xc22<4>(ctx, a, (unsigned)grid); break;
     case 5: launch_xc22<5>(ctx, a, (unsigned)grid); break;
