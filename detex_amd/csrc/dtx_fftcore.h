@@ -670,8 +670,10 @@ __device__ __forceinline__ void fft8192_x2(c32 (&va)[16], c32 (&vb)[16], c32* ld
 }
 
 // z += w p and z += w conj(p) in two packed fused multiply-adds each, the operand selection and the signs in the
-// instruction's modifiers.  Written out: the compiler's own packing of the four-fma form builds (-w.y, w.y) and
-// swapped copies in registers first -- a quarter of the scan kernel's vector instructions were v_mov.
+// instruction's modifiers (no (-w.y, w.y) or swapped copies in registers).  Used by the opt-in 16 384-point lag
+// search only: v_pk_*_f32 run at half the instruction rate on gfx950 (the Makefile builds the transform files with
+// -fno-slp-vectorize for that reason), and in the scan kernel these forms measured 3.2 against 2.75 ms for the
+// compiler's scalar fused multiply-adds (profiles/g26_cmac_ab.txt) -- what they save there is registers, not time.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cmac(f2& z, f2 w, f2 p) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"

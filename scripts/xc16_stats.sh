@@ -2,7 +2,7 @@
 # offline look at xc_fft16_kernel<13>: registers, spills, and the big basic blocks' instruction mix (no GPU needed)
 #   bash scripts/xc16_stats.sh "<extra flags>"
 cd /root/repo/detex_amd/csrc && mkdir -p /tmp/xcasm && \
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -DDTX_XC16=1 -DDTX_XC16_ONLY=13 $1 -c dtx_xcfft.hip -o /tmp/xcasm/x.o --save-temps=obj 2>&1 | grep -E "error" 
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -DDTX_XC16=1 -DDTX_XC16_ONLY=13 $1 -c dtx_xcfft.hip -o /tmp/xcasm/x.o --save-temps=obj 2>&1 | grep -E "error" 
 mv /root/repo/detex_amd/csrc/dtx_xcfft-hip* /root/repo/detex_amd/csrc/dtx_xcfft-host* /root/repo/detex_amd/csrc/dtx_xcfft.hip-hip* /tmp/xcasm/ 2>/dev/null
 python3 - <<'PY'
 import re, collections
