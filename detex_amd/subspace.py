@@ -283,6 +283,12 @@ class _StationUploader(object):
         self.cur = None
 
 
+def _same_unit(a, b):
+    """(station, chunk indices or None) twice the same?"""
+    return a[0] == b[0] and ((a[1] is None and b[1] is None) or
+                             (a[1] is not None and b[1] is not None and list(a[1]) == list(b[1])))
+
+
 def _merge_ranks(parts, names_order=None):
     """Results of one station in several parts -- from every rank (each scanned its share of the chunks)
     and / or from the units a long record is scanned in: detection rows in the order one launch over the
@@ -366,9 +372,16 @@ class _DbWriter(object):
     def _run(self):
         try:
             con = sqlite3.connect(self.path)
+            # A commit is an fsync (2.5 ms each on the test boxes' file system); the last flushes of a call sit on
+            # its critical path (close() joins), and an 8-station call made five of them: 10 ms of a 37 ms call.
+            # The file is a result table that a run rewrites from scratch (delOldCorrs): the pages are handed to the
+            # operating system without waiting for the disk -- a process crash loses nothing, a power failure may
+            # (the reference writes through pandas' to_sql with SQLite's default).  DETEX_AMD_DB_SYNC=FULL restores it.
+            con.execute('PRAGMA synchronous=%s' % os.environ.get('DETEX_AMD_DB_SYNC', 'OFF'))
             pending = {}
 
             def flush(table=None):
+                wrote = False
                 for tab in ([table] if table else list(pending)):
                     rows = pending.pop(tab, [])
                     if rows:
@@ -376,7 +389,9 @@ class _DbWriter(object):
                             tab, ', '.join('"%s" %s' % ct for ct in zip(self.COLS, self.TYPES))))
                         con.executemany('INSERT INTO "%s" VALUES (%s)' % (tab, ','.join('?' * len(self.COLS))),
                                         rows)
-                        con.commit()
+                        wrote = True
+                if wrote:
+                    con.commit()                            # one commit for everything flushed together
             try:
                 while True:
                     kind, a, b = self.q.get()
@@ -794,6 +809,7 @@ class SubSpace(object):
         stations = []
         results, failure = {}, None
         bounds, banks = {}, {}
+        early = None                                        # the unit whose upload was started ahead of the banks
         try:
             if classifyEvents is not None:
                 # detect.py:51-55, 151-152: the detectors run over the event waveforms of the cluster's
@@ -801,7 +817,21 @@ class SubSpace(object):
                 fetcher = self._event_chunks(classifyEvents, device if own_ctx else None, ctx, fillZeros)
             stations = [sta for sta in self.Stations if sta in fetcher.data]
             bounds = {sta: fetcher.chunk_bounds(sta, utcStart, utcEnd) for sta in stations}
-            banks = {sta: self._detector_bank(sta, useSubSpaces, useSingles) for sta in stations}
+            if stations and not active:
+                # the call's first upload goes out before the other stations' banks are built (a bank costs the
+                # host ~0.2 ms, eight stations ~2 ms that the copy engine would otherwise idle through): the
+                # first unit is known from the first station's bank alone
+                sta0 = stations[0]
+                banks[sta0] = self._detector_bank(sta0, useSubSpaces, useSingles)
+                first = self._scan_units([sta0], bounds, {sta0: None}, banks, fetcher)
+                if first:
+                    up0 = self._uploader(dev)
+                    up0.reset()
+                    up0.start(fetcher, first[0][0], bounds[first[0][0]], first[0][1], key=0)
+                    early = first[0]
+            for sta in stations:
+                if sta not in banks:
+                    banks[sta] = self._detector_bank(sta, useSubSpaces, useSingles)
         except Exception as e:                              # noqa: BLE001
             if not active:
                 raise
@@ -830,7 +860,9 @@ class SubSpace(object):
         # fits the budget, else day by day (_scan_units) -- the pipeline below keeps INFLIGHT units in flight
         todo = [] if failure is not None else self._scan_units(stations, bounds, sel, banks, fetcher)
         up = self._uploader(dev)
-        up.reset()
+        started0 = bool(todo) and early is not None and _same_unit(todo[0], early)
+        if not started0:
+            up.reset()
         parts = {}
         # single process: the SQLite file is written by a thread of its own, fed as the units finish
         # (detect.py:207-210 flushes every 500 rows); under a process group rank 0 writes after the gather
@@ -859,7 +891,7 @@ class SubSpace(object):
         # left the GPU waiting now and then: 3.7 - 4.7 ms per station-day from call to call.)
         queue = []                                          # jobs started, oldest first
         try:
-            if todo:
+            if todo and not started0:
                 up.start(fetcher, todo[0][0], bounds[todo[0][0]], todo[0][1], key=0)
             for i, (sta, chunks) in enumerate(todo):
                 if own_ctx:
