@@ -189,7 +189,7 @@ def test_stalta_screen_kernel():
     """dtx_stalta_max (the device form of fas._checkSTALTA's screen, fas.py:175-205 of the reference) against the
     host restatement of obspy's classic_sta_lta: traces at arbitrary offsets of one buffer, contiguous and strided
     (one channel of a multiplexed chunk), shorter than the LTA window (no value: 0), a burst at the very start / end,
-    a dead trace; and getFAS choosing the same chunks as the host screen would."""
+    a dead trace."""
     from detex_amd import fas
     from detex_amd.hip import HipContext
     rs = np.random.RandomState(11)
@@ -210,6 +210,41 @@ def test_stalta_screen_kernel():
             want = float(np.max(fas.classic_sta_lta(tr, nsta, nlta))) if m >= nlta else 0.0
             assert abs(g - want) <= 1e-9 * max(1.0, want), (nsta, nlta, stride, a, m, g, want)
     ctx.close()
+
+
+def test_getfas_screen_picks_the_chunks_the_host_rule_picks(workflow):
+    """getFAS with its STA/LTA limit on a record whose chunks hold the planted events (bursts well above the
+    limit on the Z channel in some of them): the chunks the device screen lets through are the ones
+    fas._checkSTALTA lets through on the host, in the same random order (fas.py:45-68, 92-93, 175-205) -- read off the
+    histogram's total, which is the number of windows of the chosen chunks."""
+    from detex_amd import fas
+    ss, cf = workflow['ss'], workflow['cf']
+    ss.SVD(selectCriteria=4, selectValue=1, threshold=0.4, useSingles=False)
+    names, kinds, U, off, _, _ = ss._detector_bank('TA.M17A', useSingles=False)
+    n = U.shape[1]
+    data = cf.data['TA.M17A'][0]
+    bounds = [b for b in cf.chunk_bounds('TA.M17A') if b[1] * NC > n]
+    for (limit, seed, want_n) in ((3.0, 5, 2), (3.0, 6, 3), (50.0, 7, 2), (1.001, 8, 2)):
+        rs = np.random.RandomState(seed)
+        order = rs.permutation(len(bounds))[:want_n * 4]
+
+        def pick(lim):
+            chosen, count = [], 0
+            for k in order:
+                count += 1
+                s0, cnt, _ = bounds[k]
+                if lim is not None and not fas._checkSTALTA(data[:, s0:s0 + cnt], cf.channels, SR, 0.5, 5, lim):
+                    continue
+                if len(chosen) >= want_n:
+                    break
+                chosen.append(k)
+            return chosen, count
+        chosen, count = pick(limit)
+        if count and float(len(chosen)) / count <= .25:
+            chosen, count = pick(None)
+        ss.getFAS(want_n, LTATime=5, STATime=0.5, staltalimit=limit, recalc=True, seed=seed)
+        rec = ss.subspaces['TA.M17A'].FAS.iloc[0]
+        assert int(np.sum(rec['hist'])) == sum((bounds[k][1] * NC - n) // NC + 1 for k in chosen), (limit, seed, chosen)
 
 
 def test_trigger_stats_kernel():
