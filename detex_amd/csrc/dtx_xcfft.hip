@@ -679,6 +679,349 @@ __global__ __launch_bounds__(kT2, 1) void xc_fft22_kernel(const XcFftArgs a) {
   }
 }
 
+// ---- two workgroups per CU: one pair spectrum x two later events ------------------------------------------------
+// The 2 x 2 workgroup runs its phases one after the other -- products (bound by the bytes through the L1), transforms
+// (vector issue and dependency chains), lag search -- and nothing else fits on its CU.  Here a workgroup is HALF the
+// size: 512 threads (the transform's own layout), ONE pair spectrum in registers x TWO later events, whose block
+// spectra it stages through LDS by LDS-DMA -- single-buffered, 2 x 32 KB, the same 64 KB that are the transform image
+// afterwards -- in 128 registers: TWO such workgroups share a CU, and while one waits for its staging or runs its
+// transforms the other multiplies.  A product costs 64 KB through the L1 instead of 48 (the pair spectrum serves two
+// later events, the staged spectra one pair instead of two); what it buys is the overlap of the phases.
+#ifndef DTX_XC_T12
+#define DTX_XC_T12 1
+#endif
+#ifndef DTX_XC12_HALVES
+#define DTX_XC12_HALVES 0    // 1 (measured slower: 134.8 against 128.1 ms at configs[2], 22.3 against 20.9 at L = 3000): the step in two phases on half spectra (lower / upper 256 slots of the eight rows), double-buffered
+#endif                       // inside the 64 KB: a staging load has half a step to land instead of being waited for at once
+#ifndef DTX_XC12_ABLATE
+#define DTX_XC12_ABLATE 0    // timing only (results wrong): 1 no pair-spectrum loads, 2 no staging, 4 no lag search, 8 no transforms
+#endif
+template <int VM>
+__global__ __launch_bounds__(kT, 4) void xc_fft12_kernel(const XcFftArgs a) {
+  __shared__ c32 lds[kLdsC];                    // [later event][kXh] staged block spectra; then the transform image
+  static_assert(kLdsC == 2 * kXh, "two staged half spectra fill the image");
+  __shared__ unsigned long long wred[4][kT / 64];   // [(later event, row)][wave]
+  const int tid = threadIdx.x;
+  const int64_t logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if (logical >= a.nwork) return;
+  // (item, which of its two pair spectra, lag block): the two pair spectra of an item side by side
+  const int blk = (int)(logical % a.nblk);
+  const int64_t ip = logical / a.nblk;
+  const int item = (int)(ip >> 1), hp = (int)(ip & 1);
+  const int2 it = a.items[item];
+  const int ity = __builtin_amdgcn_readfirstlane(it.y);
+  const int c0 = __builtin_amdgcn_readfirstlane(it.x), has1 = (ity >> 30) & 1, pr = (ity & 0x3fffffff) + hp;
+  const int c1 = has1 ? c0 + 1 : c0;
+  if (pr >= (a.N + 1) / 2 || 2 * pr >= c1) return;          // no such pair spectrum / no row below the later events
+  const LdsBases lb = lds_bases(tid);
+  const int p0 = blk * a.V;
+  const int nse = min(a.nseg, max(1, (a.zend - p0 + a.seglen - 1) / a.seglen));
+  const int nsteps = a.Nc * nse;
+  const int64_t xstride = (int64_t)a.nblk * a.nseg * a.Nc * kXh;
+  const c32* xh0 = a.xh + c0 * xstride + (int64_t)blk * a.nseg * a.Nc * kXh;     // (uniform: scalar registers)
+  const c32* xh1 = a.xh + c1 * xstride + (int64_t)blk * a.nseg * a.Nc * kXh;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+  const int xlo = 512 * wv + ln, xhi = wv ? 512 * (8 - wv) + 1023 - ln : 1024 - ln;
+  auto x_slot = [&](int r) { return r < 8 ? xlo + 64 * r : ((r == 8 && tid == 0) ? 0 : xhi - 64 * r); };
+  auto fix_x = [&](c32 xx, int r) {
+    if (r == 0 && tid == 0) xx.y = 0.f;
+    if (r == 8 && tid == 0) return make_float2(xx.y, 0.f);
+    if (r >= 8) xx.y = -xx.y;
+    return xx;
+  };
+  const int nvc = a.Nc * a.nseg;
+  const char* wq = reinterpret_cast<const char*>(a.W + (int64_t)pr * nvc * kN);       // uniform
+  const unsigned wlane = 16u * (unsigned)(512 * wv + ln);
+  auto voff = [&](int i) {                      // (channel, segment) of step i as an index into [nseg][Nc] / [Nc][nseg]
+    const int ch = i / nse, sg = i - ch * nse;
+    return make_int2(sg * a.Nc + ch, ch * a.nseg + sg);
+  };
+  float r1v[2][2], s1v[2][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = 2 * pr + h;
+      const bool rowok = b < (k ? c1 : c0) && (k == 0 || has1);
+      r1v[k][h] = rowok ? a.frs[b] : 0.f;
+      s1v[k][h] = rowok ? a.fsum[b] * r1v[k][h] : 0.f;
+    }
+  c32 z0[16], z1[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) z0[m] = z1[m] = make_float2(0.f, 0.f);
+  float4 w[2][2];
+  auto issue_w = [&](int i, auto qc, auto sc) {       // batch q of step i (frequency registers 4 q .. 4 q + 3) into slot s
+    constexpr int q = qc, sl = sc;
+    const char* src = wq + (int64_t)voff(i).y * (kN * 8);
+#if DTX_XC12_ABLATE & 1
+    w[sl][0] = w[sl][1] = make_float4(1.f, 0.5f, 1.f, 0.5f);
+    if (src == nullptr) w[sl][0].x = 2.f;
+#else
+    w[sl][0] = *reinterpret_cast<const float4*>(src + wlane + 16 * 64 * (2 * q));
+    w[sl][1] = *reinterpret_cast<const float4*>(src + wlane + 16 * 64 * (2 * q + 1));
+#endif
+  };
+  // the step's block spectra, both later events: 2 x 4096 complex = 4096 float4, eight per thread, a wave's 64 lanes
+  // side by side at a wave-uniform LDS address (LDS-DMA: no staging registers, no ds_write)
+  [[maybe_unused]] auto stage = [&](int i) {
+    const int64_t o = (int64_t)voff(i).x * kXh * 8;
+    const char* s0 = reinterpret_cast<const char*>(xh0) + o + 16u * (unsigned)tid;
+    const char* s1 = reinterpret_cast<const char*>(xh1) + o + 16u * (unsigned)tid;
+    float4* d = reinterpret_cast<float4*>(lds) + 64 * wv;
+#if DTX_XC12_ABLATE & 2
+    if (s0 == nullptr)
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + 16 * 512 * k),
+                                       (__attribute__((address_space(3))) void*)(d + 512 * k), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + 16 * 512 * k),
+                                       (__attribute__((address_space(3))) void*)(d + 2048 + 512 * k), 16, 0, 0);
+    }
+  };
+  [[maybe_unused]] auto mac_q = [&](auto qc, auto sc) {
+    constexpr int q = qc, sl = sc;
+    c32 pa[4], pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      pa[e] = fix_x(lds[x_slot(r)], r);
+      pb[e] = fix_x(lds[kXh + x_slot(r)], r);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = 4 * q + e;
+      const float4 t = w[sl][e >> 1];
+      const c32 pw = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+      z0[m].x = __fmaf_rn(-pw.y, pa[e].y, __fmaf_rn(pw.x, pa[e].x, z0[m].x));
+      z0[m].y = __fmaf_rn(pw.y, pa[e].x, __fmaf_rn(pw.x, pa[e].y, z0[m].y));
+      z1[m].x = __fmaf_rn(-pw.y, pb[e].y, __fmaf_rn(pw.x, pb[e].x, z1[m].x));
+      z1[m].y = __fmaf_rn(pw.y, pb[e].x, __fmaf_rn(pw.x, pb[e].y, z1[m].y));
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2c = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+#if DTX_XC12_HALVES
+  // Phase L: frequency registers 0..3 and 12..15 (own + mirrored) read the LOWER 256 slots of the eight 512-slot rows
+  // of a stored half spectrum, phase U: registers 4..11 the upper ones.  Buffer L = lds[0 .. 4096) (both later events'
+  // lower halves, 2048 slots each), buffer U = lds[4096 .. 8192): while one is read the other is filled.  Thread 0's
+  // two mirrored reads outside their half (slot 256 in phase L, the (X[0], X[4096]) pair of slot 0 in phase U) come
+  // through a uniform load and a select.
+  constexpr int kHalf = 2048;
+  const int hlo = 256 * wv + ln;                                        // r < 8: + 64 r (phase U: - 256)
+  const int hhi = wv ? 256 * (8 - wv) + 1023 - ln : 1024 - ln;          // r >= 8: - 64 r (phase U: - 256)
+  auto h_slot = [&](int r) {
+    if (r < 4) return hlo + 64 * r;
+    if (r < 8) return hlo + 64 * r - 256;
+    if (r < 12) return hhi - 256 - 64 * r;
+    return hhi - 64 * r;
+  };
+  c32 st0 = make_float2(0.f, 0.f), st1 = st0;
+  auto load_stray = [&](int i, int ph) {        // slot 256 for phase L, slot 0 (its .y = X[4096]) for phase U
+    const int64_t o = (int64_t)voff(i).x * kXh + (ph ? 0 : 256);
+    const c32 a0 = xh0[o], a1 = xh1[o];
+    st0 = ph ? make_float2(a0.y, 0.f) : a0;
+    st1 = ph ? make_float2(a1.y, 0.f) : a1;
+  };
+  const unsigned sthr = 16u * (unsigned)((tid >> 7) * 256 + (tid & 127));     // the thread's float4 of a half: row (tid >> 7) + 4 k
+  auto stage_half = [&](int i, int ph) {        // both later events' halves of step i into buffer ph
+    const int64_t o = (int64_t)voff(i).x * kXh * 8 + 16 * 128 * ph;
+    const char* s0 = reinterpret_cast<const char*>(xh0) + o + sthr;
+    const char* s1 = reinterpret_cast<const char*>(xh1) + o + sthr;
+    float4* d = reinterpret_cast<float4*>(lds + 2 * kHalf * ph) + 64 * wv;
+#if DTX_XC12_ABLATE & 2
+    if (s0 == nullptr)
+#endif
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + 16 * 1024 * k),
+                                       (__attribute__((address_space(3))) void*)(d + 512 * k), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + 16 * 1024 * k),
+                                       (__attribute__((address_space(3))) void*)(d + 1024 + 512 * k), 16, 0, 0);
+    }
+  };
+  const bool t0 = tid == 0;
+  auto mac_h = [&](int ph, auto qc, auto sc, c32 sv0, c32 sv1) {
+    constexpr int q = qc, sl = sc;
+    const c32* x0 = lds + 2 * kHalf * ph;
+    const c32* x1 = x0 + kHalf;
+    c32 pa[4], pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * q + e;
+      pa[e] = x0[h_slot(r)];
+      pb[e] = x1[h_slot(r)];
+      if (r == 0) { pa[e].y = t0 ? 0.f : pa[e].y; pb[e].y = t0 ? 0.f : pb[e].y; }
+      if (r == 8 || r == 12) {
+        pa[e].x = t0 ? sv0.x : pa[e].x; pa[e].y = t0 ? sv0.y : pa[e].y;
+        pb[e].x = t0 ? sv1.x : pb[e].x; pb[e].y = t0 ? sv1.y : pb[e].y;
+      }
+      if (r >= 8) { pa[e].y = -pa[e].y; pb[e].y = -pb[e].y; }            // X[kN - f] = conj X[f]
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = 4 * q + e;
+      const float4 t = w[sl][e >> 1];
+      const c32 pw = (e & 1) ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+      z0[m].x = __fmaf_rn(-pw.y, pa[e].y, __fmaf_rn(pw.x, pa[e].x, z0[m].x));
+      z0[m].y = __fmaf_rn(pw.y, pa[e].x, __fmaf_rn(pw.x, pa[e].y, z0[m].y));
+      z1[m].x = __fmaf_rn(-pw.y, pb[e].y, __fmaf_rn(pw.x, pb[e].x, z1[m].x));
+      z1[m].y = __fmaf_rn(pw.y, pb[e].x, __fmaf_rn(pw.x, pb[e].y, z1[m].y));
+    }
+  };
+  // batch order in time: (i, 0) (i, 3) | (i, 1) (i, 2) | (i + 1, 0) ...; slot = position in that order & 1, the batch
+  // two further on is fetched into a slot as soon as its products are done
+  issue_w(0, I0{}, I0{});
+  issue_w(0, I3{}, I1{});
+  stage_half(0, 0);
+  load_stray(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma nounroll
+  for (int i = 0; i < nsteps; ++i) {
+    const int nx = min(i + 1, nsteps - 1);      // (the last step fetches its own operands again: straight-line steps)
+    // ---- phase L (buffer U is free: every wave passed the barrier behind its last read of it)
+    // (the strays of the half-step just begun are in registers; the next one's are fetched into a second pair)
+    stage_half(i, 1);
+    const c32 sa0 = st0, sa1 = st1;
+    load_stray(i, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mac_h(0, I0{}, I0{}, sa0, sa1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(i, I1{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_h(0, I3{}, I1{}, sa0, sa1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(i, I2c{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    // the four DMA loads (and the strays) are older than the four pair-spectrum loads issued behind them (loads
+    // return in order): wait for all but those, which stay in flight across the barrier
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- phase U
+    stage_half(nx, 0);
+    const c32 sb0 = st0, sb1 = st1;
+    load_stray(nx, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mac_h(1, I1{}, I0{}, sb0, sb1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(nx, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_h(1, I2c{}, I1{}, sb0, sb1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(nx, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#else
+  issue_w(0, I0{}, I0{});
+  issue_w(0, I1{}, I1{});
+#pragma nounroll
+  for (int i = 0; i < nsteps; ++i) {
+    const int nx = min(i + 1, nsteps - 1);      // (the last step fetches its own operands again: straight-line steps)
+    __syncthreads();                            // every wave has read the previous step's spectra
+    stage(i);
+    // the eight DMA loads are younger than the step's first two pair-spectrum batches: everything has landed
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(i, I2c{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(i, I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(I2c{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(nx, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mac_q(I3{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(nx, I1{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+  // the transforms on the staging memory (fft8192's first barrier is behind every wave's last read of it)
+  auto finish = [&](c32 (&z)[16], auto kc) {
+    constexpr int k = kc;
+    const int c = k ? c1 : c0;
+#if DTX_XC12_ABLATE & 8
+    if (z[0].x == 1.2345f && z[3].y == 5.4321f) a.keys[1] = 1ull;
+#else
+    fft8192<1>(z, lds, lb, a.tab, tid);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#if DTX_XC12_ABLATE & 4
+    if (z[0].x == 1.2345f && z[5].y == 5.4321f) a.keys[1] = 1ull;
+    if ((tid & 63) == 0) { wred[2 * k][wv] = 0ull; wred[2 * k + 1][wv] = 0ull; }
+    return;
+#endif
+    const char* mwc = reinterpret_cast<const char*>(a.mean_w + (int64_t)c * a.Ppad);
+    const char* rwc = reinterpret_cast<const char*>(a.rsw + (int64_t)c * a.Ppad);
+    const unsigned last = 4u * (unsigned)(a.Pz - 1);
+    float best[2] = {-INFINITY, -INFINITY};
+    int bm[2] = {0, 0};
+    constexpr int kStat = VM <= 9 ? VM : (VM + 1) / 2;
+    dtx::static_for<0, (VM + kStat - 1) / kStat>([&](auto chc) {
+      constexpr int m0 = chc * kStat, m1 = m0 + kStat < VM ? m0 + kStat : VM;
+      float mu[m1 - m0], rw[m1 - m0];
+#pragma unroll
+      for (int m = m0; m < m1; ++m) {
+        const unsigned p4 = 4u * (unsigned)(p0 + tid + 512 * m), o = min(p4, last);
+        mu[m - m0] = *reinterpret_cast<const float*>(mwc + o);
+        const float rv = *reinterpret_cast<const float*>(rwc + o);
+        rw[m - m0] = p4 <= last ? rv : __builtin_nanf("");      // NaN (a lag past Pz) never wins a comparison
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int m = m0; m < m1; ++m) {
+          const float y = h ? z[m].y : z[m].x;
+          float cc = (y - s1v[k][h] * mu[m - m0]) * rw[m - m0];
+          cc = (fabsf(cc) > 1.f + kScrubTolF) ? 0.f : cc;           // construct.py:458-462 (NaN stays NaN)
+          const bool gt = cc > best[h];
+          best[h] = gt ? cc : best[h];
+          bm[h] = gt ? m : bm[h];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float r1 = r1v[k][h];
+      const float wmax = wave_max_f32(best[h]);
+      const unsigned pcand = (best[h] == wmax) ? (unsigned)(p0 + tid + 512 * bm[h]) : 0xFFFFFFFFu;
+      const unsigned pmin = wave_min_u32(pcand);
+      if ((tid & 63) == 0) {
+        unsigned long long key = 0ull;
+        if (r1 > 0.f && wmax > -INFINITY) {
+          const unsigned bits = __float_as_uint(wmax);
+          const unsigned ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+          key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - pmin);
+        }
+        wred[2 * k + h][wv] = key;
+      }
+    }
+  };
+  finish(z0, I0{});
+  finish(z1, I1{});
+  __syncthreads();
+  if (tid < 4) {
+    unsigned long long key = wred[tid][0];
+#pragma unroll
+    for (int q = 1; q < kT / 64; ++q) key = max(key, wred[tid][q]);
+    const int k = tid >> 1, h = tid & 1;
+    const int b = 2 * pr + h, c = k ? c1 : c0;
+    if (key != 0ull && b < c && (k == 0 || has1)) {
+      const int64_t idx = condensed_index_x(a.N, b, c);
+      if (idx >= a.pair_begin && idx < a.pair_end) atomicMax(a.keys + idx, key);
+    }
+  }
+}
+
+template <int VM>
+void launch_xc12(dtx_ctx* ctx, const XcFftArgs& a, unsigned grid) {
+  hipLaunchKernelGGL((xc_fft12_kernel<VM>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+}
+
 #ifndef DTX_XC16
 #define DTX_XC16 0           // the 16 384-point lag search: built, parity-green, measured SLOWER than the 2 x 2 kernel at configs[2]
 #endif                       // (157 against 126 ms: profiles/x11_xc16_ablations.txt, profiles/README.md); make EXTRA=-DDTX_XC16=1 builds it
@@ -1074,10 +1417,24 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   // 13 000 at N = 2000: 127 / 152).
   bool t22 = t16 || (DTX_XC_T22 != 0 && V / 512 <= 9);       // (the 16 384-point kernel walks the 2 x 2 kernel's items)
   if (const char* e = std::getenv("DETEX_AMD_XC22")) t22 = t16 || e[0] == '1';
+  // The half-size workgroup, two per CU (xc_fft12_kernel), is the default: as fast or faster than either of the others
+  // from L = 1024 to 32 768 (scripts/xc_sweep_L.sh, N = 1000, Nc = 3, kernel ms: L = 1024 6.8 / 7.9 / 7.4 for this
+  // kernel / the 2 x 2 workgroup / the round-3 kernel, 3000 5.7 / 7.0 / 7.0, 5000 9.9 / 11.3 / 13.3, 9000 19.5 / 22.6 /
+  // 23.7, 20 000 74.4 / 75.4 / 95.1) -- except where a lag block has twelve or more product steps (configs[2]: 12;
+  // L = 6500: 15; six channels at L = 6000: 18): there the bytes per product decide and the 2 x 2 workgroup moves a
+  // quarter fewer (126 against 128 ms at configs[2], 16.6 / 17.2 at L = 6500, 18.1 / 19.8 at Nc = 6).  It walks the
+  // 2 x 2 kernel's items, one pair spectrum each.  DETEX_AMD_XC12=1 / 0 forces / forbids it; DETEX_AMD_XC22 names one of
+  // the other two.
+  int maxsteps = 0;
+  for (int b = 0; b < nblk; ++b)
+    maxsteps = std::max(maxsteps, Nc * std::min(nseg, std::max(1, (S + L - b * V + seglen - 1) / seglen)));
+  bool t12 = DTX_XC_T12 != 0 && !t16 && !std::getenv("DETEX_AMD_XC22") && !(V / 512 <= 9 && maxsteps >= 12);
+  if (const char* e = std::getenv("DETEX_AMD_XC12")) t12 = !t16 && e[0] == '1';
+  if (t12) t22 = true;
   const std::vector<dtxplan::I2> items = t22 ? dtxplan::plan_xc_items22(N, b_begin, b_end, kGroupX, kCtileX)
                                              : dtxplan::plan_xc_items(N, b_begin, b_end, kUnitX, kGroupX, kCtileX);
   if (items.empty()) return DTX_OK;
-  const int64_t nwork = (int64_t)items.size() * (t16 ? 2 * nblk : ((DTX_XC_BLKLOOP && !t22) || (DTX_XC_ABLATE & 32) ? 1 : nblk));
+  const int64_t nwork = (int64_t)items.size() * ((t16 || t12) ? 2 * nblk : ((DTX_XC_BLKLOOP && !t22) || (DTX_XC_ABLATE & 32) ? 1 : nblk));
   const int64_t per_xcd = (nwork + 7) / 8, grid = per_xcd * 8;
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "xcorr (FFT): grid too large");
 
@@ -1157,7 +1514,22 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   }
   else
 #endif
-  if (t22) switch (V / 512) {
+  if (t12) switch (V / 512) {
+    case 4: launch_xc12<4>(ctx, a, (unsigned)grid); break;
+    case 5: launch_xc12<5>(ctx, a, (unsigned)grid); break;
+    case 6: launch_xc12<6>(ctx, a, (unsigned)grid); break;
+    case 7: launch_xc12<7>(ctx, a, (unsigned)grid); break;
+    case 8: launch_xc12<8>(ctx, a, (unsigned)grid); break;
+    case 9: launch_xc12<9>(ctx, a, (unsigned)grid); break;
+    case 10: launch_xc12<10>(ctx, a, (unsigned)grid); break;
+    case 11: launch_xc12<11>(ctx, a, (unsigned)grid); break;
+    case 12: launch_xc12<12>(ctx, a, (unsigned)grid); break;
+    case 13: launch_xc12<13>(ctx, a, (unsigned)grid); break;
+    case 14: launch_xc12<14>(ctx, a, (unsigned)grid); break;
+    case 15: launch_xc12<15>(ctx, a, (unsigned)grid); break;
+    default: return dtx_fail(ctx, DTX_E_STATE, "xcorr (FFT): bad block advance %d", V);
+  }
+  else if (t22) switch (V / 512) {
     case 4: launch_xc22<4>(ctx, a, (unsigned)grid); break;
     case 5: launch_xc22<5>(ctx, a, (unsigned)grid); break;
     case 6: launch_xc22<6>(ctx, a, (unsigned)grid); break;
