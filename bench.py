@@ -362,7 +362,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
                  # one segment, one lag block (3001 lags in a block of 8192): one transform and Nc products per event pair;
                  # outside the lag search: the float64 finish (xc_finish2_kernel) + preparation, seconds - kernel_ms
                  'outside_lag_search_ms': 1e3 * (time.perf_counter() - t1) - ks,
-                 'roofline': {'bound': 'hbm', 'kernel': 'xc_fft_kernel<6>', 'kernel_ms': ks, 'bytes_per_launch': b_s,
+                 'roofline': {'bound': 'hbm', 'kernel': 'xc_fft12_kernel<10>', 'kernel_ms': ks, 'bytes_per_launch': b_s,
                               'achieved': b_s / (ks * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                               'frac': b_s / (ks * 1e-3) / 1e9 / 8000.0, 'traffic': None,
                               'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
