@@ -688,6 +688,47 @@ def test_resolve_overlaps_rule():
     assert nover > 200
 
 
+def test_clip_fragments_keeps_data_and_trace_extents():
+    """getdata.clip_fragments (the shard of a rank / the window of an event: parallel.rebase_fragments,
+    construct._preprocess_events): resolved fragments clipped to spans and re-based give the dense record restricted
+    to the spans, and the ORIGINAL traces' extents are clipped the same way (the 'fractured' decisions of a shard
+    equal those of the whole record on the chunks it holds)."""
+    from detex_amd.getdata import clip_fragments, resolve_overlaps, trace_extents
+    rs = np.random.RandomState(3)
+    for trial in range(200):
+        Nc, T = int(rs.randint(1, 4)), int(rs.randint(60, 300))
+        base = rs.randint(1, 50, size=(Nc, T)).astype(np.int32)
+        frags = []
+        for ch in range(Nc):
+            for _ in range(int(rs.randint(1, 6))):
+                lo = int(rs.randint(0, T - 1))
+                hi = int(rs.randint(lo + 1, min(T, lo + 80) + 1))
+                x = base[ch, lo:hi].copy()
+                if rs.rand() < 0.3:
+                    x[rs.randint(len(x))] += 1
+                frags.append((ch, lo, x))
+        res = resolve_overlaps(frags)
+        dense = orc.merge_fill_overlaps(frags, Nc, T)
+        # two disjoint spans laid end to end (parallel.plan_shard's runs)
+        a0 = int(rs.randint(0, T // 2)); b0 = int(rs.randint(a0 + 1, T // 2 + 1))
+        a1 = int(rs.randint(T // 2, T - 1)); b1 = int(rs.randint(a1 + 1, T + 1))
+        spans = [(a0, b0, 0), (a1, b1, b0 - a0)]
+        cl = clip_fragments(res, spans)
+        got = np.zeros((Nc, (b0 - a0) + (b1 - a1)))
+        for (c, t0, x) in cl:
+            assert not got[c, t0:t0 + len(x)].any()
+            got[c, t0:t0 + len(x)] = x
+        want = np.concatenate([dense[:, a0:b0], dense[:, a1:b1]], axis=1)
+        assert np.array_equal(got, want), trial
+        # the traces' extents: every original trace clipped to every span
+        ext = sorted((c, off + max(t0, a) - a, min(t0 + len(x), b) - max(t0, a))
+                     for (c, t0, x) in frags for (a, b, off) in spans if min(t0 + len(x), b) > max(t0, a))
+        if res.traces is not None:
+            assert sorted(trace_extents(cl)) == ext, trial
+        else:
+            assert sorted(trace_extents(cl)) == sorted((c, t0, len(x)) for (c, t0, x) in cl)
+
+
 def test_raw_counts_with_resent_packets():
     """A record with re-sent (overlapping) packets through ContinuousFetcher.add_counts -> SubSpace.detex on the
     CPU stand-in, against the oracle's chunk_span -> filter -> DS chain on the ORIGINAL traces:
