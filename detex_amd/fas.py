@@ -108,6 +108,12 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             Nc = len(fetcher.channels)
             sr = fetcher.sampling_rate
             n = U.shape[1]
+            if getattr(fetcher, 'counts', {}).get(sta) is not None:
+                # (add_counts keeps fragments, not planes: the per-chunk merge / longest-run trimming of
+                # detect._trim_to_gapfree would have to run for every candidate chunk first)
+                raise DetexHipError('getFAS on a fetcher of raw count fragments (add_counts) is not supported: '
+                                    'attach merged data (ContinuousFetcher.add) for the false-alarm statistics, '
+                                    'or set the thresholds directly (SVD(threshold=...))')
             data, _t0 = fetcher.data[sta]
             raw = bool(getattr(fetcher, 'raw', False))
             dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
