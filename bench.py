@@ -1080,10 +1080,13 @@ def main():
         """Per-step spread of the loop that just ran: the scan kernel's durations one by one (HIP events, the
         last <= 64 launches) and the host's step-to-step intervals (a step's results arrive while the next one
         runs, so an interval is one step of the pipeline)."""
-        ks = sorted(ctx.kernel_ms_list(min(steps, 64)))
+        each = ctx.kernel_ms_list(min(steps, 64))
+        ks = sorted(each)
         iv = sorted(1e3 * (b - a_) for a_, b in zip(stamps[:-1], stamps[1:]))
         o = {'kernel_ms_min': ks[0], 'kernel_ms_median': ks[len(ks) // 2], 'kernel_ms_max': ks[-1],
              'kernel_ms_launches': len(ks)}
+        if steps <= 64:
+            o['kernel_ms_each'] = [round(v, 3) for v in each]      # in launch order: WHICH step was slow
         if iv:
             o.update({'step_ms_min': iv[0], 'step_ms_median': iv[len(iv) // 2], 'step_ms_max': iv[-1]})
         return o
