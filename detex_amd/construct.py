@@ -170,7 +170,8 @@ def _loadEvents(fetcher, dtype, filt=None, trim=None, decimate=None, enforceOrig
                 start = start + k / sr
             if data.shape[1] == 0:
                 continue
-            if any(not np.any(c) for c in data):                  # construct.py:896-897
+            # construct.py:896-897: a channel that is all zeros (looked for only where a channel STARTS with a zero)
+            if not np.all(data[:, 0]) and not data.any(axis=1).all():
                 allzeros.append(name)
             planes[name] = data                                   # [Nc, L]: multiplexed when asked for (_LazyMPtd)
             lens[name] = data.size                                # STlens: total samples of the stream
