@@ -1076,15 +1076,19 @@ class SubSpace(object):
         # unit of its own and the last quarter of the last one comes behind as one: both ends of the pipeline are
         # short units (the tables do not depend on the cut).  ~13 ms of fixed cost per call was a third of an
         # 8-station-day call.
-        if os.environ.get('DETEX_AMD_RAMP', '1') != '0' and units:
+        # (OFF by default since the call's first upload goes out ahead of the banks -- SubSpace.detex --: with that in
+        # place the extra units cost the host more than they hide, 4.80 / 4.87 / 4.77 ms per station-day without against
+        # 4.84 / 4.88 / 4.94 with, profiles/p6_ramp_e2e.txt)
+        ramp = os.environ.get('DETEX_AMD_RAMP', '0')            # '1' both ends, 'head' / 'tail' one of them, '0' none
+        if ramp != '0' and units:
             def chunks_of(u):
                 return list(range(len(bounds[u[0]]))) if u[1] is None else [int(i) for i in u[1]]
             head = chunks_of(units[0])
-            if banks[units[0][0]][0] and len(head) >= 8:
+            if ramp in ('1', 'head') and banks[units[0][0]][0] and len(head) >= 8:
                 k = max(2, len(head) // 4)
                 units[0:1] = [(units[0][0], head[:k]), (units[0][0], head[k:])]
             tail = chunks_of(units[-1])
-            if banks[units[-1][0]][0] and len(tail) >= 8:
+            if ramp in ('1', 'tail') and banks[units[-1][0]][0] and len(tail) >= 8:
                 k = max(2, len(tail) // 4)
                 units[-1:] = [(units[-1][0], tail[:-k]), (units[-1][0], tail[-k:])]
         return units
