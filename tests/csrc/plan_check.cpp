@@ -116,6 +116,20 @@ static void check_xc(int N, int L, int Nc) {
   CHECK((int64_t)sp.nseg * sp.seglen >= L && (int64_t)(sp.nseg - 1) * sp.seglen < L);
   CHECK(sp.nblk == (Pz + sp.V - 1) / sp.V && sp.nblk >= 1);
   if (L > kMaxSingle) CHECK(sp.V >= 4 * 512 && sp.nseg >= 2 && sp.nseg <= 16);
+  CHECK(xc_plan_cost(sp, L, Pz, Nc) > 0);
+  {
+    // the 16 384-point plan (opt-in build of the lag search): lag blocks a multiple of 1024 apart, at most 16 lags
+    // per thread, every block's lags valid (N - seglen + 1 of them), the segments cover the event
+    const XcSegPlan16 p = plan_xc_segments16(L, Pz, Nc);
+    if (p.ok) {
+      CHECK(p.V % 1024 == 0 && p.V >= 4 * 1024 && p.V <= 16 * 1024);
+      CHECK(p.nblk == (Pz + p.V - 1) / p.V && p.nblk >= 1);
+      CHECK(p.nseg >= 1 && p.nseg <= 16 && (int64_t)p.nseg * p.seglen >= L);
+      CHECK(p.nseg == 1 || (int64_t)(p.nseg - 1) * p.seglen < L);
+      CHECK(std::min(p.V, Pz) <= 16384 - p.seglen + 1);
+      CHECK(p.cost > 0 && p.cost < 1e9);
+    }
+  }
   const int64_t npairs = (int64_t)N * (N - 1) / 2;
   auto row_of = [&](int64_t idx) {                             // row b of condensed index idx
     int64_t b = 0;
