@@ -688,6 +688,28 @@ def test_resolve_overlaps_rule():
     assert nover > 200
 
 
+def test_pickled_cluster_stream_rebuilds_the_same_subspaces(tmp_path, monkeypatch):
+    """ClusterStream.write() (subspace.py:261-267) with the lazily multiplexed MPtd of round 5: a cluster read back
+    from its pickle gives createSubSpace the same aligned waveforms."""
+    import pickle
+    monkeypatch.chdir(tmp_path)
+    ctx = OracleCtx()
+    ss, cf, plants, _ = small_workflow(ctx)
+    cl = ss.clusters
+    cl.filename = 'clust.pkl'
+    cl.write()
+    with open('clust.pkl', 'rb') as f:
+        cl2 = pickle.load(f)
+    ss2 = createSubSpace(Pf=1e-10, clust=cl2, conDatFetcher=cf)
+    for sta in ss.subspaces:
+        for (_, r1), (_, r2) in zip(ss.subspaces[sta].iterrows(), ss2.subspaces[sta].iterrows()):
+            assert r1.Events == r2.Events
+            assert all(np.array_equal(r1.AlignedTD[k], r2.AlignedTD[k]) for k in r1.AlignedTD)
+    for sta in ss.singles:
+        for (_, r1), (_, r2) in zip(ss.singles[sta].iterrows(), ss2.singles[sta].iterrows()):
+            assert all(np.array_equal(r1.MPtd[k], r2.MPtd[k]) for k in r1.MPtd)
+
+
 def test_clip_fragments_keeps_data_and_trace_extents():
     """getdata.clip_fragments (the shard of a rank / the window of an event: parallel.rebase_fragments,
     construct._preprocess_events): resolved fragments clipped to spans and re-based give the dense record restricted
