@@ -1063,8 +1063,19 @@ def main():
                'cap_s': a.prewarm, 'min_s': a.prewarm_min,
                'kernel_ms_first10': (sum(pre_k[:10]) / len(pre_k[:10])) if pre_k else None,
                'kernel_ms_last10': (sum(pre_k[-10:]) / len(pre_k[-10:])) if pre_k else None}
+    # the W warm-up steps run the way the timed ones do -- one step's results fetched while the next step runs -- so
+    # that everything the pipelined loop allocates exists before the clock starts: with two steps in flight torch's
+    # caching allocators hand out a SECOND set of result tensors (12 MB on the device, the pinned host buffers behind
+    # them), and a first-time hipMalloc / hipHostMalloc inside the timed region cost one of its 20 kernels a
+    # millisecond (kernel_ms_each showed 3.7 ms among 2.8s; the 200-step leg behind it never did)
+    pend = None
     for _ in range(a.warmup):
-        res = step()()
+        f = step()
+        if pend is not None:
+            res = pend()
+        pend = f
+    if pend is not None:
+        res = pend()
 
     def timed_loop(steps, barrier):
         # K steps, each one's results fetched inside the timed region -- while the next step runs, as
