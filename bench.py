@@ -246,11 +246,16 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
     for i in range(2):
         done[i].record(main)
     thr = torch.from_numpy(np.asarray(thr, dtype=np.float32)).cuda()
-    for i in range(2):                       # warm-up: pinned result buffers, side stream
-        upload(i)
-        main.wait_event(ready[i])
-        ctx.subspace_scan(bufs[i], out=ds, thr=thr, hist=hist, lazy=True)[1]()
-        done[i].record(main)
+    prev = None
+    for i in range(4):                       # warm-up, pipelined like the timed loop: result buffers of BOTH steps in flight
+        upload(i & 1)
+        main.wait_event(ready[i & 1])
+        f = ctx.subspace_scan(bufs[i & 1], out=ds, thr=thr, hist=hist, lazy=True)[1]
+        done[i & 1].record(main)
+        if prev is not None:
+            prev()
+        prev = f
+    prev()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     upload(0)
