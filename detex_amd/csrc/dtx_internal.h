@@ -150,6 +150,9 @@ int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
 // under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
 constexpr float kFftGuard = 200.f;
+// ... and the repair leaves alone the windows that hold at least 1 / kFftKeep of the loudest window's energy
+// (1.8e-8 * sqrt(256) = 2.9e-7: the frequency-domain engine's value is the better one there)
+constexpr float kFftKeep = 256.f;
 // split-bf16 engine: windows per guard block, and the share of a window's energy one sample (times the basis'
 // largest column energy) may hold before the block goes to the float32 engine (dtx_subspace.hip)
 constexpr int kSplitGuardV = 1024;

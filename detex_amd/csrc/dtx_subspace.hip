@@ -287,6 +287,11 @@ struct DsArgs {
   const int* list;
   int lV, lnblk;
   int64_t lw0, lw1;     // list mode: only windows [lw0, lw1) of the tile are stored (the listed block's)
+  // repair behind the frequency-domain engine: lkeep[cb] = the window energy from which that engine's own value
+  // stays (guard_kernel: its rounding is relative to the block's loudest window, so at the loud windows
+  // themselves -- a dominant event -- it is the more accurate of the two); NULL / +inf: every window is stored
+  const float* lkeep;
+  float lkeepv;
 };
 
 // mean correction, per-detector energy (membership MFMA on the accumulator tile),
@@ -355,7 +360,7 @@ __device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int det = 16 * db + 4 * kq + e;
-        if (det < a.nd && p < a.P && p >= a.lw0 && p < a.lw1) {
+        if (det < a.nd && p < a.P && p >= a.lw0 && p < a.lw1 && dn[t] < a.lkeepv) {
           float v = (dn[t] > 0.f) ? out[t][e] / dn[t] : 0.f;
           if (__builtin_isinf(v)) v = 0.f;
           a.ds[((int64_t)chunk * a.D + a.det0 + det) * a.ldp + p] = v;
@@ -403,6 +408,7 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
     if (p0 >= w1 || p0 >= a.P) continue;             // uniform over the workgroup
     DsArgs b = a;
     b.lw0 = w0; b.lw1 = w1;
+    if (a.lkeep != nullptr) b.lkeepv = a.lkeep[cb];
     ds_mfma_tile<RM, TN, TAIL>(b, chunk, p0, lds);
     __syncthreads();
   }
@@ -771,7 +777,9 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
 
   const int64_t Tvalid = P + ctx->L - 1;
   // block offsets (one pass over the stream + a 24-block reduction)
-  const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 256));
+  // (slices of at least 16 samples: a record of a few hundred samples still has enough of them for the median to
+  // ignore a spike -- with M / 256 a chunk under 768 samples had one or two slices, and its level followed the spike)
+  const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 16));
   if ((rc = dtx_reserve(ctx, ctx->ws_csum,
                         (size_t)nchunk * (nsl * kCsum * sizeof(double) + sizeof(float) + sizeof(int)))))
     return rc;
@@ -789,7 +797,8 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
       return rc;
     fV = ctx->fft.V;
     fnblk = (int)((P + fV - 1) / fV);
-    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int)))) return rc;
+    // list[0] = count, list[1 ..] = the listed blocks, behind them one float per block (DsArgs::lkeep)
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int) + (size_t)nchunk * fnblk * sizeof(float)))) return rc;
     list = (int*)ctx->ws_flag.p;
   }
   // split-bf16 contraction: blocks of windows a single sample dominates go to the float32 engine
@@ -841,6 +850,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
       a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
       a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
       a.list = list; a.lV = fV; a.lnblk = fnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
+      a.lkeep = (const float*)(list + 1 + (size_t)nchunk * fnblk); a.lkeepv = INFINITY;
       if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
     }
     if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
@@ -879,7 +889,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
     a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-    a.list = nullptr; a.lV = 0; a.lnblk = 0; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
+    a.list = nullptr; a.lV = 0; a.lnblk = 0; a.lw0 = 0; a.lw1 = (int64_t)1 << 62; a.lkeep = nullptr; a.lkeepv = INFINITY;
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
   if (split)      // the guard's blocks again, on the float32 engine (a 256-workgroup launch that finds an empty list on ordinary data)
@@ -890,7 +900,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
       a.mean = mean; a.den = den; a.ds = ds_dev;
       a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
       a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-      a.list = list; a.lV = kSplitGuardV; a.lnblk = gnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
+      a.list = list; a.lV = kSplitGuardV; a.lnblk = gnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62; a.lkeep = nullptr; a.lkeepv = INFINITY;
       if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
     }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));

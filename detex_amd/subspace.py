@@ -3,6 +3,7 @@
 selection, thresholds, and the detection scan ``SubSpace.detex`` that drives the
 HIP kernels.  Plotting, GUI picking, HypoDD/KML writers are out of scope.
 """
+import functools
 import os
 import pickle
 import sqlite3
@@ -289,6 +290,15 @@ def _same_unit(a, b):
                              (a[1] is not None and b[1] is not None and list(a[1]) == list(b[1])))
 
 
+def _sum_hists(parts, hk):
+    """{detector: counts} of several parts added."""
+    acc = {}
+    for p in parts:
+        for nm, h in p[hk].items():
+            acc[nm] = acc[nm] + h if nm in acc else np.array(h, copy=True)
+    return acc
+
+
 def _merge_ranks(parts, names_order=None):
     """Results of one station in several parts -- from every rank (each scanned its share of the chunks)
     and / or from the units a long record is scanned in: detection rows in the order one launch over the
@@ -308,11 +318,7 @@ def _merge_ranks(parts, names_order=None):
         out[kind] = [rows[i] for i in order]
         out['key_' + kind] = keys[order] if len(rows) else keys
     for hk in ('hist_ss', 'hist_sg'):
-        acc = {}
-        for p in parts:
-            for nm, h in p[hk].items():
-                acc[nm] = acc[nm] + h if nm in acc else np.array(h, copy=True)
-        out[hk] = acc
+        out[hk] = _sum_hists(parts, hk)
     out['names'] = parts[0].get('names', [])
     out['maxds'] = {}
     for p in parts:                                  # every chunk was scanned by exactly one rank
@@ -867,6 +873,10 @@ class SubSpace(object):
         # single process: the SQLite file is written by a thread of its own, fed as the units finish
         # (detect.py:207-210 flushes every 500 rows); under a process group rank 0 writes after the gather
         writer = _DbWriter(subspaceDB) if (subspaceDB is not None and not active) else None
+        units_left = {}
+        for sta, _ in todo:
+            units_left[sta] = units_left.get(sta, 0) + 1
+        hist_written = set()
         if writer is not None:
             writer.call(self._write_static_tables)      # (nothing in them depends on the scan: written under it)
 
@@ -881,6 +891,13 @@ class SubSpace(object):
                 if writer is not None:
                     writer.put('ss_df', res['ss'])
                     writer.put('sg_df', res['sg'])
+            units_left[job.sta] -= 1
+            if writer is not None and units_left[job.sta] == 0 and parts.get(job.sta):
+                # the station's histograms are final: their rows (400 counts as text per detector, ~30 us each:
+                # 5 ms for 8 stations x 25 detectors) are rendered and written under the next station's scans
+                hs = tuple(_sum_hists(parts[job.sta], hk) for hk in ('hist_ss', 'hist_sg'))
+                writer.call(functools.partial(self._write_hist_tables, only={job.sta: hs}))
+                hist_written.add(job.sta)
 
         # INFLIGHT (four) units are in flight: S_i (a unit's scans) is enqueued on its station's stream, then the host
         # picks unit i - 1's triggers and enqueues T_{i-1} (its trigger-time kernel) on that context's TRIGGER stream,
@@ -953,7 +970,7 @@ class SubSpace(object):
         for k in out:                                       # one DataFrame per table (the units hand over row lists)
             out[k] = pd.DataFrame(out[k], columns=cols)
         if writer is not None:
-            self._write_db(None, out, writer)               # the info / histogram tables; joins the thread
+            self._write_db(None, out, writer, hist_written)   # the remaining histogram rows; joins the thread
         elif subspaceDB is not None and rank == 0:
             self._write_db(subspaceDB, out)
         if classifyEvents is not None:
@@ -1152,7 +1169,7 @@ class SubSpace(object):
             d.pop(k, None)                                  # device contexts / buffers are not picklable
         return d
 
-    def _write_db(self, path, out, writer=None):
+    def _write_db(self, path, out, writer=None, hist_written=()):
         """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /
         sg_hist, filt_params.  writer: the call's _DbWriter -- the detection rows and the tables that do not
         depend on the scan (info, filter parameters: queued when the call began) are in, or on their way into,
@@ -1162,7 +1179,7 @@ class SubSpace(object):
             for k, df in out.items():
                 writer.put(k, df)
             writer.call(self._write_static_tables)
-        writer.call(self._write_hist_tables)
+        writer.call(functools.partial(self._write_hist_tables, skip=frozenset(hist_written)))
         writer.close()
 
     @staticmethod
@@ -1197,19 +1214,26 @@ class SubSpace(object):
         if info:
             self._replace_table(con, 'sg_info', [('Name', 'TEXT'), ('Sta', 'TEXT'), ('Events', 'TEXT'),
                                                  ('Threshold', 'REAL'), ('beta1', 'REAL'), ('beta2', 'REAL')], info)
+        for tab in ('ss_hist', 'sg_hist'):                  # (to_sql(if_exists='replace'): rows follow per station)
+            con.execute('DROP TABLE IF EXISTS "%s"' % tab)
         cl = self.clusters
         self._replace_table(con, 'filt_params', [('FREQMIN', 'REAL'), ('FREQMAX', 'REAL'), ('CORNERS', 'INTEGER'),
                                                  ('ZEROPHASE', 'INTEGER'), ('DECIMATE', 'INTEGER')],
                             [(cl.filt[0], cl.filt[1], int(cl.filt[2]), int(bool(cl.filt[3])),
                               None if cl.decimate is None else int(cl.decimate))])
 
-    def _write_hist_tables(self, con):
-        # subspace.py:1956-1995: one row per detector, the 400 counts as a blank-separated string
-        for tab, hd in (('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles)):
-            rows = [(sta, name, ' '.join(map(str, np.asarray(h, dtype=np.int64).tolist())))
-                    for sta, d in hd.items() for name, h in (d or {}).items()]
+    def _write_hist_tables(self, con, only=None, skip=()):
+        """subspace.py:1956-1995: one row per detector, the 400 counts as a blank-separated string.  Rows are
+        appended (the tables were dropped with the static ones): only = {station: (hist_ss, hist_sg)} writes those
+        stations' rows, else every station of self.hist* not in `skip`."""
+        for i, (tab, hd) in enumerate((('ss_hist', self.histSubSpaces), ('sg_hist', self.histSingles))):
+            if only is not None:
+                hd = {sta: h[i] for sta, h in only.items()}
+            rows = [(sta, name, str(np.asarray(h, dtype=np.int64).tolist())[1:-1].replace(',', ''))
+                    for sta, d in hd.items() if sta not in skip for name, h in (d or {}).items()]
             if rows:
-                self._replace_table(con, tab, [('Sta', 'TEXT'), ('Name', 'TEXT'), ('Value', 'TEXT')], rows)
+                con.execute('CREATE TABLE IF NOT EXISTS "%s" ("Sta" TEXT, "Name" TEXT, "Value" TEXT)' % tab)
+                con.executemany('INSERT INTO "%s" VALUES (?,?,?)' % tab, rows)
 
     def write(self, filename='subspace.pkl'):
         """subspace.py:2018-2026."""

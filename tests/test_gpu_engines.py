@@ -187,6 +187,35 @@ def test_engines_agree_fullsize(ctx):
     c32.close()
 
 
+@pytest.mark.parametrize('Nc,L', [(3, 1000), (3, 3000), (12, 1500), (6, 3000), (2, 9000)])
+def test_dominant_event_window(Nc, L):
+    """A 300-sigma event that IS a basis vector (the template's own event in the continuous data: every product
+    of the window's dot product has the same sign, DS ~ 1).  Its block goes through the dynamic-range guard; the
+    repair recomputes the block's quiet windows on the float32 contraction and leaves the loud ones -- where the
+    transforms' rounding is 3e-7 of the statistic and the contraction's grows with sqrt(n) (4e-6 at n = 18 000;
+    found by a soak run of test_random_scan_long: 1.1e-5 on one draw) -- with the frequency-domain engine.
+    scripts/probe/coherent_bias.py prints the same for every engine."""
+    from detex_amd.hip import HipContext
+    rs = np.random.RandomState(Nc * 100000 + L)
+    n, k = Nc * L, 7
+    U = rs.standard_normal((k, n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    off = np.array([0, k], np.int32)
+    M = Nc * (L + 9000)
+    buf = rs.standard_normal(M) * 140.0 + 7.0
+    p_ev = 4000
+    buf[p_ev * Nc: p_ev * Nc + n] += 300.0 * np.std(buf) * np.sqrt(n) * U[k - 1]
+    ref = orc.mpxds_fft(buf.astype(np.float32).astype(np.float64), U.astype(np.float32).astype(np.float64), Nc)
+    c = HipContext(0)
+    try:
+        ds = _gpu_ds(c, buf, U, off, Nc)[0]
+    finally:
+        c.close()
+    err = np.abs(ds - ref)
+    assert err[p_ev] <= 1e-6, (Nc, L, float(err[p_ev]))
+    assert np.delete(err, p_ev).max() <= 2e-7
+
+
 @pytest.mark.parametrize('burst', [0.0, 3e3])
 def test_fused_scan_equals_two_calls(ctx, burst):
     """dtx_subspace_scan returns the DS

@@ -1049,7 +1049,17 @@ def test_long_records_are_scanned_in_day_units(tmp_path, monkeypatch):
         rows.append(pd.read_sql('select * from ss_df', con))
         tabs = set(r[0] for r in con.execute("select name from sqlite_master where type='table'"))
         assert {'ss_df', 'ss_info', 'ss_hist', 'filt_params'} <= tabs
+        # the histogram rows go in as each station finishes (and once: the second call rewrote db2's from scratch)
+        hrows = con.execute('select Sta, Name, Value from ss_hist').fetchall()
+        assert sorted((s, n) for s, n, _ in hrows) == sorted((s, n) for s in stas for n in hist[s])
+        for s, n, v in hrows:
+            assert np.array_equal(np.array(v.split(), dtype=np.int64), hist[s][n])
         con.close()
+    # a second run into an existing file replaces the histogram tables (to_sql(if_exists='replace'))
+    ss.detex(subspaceDB=db2, ctx=ctx, delOldCorrs=False)
+    con = sqlite3.connect(db2)
+    assert con.execute('select count(*) from ss_hist').fetchone()[0] == len(hrows)
+    con.close()
     assert rows[0].values.tolist() == rows[1].values.tolist() == ref['ss_df'].values.tolist()
     assert list(rows[0].columns) == list(ref['ss_df'].columns)
     # the units overlap by the chunks' 120 s buffer: a little more goes over the host link than the record holds
