@@ -273,8 +273,10 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
     pending()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ks = sorted(ctx.kernel_ms_list(min(steps, 64)))
     return {'value': windows * steps / dt, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt / steps,
             'steps': steps, 'kernel_ms': ctx.kernel_ms_mean(min(steps, 64)),
+            'kernel_ms_min': ks[0], 'kernel_ms_median': ks[len(ks) // 2], 'kernel_ms_max': ks[-1],
             'note': 'host buffers: %.0f MB per station-day from pinned memory, double-buffered on a copy '
                     'stream; candidate list / maxima / histograms copied back, DS stays in HBM'
                     % (x.nbytes / 1e6)}
