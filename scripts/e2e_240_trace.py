@@ -40,6 +40,30 @@ if len(sys.argv) > 1 and sys.argv[1] == 'analyse':
     print('idle before kernel (us per unit):')
     for n, g in sorted(gs.items(), key=lambda kv: -kv[1])[:8]:
         print('   %-42s %8.1f' % (n, g / 1e3 / units))
+    # what runs between the end of one unit's scan kernel and the start of the next one's: mean start (relative to
+    # the scan's end), duration and queue of every kernel in that interval, in order of start
+    per = {}
+    inter = []
+    for a, b in zip(scans[-units - 1:-1], scans[-units:]):
+        inter.append((b[0] - a[1]) / 1e3)
+        for r in rows:
+            st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            if a[1] <= st < b[0] or (st < a[1] < en and not r['Kernel_Name'].count('ds_fft')):
+                nm = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:36]
+                key = (nm, r.get('Queue_Id', '?'))
+                per.setdefault(key, []).append(((st - a[1]) / 1e3, (en - st) / 1e3))
+    print('scan end -> next scan start: %.1f us mean (min %.1f max %.1f)' % (sum(inter) / len(inter), min(inter), max(inter)))
+    for (nm, q), v in sorted(per.items(), key=lambda kv: sum(x[0] for x in kv[1]) / len(kv[1])):
+        print('   %-38s queue %-3s  start %+8.1f us  duration %7.1f us  (%.2f per unit)'
+              % (nm, q, sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v) / units))
+    # three consecutive units as they ran
+    print('columns:', ', '.join(rows[0].keys()))
+    a0, a1 = scans[-units // 2][0], scans[-units // 2 + 3][1]
+    for r in sorted(rows, key=lambda r: int(r['Start_Timestamp'])):
+        st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if a0 <= st <= a1:
+            print('   %9.1f us  %8.1f us  queue %-2s stream %-3s %s' % ((st - a0) / 1e3, (en - st) / 1e3, r.get('Queue_Id', '?'), r.get('Stream_Id', '?'),
+                                                        r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:44]))
     sys.exit(0)
 
 import numpy as np  # noqa: E402
