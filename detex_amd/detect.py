@@ -315,6 +315,7 @@ class StationScan(object):
         self.batches = []
         self.picked = None
         self.scan_ev = None
+        self.packed = False
 
     def close(self):
         if self.own and self.ctx is not None:
@@ -396,8 +397,16 @@ class StationScan(object):
         del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         from .hip import h2d_async
-        thr_dev = h2d_async(thr_arr, ctx.device)
-        hist = torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
+        # the thresholds stay on the device with the bank they belong to (a day unit re-sent 100 bytes)
+        held = getattr(ctx, '_thr_dev', None)
+        if held is None or held[0] is not U or held[1] != thr_arr.tobytes():
+            held = (U, thr_arr.tobytes(), h2d_async(thr_arr, ctx.device))
+            ctx._thr_dev = held
+        thr_dev = held[2]
+        # a HipContext scan owns its (zeroed) histogram and hands it back on the host with the candidates:
+        # one fill and two copies per scan instead of two fills and five copies (hip._post_buffers)
+        self.packed = bool(getattr(ctx, 'packed_results', False))
+        hist = None if self.packed else torch.zeros((D, 400), dtype=torch.int32, device=ctx.device)
         if counts is not None and not fillZeros and not trimmed:
             bounds = _trim_to_gapfree(ctx, rawdev, counts, bounds, fetcher.sampling_rate, sta)
         # detect.py:262-274: blocks not longer than the template, or giving < 10 windows, are skipped
@@ -438,7 +447,7 @@ class StationScan(object):
                     xarg, xM, xstride, cstride = xb, M, stride * Nc, stride * Nc
                 ds, fetch = ctx.subspace_scan(xarg, M=xM, chunk_stride=xstride, nchunk=None if raw else i1 - i0,
                                               thr=thr_dev, hist=hist if calcHist else None, cand_cap=CAND_CAP,
-                                              lazy=True)
+                                              lazy=True, **({'packed': True} if self.packed else {}))
                 self.batches.append((i0, i1, xb, M, cstride, ds, fetch, None))
             except DetexHipError as e:
                 self._skip(i0, i1, e)
@@ -446,7 +455,10 @@ class StationScan(object):
         # only (a stream-wide synchronisation there would also wait for the NEXT stations' scans,
         # which are queued behind: it drained the queue once per station-day)
         self.hist_host = self.hist_ev = None
-        if hist.is_cuda:
+        if self.packed:
+            self.scan_ev = torch.cuda.Event()
+            self.scan_ev.record(_stream_of(ctx, ctx.device))
+        elif hist.is_cuda:
             # behind this unit's scans: what the trigger-time kernel (on a stream of its own) waits for
             self.scan_ev = torch.cuda.Event()
             self.scan_ev.record(_stream_of(ctx, hist.device))
@@ -511,7 +523,8 @@ class StationScan(object):
             xb = xdev
             starts = np.array([c[0] * Nc for c in b], dtype=np.int64)
         ctab = ctx.chunk_table(starts, lens)
-        ds, fetch = ctx.subspace_scan(xb, thr=thr_dev, hist=hist, cand_cap=CAND_CAP, lazy=True, chunk_tab=ctab)
+        ds, fetch = ctx.subspace_scan(xb, thr=thr_dev, hist=hist, cand_cap=CAND_CAP, lazy=True, chunk_tab=ctab,
+                                      **({'packed': True} if self.packed else {}))
         self.batches.append((0, len(b), xb, int(lens.max()), None, ds, fetch, ctab))
 
     def _skip(self, i0, i1, e):
@@ -551,7 +564,13 @@ class StationScan(object):
             _batch_rows(self.sta, st, self.args[5], self.args[6], i0, trigs, bad, stats, rows, keys)
         utc_rows = self._utc_rows() if self.utc_saves is not None else None
         self.batches, self.picked = [], None
-        if self.hist_ev is not None:
+        if self.packed:
+            # every scan of the unit counted into a histogram of its own (fetched with its candidates)
+            h = np.zeros((st['D'], 400), dtype=np.int64)
+            if self.args[4]:                                 # calcHist
+                for part in st.get('hist_parts', ()):
+                    h += part.numpy()
+        elif self.hist_ev is not None:
             self.hist_ev.synchronize()
             h = self.hist_host.numpy()
         else:
@@ -721,6 +740,8 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
                                             st['STA'], st['mbank'])
     nb = i1 - i0
     res = fetch()
+    if st.get('hist') is None and res.get('hist') is not None:
+        st.setdefault('hist_parts', []).append(res['hist'])      # packed results: this scan's own histogram, on the host
     if res['ncand'] > CAND_CAP:
         # the candidate list is sized for ordinary thresholds; one that overflows is listed
         # again from the DS tensor at the size the device counted (no second scan; the

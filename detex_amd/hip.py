@@ -87,6 +87,7 @@ class HipContext(object):
     caller's stream.  Result tensors are allocated from the context stream's pool: a caller that
     consumes them on yet another stream than the one the call was made from orders that stream
     itself (``t.record_stream(s)`` / ``s.wait_stream(ctx.stream)``), as with any torch tensor."""
+    packed_results = True        # subspace_scan(packed=True): histogram / maxima / candidates in one allocation, one copy back
 
     def __init__(self, device=0):
         self.lib = _lib.load()
@@ -223,7 +224,25 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_ds')
         return out
 
-    def _post_buffers(self, nchunk, D, dev, thr, hist, want_max, cand_cap):
+    def _post_buffers(self, nchunk, D, dev, thr, hist, want_max, cand_cap, packed=False):
+        if packed:
+            # ONE allocation for everything small the post pass writes -- [histogram | candidate count | maxima |
+            # candidate values] as 4-byte words: one fill clears histogram and count, and ONE copy brings
+            # histogram, count, maxima and the first candidates' values to the host (_lazy_fetch).  (Apart: two
+            # fills and five small copies per scan; each small operation costs its stream 10 - 20 us of bubbles.)
+            if hist is not None or thr is None or not want_max:
+                raise ValueError('packed results: histogram, maxima and candidates all belong to the call')
+            nh, nm = D * HIST_BINS, nchunk * D
+            pack = torch.empty((nh + 1 + nm + int(cand_cap),), dtype=torch.int32, device=dev)
+            pack[:nh + 1].zero_()
+            hist = pack[:nh].view(D, HIST_BINS)
+            cnt = pack[nh:nh + 1]
+            maxds = pack[nh + 1:nh + 1 + nm].view(torch.float32).view(nchunk, D)
+            val = pack[nh + 1 + nm:].view(torch.float32)
+            thr_t = thr if isinstance(thr, torch.Tensor) else torch.as_tensor(
+                np.broadcast_to(np.asarray(thr, dtype=np.float32), (D,)).copy(), device=dev)
+            key = torch.empty((cand_cap,), dtype=torch.int64, device=dev)
+            return hist, maxds, thr_t, key, val, cnt, pack
         if hist is None:
             hist = torch.zeros((D, HIST_BINS), dtype=torch.int32, device=dev)
         elif (hist.dtype != torch.int32 or not hist.is_cuda or tuple(hist.shape) != (D, HIST_BINS) or
@@ -240,7 +259,7 @@ class HipContext(object):
             key = torch.empty((cand_cap,), dtype=torch.int64, device=dev)
             val = torch.empty((cand_cap,), dtype=torch.float32, device=dev)
             cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
-        return hist, maxds, thr_t, key, val, cnt
+        return hist, maxds, thr_t, key, val, cnt, None
 
     @_on_ctx_stream
     def chunk_table(self, starts, lengths):
@@ -254,8 +273,10 @@ class HipContext(object):
 
     @_on_ctx_stream
     def subspace_scan(self, x, M=None, chunk_stride=None, nchunk=None, out=None, thr=None,
-                      hist=None, want_max=True, cand_cap=1 << 20, lazy=False, chunk_tab=None):
+                      hist=None, want_max=True, cand_cap=1 << 20, lazy=False, chunk_tab=None, packed=False):
         """subspace_ds + ds_post in one call (dtx_subspace_scan).
+        packed=True (with lazy=True, thr given, hist=None): the call owns a zeroed histogram; fetch() returns it
+        on the HOST (res['hist'], int32 [D, 400]) with the maxima and candidates -- one copy (_post_buffers).
         Returns (ds, result dict as ds_post).  lazy=True returns (ds, fetch) instead, where
         fetch() synchronises and builds that dict: nothing here then waits for the device, so
         independent scans (other contexts on other streams) can be enqueued behind each other.
@@ -292,8 +313,10 @@ class HipContext(object):
                               device=x.device)[:, :, :max(P, 0)]
         else:
             self._check_out(out, nchunk, P)
-        hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, self.D, x.device, thr, hist,
-                                                               want_max, cand_cap)
+        if packed and not lazy:
+            raise ValueError('packed results come through fetch(): lazy=True')
+        hist, maxds, thr_t, key, val, cnt, pack = self._post_buffers(nchunk, self.D, x.device, thr, hist,
+                                                                     want_max, cand_cap, packed)
         if chunk_tab is not None:
             rc = self.lib.dtx_subspace_scan_ragged(self.h, _ptr(x), _ptr(tab_dev), int(M), int(nchunk),
                                                    _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
@@ -304,10 +327,10 @@ class HipContext(object):
                                             _ptr(thr_t), _ptr(key), _ptr(val), int(cand_cap), _ptr(cnt))
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
-            return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap)
+            return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap, pack=pack)
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
 
-    def _lazy_fetch(self, hist, maxds, thr, key, val, cnt, cand_cap, fast=1 << 14):
+    def _lazy_fetch(self, hist, maxds, thr, key, val, cnt, cand_cap, fast=1 << 14, pack=None):
         """The small results of an enqueued scan copied to pinned host memory on a side stream
         as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
         whatever was enqueued on the context's stream after the scan (the next station's scan)."""
@@ -320,11 +343,24 @@ class HipContext(object):
         host = {}
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            if maxds is not None:
+            if pack is not None:
+                nf = min(int(cand_cap), int(fast))
+                nh, nm = hist.numel(), maxds.numel()
+                hp = torch.empty((nh + 1 + nm + nf,), dtype=torch.int32, pin_memory=True)
+                hp.copy_(pack[:nh + 1 + nm + nf], non_blocking=True)
+                host['key'] = torch.empty((nf,), dtype=torch.int64, pin_memory=True)
+                host['key'].copy_(key[:nf], non_blocking=True)
+                pack.record_stream(side)
+                key.record_stream(side)
+                host['hist'] = hp[:nh].view(hist.shape)
+                host['cnt'] = hp[nh:nh + 1]
+                host['maxds'] = hp[nh + 1:nh + 1 + nm].view(torch.float32).view(maxds.shape)
+                host['val'] = hp[nh + 1 + nm:].view(torch.float32)
+            elif maxds is not None:
                 host['maxds'] = torch.empty(maxds.shape, dtype=maxds.dtype, pin_memory=True)
                 host['maxds'].copy_(maxds, non_blocking=True)
                 maxds.record_stream(side)
-            if thr is not None:
+            if thr is not None and pack is None:
                 nf = min(int(cand_cap), int(fast))
                 host['cnt'] = torch.empty((1,), dtype=torch.int32, pin_memory=True)
                 host['key'] = torch.empty((nf,), dtype=torch.int64, pin_memory=True)
@@ -339,12 +375,14 @@ class HipContext(object):
 
         def fetch():
             done.synchronize()
-            res = dict(hist=hist, maxds=host.get('maxds', maxds), cand=None, ncand=0)
+            res = dict(hist=host.get('hist', hist), maxds=host.get('maxds', maxds), cand=None, ncand=0)
             if thr is not None:
                 n = int(host['cnt'][0])
                 if n > len(host['key']):          # more candidates than the fast path copies: the plain way
                     self.sync()
-                    return self._post_result(hist, host.get('maxds', maxds), thr, key, val, cnt, cand_cap)
+                    r = self._post_result(hist, host.get('maxds', maxds), thr, key, val, cnt, cand_cap)
+                    r['hist'] = host.get('hist', hist)
+                    return r
                 res['ncand'] = n
                 k = host['key'][:n].numpy().astype(np.uint64)
                 v = host['val'][:n].numpy().copy()
@@ -364,8 +402,8 @@ class HipContext(object):
         cand=(chunk, det, index, value) numpy arrays sorted by (chunk, det, index),
         ncand=total found)."""
         nchunk, D, P = (int(s) for s in ds.shape)
-        hist, maxds, thr_t, key, val, cnt = self._post_buffers(nchunk, D, ds.device, thr, hist,
-                                                               want_max, cand_cap)
+        hist, maxds, thr_t, key, val, cnt, _ = self._post_buffers(nchunk, D, ds.device, thr, hist,
+                                                                  want_max, cand_cap)
         rc = self.lib.dtx_ds_post(self.h, _ptr(ds), P, int(ds.stride(1)), nchunk, D,
                                   _ptr(hist), _ptr(maxds), _ptr(thr_t), _ptr(key), _ptr(val),
                                   int(cand_cap), _ptr(cnt))
