@@ -247,7 +247,10 @@ def pcie_inclusive(ctx, x, ds, thr, hist, windows, steps):
         done[i].record(main)
     thr = torch.from_numpy(np.asarray(thr, dtype=np.float32)).cuda()
     prev = None
-    for i in range(4):                       # warm-up, pipelined like the timed loop: result buffers of BOTH steps in flight
+    # warm-up, pipelined like the timed loop: result buffers of BOTH steps in flight; ten steps -- the first uses of the
+    # freshly pinned buffer and of the two device buffers run slow (scripts/probe/pcie_leg.py: 3.55 ms per step
+    # over the first 20 steps of a process, 3.28 from then on)
+    for i in range(10):
         upload(i & 1)
         main.wait_event(ready[i & 1])
         f = ctx.subspace_scan(bufs[i & 1], out=ds, thr=thr, hist=hist, lazy=True)[1]
@@ -1207,7 +1210,7 @@ def main():
                                                  Uh, det_off, n)
         except Exception as e:                         # noqa: BLE001 -- a secondary field never takes the line down
             out['dist_overhead'] = {'error': repr(e)}
-        out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, min(a.steps, 50))
+        out['pcie_inclusive'] = pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, max(40, min(a.steps, 80)))
         out['xcorr_full'] = xcorr_full(ctx, synth, Nc, cpu=not a.no_cpu_baseline)
         out['config5'] = config5(ctx, synth)
         try:

@@ -97,6 +97,7 @@ for sta in stas:
     cf.add(sta, rec.numpy(), starttime=1499997600.0)
 if PIN:
     cf.pinned = {sta: rec for sta in stas}
+_dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get('E2E_DUMMY_STREAMS', '0')))]   # shifts which hardware queue later streams get
 cl = createCluster(CCreq=0.5, fetch_arg=ef, device=0, saveclust=False)
 ss = createSubSpace(Pf=1e-10, clust=cl, conDatFetcher=cf)
 ss.attachPickTimes(startSeconds=1.0, defaultDuration=30.0)
