@@ -12,6 +12,9 @@ import pytest
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
+# DETEX_TEST_SEED_BASE=k re-draws every seeded case of this file (soak runs: scripts/soak.sh); 0 = the committed cases
+SOAK = 100000 * int(__import__('os').environ.get('DETEX_TEST_SEED_BASE', 0))
+
 from oracle import detex_oracle as orc  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -55,7 +58,7 @@ def test_golden_mpxds(ctx):
     (5, 40, [8, 3]), (7, 33, [4]), (8, 64, [16, 1]), (9, 30, [5, 11]), (12, 25, [6]), (5, 300, [8, 1]), (9, 280, [4]),
 ])
 def test_ds_vs_oracle_shapes(ctx, Nc, L, ks):
-    rs = np.random.RandomState(sum(ks) + L)
+    rs = np.random.RandomState(sum(ks) + L + SOAK)
     n, K = Nc * L, sum(ks)
     U = rs.standard_normal((K, n))
     U /= np.linalg.norm(U, axis=1, keepdims=True)
@@ -74,7 +77,7 @@ def test_ds_vs_oracle_shapes(ctx, Nc, L, ks):
 
 def test_dynamic_range_is_local(ctx):
     """A 10^4 x amplitude burst does not degrade windows that do not contain it."""
-    rs = np.random.RandomState(4)
+    rs = np.random.RandomState(4 + SOAK)
     Nc, L, K, T = 3, 300, 8, 9000
     n = Nc * L
     A = rs.standard_normal((n, K))
@@ -95,7 +98,7 @@ def test_extreme_burst_stays_local(ctx):
     frequency-domain engine's error is relative to the loudest amplitude in its 8192-sample
     block), so its dynamic-range guard hands the block to the float32 MFMA contraction;
     the quiet windows hold 1e-5 under every engine."""
-    rs = np.random.RandomState(14)
+    rs = np.random.RandomState(14 + SOAK)
     Nc, L, K, T = 3, 300, 8, 20000
     n = Nc * L
     A = rs.standard_normal((n, K))
@@ -125,7 +128,7 @@ def test_burst_in_the_unused_tail_of_a_block(ctx, L, burst):
     also use).  The block's own window energies do not see it, so the guard alone would not
     repair block 0: single-segment templates transform that tail as zeros, segmented ones let
     the guard look one block further.  Every quiet window holds 1e-5."""
-    rs = np.random.RandomState(15)
+    rs = np.random.RandomState(15 + SOAK)
     Nc, K, T = 3, 6, 26000
     n = Nc * L
     A = rs.standard_normal((n, K))
@@ -168,7 +171,7 @@ def test_engines_agree_fullsize(ctx):
     assert float((ds_s - ds_f).abs().max()) <= 5e-6
     # spot checks of the split engine against the float64 closed form
     dsh = ds_s.cpu().numpy()
-    rs = np.random.RandomState(1)
+    rs = np.random.RandomState(1 + SOAK)
     P = dsh.shape[2]
     pts = [(b, p, d) for (b, p, d) in plants] + [(0, int(rs.randint(P)), int(rs.randint(D)))
                                                   for _ in range(10)]
@@ -196,7 +199,7 @@ def test_dominant_event_window(Nc, L):
     found by a soak run of test_random_scan_long: 1.1e-5 on one draw) -- with the frequency-domain engine.
     scripts/probe/coherent_bias.py prints the same for every engine."""
     from detex_amd.hip import HipContext
-    rs = np.random.RandomState(Nc * 100000 + L)
+    rs = np.random.RandomState(Nc * 100000 + L + SOAK)
     n, k = Nc * L, 7
     U = rs.standard_normal((k, n))
     U /= np.linalg.norm(U, axis=1, keepdims=True)
@@ -224,7 +227,7 @@ def test_fused_scan_equals_two_calls(ctx, burst):
     from detex_amd import synth
     Nc, L, D, k = 3, 700, 5, [8, 1, 1, 3, 2]
     n = Nc * L
-    rs = np.random.RandomState(21)
+    rs = np.random.RandomState(21 + SOAK)
     off = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
     U = np.concatenate([synth.orthonormal_basis(rs, n, kk) for kk in k]).astype(np.float32)
     nchunk, T = 2, 17000
@@ -263,7 +266,7 @@ def test_scan_grid_shapes_agree(nchunk, T):
     from detex_amd.hip import HipContext
     Nc, L, ks = 3, 1200, [8, 1, 1, 3, 9, 2, 8, 8, 5, 1, 4, 8, 7]
     n = Nc * L
-    rs = np.random.RandomState(5)
+    rs = np.random.RandomState(5 + SOAK)
     off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
     U = np.concatenate([synth.orthonormal_basis(rs, n, k) for k in ks]).astype(np.float32)
     x = rs.standard_normal((nchunk, Nc * T)).astype(np.float32)

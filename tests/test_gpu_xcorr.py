@@ -62,7 +62,10 @@ def _check_pair(x1, x2, Nc, got, what):
     if abs(ss) <= .5:
         assert abs(got[2] - ss) <= 1e-4, (what, got, ss)
     else:
-        assert got[2] == np.float32(ss), (what, got, ss)
+        # (_subSamp's arccos of a ratio outside [-1, 1] is NaN in the reference too -- construct.py:397-422 -- and
+        # NaN > .5 is false, so NaN is what it returns: the same NaN is parity; found by a soak run, the committed
+        # draw of pairs holds none)
+        assert got[2] == np.float32(ss) or (np.isnan(got[2]) and np.isnan(ss)), (what, got, ss)
     return 'ok'
 
 
@@ -136,7 +139,7 @@ def test_allpairs_vs_oracle(ctx, N, Nc, L):
     if len(td) < N:
         td = np.concatenate([td, synth.event_families(7, N - len(td), 1, Nc, L, L // 8)])
     cc, lag, ss = _gpu(ctx, td, Nc)
-    rs = np.random.RandomState(N)
+    rs = np.random.RandomState(N + SOAK)
     pairs = [(b, c) for b in range(N) for c in range(b + 1, N)]
     if len(pairs) > 150:
         pairs = [pairs[i] for i in rs.choice(len(pairs), 150, replace=False)]
@@ -169,7 +172,7 @@ def test_pair_range_sharding(ctx, N, Nc, L):
 
 
 def test_dead_and_degenerate_events(ctx):
-    rs = np.random.RandomState(2)
+    rs = np.random.RandomState(2 + SOAK)
     Nc, L = 3, 40
     td = rs.standard_normal((4, Nc * L)).astype(np.float32)
     td[1] = 0.0                       # all-zero event -> (0, 0, 0) (construct.py:463-464)
@@ -199,7 +202,7 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
     contraction engine and the float64 oracle -- cc 1e-5, lag exact, subsamp 1e-4; includes an
     odd event count (a pair with a zero row), an identical pair and a dead event."""
     from detex_amd import synth
-    rs = np.random.RandomState(L + N)
+    rs = np.random.RandomState(L + N + SOAK)
     nfam = 2
     td = synth.event_families(L, nfam, (N + nfam - 1) // nfam, Nc, L, maxshift=max(1, L // 40))[:N]
     td = td * np.float32(10 ** rs.uniform(-3, 3))
@@ -349,7 +352,7 @@ def test_fast_normcorr_golden(ctx):
         got2 = fast_normcorr(s, t, ctx=ctx)              # arguments in either order (473-474)
         assert np.max(np.abs(got2 - ref)) <= 2e-6, i
     # a long series: every window against the float64 oracle
-    rs = np.random.RandomState(9)
+    rs = np.random.RandomState(9 + SOAK)
     t, s = rs.standard_normal(3000), rs.standard_normal(40000) + 2.0
     s[7000:10000] += 3 * t
     got = fast_normcorr(t, s, ctx=ctx)
