@@ -25,9 +25,13 @@ def _wavelets(rs, nfam):
              for _ in range(NC)] for _ in range(nfam)]
 
 
+# DETEX_TEST_SEED_BASE=k re-draws the workflow's wavelets, events and noise (soak runs); 0 = the committed case
+SOAK = 100000 * int(os.environ.get('DETEX_TEST_SEED_BASE', 0))
+
+
 @pytest.fixture(scope='module')
 def workflow():
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(0 + SOAK)
     fams = _wavelets(rs, 2)
     ef = EventFetcher(SR, ['HHE', 'HHN', 'HHZ'])
     shifts = {}
@@ -102,7 +106,7 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
                         want.append((nm, t['STMP'], t['DS'], t['DS_STALTA'], t['MSTAMPmin'],
                                      t['MSTAMPmax'], mg))
     got = pd.concat([res['ss_df'], res['sg_df']], ignore_index=True)
-    assert len(got) == len(want) and len(want) >= 6
+    assert len(got) == len(want) and (SOAK or len(want) >= 6)     # (how many trigger depends on the draw: the committed one is pinned)
     got = got.sort_values(['Name', 'STMP']).reset_index(drop=True)
     want.sort(key=lambda r: (r[0], r[1]))
     for (_, g), w in zip(got.iterrows(), want):
@@ -123,7 +127,7 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
     t0 = 1.2e6
     for (t, f, a) in workflow['plants']:
         hit = got[(np.abs(got.STMP - (t0 + (t + 0) / SR)) < 2.0) & got.Name.str.startswith('SS')]
-        assert len(hit) >= 1, (t, f, a)
+        assert SOAK or len(hit) >= 1, (t, f, a)
     # histograms agree with the oracle except for bin-edge flips within 1e-6 of an edge
     for nm in names:
         h = (ss.histSubSpaces['TA.M17A'] | ss.histSingles['TA.M17A'])[nm] \
@@ -140,7 +144,7 @@ def test_detex_matches_oracle_workflow(workflow, tmp_path):
     # the planted copies are new detections, none coincides with a template origin time
     from detex_amd import detResults
     assoc = detResults(ssDB=db, templateKey=workflow['ef'], requiredNumStations=1)
-    assert len(assoc.Autos) == 0 and len(assoc.Dets) >= len(workflow['plants']) - 1
+    assert len(assoc.Autos) == 0 and (SOAK or len(assoc.Dets) >= len(workflow['plants']) - 1)
     assert assoc.info is not None and set(assoc.info.Sta) == {'TA.M17A'}
     assert all(',' in e or len(e) for e in assoc.info.Events)
 
@@ -473,7 +477,7 @@ def test_trigger_stream_and_day_units_do_not_change_the_tables(workflow, monkeyp
         df = pd.concat([r['ss_df'], r['sg_df']], ignore_index=True)
         return df.fillna(-999.0).values.tolist()
     ref = table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True))
-    assert len(ref) >= 6
+    assert SOAK or len(ref) >= 6
     monkeypatch.setenv('DETEX_AMD_TRIG_STREAM', '0')
     assert table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True)) == ref
     monkeypatch.delenv('DETEX_AMD_TRIG_STREAM')
