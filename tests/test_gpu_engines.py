@@ -211,6 +211,7 @@ def test_dominant_event_window(Nc, L):
     ref = orc.mpxds_fft(buf.astype(np.float32).astype(np.float64), U.astype(np.float32).astype(np.float64), Nc)
     c = HipContext(0)
     try:
+        c.set_engine('auto')                 # (a DETEX_AMD_ENGINE in the environment picks new contexts' engine)
         ds = _gpu_ds(c, buf, U, off, Nc)[0]
     finally:
         c.close()
