@@ -360,6 +360,7 @@ class StationScan(object):
             planes_dev, T = None, data.shape[1]
         else:
             counts, bounds, planes_dev, T = shard['counts'], list(shard['bounds']), shard['planes'], shard['T']
+        xdev_up = None if shard is None else shard.get('xdev')    # the uploader interleaved the planes already
         del shard
         trimmed = False
         if counts is not None:
@@ -393,7 +394,8 @@ class StationScan(object):
         else:
             # channel planes are interleaved on the device
             # (construct.py:977-978; dtx_preprocess without filter or detrend)
-            rawdev, xdev = None, ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
+            rawdev = None
+            xdev = xdev_up if xdev_up is not None else ctx.preprocess(planes_dev[None], filt=None, detrend=False)[0]
         del planes_dev
         thr_arr = np.array([thr[k] for k in names], dtype=np.float32)
         from .hip import h2d_async

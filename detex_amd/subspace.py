@@ -196,6 +196,15 @@ class _StationUploader(object):
         self.turn = 0
         self.cur = None
         self.bytes_uploaded = 0           # host -> device bytes of station data since reset()
+        self._mux = None                  # a HipContext on the copy stream: interleaves a unit's planes behind its upload
+
+    def _mux_ctx(self):
+        import torch
+        from .hip import HipContext
+        if self._mux is None:
+            with torch.cuda.stream(self.stream):            # (a context keeps the stream current at its creation)
+                self._mux = HipContext(self.device.index or 0)
+        return self._mux
 
     def reset(self):
         self.pending = {}
@@ -262,8 +271,14 @@ class _StationUploader(object):
                 for (a, b, off) in runs:               # contiguous rows: plain asynchronous copies
                     for c in range(Nc):
                         dst[c, off:off + b - a].copy_(pinned[c, a:b], non_blocking=True)
+            xdev = None
+            if os.environ.get('DETEX_AMD_MUX_EARLY', '1') != '0' and not getattr(fetcher, 'raw', False):
+                # already filtered planes: the multiplexed stream the scan takes (construct.py:977-978) is made
+                # HERE, behind the upload on the copy stream -- under the previous unit's scan kernel -- instead
+                # of in front of this unit's scan on the station's stream (45 us per station-day)
+                xdev = self._mux_ctx().preprocess(dst[None], filt=None, detrend=False)[0]
             ready.record(self.stream)
-        job.update(planes=dst, ready=ready, slot=k)
+        job.update(planes=dst, ready=ready, slot=k, xdev=xdev)
 
     def get(self, sta, stream=None):
         """The station's upload job; `stream` (the scanning context's) waits for the copy."""
@@ -271,6 +286,8 @@ class _StationUploader(object):
         self.cur = job['slot']
         if job['ready'] is not None and stream is not None:
             stream.wait_event(job['ready'])
+            if job.get('xdev') is not None:
+                job['xdev'].record_stream(stream)          # (memory of the copy stream's pool, read on the scan's)
         return job
 
     def release(self, stream=None):
