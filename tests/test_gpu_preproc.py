@@ -30,7 +30,7 @@ def ctx():
     (372000, 3, 2, [1, 10, 2, True], 100.0, True),    # full chunk length
 ])
 def test_preprocess_matches_scipy(ctx, T, Nc, nchunk, filt, sr, detrend):
-    rs = np.random.RandomState(T + Nc)
+    rs = np.random.RandomState(T + Nc + SOAK)
     t = np.arange(T)
     raw = (rs.standard_normal((nchunk, Nc, T)) * 50 + 300.0 + 0.01 * t[None, None, :] *
            rs.uniform(-1, 1, (nchunk, Nc, 1)) +
@@ -84,7 +84,7 @@ def test_preprocess_random_shapes(ctx, seed):
 def test_preprocess_feeds_the_scan(ctx):
     """Raw counts -> device pre-processing -> detection statistic, against the
     oracle pipeline on the same raw data."""
-    rs = np.random.RandomState(3)
+    rs = np.random.RandomState(3 + SOAK)
     Nc, T, sr, L = 3, 6000, 100.0, 150
     filt = [1, 10, 2, True]
     raw = (rs.standard_normal((1, Nc, T)) * 100 + 1000).astype(np.float32)
@@ -107,7 +107,7 @@ def test_detex_on_raw_continuous_data(ctx, dec):
     at the decimated rate (detect.py:239)."""
     from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
     from detex_amd.getdata import multiplex
-    rs = np.random.RandomState(12)
+    rs = np.random.RandomState(12 + SOAK)
     q = dec or 1
     sr, Nc, L = 20.0, 3, 160                 # rate / template length AFTER decimation
     sr_raw, Lr = sr * q, L * q
@@ -177,7 +177,7 @@ def test_detex_on_raw_continuous_data(ctx, dec):
 def test_decimate_matches_scipy(ctx, T, factor, sr, shape):
     """dtx_decimate (construct.py:1016-1017) against the SciPy arithmetic ObsPy's
     Trace.decimate delegates to; float32 output, 2e-6 of the peak amplitude."""
-    rs = np.random.RandomState(T + factor)
+    rs = np.random.RandomState(T + factor + SOAK)
     raw = (rs.standard_normal(shape + (T,)) * 50 + 300.0).astype(np.float32)
     got = ctx.decimate(torch.from_numpy(raw).cuda(), factor, sr)
     ctx.sync()
@@ -266,7 +266,7 @@ def test_detex_on_raw_counts_with_gaps(ctx):
     scans the zero-filled chunks whole."""
     from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
     from detex_amd.getdata import multiplex
-    rs = np.random.RandomState(21)
+    rs = np.random.RandomState(21 + SOAK)
     sr, Nc, L = 20.0, 3, 160
     filt = [1, 8, 2, True]
     wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
@@ -345,7 +345,7 @@ def test_detex_on_raw_counts_with_resent_packets(ctx):
     as a record that was delivered clean wherever the duplicates were identical."""
     from detex_amd import ContinuousFetcher, EventFetcher, createCluster, createSubSpace
     from detex_amd.getdata import multiplex
-    rs = np.random.RandomState(34)
+    rs = np.random.RandomState(34 + SOAK)
     sr, Nc, L = 20.0, 3, 160
     filt = [1, 8, 2, True]
     wav = [np.convolve(rs.standard_normal(L + 6), np.hanning(7), 'valid') * np.exp(-np.arange(L) / 50.0)
@@ -429,7 +429,7 @@ def test_raw_templates_and_raw_continuous_equal_prefiltered_run(ctx, dec):
     for r in recs:
         efr.add_raw('XX.RAW', r['name'], r['data'], r['starttime'], r['origintime'], r['magnitude'])
     # continuous data: noise + drift + copies of the two families' records around their arrivals
-    rs = np.random.RandomState(2)
+    rs = np.random.RandomState(2 + SOAK)
     T = int(2400 * sr)
     con = rs.standard_normal((Nc, T)) * 6.0 + (0.0 if dec else 1000.0) + 0.002 * np.arange(T)[None, :]
     pre = int(30 * sr)
