@@ -312,7 +312,7 @@ def test_trigger_stats_kernel():
     ctx.close()
 
 
-def test_stations_in_flight_equal_one_at_a_time():
+def test_stations_in_flight_equal_one_at_a_time(monkeypatch):
     """SubSpace.detex keeps three stations in flight on per-station contexts (scans enqueued ahead,
     trigger picking and the trigger-time kernel of one station under the scan of the next, results
     waited for by event); with a caller's context every station is finished before the next starts.
@@ -358,6 +358,11 @@ def test_stations_in_flight_equal_one_at_a_time():
     for s in stas:
         for k, v in ss.histSubSpaces[s].items():
             assert np.array_equal(v, hist_p[s][k]), (s, k)
+    # the planes interleaved in front of each station's scan instead of behind its upload on the copy stream
+    monkeypatch.setenv('DETEX_AMD_MUX_EARLY', '0')
+    late = ss.detex(subspaceDB=None, triggerLTATime=5, triggerSTATime=0, estimateMags=True)
+    pd.testing.assert_frame_equal(piped['ss_df'], late['ss_df'])
+    pd.testing.assert_frame_equal(piped['sg_df'], late['sg_df'])
 
 
 def test_stream_contract_non_default_current_stream(workflow):

@@ -163,7 +163,14 @@ def test_detex_on_raw_continuous_data(ctx, dec):
     fas = ss.subspaces['XX.STA'].FAS.iloc[0]
     ref = np.histogram(np.concatenate(alld), bins=np.linspace(-.01, 1, 401))[0]
     assert fas['hist'].sum() == ref.sum()
-    assert np.max(np.abs(np.cumsum(fas['hist']) - np.cumsum(ref))) <= 3    # bin-edge ties only
+    # bin-edge ties only: the counts below an edge differ by no more than the values that lie within the parity
+    # tolerance (1e-5) of that edge (a fixed "<= 3" held for the committed draw and failed, with 4, on one of 30
+    # re-draws of a soak run: the noise windows' statistic crowds the first bins, ~9000 values per bin)
+    allv = np.sort(np.concatenate(alld))
+    edges = np.linspace(-.01, 1, 401)[1:]
+    near = np.searchsorted(allv, edges + 1e-5, 'right') - np.searchsorted(allv, edges - 1e-5, 'left')
+    flips = np.abs(np.cumsum(fas['hist']) - np.cumsum(ref))
+    assert np.all(flips <= near) and flips.max() <= 8, (int(flips.max()), int(near[np.argmax(flips)]))
 
 
 @pytest.mark.parametrize('T,factor,sr,shape', [
