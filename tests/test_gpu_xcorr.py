@@ -211,6 +211,10 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
     if N >= 8:
         td[5] = td[2]                      # identical pair: cc = 1, lag 0
         td[7] = 0.0                        # dead event: cc 0 with everything
+        if Nc > 1:
+            td[6].reshape(L, Nc)[:, 1] = 0.0   # one channel of an event zeroed (a dead component: the golden 'zeroed_chan' cases, long)
+    if N >= 9:
+        td[8] = 2.5                        # constant event: zero variance -> (0, 0, 0) with everything (construct.py:463-464)
     ctx.set_engine('auto')
     cc, lag, ss = _gpu(ctx, td, Nc)
     ctx.set_engine('bf16x3')
