@@ -489,6 +489,41 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     mo[p0] = (float)(a1 / dn);
     so[p0] = constant(p0, a3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(a2, a1, dn));
   }
+  // The sliding sums of a block pass through the largest window power of the block, and what float64 rounds
+  // off there (~1e-16 of it) stays in every later window's sums: a 10^4-sigma spike leaves 4e-9 behind, 2e-3 of
+  // the sum of squares of a window that holds ONE live sample at the edge of a dead stretch (found by a soak run of
+  // test_random_scan: DS off by 2.5e-4 there).  A window whose variance is below kStatsRecheck of the block's
+  // largest power is therefore summed again directly (mean first, then the squares of the residuals): rare, exact.
+  __shared__ double shm[4];
+  __shared__ double blockmax;
+  {
+    double m2 = a2;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (p0 + (int64_t)E * tid + e + 1 < P) m2 = fmax(m2, a2 + off2 + l2[e]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));
+    if (lane == 0) shm[wv] = m2;
+    __syncthreads();
+    if (tid == 0) blockmax = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+    __syncthreads();
+  }
+  constexpr double kStatsRecheck = 1e-7;
+  const double recheck = kStatsRecheck * blockmax;
+  auto direct = [&](int64_t pw, double& S1, double& var) {
+    double s = 0.0;
+    for (int c = 0; c < Nc; ++c)
+      for (int j = 0; j < L; ++j) s += (double)at(c, pw + j);
+    const double mu = s / dn;
+    double q = 0.0;
+    for (int c = 0; c < Nc; ++c)
+      for (int j = 0; j < L; ++j) {
+        const double d = (double)at(c, pw + j) - mu;
+        q += d * d;
+      }
+    S1 = s;
+    var = q;
+  };
 #if DTX_STATS_ROWSTORE
   // a thread's eight results are eight consecutive windows: stored directly, a wave instruction
   // writes 64 four-byte pieces 32 bytes apart.  Through LDS (slot q + (q >> 5): the strided writes are
@@ -499,9 +534,13 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     const int64_t pw = p0 + (int64_t)E * tid + e + 1;
     float m = 0.f, sd = 0.f;
     if (pw < P && pw < p0 + kStatsPB) {
-      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
+      double S1 = a1 + off1 + l1[e];
+      const double S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
+      const bool flat = constant(pw, S3);
+      double var = flat ? 0.0 : clamp_var(S2, S1, dn);
+      if (!flat && S2 - S1 * S1 / dn < recheck) direct(pw, S1, var);
       m = (float)(S1 / dn);
-      sd = constant(pw, S3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
+      sd = stats_out(scale, var);
     }
     const int q = E * tid + e;                           // window p0 + 1 + q
     stm[q + (q >> 5)] = m;
@@ -522,9 +561,13 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   for (int e = 0; e < E; ++e) {
     const int64_t pw = p0 + (int64_t)E * tid + e + 1;
     if (pw < P && pw < p0 + kStatsPB) {
-      const double S1 = a1 + off1 + l1[e], S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
+      double S1 = a1 + off1 + l1[e];
+      const double S2 = a2 + off2 + l2[e], S3 = a3 + off3 + l3[e];
+      const bool flat = constant(pw, S3);
+      double var = flat ? 0.0 : clamp_var(S2, S1, dn);
+      if (!flat && S2 - S1 * S1 / dn < recheck) direct(pw, S1, var);
       mo[pw] = (float)(S1 / dn);
-      so[pw] = constant(pw, S3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
+      so[pw] = stats_out(scale, var);
     }
   }
 #endif
