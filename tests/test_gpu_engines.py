@@ -190,6 +190,38 @@ def test_engines_agree_fullsize(ctx):
     c32.close()
 
 
+def test_one_live_sample_beside_a_dead_stretch_and_a_spike(ctx):
+    """A window that holds ONE live sample (a small one) at the edge of a zero-filled stretch, 1400 windows behind a
+    10^4-sigma spike: the float64 sliding sums of the window statistics kept ~1e-16 of the spike's square, 2e-3 of this
+    window's sum of squares (DS off by 2.5e-4; found by a soak run of test_random_scan).  Windows whose variance is far
+    below their block's largest power are summed again directly (win_stats_kernel): every engine within 1e-5."""
+    rs = np.random.RandomState(77 + SOAK)
+    Nc, L, k = 2, 50, 13
+    n = Nc * L
+    U = rs.standard_normal((k, n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    U -= U.mean(axis=1, keepdims=True)
+    off = np.array([0, 2, 7, k], np.int32)
+    M = 4192
+    x = rs.standard_normal(M) * 0.538 + 5.0
+    x[505] += 5380.0                        # the spike
+    x[1694:1989] = 5.0                      # the dead stretch, at the data's level (fillZeros before detrend)
+    x[1989] = 5.0 + 0.0015                  # the first live sample behind it, by chance a small one
+    ds = _gpu_ds(ctx, x, U, off, Nc)
+    xb = x.astype(np.float32).astype(np.float64)
+    Uf = U.astype(np.float32).astype(np.float64)
+    win = np.lib.stride_tricks.sliding_window_view(xb, n)[::Nc]
+    live = win.std(axis=1) > 0
+    w = (1989 - n + 1) // Nc                # the window that ends with sample 1989
+    assert live[w] and not live[w - 1]
+    for d in range(3):
+        ref = orc.mpxds_direct(xb, Uf[off[d]:off[d + 1]], Nc)
+        scale = max(1.0, float(ref[live].max()))
+        assert np.all(ds[d][~live] == 0)
+        err = np.abs(ds[d] - ref)[live]
+        assert err.max() <= 1e-5 * scale, (ctx.engine, d, float(err.max()), int(np.argmax(err)))
+
+
 @pytest.mark.parametrize('Nc,L', [(3, 1000), (3, 3000), (12, 1500), (6, 3000), (2, 9000)])
 def test_dominant_event_window(Nc, L):
     """A 300-sigma event that IS a basis vector (the template's own event in the continuous data: every product
