@@ -190,6 +190,52 @@ def test_engines_agree_fullsize(ctx):
     c32.close()
 
 
+def test_short_chunk_with_a_spike(ctx):
+    """A chunk of a few hundred samples that holds a 10^4-sigma spike: the block offset (the median of the chunk's
+    slice means) must not follow it -- with slices of >= 256 samples such a chunk had ONE slice, its level moved by
+    spike / samples = 40 sigma, and float32 lost 4e-5 on a window of small scatter far from the spike.  The draw of
+    test_random_scan that a soak run failed on (base 46, seed 23: templates of 4 samples, five vectors in four
+    dimensions), kept as a case of its own.  Slices of >= 16 samples since."""
+    rs = np.random.RandomState(1000 + 23 + 100000 * 46)
+    Nc = int(rs.choice([1, 2, 3, 4, 6]))
+    L = int(rs.randint(4, 260))
+    n = Nc * L
+    ks = [int(rs.choice([1, 1, 2, 3, 5, 8, 13, 16, 17, 40, 100])) for _ in range(int(rs.randint(1, 7)))]
+    assert rs.rand() >= 0.2 and (Nc, L, ks) == (1, 4, [2, 5, 5, 2, 8])
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int32)
+    U = rs.standard_normal((off[-1], n))
+    U /= np.linalg.norm(U, axis=1, keepdims=True)
+    assert rs.rand() < 0.5
+    U -= U.mean(axis=1, keepdims=True)
+    nchunk = int(rs.randint(1, 4))
+    T = int(rs.randint(L + 1, L + 2500))
+    M = Nc * T - int(rs.randint(0, Nc))
+    stride = int(rs.randint(Nc, M + 1) // Nc * Nc)
+    amp = float(10 ** rs.uniform(-6, 3))
+    dc = float(rs.choice([0, 0, 5]))
+    buf = rs.standard_normal((nchunk - 1) * stride + M) * amp + dc
+    assert rs.rand() < 0.35 and len(buf) > 6 * n
+    g0 = int(rs.randint(0, len(buf) - 3 * n))
+    buf[g0: g0 + int(rs.randint(n, 3 * n))] = dc
+    assert rs.rand() < 0.35
+    buf[int(rs.randint(len(buf)))] += 1e4 * amp
+    assert (nchunk, M, stride) == (2, 237, 87)
+    ctx.upload_basis(U.astype(np.float32), off, Nc)
+    ds = ctx.subspace_ds(torch.from_numpy(buf.astype(np.float32)).cuda(), M=M, chunk_stride=stride, nchunk=nchunk)
+    ctx.sync()
+    ds = ds.cpu().numpy()
+    Uf = U.astype(np.float32).astype(np.float64)
+    bf = buf.astype(np.float32).astype(np.float64)
+    for b in range(nchunk):
+        xb = bf[b * stride: b * stride + M]
+        live = np.lib.stride_tricks.sliding_window_view(xb, n)[::Nc].std(axis=1) > 0
+        for d in range(len(ks)):
+            ref = orc.mpxds_direct(xb, Uf[off[d]:off[d + 1]], Nc)
+            scale = max(1.0, float(ref[live].max()))         # five vectors in four dimensions: DS can exceed 1
+            err = np.abs(ds[b, d] - ref)[live]
+            assert err.max() <= 1e-5 * scale, (ctx.engine, b, d, float(err.max()))
+
+
 def test_one_live_sample_beside_a_dead_stretch_and_a_spike(ctx):
     """A window that holds ONE live sample (a small one) at the edge of a zero-filled stretch, 1400 windows behind a
     10^4-sigma spike: the float64 sliding sums of the window statistics kept ~1e-16 of the spike's square, 2e-3 of this
