@@ -10,5 +10,5 @@ __version__ = '0.1.0'
 from ._lib import DetexHipError  # noqa: F401
 from .construct import createCluster, createSubSpace, fast_normcorr  # noqa: F401,E402
 from .getdata import ContinuousFetcher, EventFetcher, multiplex  # noqa: F401,E402
-from .subspace import Cluster, ClusterStream, SubSpace  # noqa: F401,E402
+from .subspace import Cluster, ClusterStream, SubSpace, loadClusters, loadSubSpace  # noqa: F401,E402
 from .results import detResults, SSResults  # noqa: F401,E402

@@ -370,10 +370,27 @@ class _DbWriter(object):
     COLS = ['DS', 'DS_STALTA', 'STMP', 'Name', 'Sta', 'MSTAMPmin', 'MSTAMPmax', 'Mag', 'SNR', 'ProEnMag']
     TYPES = ['REAL', 'REAL', 'REAL', 'TEXT', 'TEXT', 'REAL', 'REAL', 'REAL', 'REAL', 'REAL']
 
-    def __init__(self, path):
+    SYNC_MODES = ('OFF', 'NORMAL', 'FULL', 'EXTRA')
+
+    def __init__(self, path, fresh=False):
+        """fresh: the caller has just removed the file (delOldCorrs) -- everything in it will be this call's."""
         import queue
         import threading
         self.path = path
+        # Durability.  A commit is an fsync (2.5 ms each on the test boxes' file system); the last flushes of a
+        # call sit on its critical path (close() joins), and an 8-station call made five of them: 10 ms of a 37 ms
+        # call.  Only a file this call creates from scratch (delOldCorrs removed the old one, or there was none)
+        # is written with synchronous=OFF: a crash of the operating system can then cost nothing but this call's
+        # own rows, which a re-run writes again.  A file that already holds earlier runs' detections (the
+        # reference's append mode, delOldCorrs=False, subspace.py:1847-1854) is written with SQLite's default,
+        # FULL, like the reference's to_sql.  DETEX_AMD_DB_SYNC overrides either way.
+        mode = os.environ.get('DETEX_AMD_DB_SYNC')
+        if mode is None:
+            mode = 'OFF' if (fresh and not os.path.exists(path)) else 'FULL'
+        mode = mode.strip().upper()
+        if mode not in self.SYNC_MODES:
+            raise ValueError('DETEX_AMD_DB_SYNC must be one of %s (got %r)' % ('/'.join(self.SYNC_MODES), mode))
+        self.sync = mode
         self.q = queue.Queue()
         self.error = None
         self.thread = threading.Thread(target=self._run, name='detex-db-writer', daemon=True)
@@ -395,12 +412,7 @@ class _DbWriter(object):
     def _run(self):
         try:
             con = sqlite3.connect(self.path)
-            # A commit is an fsync (2.5 ms each on the test boxes' file system); the last flushes of a call sit on
-            # its critical path (close() joins), and an 8-station call made five of them: 10 ms of a 37 ms call.
-            # The file is a result table that a run rewrites from scratch (delOldCorrs): the pages are handed to the
-            # operating system without waiting for the disk -- a process crash loses nothing, a power failure may
-            # (the reference writes through pandas' to_sql with SQLite's default).  DETEX_AMD_DB_SYNC=FULL restores it.
-            con.execute('PRAGMA synchronous=%s' % os.environ.get('DETEX_AMD_DB_SYNC', 'OFF'))
+            con.execute('PRAGMA synchronous=%s' % self.sync)      # (validated in __init__)
             pending = {}
 
             def flush(table=None):
@@ -889,7 +901,7 @@ class SubSpace(object):
         parts = {}
         # single process: the SQLite file is written by a thread of its own, fed as the units finish
         # (detect.py:207-210 flushes every 500 rows); under a process group rank 0 writes after the gather
-        writer = _DbWriter(subspaceDB) if (subspaceDB is not None and not active) else None
+        writer = _DbWriter(subspaceDB, fresh=bool(delOldCorrs)) if (subspaceDB is not None and not active) else None
         units_left = {}
         for sta, _ in todo:
             units_left[sta] = units_left.get(sta, 0) + 1
@@ -989,7 +1001,7 @@ class SubSpace(object):
         if writer is not None:
             self._write_db(None, out, writer, hist_written)   # the remaining histogram rows; joins the thread
         elif subspaceDB is not None and rank == 0:
-            self._write_db(subspaceDB, out)
+            self._write_db(subspaceDB, out, fresh=bool(delOldCorrs))
         if classifyEvents is not None:
             out['event_cors'] = self._event_cors(fetcher, stations, results, banks, eventCorFile, rank)
         if utc is not None:
@@ -1186,13 +1198,13 @@ class SubSpace(object):
             d.pop(k, None)                                  # device contexts / buffers are not picklable
         return d
 
-    def _write_db(self, path, out, writer=None, hist_written=()):
+    def _write_db(self, path, out, writer=None, hist_written=(), fresh=False):
         """subspace.py:1882-1902: ss_df / sg_df, ss_info / sg_info, ss_hist /
         sg_hist, filt_params.  writer: the call's _DbWriter -- the detection rows and the tables that do not
         depend on the scan (info, filter parameters: queued when the call began) are in, or on their way into,
         the file already; the histograms follow on its thread and the thread is joined."""
         if writer is None:
-            writer = _DbWriter(path)
+            writer = _DbWriter(path, fresh=fresh)
             for k, df in out.items():
                 writer.put(k, df)
             writer.call(self._write_static_tables)
@@ -1256,3 +1268,25 @@ class SubSpace(object):
         """subspace.py:2018-2026."""
         with open(filename, 'wb') as f:
             pickle.dump(self, f, pickle.HIGHEST_PROTOCOL)
+
+
+# --------------------------------------------------------------------------
+# loaders                                          util.py:934-969
+# --------------------------------------------------------------------------
+
+def loadClusters(filename='clust.pkl'):
+    """util.py:934-950: the ClusterStream that ``ClusterStream.write()`` (``createCluster(saveclust=True)``)
+    pickled; anything else in the file is an error, as in the reference (``detex.log(level='error')`` raises)."""
+    cl = pd.read_pickle(filename)
+    if not isinstance(cl, ClusterStream):
+        _error('%s is not a ClusterStream instance' % filename)
+    return cl
+
+
+def loadSubSpace(filename='subspace.pkl'):
+    """util.py:953-969: the SubSpace that ``SubSpace.write()`` pickled (device contexts, banks and uploaders are
+    not in the file: the first ``detex()`` of the loaded object builds them again)."""
+    ss = pd.read_pickle(filename)
+    if not isinstance(ss, SubSpace):
+        _error('%s is not a SubSpace instance' % filename)
+    return ss

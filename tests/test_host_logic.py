@@ -1158,3 +1158,72 @@ def test_dendrogram_cut_equals_the_subset_form(seed):
         assert c.dflink[a]['II'] == mem[N + a] == c2.dflink[a]['II']
     with pytest.raises(KeyError):
         c.dflink[0]['nope']
+
+
+def test_db_sync_mode_follows_delOldCorrs(tmp_path, monkeypatch):
+    """_DbWriter: synchronous=OFF only for a file this call creates from scratch (delOldCorrs removed the old one);
+    a file that holds earlier runs' rows (append mode, subspace.py:1847-1854: delOldCorrs=False) is written with
+    SQLite's default FULL, as the reference's to_sql does.  DETEX_AMD_DB_SYNC overrides and is validated."""
+    import sqlite3
+    import pandas as pd
+    from detex_amd import subspace as ssmod
+    monkeypatch.delenv('DETEX_AMD_DB_SYNC', raising=False)
+    made = []
+    orig = ssmod._DbWriter.__init__
+
+    def spy(self, path, fresh=False):
+        orig(self, path, fresh=fresh)
+        made.append(self.sync)
+    monkeypatch.setattr(ssmod._DbWriter, '__init__', spy)
+    ctx = OracleCtx()
+    ss, cf, plants, _ = small_workflow(ctx)
+    db = str(tmp_path / 'SubSpace.db')
+    r1 = ss.detex(subspaceDB=db, ctx=ctx, estimateMags=False)                  # no file yet, delOldCorrs=True
+    r2 = ss.detex(subspaceDB=db, ctx=ctx, estimateMags=False)                  # file removed first: fresh again
+    n1 = len(pd.read_sql('SELECT * FROM ss_df', sqlite3.connect(db)))
+    r3 = ss.detex(subspaceDB=db, ctx=ctx, estimateMags=False, delOldCorrs=False)   # appends to r2's rows
+    n3 = len(pd.read_sql('SELECT * FROM ss_df', sqlite3.connect(db)))
+    assert made == ['OFF', 'OFF', 'FULL'], made
+    assert n1 == len(r1['ss_df']) == len(r2['ss_df']) and n3 == 2 * n1 and n1 > 0
+    # a file that exists and is NOT removed is never written without durability, whatever `fresh` says
+    w = ssmod._DbWriter(db, fresh=True)
+    w.close()
+    assert w.sync == 'FULL'
+    # delOldCorrs=False with no file yet: also FULL (nothing said the file is this call's alone)
+    w = ssmod._DbWriter(str(tmp_path / 'new.db'), fresh=False)
+    w.close()
+    assert w.sync == 'FULL'
+    monkeypatch.setenv('DETEX_AMD_DB_SYNC', 'normal')
+    w = ssmod._DbWriter(db)
+    w.close()
+    assert w.sync == 'NORMAL'
+    monkeypatch.setenv('DETEX_AMD_DB_SYNC', "OFF; DROP TABLE ss_df")
+    with pytest.raises(ValueError):
+        ssmod._DbWriter(db)
+
+
+def test_loadClusters_loadSubSpace_round_trip(tmp_path, monkeypatch):
+    """util.py:934-969: write() -> loadClusters / loadSubSpace -> the loaded objects give the same subspaces and the
+    same detection tables; a file of the wrong kind is an error."""
+    import pandas as pd
+    import detex_amd
+    monkeypatch.chdir(tmp_path)
+    ctx = OracleCtx()
+    ss, cf, plants, _ = small_workflow(ctx)
+    ref = ss.detex(subspaceDB=None, ctx=ctx, useSingles=True)
+    cl = ss.clusters
+    cl.filename = 'clust.pkl'
+    cl.write()
+    ss.write()                                               # 'subspace.pkl'
+    cl2 = detex_amd.loadClusters()
+    ss2 = detex_amd.loadSubSpace()
+    assert isinstance(cl2, detex_amd.ClusterStream) and isinstance(ss2, detex_amd.SubSpace)
+    assert [c.station for c in cl2] == [c.station for c in cl]
+    got = ss2.detex(subspaceDB=None, ctx=OracleCtx(), useSingles=True)
+    for k in ('ss_df', 'sg_df'):
+        pd.testing.assert_frame_equal(got[k], ref[k])
+    assert len(ref['ss_df']) >= len(plants) - 1
+    with pytest.raises(detex_amd.DetexHipError):
+        detex_amd.loadClusters('subspace.pkl')
+    with pytest.raises(detex_amd.DetexHipError):
+        detex_amd.loadSubSpace('clust.pkl')
