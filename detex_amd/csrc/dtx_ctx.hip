@@ -40,6 +40,8 @@ void dtx_free_tiles_internal(dtx_ctx* c) {
     if (t.ut16_dev) (void)hipFree(t.ut16_dev);
     if (t.srow_dev) (void)hipFree(t.srow_dev);
     if (t.doff_dev) (void)hipFree(t.doff_dev);
+    if (t.sub_dev) (void)hipFree(t.sub_dev);
+    if (t.sdoff_dev) (void)hipFree(t.sdoff_dev);
   }
   c->tiles.clear();
   dtx_fft_free(c);

@@ -52,14 +52,10 @@ namespace {
 // windows w0 .. w0 + 2 V - 1 reach sample w0 + 2 V + L - 2 >= w0 + (nseg + 1) V - 1).
 __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ den, int64_t Ppad,
                                                     int64_t P, int V, int nblk, int wspan,
-                                                    int* __restrict__ list, const int* __restrict__ pb) {
+                                                    const DtxRepairWs ws, const int* __restrict__ pb) {
   __shared__ float red[8];
   const int cb = blockIdx.x, tid = threadIdx.x;
   const int chunk = cb / nblk, blk = cb - chunk * nblk;
-  // behind the list (1 + gridDim.x ints): the window energy from which the repair leaves this engine's value
-  // standing -- at a window within kFftKeep of the loudest the transforms' rounding is < 3e-7 of the statistic,
-  // less than the float32 contraction's over a long template (its error grows with sqrt(n): ~4e-6 at n = 18 000)
-  float* keep = reinterpret_cast<float*>(list + 1 + gridDim.x);
   if (pb != nullptr) P = min(P, (int64_t)pb[chunk]);     // ragged batch: the chunk's own windows
   const int64_t w0 = (int64_t)blk * V, w1 = min(w0 + V, P), w2 = min(w0 + wspan, P);
   const float* d = den + (int64_t)chunk * Ppad;
@@ -89,9 +85,188 @@ __global__ __launch_bounds__(256) void guard_kernel(const float* __restrict__ de
 #pragma unroll
     for (int q = 1; q < 4; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[4 + q]); }
     if (mx > kFftGuard * kFftGuard * mn) {
-      list[1 + atomicAdd(list, 1)] = cb;
-      keep[cb] = mx * (1.f / kFftKeep);
+      ws.list[atomicAdd(ws.count, 1)] = cb;
+      ws.gmn[cb] = mn;
+      ws.gmx[cb] = mx;
     }
+  }
+}
+
+// What becomes of a listed block (one workgroup each; a launch that finds an empty list on ordinary data).
+//
+// (1) Outliers.  Most listings on real records are a glitch: a few samples thousands of times the noise.  The
+//     transforms are linear, so such samples need not go through them: a sample whose square exceeds a quarter of
+//     what the guard tolerates for a WINDOW (theta = kFftGuard^2 / 4 x the quietest live window's energy) is taken
+//     out of the block (spk: at most kMaxSpk per block, in (frame, channel) order) -- xhat_clean_kernel transforms
+//     the block again without them, ds_fft_rescan_kernel scans it again and adds their products U[k][t - p] v to
+//     the projections directly: K L multiply-adds per outlier instead of a block of the float32 contraction
+//     (18 GFLOP at configs[1]).  Only single-segment templates (the block's samples fit the workgroup's LDS).
+// (2) What is still out of range.  emax = the loudest window energy of what the transforms now see (prefix sums
+//     of the frame energies, float64 in LDS).  A window is in need when emax > kFftGuard^2 x its own energy (den:
+//     a window that holds an outlier is loud and never in need); every column tile of kRepairPT windows that holds
+//     one becomes a repair task for the float32 contraction, which stores the windows below emax / kFftKeep.
+//     (Round 5 sent ALL 22 column tiles of a listed block there; a zero-filled gap's edge next to an event has
+//     its windows in need in one or two.)
+constexpr int kSplitT = 512;
+__global__ __launch_bounds__(kSplitT) void spike_split_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc,
+                                                              int L, const float* __restrict__ den, int64_t Ppad,
+                                                              int64_t P, int V, int nblk, int nseg,
+                                                              const DtxRepairWs ws, const int* __restrict__ pb) {
+  __shared__ double sS[kN + 1];                // prefix sums of the frame energies
+  __shared__ double swave[kSplitT / 64];
+  __shared__ float sred[kSplitT / 64];
+  __shared__ DtxSpike sp[kMaxSpk];
+  __shared__ int scnt;
+  __shared__ int sneed[kN / kRepairPT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nlist = ws.count[0];
+  for (int e = blockIdx.x; e < nlist; e += gridDim.x) {
+    const int cb = ws.list[e];
+    const int chunk = cb / nblk, blk = cb - chunk * nblk;
+    const int64_t Pc = pb != nullptr ? min(P, (int64_t)pb[chunk]) : P;
+    const int64_t w0 = (int64_t)blk * V;
+    const int nwin = (int)(min(w0 + V, Pc) - w0);
+    float emax = ws.gmx[cb];
+    int ns = 0;
+    if (nseg == 1) {
+      const int F = (int)min((int64_t)(nwin + L - 1), Tpad - w0);     // frames the block's windows read (<= kN)
+      const float theta = 0.25f * kFftGuard * kFftGuard * ws.gmn[cb];
+      const float* xb = xp + (int64_t)chunk * Nc * Tpad + w0;
+      if (tid == 0) scnt = 0;
+      __syncthreads();
+      for (int c = 0; c < Nc; ++c) {
+        const float* x = xb + (int64_t)c * Tpad;
+        for (int t = tid; t < F; t += kSplitT) {
+          const float v = x[t];
+          if (v * v > theta) {
+            const int k = atomicAdd(&scnt, 1);
+            if (k < kMaxSpk) sp[k] = DtxSpike{(int)w0 + t, c, v};
+          }
+        }
+      }
+      __syncthreads();
+      ns = scnt;
+      const bool split = ns >= 1 && ns <= kMaxSpk;
+      if (!split) ns = 0;
+      if (split) {                                     // (frame, channel) order: the products are added in a fixed order
+        DtxSpike mine = DtxSpike{0, 0, 0.f};
+        int rank = 0;
+        if (tid < ns) {
+          mine = sp[tid];
+          const int64_t key = (int64_t)mine.t * Nc + mine.c;
+          for (int j = 0; j < ns; ++j) rank += ((int64_t)sp[j].t * Nc + sp[j].c) < key;
+        }
+        __syncthreads();
+        if (tid < ns) sp[rank] = mine;
+        __syncthreads();
+      }
+      // frame energies of what the transforms see, a thread's kN / kSplitT consecutive frames; inclusive scan
+      constexpr int kPer = kN / kSplitT;
+      double loc[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) loc[q] = 0.0;
+      for (int c = 0; c < Nc; ++c) {
+        const float* x = xb + (int64_t)c * Tpad;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const int t = kPer * tid + q;
+          const float v = t < F ? x[t] : 0.f;
+          if (!(split && v * v > theta)) loc[q] += (double)v * (double)v;
+        }
+      }
+#pragma unroll
+      for (int q = 1; q < kPer; ++q) loc[q] += loc[q - 1];
+      double incl = loc[kPer - 1];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) swave[wv] = incl;
+      __syncthreads();
+      double base = incl - loc[kPer - 1];
+      for (int w = 0; w < wv; ++w) base += swave[w];
+      if (tid == 0) sS[0] = 0.0;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) sS[kPer * tid + q + 1] = base + loc[q];
+      __syncthreads();
+      float m = 0.f;
+      for (int p = tid; p < nwin; p += kSplitT) m = fmaxf(m, (float)(sS[min(p + L, F)] - sS[p]));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) sred[wv] = m;
+      __syncthreads();
+      emax = sred[0];
+#pragma unroll
+      for (int w = 1; w < kSplitT / 64; ++w) emax = fmaxf(emax, sred[w]);
+    }
+    if (tid < kN / kRepairPT) sneed[tid] = 0;
+    __syncthreads();
+    const float* d = den + (int64_t)chunk * Ppad + w0;
+    for (int p = tid; p < nwin; p += kSplitT) {
+      const float dn = d[p];
+      if (dn > 0.f && kFftGuard * kFftGuard * dn < emax) sneed[p / kRepairPT] = 1;
+    }
+    __syncthreads();
+    if (tid < (nwin + kRepairPT - 1) / kRepairPT && sneed[tid])
+      ws.tasks[atomicAdd(ws.count + 1, 1)] =
+          make_int4(chunk, (int)(w0 / kRepairPT) + tid, __float_as_int(emax * (1.f / kFftKeep)), cb);
+    if (tid == 0) {
+      ws.nspk[cb] = ns;
+      if (ns > 0) ws.slist[atomicAdd(ws.count + 2, 1)] = cb;
+    }
+    if (tid < ns) ws.spk[(int64_t)cb * kMaxSpk + tid] = sp[tid];
+    __syncthreads();
+  }
+}
+
+// The block spectra of the blocks whose outliers were split off, again without them (in place: the scan that
+// read the originals is done).  As xhat_kernel; grid (any, Nc).
+__global__ __launch_bounds__(kT) void xhat_clean_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc, int V,
+                                                        int nblk, int nblkx, int keep,
+                                                        const c32* __restrict__ tab, c32* __restrict__ xh,
+                                                        const DtxRepairWs ws) {
+  __shared__ c32 lds[kLdsC];
+  const int tid = threadIdx.x, c = blockIdx.y;
+  const LdsBases lb = lds_bases(tid);
+  const int tb = 8 * (tid & 63) + (tid >> 6);          // sample within the block
+  const int nsl = ws.count[2];
+  for (int e = blockIdx.x; e < nsl; e += gridDim.x) {
+    const int cb = ws.slist[e];
+    const int chunk = cb / nblk, blk = cb - chunk * nblk;
+    const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
+    const int64_t t0 = (int64_t)blk * V + tb;
+    c32 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t t = t0 + 512 * r;
+      v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
+    }
+    const int ns = ws.nspk[cb];
+    for (int s = 0; s < ns; ++s) {
+      const DtxSpike sk = ws.spk[(int64_t)cb * kMaxSpk + s];
+      const int rel = sk.t - blk * V - tb;             // this thread's sample r when rel == 512 r
+      if (sk.c == c && rel >= 0 && (rel & 511) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rel == 512 * r) v[r].x = 0.f;
+      }
+    }
+    fft8192<-1>(v, lds, lb, tab, tid);
+    c32* row = xh + (((int64_t)chunk * nblkx + blk) * Nc + c) * kXh + (tid >> 6) * 512 + (tid & 63);
+    __syncthreads();                                     // every wave's reads of the image are done
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[m * 576 + tid + (tid >> 3)] = v[m];
+    if (tid == 0) lds[8 * 576] = v[8];                   // X[kN / 2]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t2 = 8 * (tid & 63) + (tid >> 6);        // the thread that held f = 512 j + 8 lane + wave
+      c32 o = lds[j * 576 + t2 + (t2 >> 3)];
+      if (tid == 0 && j == 0) o.y = lds[8 * 576].x;
+      row[64 * j] = o;
+    }
+    __syncthreads();
   }
 }
 
@@ -141,6 +316,12 @@ struct FftArgs {
   int64_t Tpad;
   int keep;
   const int* pb;        // ragged batch: [nchunk] windows of each chunk (NULL: P for all)
+  // re-scan of the blocks whose outliers were split off (ds_fft_rescan_kernel)
+  DtxRepairWs rws;
+  const int2* runs;     // [nruns] {first pair, pairs}: runs of whole detectors
+  const int2* prow;     // [npairs] basis rows of the real / imaginary part
+  const float* U;       // [Ktot][n] the basis itself
+  int nruns, n, L;
 };
 
 #ifndef DTX_DS_NT
@@ -155,6 +336,7 @@ struct FftArgs {
 // squared projections; when the pair closes its detector(s) (pdet.x >= 0), normalise and store.
 // pdet.y >= 0: the imaginary part is a different, single-vector detector (acc1).
 #define DTX_FFT_EPILOGUE \
+    add_spikes(ui.x + pr); \
     const float4 pi = a.pinfo[ui.x + pr]; \
     const int2 pd = a.pdet[ui.x + pr]; \
     const bool two = TWO && pd.y >= 0; \
@@ -191,30 +373,15 @@ _Pragma("unroll") \
 // NCH > 0: Nc == NCH <= 3 and the block's spectra stay in LDS beside the image (64 + 32 NCH
 // KB: with three channels exactly the CU's 160 KB), so each pair reads only its basis
 // spectra from L2 -- half the bytes; NCH == 0: any Nc, block spectra re-read per pair
-template <int VM, bool TWO, int NCH>
-__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs a) {
-  __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
-  const int tid = threadIdx.x;
-  // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
-  // every XCD a contiguous run of the logical work list, and order that list in tiles of
-  // kTileU units x kTileB blocks (1 x 16): the workgroups an XCD runs at a time then read the same
-  // unit's basis spectra and the same few blocks' spectra instead of unrelated ones; consecutive
-  // tiles are the same blocks under the next unit, so the block spectra are fetched into the
-  // L2 once per tile, not once per unit.
-  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
-  const int tile = logical / kTile, slot = logical - tile * kTile;
-#if DTX_FFT_BLOCK_MAJOR
-  const int ntu = (a.nunits + kTileU - 1) / kTileU;
-  const int tb = tile / ntu, tu = tile - tb * ntu;     // consecutive tiles: the same blocks under the next unit
-#else
-  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
-#endif
-  const int unit = tu * kTileU + slot % kTileU;
-  const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
-  if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
+// SPLIT (the re-scan): the block's outliers (a.rws.spk) did not go through the transforms; their products with
+// the pair's two basis rows are added to the finished projections, window by window
+template <int VM, bool TWO, int NCH, bool SPLIT>
+__device__ __forceinline__ void ds_fft_block(const FftArgs& a, const int cb, const int4 ui, c32* lds, c32* xst,
+                                             const int tid) {
   const int chunk = cb / a.nblk, blk = cb - chunk * a.nblk;
-  const int4 ui = a.unit[unit];
   const int64_t p0 = (int64_t)blk * a.V;
+  [[maybe_unused]] const int nspk = SPLIT ? a.rws.nspk[cb] : 0;
+  [[maybe_unused]] const DtxSpike* spk = SPLIT ? a.rws.spk + (int64_t)cb * kMaxSpk : nullptr;
 
   const LdsBases lb = lds_bases(tid);
   float acc0[VM], acc1[TWO ? VM : 1];
@@ -245,7 +412,6 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   // blocks': segment s of the template meets the data of block blk + s (advance == segment length)
   const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
-  __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];   // NCH == 0: the current / next virtual channel's block spectrum
   if constexpr (NCH > 0) {
     const float4* src = reinterpret_cast<const float4*>(xh);
     float4* dst = reinterpret_cast<float4*>(xs);
@@ -263,6 +429,27 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
     }
   };
   c32 z[16];
+  [[maybe_unused]] auto add_spikes = [&](int pair) {
+    if constexpr (SPLIT) {
+      const int2 rows = a.prow[pair];
+      const float* ua = a.U + (size_t)rows.x * a.n;
+      const float* ub = a.U + (size_t)(rows.y >= 0 ? rows.y : rows.x) * a.n;
+      const float sb = rows.y >= 0 ? 1.f : 0.f;
+      for (int s = 0; s < nspk; ++s) {
+        const DtxSpike sk = spk[s];                            // (uniform)
+        const int j0 = sk.t - (int)p0 - tid;                   // sample of the template that meets the outlier, window m = 0
+#pragma unroll
+        for (int m = 0; m < VM; ++m) {
+          const int j = j0 - 512 * m;
+          if ((unsigned)j < (unsigned)a.L) {
+            const int q = j * a.Nc + sk.c;
+            z[m].x = __fmaf_rn(ua[q], sk.v, z[m].x);
+            z[m].y = __fmaf_rn(ub[q] * sb, sk.v, z[m].y);
+          }
+        }
+      }
+    }
+  };
   if constexpr (NCH == 0) {
     // Block spectra streamed from L2 (Nc not 1 / 3, or a segmented template): pairs are taken two
     // at a time so that one load of a block spectrum feeds two MACs -- the MAC's L2 traffic is
@@ -379,6 +566,55 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
       fft8192<1>(z, lds, lb, a.tab, tid);   // (its leading barrier covers the reuse of the image)
       DTX_FFT_EPILOGUE
     }
+  }
+}
+
+// VM = V / 512 outputs kept per thread; TWO: some pair holds two single-vector detectors
+// NCH > 0: Nc == NCH <= 3 and the block's spectra stay in LDS beside the image (64 + 32 NCH
+// KB: with three channels exactly the CU's 160 KB), so each pair reads only its basis
+// spectra from L2 -- half the bytes; NCH == 0: any Nc, block spectra re-read per pair
+template <int VM, bool TWO, int NCH>
+__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs a) {
+  __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
+  __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];   // NCH == 0: the current / next virtual channel's block spectrum
+  // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
+  // every XCD a contiguous run of the logical work list, and order that list in tiles of
+  // kTileU units x kTileB blocks (1 x 16): the workgroups an XCD runs at a time then read the same
+  // unit's basis spectra and the same few blocks' spectra instead of unrelated ones; consecutive
+  // tiles are the same blocks under the next unit, so the block spectra are fetched into the
+  // L2 once per tile, not once per unit.
+  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  const int tile = logical / kTile, slot = logical - tile * kTile;
+#if DTX_FFT_BLOCK_MAJOR
+  const int ntu = (a.nunits + kTileU - 1) / kTileU;
+  const int tb = tile / ntu, tu = tile - tb * ntu;     // consecutive tiles: the same blocks under the next unit
+#else
+  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
+#endif
+  const int unit = tu * kTileU + slot % kTileU;
+  const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
+  if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
+  ds_fft_block<VM, TWO, NCH, false>(a, cb, a.unit[unit], lds, xst, threadIdx.x);
+}
+
+// The blocks whose outliers were split off (spike_split_kernel), scanned again on their clean spectra
+// (xhat_clean_kernel) with the outliers' products added directly.  Work items (block, run of whole detectors'
+// pairs), walked by a grid sized for the chip in tiles of 16 blocks x all runs (the workgroups running at a time
+// share a few blocks' spectra and walk the same pair spectra); finds an empty list on ordinary data.
+template <int VM, bool TWO, int NCH>
+__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_rescan_kernel(const FftArgs a) {
+  __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
+  __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];
+  constexpr int kTB = 16;
+  const int nsl = a.rws.count[2];
+  const int nwork = nsl * a.nruns;
+  for (int e = blockIdx.x; e < nwork; e += gridDim.x) {
+    const int tile = e / (kTB * a.nruns), r = e - tile * kTB * a.nruns;
+    const int nb = min(kTB, nsl - tile * kTB);           // blocks of this tile (every tile but the last is full)
+    const int run = r / nb, slot = tile * kTB + (r - run * nb);
+    const int2 rn = a.runs[run];
+    ds_fft_block<VM, TWO, NCH, true>(a, a.rws.slist[slot], make_int4(rn.x, rn.y, 0, 0), lds, xst, threadIdx.x);
+    __syncthreads();
   }
 }
 
@@ -767,6 +1003,15 @@ void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   }
 }
 
+// the re-scan: the one-role kernel whatever the main scan ran (block spectra LDS-resident for three channels,
+// streamed otherwise)
+template <int VM>
+void launch_rescan(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
+  if (two) hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  else if (a.Nc == 3 && DTX_FFT_XLDS) hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, false, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+}
+
 // Pair spectra in FLOAT64 on the device: W[task][wave-major f] = 1/kN sum_j (u_ra,c[j0 + j] +
 // i u_rb,c[j0 + j]) e^{+2 pi i j f / kN}, task = pair * nvc + (c * nseg + seg).  One workgroup
 // per task; a plain radix-2 transform of 8192 complex128 points in 128 KB of LDS (twiddles from
@@ -834,6 +1079,7 @@ void dtx_fft_free(dtx_ctx* ctx) {
   if (f.pdet_dev) (void)hipFree(f.pdet_dev);
   if (f.prow_dev) (void)hipFree(f.prow_dev);
   if (f.upre_dev) (void)hipFree(f.upre_dev);
+  if (f.runs_dev) (void)hipFree(f.runs_dev);
   f = DtxFft();
 }
 
@@ -874,6 +1120,8 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
     f.unit_pairs = pl.unit_pairs;
   }
   static_assert(sizeof(int4) == sizeof(dtxplan::I4) && sizeof(int2) == sizeof(dtxplan::I2), "plan tables are int2 / int4");
+  const std::vector<dtxplan::I2> runs = dtxplan::plan_fft_runs(pl, f.pingpong);
+  f.nruns = (int)runs.size();
   const std::vector<dtxplan::I4>& units = pl.units;
   const std::vector<dtxplan::I2>&pdet = pl.pdet, &prow = pl.prow, &upre = pl.upre;
 
@@ -892,12 +1140,14 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   DTX_HIP(ctx, hipMalloc(&f.pdet_dev, pdet.size() * sizeof(int2)));
   DTX_HIP(ctx, hipMalloc(&f.prow_dev, prow.size() * sizeof(int2)));
   DTX_HIP(ctx, hipMalloc(&f.upre_dev, upre.size() * sizeof(int2)));
+  DTX_HIP(ctx, hipMalloc(&f.runs_dev, runs.size() * sizeof(int2)));
   // small synchronous copies into fresh buffers
   hipError_t e = hipMemcpy(f.prow_dev, prow.data(), prow.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.pdet_dev, pdet.data(), pdet.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.tab_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.unit_dev, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(f.upre_dev, upre.data(), upre.size() * sizeof(int2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f.runs_dev, runs.data(), runs.size() * sizeof(int2), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(pinfo_kernel, dim3((unsigned)((f.npairs + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const int2*)f.prow_dev, (const float*)ctx->srow_all.p, f.npairs,
@@ -917,7 +1167,7 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 // stream (forked by the caller): the guard pass follows them there, the block spectra are taken on the
 // main stream meanwhile, and the two streams meet in front of the scan kernel
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list,
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, const DtxRepairWs& ws,
                  const int* pb) {
   DtxFft& f = ctx->fft;
   if (!f.ok) return dtx_fail(ctx, DTX_E_STATE, "FFT engine: no spectra for this basis");
@@ -974,8 +1224,15 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
 #endif
   a.upre = (const int2*)f.upre_dev; a.nfull = nfull; a.nrem = std::max(nrem, 1); a.ngroups = ng;
   std::copy(gb, gb + kMaxGroups + 1, a.gb);
+  a.rws = ws; a.runs = (const int2*)f.runs_dev; a.nruns = f.nruns; a.prow = (const int2*)f.prow_dev;
+  a.U = (const float*)ctx->U_buf.p; a.n = ctx->n; a.L = ctx->L;
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->aux, den,
-                     Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, guard_list, pb);
+                     Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, ws, pb);
+  DTX_HIP(ctx, hipGetLastError());
+  // what becomes of the listed blocks (outliers split off, repair tasks): still on the side stream, beside the
+  // block spectra -- the scan does not wait longer for it than for the statistics
+  hipLaunchKernelGGL(spike_split_kernel, dim3((unsigned)ctx->ncu), dim3(kSplitT), 0, ctx->aux, xp, Tpad, Nc, ctx->L,
+                     den, Ppad, P, V, nblk, f.nseg, ws, pb);
   DTX_HIP(ctx, hipGetLastError());
   {
     const int rcj = dtx_aux_join(ctx);
@@ -1008,6 +1265,38 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   DTX_HIP(ctx, hipGetLastError());
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   dtx_kev_commit(ctx);
+  if (f.nseg == 1) {
+    // blocks with outliers split off: their spectra again without them, in place (the scan above is done with
+    // the originals), then the blocks again on the one-role kernel; both launches are sized for the chip and find
+    // an empty list on ordinary data
+    hipLaunchKernelGGL(xhat_clean_kernel, dim3((unsigned)ctx->ncu, (unsigned)Nc), dim3(kT), 0, ctx->stream, xp, Tpad,
+                       Nc, V, nblk, nblkx, keep, (const c32*)f.tab_dev, xh, ws);
+    DTX_HIP(ctx, hipGetLastError());
+    const unsigned rgrid = (unsigned)(4 * ctx->ncu);
+    switch (V / 512) {
+#ifndef DTX_FFT_ONLY_VM
+      case 1: launch_rescan<1>(ctx, a, rgrid, f.two); break;
+      case 2: launch_rescan<2>(ctx, a, rgrid, f.two); break;
+      case 3: launch_rescan<3>(ctx, a, rgrid, f.two); break;
+      case 4: launch_rescan<4>(ctx, a, rgrid, f.two); break;
+      case 5: launch_rescan<5>(ctx, a, rgrid, f.two); break;
+      case 6: launch_rescan<6>(ctx, a, rgrid, f.two); break;
+      case 7: launch_rescan<7>(ctx, a, rgrid, f.two); break;
+      case 8: launch_rescan<8>(ctx, a, rgrid, f.two); break;
+      case 9: launch_rescan<9>(ctx, a, rgrid, f.two); break;
+#endif
+      case 10: launch_rescan<10>(ctx, a, rgrid, f.two); break;
+#ifndef DTX_FFT_ONLY_VM
+      case 11: launch_rescan<11>(ctx, a, rgrid, f.two); break;
+      case 12: launch_rescan<12>(ctx, a, rgrid, f.two); break;
+      case 13: launch_rescan<13>(ctx, a, rgrid, f.two); break;
+      case 14: launch_rescan<14>(ctx, a, rgrid, f.two); break;
+      case 15: launch_rescan<15>(ctx, a, rgrid, f.two); break;
+#endif
+      default: break;
+    }
+    DTX_HIP(ctx, hipGetLastError());
+  }
 #ifdef DTX_PP_STAMPS
   if (a.stamps) {       // dump the last launch's stamps: [workgroup][half][round][16], zeros = not taken
     std::vector<long long> h(stamp_n);

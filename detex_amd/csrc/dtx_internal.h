@@ -25,6 +25,11 @@ struct DtxKTile {
   uint16_t* ut16_dev = nullptr; // split-bf16 image [Nc][Lp/8][2][KT][8]
   float* srow_dev = nullptr;    // [KT] row sums S_k
   int32_t* doff_dev = nullptr;  // [nd+1] detector row offsets local to the tile
+  // repair sub-tiles (dtxplan::plan_repair_subtiles): runs of whole detectors inside `rms` row blocks of this tile's
+  // images -- the row groups of the repair pass's tasks (ds_mfma_task_kernel)
+  int rms = 0, nsub = 0;
+  void* sub_dev = nullptr;      // [nsub] int4 {first row block, first detector (tile-local), detectors, offset into sdoff}
+  int32_t* sdoff_dev = nullptr; // the sub-tiles' detector row offsets, relative to their first row block
 };
 
 // Frequency-domain engine (dtx_fft.hip): pair spectra of the basis, built on first use
@@ -45,6 +50,8 @@ struct DtxFft {
   void* pdet_dev = nullptr;    // [npairs] int2
   void* prow_dev = nullptr;    // [npairs] int2: basis rows of the real / imaginary part
   void* upre_dev = nullptr;    // [nunits + 1] int2: pairs of half 0 / half 1 before each unit (ping-pong kernel)
+  void* runs_dev = nullptr;    // [nruns] int2 {first pair, pairs}: runs of whole detectors (the re-scan's work items)
+  int nruns = 0;
   std::vector<int> unit_pairs; // pairs per unit (host copy: dtx_fft_scan groups units per launch)
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
@@ -103,6 +110,7 @@ struct dtx_ctx {
   std::vector<double> pp_key[kPpCache];
   int pp_next = 0;                     // round-robin replacement
   int engine = DTX_ENGINE_AUTO;
+  bool guard_ran = false;              // the last scan filled DtxRepairWs::count (dtx_repair_counts)
 
   // small host tables on their way to the device without a stream synchronisation: a ring of page-locked
   // staging buffers, each guarded by the event recorded behind its last copy (dtx_stage_h2d)
@@ -123,6 +131,42 @@ struct dtx_ctx {
   bool kernel_timed = false;
 };
 
+// ---- repair of what the dynamic-range guards list (dtx_subspace.hip, dtx_fft.hip)
+// An outlier sample the frequency-domain engine takes out of a listed block's transforms and adds back directly
+// (spike_split_kernel): frame t of its chunk's channel plane c, value v (block offset already removed).
+struct DtxSpike { int t, c; float v; };
+constexpr int kMaxSpk = 48;            // outliers per block; more: the block keeps its transforms and goes to the contraction
+constexpr int kRepairPT = 256;         // windows per repair task (column tile of the float32 contraction)
+// One workspace (ctx->ws_flag) for a call's guard lists; count[] is cleared by chunk_offset_final_kernel.
+struct DtxRepairWs {
+  int* count;        // [0] listed blocks, [1] repair tasks, [2] blocks re-scanned with outliers split off, [3] -
+  int4* tasks;       // [ntile] {chunk, first window / kRepairPT, bits of the window energy below which a window is stored, block}
+  int* list;         // [nb] listed blocks (chunk * nblk + blk), in the order found
+  int* slist;        // [nb] blocks with outliers split off
+  float* gmn;        // [nb] by block: quietest live own window energy / loudest window energy (guard_kernel)
+  float* gmx;
+  int* nspk;         // [nb] by block: outliers split off
+  DtxSpike* spk;     // [nb][kMaxSpk]
+};
+inline size_t dtx_repair_ws_bytes(size_t nb, size_t ntile) {
+  return 16 + ntile * 16 + nb * (5 * 4 + kMaxSpk * sizeof(DtxSpike));
+}
+inline DtxRepairWs dtx_repair_ws_carve(void* base, size_t nb, size_t ntile) {
+  DtxRepairWs w;
+  char* p = (char*)base;
+  w.count = (int*)p; p += 16;
+  w.tasks = (int4*)p; p += ntile * 16;
+  w.list = (int*)p; p += nb * 4;
+  w.slist = (int*)p; p += nb * 4;
+  w.gmn = (float*)p; p += nb * 4;
+  w.gmx = (float*)p; p += nb * 4;
+  w.nspk = (int*)p; p += nb * 4;
+  w.spk = (DtxSpike*)p;
+  return w;
+}
+// the listed tasks again on the float32 contraction (dtx_subspace.hip); every launch finds an empty list on ordinary data
+int dtx_launch_repair(dtx_ctx* ctx, const DtxRepairWs& ws, const float* xp, int64_t Tpad, const float* mean,
+                      const float* den, int64_t Ppad, int64_t P, float* ds, int64_t ldp);
 int dtx_fail(dtx_ctx* ctx, int code, const char* fmt, ...);
 int dtx_reserve(dtx_ctx* ctx, DtxBuf& b, size_t bytes);
 void dtx_free_tiles_internal(dtx_ctx* c);
@@ -137,7 +181,7 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
 // main stream meanwhile, and the two streams meet in front of the scan kernel
 // pb != NULL (ragged batch): blocks wholly past their chunk's own pb[chunk] windows are skipped
 int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean, const float* den,
-                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, int* guard_list,
+                 int64_t Ppad, int64_t P, int nchunk, float* ds, int64_t ldp, const DtxRepairWs& ws,
                  const int* pb = nullptr);
 // dst_dev <- bytes of src_host, asynchronously on the context's stream; src_host may be reused at once
 int dtx_stage_h2d(dtx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

@@ -112,6 +112,55 @@ inline void reorder_pairs_for_halves(FftBasisPlan& f) {
   f.prow.swap(prow2);
 }
 
+// Runs of pairs that close whole detectors, in the order the pair tables are stored: the work items of the
+// re-scan of a block whose outliers were split off (ds_fft_rescan_kernel).  after_reorder: the tables went
+// through reorder_pairs_for_halves (a unit's pairs then lie in two runs, one per half).
+inline std::vector<I2> plan_fft_runs(const FftBasisPlan& f, bool after_reorder) {
+  std::vector<I2> runs;
+  if (!after_reorder) {
+    for (const I4& un : f.units) runs.push_back(I2{un.x, un.y});
+    return runs;
+  }
+  const int h0 = f.upre.back().x;
+  for (size_t u = 0; u + 1 < f.upre.size(); ++u) {
+    const int n0 = f.upre[u + 1].x - f.upre[u].x, n1 = f.upre[u + 1].y - f.upre[u].y;
+    if (n0 > 0) runs.push_back(I2{f.upre[u].x, n0});
+    if (n1 > 0) runs.push_back(I2{h0 + f.upre[u].y, n1});
+  }
+  return runs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Float32 contraction: row groups of the repair pass  (dtx_subspace.hip, dtx_basis_upload)
+// ------------------------------------------------------------------------------------------------
+// A K-tile holds nd whole detectors in rm row blocks of 16 (doff[nd + 1]: tile-local row offsets).  The repair
+// pass recomputes a few windows for ALL rows: its tasks take the rows in sub-tiles of `rms` row blocks, each
+// holding whole detectors (the per-detector sums are formed inside a workgroup), so that one listed column tile
+// spreads over nsub workgroups.  rms = the most row blocks any single detector touches; a sub-tile starts at the
+// row block its first detector starts in (moved down where it would reach past the tile: the window then covers
+// rows of earlier detectors, which its detector table ignores).  sdoff: the sub-tiles' detector offsets
+// relative to their first row block, concatenated (sub.w = offset of the sub-tile's nd + 1 entries).
+struct RepairSubPlan {
+  int rms = 1;
+  std::vector<I4> sub;        // {first row block, first detector, detectors, offset into sdoff}
+  std::vector<int32_t> sdoff;
+};
+inline RepairSubPlan plan_repair_subtiles(const int32_t* doff, int nd, int rm) {
+  RepairSubPlan p;
+  for (int d = 0; d < nd; ++d) p.rms = std::max(p.rms, (doff[d + 1] + 15) / 16 - doff[d] / 16);
+  p.rms = std::min(p.rms, std::max(rm, 1));
+  for (int d = 0; d < nd;) {
+    const int rb = doff[d] / 16;
+    int e = d + 1;
+    while (e < nd && (doff[e + 1] + 15) / 16 - rb <= p.rms) ++e;
+    const int rb0 = std::max(0, std::min(rb, rm - p.rms));
+    p.sub.push_back(I4{rb0, d, e - d, (int)p.sdoff.size()});
+    for (int q = d; q <= e; ++q) p.sdoff.push_back(doff[q] - 16 * rb0);
+    d = e;
+  }
+  return p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Frequency-domain scan: grid of the ping-pong kernel  (dtx_fft.hip, dtx_fft_scan)
 // ------------------------------------------------------------------------------------------------

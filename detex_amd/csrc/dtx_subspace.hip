@@ -18,6 +18,7 @@
 #include "dtx_hankel.h"
 #include "dtx_hankel_bf16.h"
 #include "dtx_internal.h"
+#include "dtx_plan.h"
 #include "dtx_postdev.h"
 
 using namespace dtx;
@@ -43,8 +44,9 @@ namespace {
 // the slices it touches.  (Rounds 1-2 took a chunk-wide mean and a 3-sigma clipped second pass:
 // two launches, two reads of the stream, float64 atomics -- 39 + 31 us per station-day.)
 constexpr int kMeanSlices = 64;                 // one slice per lane of the wave that takes the median
-constexpr int kCsum = 2;                       // per slice: {sum, count} of the non-zero samples
+constexpr int kCsum = 3;                       // per slice: {sum, count, sum of squares} of the non-zero samples
 constexpr int kOffStride = 8;                  // long slices: one run of 256 samples in eight is read
+constexpr double kStatsBig = 1048576.0;        // samples beyond 1024 x the chunk's ordinary scatter are summed apart (win_stats_kernel)
 // ctab != NULL (ragged batch): chunk b starts at x + ctab[2 b] and holds min(ctab[2 b + 1], M) samples
 __device__ inline const float* chunk_base(const float* x, int64_t chunk_stride, const int64_t* ctab, int b,
                                           int64_t& M) {
@@ -57,14 +59,14 @@ __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restri
                                                            int64_t chunk_stride, int nsl,
                                                            double* __restrict__ cslice,
                                                            const int64_t* __restrict__ ctab) {
-  __shared__ double sh[2][4];
+  __shared__ double sh[3][4];
   const int b = blockIdx.y, tid = threadIdx.x;
   const float* xb = chunk_base(x, chunk_stride, ctab, b, M);
   const int64_t per = (M + nsl - 1) / nsl;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, M);
-  double s0 = 0.0, s2 = 0.0;
+  double s0 = 0.0, s2 = 0.0, s3 = 0.0;
   auto take = [&](float vf) {
-    if (vf != 0.f) { s0 += (double)vf; s2 += 1.0; }
+    if (vf != 0.f) { s0 += (double)vf; s2 += 1.0; s3 += (double)vf * (double)vf; }
   };
   // a slice longer than 8 x 256 samples is sampled: one run of 256 consecutive samples out of every
   // kOffStride runs, spread over the whole slice (gaps and bursts are met in proportion); the level only
@@ -84,13 +86,15 @@ __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restri
   for (int off = 32; off > 0; off >>= 1) {
     s0 += __shfl_down(s0, off, 64);
     s2 += __shfl_down(s2, off, 64);
+    s3 += __shfl_down(s3, off, 64);
   }
-  if ((tid & 63) == 0) { sh[0][tid >> 6] = s0; sh[1][tid >> 6] = s2; }
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s0; sh[1][tid >> 6] = s2; sh[2][tid >> 6] = s3; }
   __syncthreads();
   if (tid == 0) {
     double* cs = cslice + ((int64_t)b * nsl + blockIdx.x) * kCsum;
     cs[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
     cs[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    cs[2] = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
   }
 }
 
@@ -98,40 +102,51 @@ __global__ __launch_bounds__(256) void chunk_offset_kernel(const float* __restri
 // all-zero chunk.  One wave per chunk, ranks by counting: deterministic, every consumer reads the same float
 // ragged batch: also pb[b] = the chunk's own number of windows (0 when it is not longer than the basis)
 // It also clears what later passes of the same call accumulate into (two fill launches less per call): the
-// guard's list counter and the chunk's row of maxima (zmax: [nchunk][D], may be NULL).
+// guards' counters (DtxRepairWs::count) and the chunk's row of maxima (zmax: [nchunk][D], may be NULL).
 __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __restrict__ cslice, int nsl,
-                                                                float* __restrict__ m0,
+                                                                float* __restrict__ m0, float* __restrict__ tau,
                                                                 const int64_t* __restrict__ ctab, int64_t M,
                                                                 int n, int Nc, int* __restrict__ pb,
                                                                 int* __restrict__ zlist, float* __restrict__ zmax,
                                                                 int D) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  if (zlist != nullptr && b == 0 && lane == 0) zlist[0] = 0;
+  if (zlist != nullptr && b == 0 && lane < 4) zlist[lane] = 0;      // DtxRepairWs::count
   if (zmax != nullptr)
     for (int d = lane; d < D; d += 64) zmax[(int64_t)b * D + d] = 0.f;
   if (ctab != nullptr && lane == 0) {
     const int64_t Mb = max((int64_t)0, min(M, ctab[2 * b + 1]));
     pb[b] = Mb > n ? (int)((Mb - n) / Nc + 1) : 0;
   }
-  double v = 0.0;
+  double v = 0.0, var = 0.0;
   bool ok = false;
   if (lane < nsl) {
     const double* cs = cslice + ((int64_t)b * nsl + lane) * kCsum;
-    if (cs[1] >= 0.5) { v = cs[0] / cs[1]; ok = v == v; }      // (a slice that holds a NaN is left out)
+    if (cs[1] >= 0.5) {                                          // (a slice that holds a NaN is left out)
+      v = cs[0] / cs[1];
+      var = fmax(cs[2] / cs[1] - v * v, 0.0);
+      ok = v == v && var == var;
+    }
   }
   const unsigned long long mask = __ballot(ok);
   const int nv = __popcll(mask);
   if (nv == 0) {
-    if (lane == 0) m0[b] = 0.f;
+    if (lane == 0) { m0[b] = 0.f; tau[b] = INFINITY; }
     return;
   }
-  int rank = 0;
+  int rank = 0, rankv = 0;
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
-    const double vj = __shfl(v, j, 64);
-    if (((mask >> j) & 1ull) && (vj < v || (vj == v && j < lane))) ++rank;
+    const double vj = __shfl(v, j, 64), wj = __shfl(var, j, 64);
+    if ((mask >> j) & 1ull) {
+      if (vj < v || (vj == v && j < lane)) ++rank;
+      if (wj < var || (wj == var && j < lane)) ++rankv;
+    }
   }
   if (ok && rank == (nv - 1) / 2) m0[b] = (float)v;
+  // the (lower) median of the slices' variances, times kStatsBig: a sample whose square (offset removed) lies above
+  // it is summed apart by win_stats_kernel.  Only a conditioning device, like the offset: any value gives the
+  // same sums in exact arithmetic.  0 (constant slices) -> +inf: nothing is summed apart
+  if (ok && rankv == (nv - 1) / 2) tau[b] = var > 0.0 ? (float)fmin(kStatsBig * var, 3.0e38) : INFINITY;
 }
 
 // xp[b][c][t] = x_b[Nc*t + c] - m0[b] for the samples the windows touch, 0 beyond.
@@ -282,15 +297,10 @@ struct DsArgs {
   int64_t V;
   int64_t Tpad, Ppad, ldp, P;
   int Nc, Lp, D, det0, nd, nptiles;
-  // list mode (repair pass behind the frequency-domain engine): recompute only the column
-  // tiles that overlap the listed blocks; list[0] = count, list[1 + e] = chunk * lnblk + block
-  const int* list;
-  int lV, lnblk;
-  int64_t lw0, lw1;     // list mode: only windows [lw0, lw1) of the tile are stored (the listed block's)
-  // repair behind the frequency-domain engine: lkeep[cb] = the window energy from which that engine's own value
-  // stays (guard_kernel: its rounding is relative to the block's loudest window, so at the loud windows
-  // themselves -- a dominant event -- it is the more accurate of the two); NULL / +inf: every window is stored
-  const float* lkeep;
+  int ldk;              // row stride of ut (the K-tile's KT; a repair sub-tile reads a slice of its rows)
+  // repair behind the frequency-domain engine: a window is stored only when its energy lies below lkeepv -- that
+  // engine's rounding is relative to the block's loudest content, so at the loud windows themselves (a dominant
+  // event) its own value is the more accurate of the two; +inf: every window is stored
   float lkeepv;
 };
 
@@ -360,7 +370,7 @@ __device__ __forceinline__ void ds_epilogue(f32x4 (&acc)[RM][TN], const DsArgs& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int det = 16 * db + 4 * kq + e;
-        if (det < a.nd && p < a.P && p >= a.lw0 && p < a.lw1 && dn[t] < a.lkeepv) {
+        if (det < a.nd && p < a.P && dn[t] < a.lkeepv) {
           float v = (dn[t] > 0.f) ? out[t][e] / dn[t] : 0.f;
           if (__builtin_isinf(v)) v = 0.f;
           a.ds[((int64_t)chunk * a.D + a.det0 + det) * a.ldp + p] = v;
@@ -390,26 +400,52 @@ template <int RM, int TN, bool TAIL>
 __global__ __launch_bounds__(kThreads, 2) void ds_mfma_kernel(const DsArgs a) {
   constexpr int PT = 128 * TN;
   __shared__ __attribute__((aligned(16))) float lds[lds_floats(RM)];
-  if (a.list == nullptr) {
-    const int chunk = blockIdx.x / a.nptiles;
-    const int pt = blockIdx.x - chunk * a.nptiles;
-    ds_mfma_tile<RM, TN, TAIL>(a, chunk, (int64_t)pt * PT, lds);
-    return;
-  }
-  // list mode: a small persistent grid walks (listed block) x (column tiles overlapping it)
-  const int nlist = a.list[0];
-  const int tpb = a.lV / PT + 2;                     // tiles that can overlap one block
-  for (int e = blockIdx.x; e < nlist * tpb; e += gridDim.x) {
-    const int cb = a.list[1 + e / tpb];
-    const int chunk = cb / a.lnblk, blk = cb - chunk * a.lnblk;
-    const int64_t w0 = (int64_t)blk * a.lV, w1 = w0 + a.lV;      // windows of the block
-    const int64_t pt = w0 / PT + (e % tpb);
-    const int64_t p0 = pt * PT;
-    if (p0 >= w1 || p0 >= a.P) continue;             // uniform over the workgroup
-    DsArgs b = a;
-    b.lw0 = w0; b.lw1 = w1;
-    if (a.lkeep != nullptr) b.lkeepv = a.lkeep[cb];
-    ds_mfma_tile<RM, TN, TAIL>(b, chunk, p0, lds);
+  const int chunk = blockIdx.x / a.nptiles;
+  const int pt = blockIdx.x - chunk * a.nptiles;
+  ds_mfma_tile<RM, TN, TAIL>(a, chunk, (int64_t)pt * PT, lds);
+}
+
+// Repair pass.  What the dynamic-range guards list comes here as TASKS {chunk, column tile of kRepairPT windows,
+// the window energy below which a window is stored}; a task's rows are taken in sub-tiles of RM row blocks
+// that hold whole detectors (dtxplan::plan_repair_subtiles), one workgroup per (task, sub-tile): one listed
+// column tile spreads over nsub workgroups, a listed block over nsub * (tiles with a window in need).  (Round
+// 5 walked (listed block) x (22 column tiles, all rows): 22 workgroups busy for 1.6 ms where the chip needs 0.13.)
+// The launch is sized for the chip and finds an empty list on ordinary data.
+struct RepairArgs {
+  DsArgs a;             // the K-tile's images; ut / srow / doff / det0 / nd are set per sub-tile
+  const int4* tasks;
+  const int* ntask;
+  const int4* sub;      // [nsub] {first row block, first detector, detectors, offset into sdoff}
+  const int32_t* sdoff;
+  int nsub;
+};
+constexpr int repair_lds_floats(int rm) {
+  const int loop = 2 * (kBQ * kts_for(rm) + kRepairPT + kBQ);
+  const int epi = 2 * 16 * rm + 64;
+  return loop > epi ? loop : epi;
+}
+template <int RM>
+__global__ __launch_bounds__(kThreads, 2) void ds_mfma_task_kernel(const RepairArgs r) {
+  constexpr int TN = kRepairPT / 128;
+  __shared__ __attribute__((aligned(16))) float lds[repair_lds_floats(RM)];
+  const int nwork = r.ntask[0] * r.nsub;
+  for (int e = blockIdx.x; e < nwork; e += gridDim.x) {
+    const int4 tk = r.tasks[e / r.nsub];
+    const int4 sb = r.sub[e % r.nsub];
+    DsArgs b = r.a;
+    b.ut += 16 * sb.x; b.srow += 16 * sb.x;
+    b.doff = r.sdoff + sb.w; b.det0 += sb.y; b.nd = sb.z;
+    b.lkeepv = __int_as_float(tk.z);
+    const int chunk = tk.x;
+    const int64_t p0 = (int64_t)tk.y * kRepairPT;
+    f32x4 acc[RM][TN];
+#pragma unroll
+    for (int q = 0; q < RM; ++q)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    hankel_mainloop<RM, TN, false, false>(acc, b.ut, b.ldk, b.Lp, b.xp + (int64_t)chunk * b.Nc * b.Tpad + p0, b.Tpad,
+                                          b.Nc, 0, b.Lp, lds);
+    ds_epilogue<RM, TN>(acc, b, chunk, p0, lds);
     __syncthreads();
   }
 }
@@ -447,12 +483,12 @@ int launch_tile_s(dtx_ctx* ctx, const DsArgs& a, int nchunk) {
 
 template <int RM>
 int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk, bool tail) {
-  if (a.ut16 && !a.list) return launch_tile_s<RM>(ctx, a, nchunk);
+  if (a.ut16) return launch_tile_s<RM>(ctx, a, nchunk);
   constexpr int TN = tn_for(RM);
   constexpr int PT = 128 * TN;
   DsArgs b = a;
   b.nptiles = (int)((a.P + PT - 1) / PT);
-  dim3 grid(a.list ? 256u : (unsigned)(b.nptiles * nchunk));   // list mode: one workgroup per CU
+  dim3 grid((unsigned)(b.nptiles * nchunk));
   if constexpr (RM >= 2) {
     if (tail) {
       hipLaunchKernelGGL((ds_mfma_kernel<RM, TN, true>), grid, dim3(kThreads), 0, ctx->stream, b);
@@ -556,14 +592,15 @@ __global__ __launch_bounds__(256) void basis_colmax_kernel(const float* __restri
 // delta DS ~ 2 * 2^-16 * (sum_k U[k][j]^2) * x_j^2 / den, up to 3e-5 when that sample's share of the statistic is
 // of order one.  A block of kSplitGuardV windows is listed for the float32 engine (whose products are exact
 // fused multiply-adds) when cmax * max x^2 over the samples its windows read exceeds kSplitGuardTau times the
-// smallest live window energy of the block: the listed blocks are recomputed right behind the split launch,
-// like the frequency-domain engine's guard list.  On ordinary data (no sample above a few sigma, orthonormal
+// smallest live window energy of the block: the listed blocks become repair tasks (ds_mfma_task_kernel) that run
+// right behind the split launch, like the frequency-domain engine's.  On ordinary data (no sample above a few sigma, orthonormal
 // bases of realistic length: cmax ~ K / n) the list is empty.
 __global__ __launch_bounds__(256) void split_guard_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc,
                                                           int L, const float* __restrict__ den, int64_t Ppad,
                                                           int64_t P, int V, int nblk,
                                                           const float* __restrict__ cmax, float tau,
-                                                          int* __restrict__ list, const int* __restrict__ pb) {
+                                                          int* __restrict__ count, int4* __restrict__ tasks,
+                                                          const int* __restrict__ pb) {
   __shared__ float red[8];
   const int cb = blockIdx.x, tid = threadIdx.x;
   const int chunk = cb / nblk, blk = cb - chunk * nblk;
@@ -595,11 +632,59 @@ __global__ __launch_bounds__(256) void split_guard_kernel(const float* __restric
 #pragma unroll
     for (int q = 1; q < 4; ++q) { mn = fminf(mn, red[q]); mx = fmaxf(mx, red[4 + q]); }
     // (mn stays 3e38 when no window of the block is live: nothing to repair; a NaN sample lists the block)
-    if (!(cmax[0] * mx <= tau * mn)) list[1 + atomicAdd(list, 1)] = cb;
+    if (!(cmax[0] * mx <= tau * mn)) {
+      // every column tile of the block, every window stored (the float32 engine's value is the better one throughout)
+      atomicAdd(count, 1);
+      const int nt = (int)((w1 - w0 + kRepairPT - 1) / kRepairPT);
+      const int at = atomicAdd(count + 1, nt);
+      for (int q = 0; q < nt; ++q)
+        tasks[at + q] = make_int4(chunk, (int)(w0 / kRepairPT) + q, __float_as_int(INFINITY), cb);
+    }
   }
 }
 
 }  // namespace
+
+template <int RM>
+static void launch_repair_rm(dtx_ctx* ctx, const RepairArgs& r, unsigned grid) {
+  hipLaunchKernelGGL((ds_mfma_task_kernel<RM>), dim3(grid), dim3(kThreads), 0, ctx->stream, r);
+}
+
+int dtx_launch_repair(dtx_ctx* ctx, const DtxRepairWs& ws, const float* xp, int64_t Tpad, const float* mean,
+                      const float* den, int64_t Ppad, int64_t P, float* ds, int64_t ldp) {
+  for (const DtxKTile& t : ctx->tiles) {
+    RepairArgs r;
+    DsArgs& a = r.a;
+    a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
+    a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
+    a.mean = mean; a.den = den; a.ds = ds;
+    a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
+    a.Nc = ctx->Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
+    a.ldk = 16 * t.rm; a.lkeepv = INFINITY;
+    r.tasks = ws.tasks; r.ntask = ws.count + 1;
+    r.sub = (const int4*)t.sub_dev; r.sdoff = t.sdoff_dev; r.nsub = t.nsub;
+    // two workgroups per CU are resident; twice that many walk the list (a workgroup's tasks are of equal length)
+    const unsigned grid = (unsigned)(4 * ctx->ncu);
+    switch (t.rms) {
+      case 1: launch_repair_rm<1>(ctx, r, grid); break;
+      case 2: launch_repair_rm<2>(ctx, r, grid); break;
+      case 3: launch_repair_rm<3>(ctx, r, grid); break;
+      case 4: launch_repair_rm<4>(ctx, r, grid); break;
+      case 5: launch_repair_rm<5>(ctx, r, grid); break;
+      case 6: launch_repair_rm<6>(ctx, r, grid); break;
+      case 7: launch_repair_rm<7>(ctx, r, grid); break;
+      case 8: launch_repair_rm<8>(ctx, r, grid); break;
+      case 9: launch_repair_rm<9>(ctx, r, grid); break;
+      case 10: launch_repair_rm<10>(ctx, r, grid); break;
+      case 11: launch_repair_rm<11>(ctx, r, grid); break;
+      case 12: launch_repair_rm<12>(ctx, r, grid); break;
+      case 13: launch_repair_rm<13>(ctx, r, grid); break;
+      default: return dtx_fail(ctx, DTX_E_STATE, "repair pass: bad sub-tile height %d", t.rms);
+    }
+    DTX_HIP(ctx, hipGetLastError());
+  }
+  return DTX_OK;
+}
 
 extern "C" {
 
@@ -690,6 +775,16 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
                                 hipMemcpyDeviceToDevice, ctx->stream));
     DTX_HIP(ctx, hipMemcpy(t.doff_dev, doff.data(), doff.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice));   // fresh buffer, a few bytes: synchronous
+    {   // the repair pass's row groups (host arithmetic: dtx_plan.h)
+      const dtxplan::RepairSubPlan rp = dtxplan::plan_repair_subtiles(doff.data(), t.nd, t.rm);
+      static_assert(sizeof(int4) == sizeof(dtxplan::I4), "sub-tile rows are int4");
+      DtxKTile& tt = ctx->tiles.back();
+      tt.rms = rp.rms; tt.nsub = (int)rp.sub.size();
+      DTX_HIP(ctx, hipMalloc(&tt.sub_dev, rp.sub.size() * sizeof(int4)));
+      DTX_HIP(ctx, hipMalloc(&tt.sdoff_dev, rp.sdoff.size() * sizeof(int32_t)));
+      DTX_HIP(ctx, hipMemcpy(tt.sub_dev, rp.sub.data(), rp.sub.size() * sizeof(int4), hipMemcpyHostToDevice));
+      DTX_HIP(ctx, hipMemcpy(tt.sdoff_dev, rp.sdoff.data(), rp.sdoff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     d = dend;
   }
   return DTX_OK;
@@ -781,25 +876,28 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   // ignore a spike -- with M / 256 a chunk under 768 samples had one or two slices, and its level followed the spike)
   const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 16));
   if ((rc = dtx_reserve(ctx, ctx->ws_csum,
-                        (size_t)nchunk * (nsl * kCsum * sizeof(double) + sizeof(float) + sizeof(int)))))
+                        (size_t)nchunk * (nsl * kCsum * sizeof(double) + 2 * sizeof(float) + sizeof(int)))))
     return rc;
   double* cslice = (double*)ctx->ws_csum.p;
   float* m0f = (float*)(cslice + (size_t)nchunk * nsl * kCsum);
+  float* tauf = m0f + nchunk;                 // per chunk: the square from which a sample is summed apart (win_stats_kernel)
   // ragged batch: every chunk's own window count, for the passes that must not look past it
-  int* pb = ctab ? (int*)(m0f + nchunk) : nullptr;
+  int* pb = ctab ? (int*)(tauf + nchunk) : nullptr;
   const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
                        (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
-  int* list = nullptr;
-  int fV = 0, fnblk = 0;
+  // the guards' lists (DtxRepairWs): the frequency-domain engine lists blocks of its advance V, the split-bf16
+  // contraction blocks of kSplitGuardV windows; both end as repair tasks of kRepairPT windows
+  const size_t ntile = (size_t)nchunk * (size_t)(Ppad / kRepairPT);
+  DtxRepairWs rws{};
+  bool guarded = false;
   if (use_fft) {
     if (!ctx->fft.ok &&
         (rc = dtx_fft_basis_build(ctx, ctx->hdoff.data(), ctx->D, n, Nc)))
       return rc;
-    fV = ctx->fft.V;
-    fnblk = (int)((P + fV - 1) / fV);
-    // list[0] = count, list[1 ..] = the listed blocks, behind them one float per block (DsArgs::lkeep)
-    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * fnblk + 1) * sizeof(int) + (size_t)nchunk * fnblk * sizeof(float)))) return rc;
-    list = (int*)ctx->ws_flag.p;
+    const size_t nb = (size_t)nchunk * (size_t)((P + ctx->fft.V - 1) / ctx->fft.V);
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, dtx_repair_ws_bytes(nb, ntile)))) return rc;
+    rws = dtx_repair_ws_carve(ctx->ws_flag.p, nb, ntile);
+    guarded = true;
   }
   // split-bf16 contraction: blocks of windows a single sample dominates go to the float32 engine
   // (split_guard_kernel); templates shorter than kSplitMinL samples per channel stay on the float32 engine:
@@ -808,14 +906,18 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   const bool split = !use_fft && ctx->engine != DTX_ENGINE_FP32 && ctx->L >= kSplitMinL;
   const int gnblk = split ? (int)((P + kSplitGuardV - 1) / kSplitGuardV) : 0;
   if (split) {
-    if ((rc = dtx_reserve(ctx, ctx->ws_flag, ((size_t)nchunk * gnblk + 1) * sizeof(int)))) return rc;
-    list = (int*)ctx->ws_flag.p;              // (its counter is cleared by chunk_offset_final_kernel)
+    const size_t nb = (size_t)nchunk * gnblk;
+    if ((rc = dtx_reserve(ctx, ctx->ws_flag, dtx_repair_ws_bytes(nb, ntile)))) return rc;
+    rws = dtx_repair_ws_carve(ctx->ws_flag.p, nb, ntile);    // (its counters are cleared by chunk_offset_final_kernel)
+    guarded = true;
   }
+  int* list = guarded ? rws.count : nullptr;
+  ctx->guard_ran = guarded;
   hipLaunchKernelGGL(chunk_offset_kernel, dim3((unsigned)nsl, (unsigned)nchunk), dim3(256), 0, ctx->stream,
                      x_dev, M, chunk_stride, nsl, cslice, ctab);
   // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
-                     (const double*)cslice, nsl, m0f, ctab, M, n, Nc, pb, list,
+                     (const double*)cslice, nsl, m0f, tauf, ctab, M, n, Nc, pb, list,
                      post ? post->maxds : (float*)nullptr, ctx->D);
   DTX_HIP(ctx, hipGetLastError());
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
@@ -832,27 +934,18 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
                  (const int*)nullptr, ctab, n, nchunk);
     if ((rc = dtx_aux_fork(ctx))) return rc;
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
-                       Nc, ctx->L, P, Ppad, scale, mean, den);
+                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf);
     DTX_HIP(ctx, hipGetLastError());
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window
     // holds more than kFftGuard^2 = 4e4 times the energy of its quietest one (a 200-sigma
     // burst) would put > 4e-6 of error on the quiet windows.  A small kernel lists such blocks
-    // (dtx_fft_scan, behind the statistics on the side stream) and the float32 MFMA contraction --
-    // whose error is local to a window -- recomputes them right behind the scan: a 256-workgroup
-    // launch that finds an empty list on ordinary data.
-    if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, list, pb))) return rc;
-    for (const DtxKTile& t : ctx->tiles) {
-      DsArgs a;
-      a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
-      a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
-      a.mean = mean; a.den = den; a.ds = ds_dev;
-      a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
-      a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-      a.list = list; a.lV = fV; a.lnblk = fnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62;
-      a.lkeep = (const float*)(list + 1 + (size_t)nchunk * fnblk); a.lkeepv = INFINITY;
-      if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
-    }
+    // (dtx_fft_scan, behind the statistics on the side stream); isolated outlier samples are split off and the
+    // block is scanned again without them (their products added directly), and where windows are still out of
+    // range the float32 MFMA contraction -- whose error is local to a window -- recomputes them right behind the
+    // scan (dtx_launch_repair): launches that find empty lists on ordinary data.
+    if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, rws, pb))) return rc;
+    if ((rc = dtx_launch_repair(ctx, rws, xp, Tpad, mean, den, Ppad, P, ds_dev, ldp))) return rc;
     if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
     return DTX_OK;
   }
@@ -860,7 +953,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp,
                (const int*)nullptr, ctab, n, nchunk);
   hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
-                     Nc, ctx->L, P, Ppad, scale, mean, den);
+                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf);
   DTX_HIP(ctx, hipGetLastError());
 
   i32x4* g16 = nullptr;
@@ -872,7 +965,8 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   if (split) {
     hipLaunchKernelGGL(split_guard_kernel, dim3((unsigned)(nchunk * gnblk)), dim3(256), 0, ctx->stream,
                        (const float*)xp, Tpad, Nc, ctx->L, (const float*)den, Ppad, P, kSplitGuardV, gnblk,
-                       (const float*)ctx->srow_all.p + ctx->Ktot, kSplitGuardTau, list, (const int*)pb);
+                       (const float*)ctx->srow_all.p + ctx->Ktot, kSplitGuardTau, rws.count, rws.tasks,
+                       (const int*)pb);
     DTX_HIP(ctx, hipGetLastError());
   }
   if (split) {
@@ -889,20 +983,11 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     a.mean = mean; a.den = den; a.ds = ds_dev;
     a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
     a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-    a.list = nullptr; a.lV = 0; a.lnblk = 0; a.lw0 = 0; a.lw1 = (int64_t)1 << 62; a.lkeep = nullptr; a.lkeepv = INFINITY;
+    a.ldk = 16 * t.rm; a.lkeepv = INFINITY;
     if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
   }
-  if (split)      // the guard's blocks again, on the float32 engine (a 256-workgroup launch that finds an empty list on ordinary data)
-    for (const DtxKTile& t : ctx->tiles) {
-      DsArgs a;
-      a.ut16 = nullptr; a.g16 = nullptr; a.V = 0;
-      a.xp = xp; a.ut = t.ut_dev; a.srow = t.srow_dev; a.doff = t.doff_dev;
-      a.mean = mean; a.den = den; a.ds = ds_dev;
-      a.Tpad = Tpad; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
-      a.Nc = Nc; a.Lp = ctx->Lp; a.D = ctx->D; a.det0 = t.det0; a.nd = t.nd; a.nptiles = 0;
-      a.list = list; a.lV = kSplitGuardV; a.lnblk = gnblk; a.lw0 = 0; a.lw1 = (int64_t)1 << 62; a.lkeep = nullptr; a.lkeepv = INFINITY;
-      if ((rc = launch_tile_rm(ctx, t.rm, t.rows, a, nchunk))) return rc;
-    }
+  if (split)      // the guard's blocks again, on the float32 engine (launches that find an empty list on ordinary data)
+    if ((rc = dtx_launch_repair(ctx, rws, xp, Tpad, mean, den, Ppad, P, ds_dev, ldp))) return rc;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   dtx_kev_commit(ctx);
   if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
@@ -937,6 +1022,18 @@ int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
   return subspace_ds_impl(ctx, x_dev, M, 0, nchunk, ds_dev, ldp, &po, chunk_tab_dev);
+}
+
+int dtx_repair_counts(dtx_ctx* ctx, int32_t counts[4]) {
+  if (!ctx) return DTX_E_ARG;
+  if (!counts) return dtx_fail(ctx, DTX_E_ARG, "dtx_repair_counts: null pointer");
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  if (!ctx->ws_flag.p || !ctx->guard_ran) return DTX_OK;      // (the float32 engine runs unguarded)
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  DTX_HIP(ctx, hipMemcpy(counts, ctx->ws_flag.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  counts[3] = 0;
+  return DTX_OK;
 }
 
 int dtx_set_engine(dtx_ctx* ctx, int engine) {

@@ -699,6 +699,14 @@ class HipContext(object):
         self._ck(self.lib.dtx_kernel_ms_list(self.h, int(n), ms), 'dtx_kernel_ms_list')
         return [float(v) for v in ms][::-1]
 
+    def repair_counts(self):
+        """What the dynamic-range guards of the last scan listed (dtx_repair_counts; waits for the stream):
+        {'blocks': listed blocks, 'tiles': column tiles of 256 windows recomputed by the float32 contraction,
+        'split': blocks scanned again with outlier samples split off}."""
+        c = (C.c_int32 * 4)()
+        self._ck(self.lib.dtx_repair_counts(self.h, c), 'dtx_repair_counts')
+        return {'blocks': int(c[0]), 'tiles': int(c[1]), 'split': int(c[2])}
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._ck(self.lib.dtx_last_kernel_ms(self.h, C.byref(ms)), 'dtx_last_kernel_ms')

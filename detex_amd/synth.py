@@ -71,3 +71,22 @@ def event_families(seed, nfam, nper, Nc, L, maxshift=50, snr=5.0):
             td[e] = np.vstack(ch).flatten(order='F')
             e += 1
     return td
+
+
+def make_dirty(x, Nc, seed, ngap=10, gap_frames=6000, nspike=10, spike_amp=1e5):
+    """What real records add to `continuous_day`'s clean noise (in place, returns the lists): `ngap` zero-filled gaps
+    of `gap_frames` sample frames on all channels (getdata's fillZeros: detect.py:231, construct.py:1038) and `nspike`
+    single-sample glitches of `spike_amp` noise sigmas on one channel each.  x: [nchunk, M] multiplexed."""
+    rs = np.random.RandomState(seed)
+    nchunk, M = x.shape
+    T = M // Nc
+    gaps, spikes = [], []
+    for _ in range(ngap):
+        b, t = int(rs.randint(nchunk)), int(rs.randint(0, max(1, T - gap_frames)))
+        x[b, t * Nc:(t + gap_frames) * Nc] = 0.0
+        gaps.append((b, t, gap_frames))
+    for _ in range(nspike):
+        b, t, c = int(rs.randint(nchunk)), int(rs.randint(T)), int(rs.randint(Nc))
+        x[b, t * Nc + c] += np.float32(spike_amp * (1 if rs.rand() < 0.5 else -1))
+        spikes.append((b, t, c))
+    return gaps, spikes

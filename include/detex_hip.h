@@ -374,6 +374,11 @@ int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms);
 /* The same n durations one by one (ms[0 .. n), in the order dtxplan::ring_last_slots lists them: newest first):
  * bench.py's per-step spread (kernel_ms_min / median / max) and its settled-clock pre-warm criterion. */
 int dtx_kernel_ms_list(dtx_ctx* ctx, int n, float* ms);
+/* What the dynamic-range guards of the last dtx_subspace_ds / dtx_subspace_scan(_ragged) call listed (waits for
+ * the stream): counts[0] = blocks listed, counts[1] = column tiles of 256 windows handed to the float32
+ * contraction again, counts[2] = blocks scanned again with outlier samples split off, counts[3] = 0.  All zero on
+ * ordinary data; the reference has no counterpart (its float64 transforms need no guard: detect.py:559-578). */
+int dtx_repair_counts(dtx_ctx* ctx, int32_t counts[4]);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,42 @@ static void check_basis(const std::vector<int32_t>& off, int L) {
     for (int q = 0; q < un.z; ++q) CHECK(g.prow[f.upre[u].x + q].x == f.prow[un.x + q].x);
     for (int q = un.z; q < un.y; ++q) CHECK(g.prow[f.cum0 + f.upre[u].y + q - un.z].x == f.prow[un.x + q].x);
   }
+  // the re-scan's runs (plain and half order): every pair in exactly one run, every run ends at a detector border
+  for (int re = 0; re < 2; ++re) {
+    const FftBasisPlan& t = re ? g : f;
+    const std::vector<I2> runs = plan_fft_runs(t, re != 0);
+    std::vector<int> cover(t.npairs, 0);
+    for (const I2& r : runs) {
+      CHECK(r.x >= 0 && r.y > 0 && r.x + r.y <= t.npairs);
+      CHECK(t.pdet[r.x + r.y - 1].x >= 0);
+      if (r.x > 0) CHECK(t.pdet[r.x - 1].x >= 0);
+      for (int q = 0; q < r.y; ++q) ++cover[r.x + q];
+    }
+    for (int v : cover) CHECK(v == 1);
+  }
+  // the repair pass's row groups over K-tiles packed like dtx_basis_upload packs them (whole detectors, <= 208 rows)
+  for (int d = 0; d < D;) {
+    int dend = d;
+    while (dend < D && off[dend + 1] - off[d] <= 208) ++dend;
+    if (dend == d) break;                                        // (a detector of more than 208 vectors is refused at upload)
+    const int nd = dend - d, rows = off[dend] - off[d], rm = (rows + 15) / 16;
+    std::vector<int32_t> doff(nd + 1);
+    for (int e = 0; e <= nd; ++e) doff[e] = off[d + e] - off[d];
+    const RepairSubPlan rp = plan_repair_subtiles(doff.data(), nd, rm);
+    CHECK(rp.rms >= 1 && rp.rms <= rm);
+    int dat = 0;
+    for (const I4& sb : rp.sub) {
+      CHECK(sb.y == dat && sb.z >= 1 && sb.x >= 0 && sb.x + rp.rms <= rm);
+      CHECK(sb.w >= 0 && sb.w + sb.z + 1 <= (int)rp.sdoff.size());
+      for (int q = 0; q <= sb.z; ++q) {
+        const int v = rp.sdoff[sb.w + q];
+        CHECK(v == doff[sb.y + q] - 16 * sb.x && v >= 0 && v <= 16 * rp.rms);   // rows lie inside the sub-tile's blocks
+      }
+      dat += sb.z;
+    }
+    CHECK(dat == nd);
+    d = dend;
+  }
   // the ping-pong grid over this basis for a few block counts / CU counts
   for (int64_t nb : {1, 7, 255, 256, 257, 1752, 5000}) {
     for (int ncu : {1, 64, 256, 304}) {
