@@ -136,7 +136,10 @@ struct dtx_ctx {
 // (spike_split_kernel): frame t of its chunk's channel plane c, value v (block offset already removed).
 struct DtxSpike { int t, c; float v; };
 constexpr int kMaxSpk = 48;            // outliers per block; more: the block keeps its transforms and goes to the contraction
-constexpr int kRepairPT = 256;         // windows per repair task (column tile of the float32 contraction)
+// windows per repair task (column tile of the float32 contraction).  A task is a chain of 3 L / 64 steps whose
+// loads nothing hides on an otherwise idle CU: 128 against 256 windows, scripts/ab_repair_pt.sh: config2_dirty
+// 3.53 / 3.57 ms per step, a loud onset (39 / 20 tiles) 3.47 / 3.60, one tile 3.44 / 3.46 (clean: 3.21 - 3.31)
+constexpr int kRepairPT = 128;
 // One workspace (ctx->ws_flag) for a call's guard lists; count[] is cleared by chunk_offset_final_kernel.
 struct DtxRepairWs {
   int* count;        // [0] listed blocks, [1] repair tasks, [2] blocks re-scanned with outliers split off, [3] -

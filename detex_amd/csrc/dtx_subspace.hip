@@ -693,8 +693,11 @@ int64_t dtx_num_windows(int64_t M, int n, int Nc) {
   return (M - n) / Nc + 1;
 }
 
-int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D, int n,
-                     int Nc) {
+// The two halves of dtx_basis_upload.  begin: checks, waits for the old images' users, and puts the copy of the
+// stacked basis on the context's stream (asynchronous when U is device memory: a peer copy); finish: every image
+// built on the device behind it.  dtx_basis_bcast runs `begin` on every receiver before any `finish`, so that the
+// peer copies of all devices are in flight together.
+static int basis_upload_begin(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D, int n, int Nc) {
   if (!ctx) return DTX_E_ARG;
   if (!U || !det_off || D <= 0 || n <= 0 || Nc <= 0)
     return dtx_fail(ctx, DTX_E_ARG, "dtx_basis_upload: null pointer or non-positive size");
@@ -730,6 +733,15 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
 
   ctx->D = D; ctx->n = n; ctx->Nc = Nc; ctx->L = L; ctx->Lp = Lp; ctx->Ktot = Ktot;
   ctx->hdoff.assign(det_off, det_off + D + 1);
+  return DTX_OK;
+}
+
+static int basis_upload_finish(dtx_ctx* ctx) {
+  DtxDeviceGuard g(ctx->device);
+  const int D = ctx->D, n = ctx->n, Nc = ctx->Nc, L = ctx->L, Lp = ctx->Lp, Ktot = ctx->Ktot;
+  const int32_t* det_off = ctx->hdoff.data();
+  float* Ud = (float*)ctx->U_buf.p;
+  float* srow_all = (float*)ctx->srow_all.p;
   {   // detector row offsets on the device (dtx_trigger_stats; the tiles hold them tile-local)
     int rc2;
     if ((rc2 = dtx_reserve(ctx, ctx->doff_all, (size_t)(D + 1) * sizeof(int32_t)))) return rc2;
@@ -790,29 +802,54 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D
   return DTX_OK;
 }
 
+int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off, int D, int n,
+                     int Nc) {
+  const int rc = basis_upload_begin(ctx, U, det_off, D, n, Nc);
+  return rc ? rc : basis_upload_finish(ctx);
+}
+
 int dtx_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int dtx_device_pci_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 16) return DTX_E_ARG;
+  buf[0] = 0;
+  return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? DTX_OK : DTX_E_HIP;
 }
 
 int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx) {
   if (!ctxs || nctx <= 0 || !ctxs[0]) return DTX_E_ARG;
   dtx_ctx* src = ctxs[0];
   if (src->tiles.empty()) return dtx_fail(src, DTX_E_STATE, "dtx_basis_bcast: no basis uploaded on the first context");
+  for (int i = 1; i < nctx; ++i)
+    if (!ctxs[i]) return dtx_fail(src, DTX_E_ARG, "dtx_basis_bcast: context %d is NULL", i);
   {
     DtxDeviceGuard g(src->device);
     DTX_HIP(src, hipStreamSynchronize(src->stream));     // the source copy of U is complete
   }
+  // (1) every receiver's copy of the stacked basis on ITS stream: device-to-device copies (peer copies over xGMI
+  // between devices), all in flight together -- xGMI is point to point, the source's links to different peers do not
+  // share bandwidth; (2) every receiver's images behind its copy, each on its own device and stream; (3) one
+  // wait per receiver at the end.  (Round 5 ran copy, builds and a stream synchronisation device after device.)
   for (int i = 1; i < nctx; ++i) {
     dtx_ctx* c = ctxs[i];
-    if (!c) return dtx_fail(src, DTX_E_ARG, "dtx_basis_bcast: context %d is NULL", i);
     if (c == src) continue;
-    // dtx_basis_upload copies from any device pointer (hipMemcpyDefault: a peer copy between devices)
-    // and builds every image on the receiving device
-    const int rc = dtx_basis_upload(c, (const float*)src->U_buf.p, src->hdoff.data(), src->D, src->n, src->Nc);
+    const int rc = basis_upload_begin(c, (const float*)src->U_buf.p, src->hdoff.data(), src->D, src->n, src->Nc);
+    if (rc) return dtx_fail(src, rc, "dtx_basis_bcast: context %d: %s", i, c->err.c_str());
+  }
+  for (int i = 1; i < nctx; ++i) {
+    dtx_ctx* c = ctxs[i];
+    if (c == src) continue;
+    const int rc = basis_upload_finish(c);
     if (rc) return dtx_fail(src, rc, "dtx_basis_bcast: context %d: %s", i, c->err.c_str());
     const int rc2 = dtx_set_engine(c, src->engine);
     if (rc2) return rc2;
+  }
+  for (int i = 1; i < nctx; ++i) {
+    dtx_ctx* c = ctxs[i];
+    if (c == src) continue;
     DtxDeviceGuard g(c->device);
     DTX_HIP(c, hipStreamSynchronize(c->stream));
   }

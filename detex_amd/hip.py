@@ -701,7 +701,7 @@ class HipContext(object):
 
     def repair_counts(self):
         """What the dynamic-range guards of the last scan listed (dtx_repair_counts; waits for the stream):
-        {'blocks': listed blocks, 'tiles': column tiles of 256 windows recomputed by the float32 contraction,
+        {'blocks': listed blocks, 'tiles': column tiles of 128 windows recomputed by the float32 contraction,
         'split': blocks scanned again with outlier samples split off}."""
         c = (C.c_int32 * 4)()
         self._ck(self.lib.dtx_repair_counts(self.h, c), 'dtx_repair_counts')

@@ -79,13 +79,20 @@ int dtx_basis_upload(dtx_ctx* ctx, const float* U, const int32_t* det_off,
 
 /* Multi-device hosts (one process driving several GPUs): number of HIP devices, and the
  * basis of ctxs[0] replicated into ctxs[1 .. nctx-1] -- the contexts may sit on different devices: the
- * stacked basis travels device to device (peer copy over xGMI where the devices are linked), every
+ * stacked basis travels device to device (peer copies over xGMI where the devices are linked: issued to all
+ * receivers' streams before anything else, so that they run together -- xGMI is point to point), every
  * image (row sums, MFMA tiles, pair spectra) is then built on the receiving device as in
- * dtx_basis_upload.  Continuous-data days shard embarrassingly: after this call each context scans
- * its own share with dtx_subspace_scan.  (One process per GPU uses an RCCL broadcast instead:
- * detex_amd.parallel.broadcast_banks.)  Synchronous. */
+ * dtx_basis_upload, each device on its own stream, and the call waits for all of them once at the end.
+ * Continuous-data days shard embarrassingly: after this call each context scans its own share with
+ * dtx_subspace_scan.  THE PRODUCT'S BROADCAST IS NOT THIS CALL: one process per GPU (torchrun) broadcasts
+ * the bases with RCCL through the process group (detex_amd.parallel.broadcast_banks -> torch.distributed
+ * backend 'nccl' over xGMI) and every rank calls dtx_basis_upload on its own device; this entry point serves
+ * a host that drives several GPUs from ONE process through the C ABI.  Synchronous.
+ * dtx_device_pci_bus_id: "domain:bus:device.function" of a HIP device (hipDeviceGetPCIBusId), the key under
+ * /sys/bus/pci/devices/ for its NUMA node and local CPUs (detex_amd.parallel.bind_to_device). */
 int dtx_device_count(void);
 int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx);
+int dtx_device_pci_bus_id(int device, char* buf, int len);
 
 /* Arithmetic engine of dtx_subspace_ds (default DTX_ENGINE_AUTO):
  *   DTX_ENGINE_AUTO    DTX_ENGINE_FFT for templates of 256 .. 32768 samples per channel
@@ -375,7 +382,7 @@ int dtx_kernel_ms_mean(dtx_ctx* ctx, int n, float* ms);
  * bench.py's per-step spread (kernel_ms_min / median / max) and its settled-clock pre-warm criterion. */
 int dtx_kernel_ms_list(dtx_ctx* ctx, int n, float* ms);
 /* What the dynamic-range guards of the last dtx_subspace_ds / dtx_subspace_scan(_ragged) call listed (waits for
- * the stream): counts[0] = blocks listed, counts[1] = column tiles of 256 windows handed to the float32
+ * the stream): counts[0] = blocks listed, counts[1] = column tiles of 128 windows handed to the float32
  * contraction again, counts[2] = blocks scanned again with outlier samples split off, counts[3] = 0.  All zero on
  * ordinary data; the reference has no counterpart (its float64 transforms need no guard: detect.py:559-578). */
 int dtx_repair_counts(dtx_ctx* ctx, int32_t counts[4]);
