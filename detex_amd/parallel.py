@@ -38,6 +38,106 @@ def local_device():
     return int(os.environ.get('LOCAL_RANK', 0)) if dist_active() else 0
 
 
+# what bind_to_device did in this process (bench.py and SubSpace.detex put it in their records)
+BINDING = {}
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs local_cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(','):
+        part = part.strip()
+        if not part:
+            continue
+        if '-' in part:
+            a, b = part.split('-')
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11' (the kernel's notation)."""
+    out, cpus = [], sorted(set(int(c) for c in cpus))
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else '%d-%d' % (cpus[i], cpus[j]))
+        i = j + 1
+    return ','.join(out)
+
+
+def device_locality(pci_bus_id, sysfs='/sys/bus/pci/devices'):
+    """NUMA node and local CPUs of the PCI device `pci_bus_id` ('0000:c1:00.0') as the kernel reports them
+    (numa_node, local_cpulist); (None, []) where sysfs does not say (containers, single-node hosts: numa_node -1)."""
+    import os
+    base = os.path.join(sysfs, pci_bus_id.strip().lower())
+    node, cpus = None, []
+    try:
+        with open(os.path.join(base, 'numa_node')) as f:
+            v = int(f.read().strip())
+            node = v if v >= 0 else None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(base, 'local_cpulist')) as f:
+            cpus = parse_cpulist(f.read())
+    except (OSError, ValueError):
+        pass
+    return node, cpus
+
+
+def bind_to_device(device, sysfs='/sys/bus/pci/devices', pci_bus_id=None):
+    """Pin this process to the CPU cores local to its GPU, BEFORE it allocates page-locked buffers: the host feed
+    (104 MB per station-day) is the one resource the ranks of a node share, and a rank whose pinned
+    record lives on the other socket pays the inter-socket link for every upload.  The kernel's first-touch policy then
+    places what the process allocates (hipHostMalloc included) on that NUMA node.  One process per GPU; a no-op
+    (recorded as such) where sysfs gives no locality, where the local CPUs are not in the process's affinity mask, or
+    under DETEX_AMD_BIND=0.  Returns / records BINDING = {device, pci, numa_node, cpus, applied, reason}."""
+    import os
+    rec = {'device': int(device), 'pci': None, 'numa_node': None, 'cpus': None, 'applied': False, 'reason': None}
+    try:
+        if os.environ.get('DETEX_AMD_BIND', '1') == '0':
+            rec['reason'] = 'DETEX_AMD_BIND=0'
+            return rec
+        if pci_bus_id is None:
+            import ctypes as C
+            from . import _lib
+            buf = C.create_string_buffer(64)
+            if _lib.load().dtx_device_pci_bus_id(int(device), buf, 64) != 0:
+                rec['reason'] = 'no PCI address for device %d' % int(device)
+                return rec
+            pci_bus_id = buf.value.decode()
+        rec['pci'] = pci_bus_id
+        node, cpus = device_locality(pci_bus_id, sysfs)
+        rec['numa_node'] = node
+        if not cpus:
+            rec['reason'] = 'sysfs reports no local CPUs'
+            return rec
+        if not hasattr(os, 'sched_setaffinity'):
+            rec['reason'] = 'no sched_setaffinity on this platform'
+            return rec
+        allowed = os.sched_getaffinity(0)
+        use = sorted(set(cpus) & set(allowed))
+        if not use:
+            rec['reason'] = 'local CPUs outside the affinity mask'
+            return rec
+        if len(use) < len(allowed):
+            os.sched_setaffinity(0, use)
+            rec['applied'] = True
+        else:
+            rec['reason'] = 'every allowed CPU is local'
+        rec['cpus'] = len(use)
+        rec['cpulist'] = format_cpulist(use)
+        return rec
+    finally:
+        BINDING.clear()
+        BINDING.update(rec)
+
+
 def shard_units(nunits, rank, world):
     """Indices of the (station, day) units this rank scans: round-robin, so
     consecutive days of one station spread over all GPUs."""

@@ -840,6 +840,11 @@ class SubSpace(object):
         dev = torch.device('cuda', int(device)) if own_ctx else ctx.device
         if active and dev.type == 'cuda':
             torch.cuda.set_device(dev)          # RCCL's object collectives run on the current device
+            if not parallel.BINDING:
+                # one process per GPU: onto the CPU cores / NUMA node next to this rank's GPU, before the uploader
+                # allocates its page-locked staging buffers (the host feed is what the ranks share);
+                # once per process, recorded in last_run['binding']
+                parallel.bind_to_device(dev.index)
         fetcher = self.cfetcher
         stations = []
         results, failure = {}, None
@@ -976,7 +981,7 @@ class SubSpace(object):
             failure = '%s: %s' % (type(e).__name__, e)
         results = {sta: _merge_ranks(parts.get(sta, [])) for sta in stations}
         results = {sta: r for sta, r in results.items() if r is not None}
-        self.last_run = dict(rank=rank, world=world, uploaded_bytes=up.bytes_uploaded,
+        self.last_run = dict(rank=rank, world=world, binding=dict(parallel.BINDING), uploaded_bytes=up.bytes_uploaded,
                              chunks={sta: (len(bounds.get(sta, ())) if sel[sta] is None else len(sel[sta]))
                                      for sta in stations})
         if active:

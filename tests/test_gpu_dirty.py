@@ -3,7 +3,7 @@ construct.py:1038), single-sample glitches of 10^5 .. 10^7 noise sigmas, short c
 planted events.  The reference's float64 transforms pay nothing for such data (detect.py:559-578); the float32
 engine's dynamic-range guard lists the blocks they touch, splits isolated outliers off the transforms
 (spike_split_kernel -> xhat_clean_kernel -> ds_fft_rescan_kernel) and hands what is still out of range to the
-float32 contraction in tasks of 256 windows x a row group (ds_mfma_task_kernel).  Every window is held to 1e-5 of
+float32 contraction in tasks of 128 windows x a row group (ds_mfma_task_kernel).  Every window is held to 1e-5 of
 the oracle's direct form, and the counters say which path ran."""
 import numpy as np
 import pytest

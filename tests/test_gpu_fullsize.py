@@ -504,6 +504,14 @@ def test_bench_two_ranks_on_one_gpu(config):
         assert d['scaling'] == 'strong' and d['config']['planted_found'] == '30/30'
         want = 6 * 4 * P
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - want) <= 1e-6 * want
+    # the host-fed leg: every rank at once, station-days from pinned memory; per-rank numbers and CPU bindings in the line
+    hf = d['host_fed']
+    assert len(hf['per_rank']) == 2 and sorted(r['rank'] for r in hf['per_rank']) == [0, 1]
+    assert all(r['ms_per_step'] > 0 and 'applied' in r['binding'] and r['binding']['device'] == 0 for r in hf['per_rank'])
+    assert hf['ms_per_step_min'] <= hf['ms_per_step_mean'] <= hf['ms_per_step_max']
+    assert d['config']['host_fed_ms_per_step'] == [hf['ms_per_step_min'], hf['ms_per_step_mean'], hf['ms_per_step_max']]
+    assert abs(hf['value'] * hf['ms_per_step_max'] * 1e-3 - want) <= 1e-6 * want
+    assert 'pci' in d['config']['binding']
 
 
 def test_fullsize_reference_fixture(ctx):

@@ -87,3 +87,44 @@ def test_rebase_fragments_keeps_every_covered_sample(frs, data):
         for j, v in enumerate(x):
             got.setdefault((c, p + j), []).append(int(v))
     assert {k: sorted(v) for k, v in got.items()} == {k: sorted(v) for k, v in want.items()}
+
+
+def test_bind_to_device_reads_sysfs(tmp_path, monkeypatch):
+    """parallel.bind_to_device: the GPU's PCI address -> numa_node / local_cpulist under sysfs -> the process's
+    affinity mask (before any page-locked allocation); every way it can find nothing is recorded, not raised."""
+    import os
+    from detex_amd import parallel
+    allowed = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / '0000:c1:00.0'
+    dev.mkdir()
+    (dev / 'numa_node').write_text('1\n')
+    assert parallel.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    assert parallel.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == '0-3,8,10-11' and parallel.format_cpulist([]) == ''
+    assert parallel.device_locality('0000:C1:00.0', str(tmp_path)) == (1, [])
+    try:
+        # no local_cpulist: nothing applied
+        rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+        assert rec['applied'] is False and rec['numa_node'] == 1 and 'no local CPUs' in rec['reason']
+        assert parallel.BINDING == rec and sorted(os.sched_getaffinity(0)) == allowed
+        # local CPUs outside the mask
+        (dev / 'local_cpulist').write_text('%d-%d\n' % (max(allowed) + 1, max(allowed) + 4))
+        rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+        assert rec['applied'] is False and 'outside' in rec['reason']
+        # the switch
+        monkeypatch.setenv('DETEX_AMD_BIND', '0')
+        assert parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')['reason'] == 'DETEX_AMD_BIND=0'
+        monkeypatch.delenv('DETEX_AMD_BIND')
+        # every allowed CPU local: nothing to do
+        (dev / 'local_cpulist').write_text('0-%d\n' % (max(allowed) + 8))
+        rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+        assert rec['applied'] is False and rec['cpus'] == len(allowed)
+        if len(allowed) >= 2:
+            # a proper subset: the mask shrinks to it
+            half = allowed[:len(allowed) // 2]
+            (dev / 'local_cpulist').write_text(','.join(map(str, half)) + '\n')
+            rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+            assert rec['applied'] is True and rec['cpus'] == len(half) and rec['device'] == 3 and rec['pci'] == '0000:c1:00.0'
+            assert sorted(os.sched_getaffinity(0)) == half
+    finally:
+        os.sched_setaffinity(0, allowed)
+        parallel.BINDING.clear()
