@@ -86,9 +86,6 @@ void dtx_kev_commit(dtx_ctx* ctx) {
 
 int dtx_aux_fork(dtx_ctx* ctx) {
   if (!ctx->aux) {
-    // DETEX_AMD_NO_AUX=1 (measurements): the "side stream" is the context's own -- everything serial
-    const char* e = getenv("DETEX_AMD_NO_AUX");
-    if (e && e[0] == '1') { ctx->aux = ctx->stream; ctx->aux_is_main = true; return DTX_OK; }
     DTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));

@@ -270,24 +270,7 @@ __global__ __launch_bounds__(kT) void xhat_clean_kernel(const float* __restrict_
   }
 }
 
-#ifndef DTX_PP_P1_IN_MAC
-#define DTX_PP_P1_IN_MAC 0     // the transform's first pass: 0 in the FRONT role, 1 at the end of the MAC round
-#endif
-#ifndef DTX_PP_MU_RES
-#define DTX_PP_MU_RES 1
-#endif
-#ifndef DTX_PP_INLINE_X
-#define DTX_PP_INLINE_X 0      // 1: the ping-pong kernel transforms its block's channels itself (no xhat_kernel, no X^ in HBM)
-#endif
-#ifndef DTX_PP_DEFER_CLOSE
-#define DTX_PP_DEFER_CLOSE 1    // a closing pair's statistic is formed by the half's next role (see the kernel)
-#endif
-#ifndef DTX_PP_ABLATE
-#define DTX_PP_ABLATE 0         // timing-only ablations (results are wrong), bit flags: 1 no basis-spectrum loads, 2 no transform fronts,
-                                // 4 no transform tail / epilogue, 8 no MAC
-#endif
 constexpr int kMaxGroups = 32;
-[[maybe_unused]] constexpr int kStampRounds = 24, kStampWgs = 56, kStampEvery = 29;   // -DDTX_PP_STAMPS builds
 struct FftArgs {
   const c32* xh;        // [nchunk][nblkx][Nc][kXh] half spectra, nblkx = nblk + nseg - 1
   const c32* W;         // [npairs][Nc][kN]
@@ -309,7 +292,6 @@ struct FftArgs {
   const int2* upre;     // [nunits + 1]
   int nfull, nrem, ngroups;
   short gb[kMaxGroups + 1];
-  long long* stamps;    // diagnostic builds (-DDTX_PP_STAMPS): [56 workgroups][2 halves][kStampRounds][16] s_memtime
   int nseg, nblkx;      // template segments (virtual channels per real channel), block spectra stored per chunk
   // ping-pong kernel with DTX_PP_INLINE_X: the block spectra are taken inside the kernel from the channel planes
   const float* xp;      // [nchunk][Nc][Tpad]
@@ -324,14 +306,7 @@ struct FftArgs {
   int nruns, n, L;
 };
 
-#ifndef DTX_DS_NT
-#define DTX_DS_NT 1
-#endif
-#if DTX_DS_NT
 #define DTX_DS_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#else
-#define DTX_DS_STORE(v, p) (*(p) = (v))
-#endif
 // epilogue of one pair (uses z, pr, ui, mean, den, acc0, acc1 of the enclosing kernel): add the
 // squared projections; when the pair closes its detector(s) (pdet.x >= 0), normalise and store.
 // pdet.y >= 0: the imaginary part is a different, single-vector detector (acc1).
@@ -574,7 +549,7 @@ __device__ __forceinline__ void ds_fft_block(const FftArgs& a, const int cb, con
 // KB: with three channels exactly the CU's 160 KB), so each pair reads only its basis
 // spectra from L2 -- half the bytes; NCH == 0: any Nc, block spectra re-read per pair
 template <int VM, bool TWO, int NCH>
-__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kT, 2) void ds_fft_kernel(const FftArgs a) {
   __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
   __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];   // NCH == 0: the current / next virtual channel's block spectrum
   // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own 4 MB L2.  Give
@@ -585,12 +560,8 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
   // L2 once per tile, not once per unit.
   const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
   const int tile = logical / kTile, slot = logical - tile * kTile;
-#if DTX_FFT_BLOCK_MAJOR
   const int ntu = (a.nunits + kTileU - 1) / kTileU;
   const int tb = tile / ntu, tu = tile - tb * ntu;     // consecutive tiles: the same blocks under the next unit
-#else
-  const int tu = tile / a.ntile_b, tb = tile - tu * a.ntile_b;
-#endif
   const int unit = tu * kTileU + slot % kTileU;
   const int cb = tb * kTileB + slot / kTileU;          // chunk * nblk + blk
   if (unit >= a.nunits || cb >= a.nchunk * a.nblk) return;
@@ -602,7 +573,7 @@ __global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_kernel(const FftArgs
 // pairs), walked by a grid sized for the chip in tiles of 16 blocks x all runs (the workgroups running at a time
 // share a few blocks' spectra and walk the same pair spectra); finds an empty list on ordinary data.
 template <int VM, bool TWO, int NCH>
-__global__ __launch_bounds__(kT, DTX_FFT_WAVES) void ds_fft_rescan_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kT, 2) void ds_fft_rescan_kernel(const FftArgs a) {
   __shared__ c32 lds[kLdsC + (NCH > 0 ? NCH * kXh : 0)];
   __shared__ c32 xst[NCH == 0 ? 2 * kXh : 1];
   constexpr int kTB = 16;
@@ -687,45 +658,6 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   };
   const int wlo = 512 * wv + ln;
   c32* xs = lds + kLdsC;
-#if DTX_PP_INLINE_X
-  {
-    // The block's spectra, taken here instead of by a kernel of its own (which wrote 172 MB per
-    // station-day for this kernel to read back): half 0 transforms channel 0 on the image while half 1
-    // transforms channel 1 on the last 64 KB of the spectra area (its own destination lies inside:
-    // the outputs wait in registers for the barrier); then half 0 takes channel 2.  Both halves meet
-    // the same six barriers.
-    const int64_t t00 = (int64_t)blk * a.V;
-    const int tb = 8 * (tid & 63) + (tid >> 6);
-    auto forward = [&](int c, c32* img, c32 (&v)[16]) {
-      const float* x = a.xp + ((int64_t)chunk * a.Nc + c) * a.Tpad;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t t = t00 + tb + 512 * r;
-        v[r] = make_float2((t < a.Tpad && tb + 512 * r < a.keep) ? x[t] : 0.f, 0.f);
-      }
-      fft8192<-1>(v, img, lb, a.tab, tid);
-      if (tid == 0) v[0].y = v[8].x;                    // X[kN / 2] rides in the imaginary part of slot 0
-    };
-    auto put = [&](int c, const c32 (&v)[16]) {
-      c32* dst = xs + c * kXh + (tid & 7) * 512 + (tid >> 3);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
-    };
-    c32 v[16];
-    if (half == 0) forward(0, lds, v);
-    else if (NCH > 1) forward(1, xs + kXh, v);
-    else { __syncthreads(); __syncthreads(); }
-    __syncthreads();                                    // every read of the scratch image is done
-    if (half == 0) put(0, v);
-    else if (NCH > 1) put(1, v);
-    if constexpr (NCH > 2) {
-      if (half == 0) forward(2, lds, v);
-      else { __syncthreads(); __syncthreads(); }
-      if (half == 0) put(2, v);
-    }
-    __syncthreads();
-  }
-#else
   const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   {
     const float4* src = reinterpret_cast<const float4*>(xh);
@@ -735,24 +667,14 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
       dst[threadIdx.x + 2 * kT * q] = src[threadIdx.x + 2 * kT * q];
     __syncthreads();
   }
-#endif
-  const int p1_mode = DTX_PP_P1_IN_MAC;   // where the transform's register-only first pass runs (measured equal)
+  const int p1_mode = 0;   // where the transform's register-only first pass runs (measured equal)
   c32 z[16];
-#ifdef DTX_PP_STAMPS
-  Stamp stamp{nullptr, 0};
-  Stamp* const st = &stamp;
-  // (wave-uniform: every lane of wave 0 of each half stores the same stamp -- a per-lane condition costs the kernel its registers)
-  const bool stamped = a.stamps && __builtin_amdgcn_readfirstlane(tid >> 6) == 0 && blockIdx.x % kStampEvery == 0 &&
-                       (int)(blockIdx.x / kStampEvery) < kStampWgs;
-#else
-  Stamp* const st = nullptr;
-#endif
   // One lambda per role; each half runs them alternately (half 0 starts with the MAC role, half 1
   // one round later), written out as a two-phase loop body so that z flows from one role to the
   // next in place (one loop with a branch on the phase's parity cost 64 register moves per pair
   // where the branches met).
   // the block's window means: the same ten for every pair -- resident while the register budget allows
-  constexpr bool kMuRes = DTX_PP_MU_RES && VM <= 10 && !TWO;
+  constexpr bool kMuRes = VM <= 10 && !TWO;
   // the window norms a closing pair divides by: loaded before the barrier (latency hidden) where the
   // registers allow, else at their use (the kernel must stay within 128 registers, no scratch)
   constexpr bool kDnEarly = NCH == 1 ? (TWO ? VM <= 12 : true) : (TWO ? VM <= 5 : VM <= 11);
@@ -767,17 +689,8 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   // round's second barrier and the next round's first this half has the longer instruction stream (transform
   // tail + accumulation + statistic against the other half's first pass)
   // (not where two accumulator sets leave no room for the window norms beside the first loads: no scratch)
-  constexpr bool kDefer = DTX_PP_DEFER_CLOSE && !(TWO && VM >= 13);
+  constexpr bool kDefer = !(TWO && VM >= 13);
   [[maybe_unused]] int2 pend = make_int2(-1, -1);          // detectors whose accumulators wait to be closed (uniform)
-  auto stamp_round = [&](int r) {
-#ifdef DTX_PP_STAMPS
-    stamp.p = (stamped && r < kStampRounds) ? a.stamps + ((((int64_t)(blockIdx.x / kStampEvery) * 2 + half) * kStampRounds + r) * 16) : nullptr;
-    stamp.n = 0;
-    DTX_STAMP(st);     // 0: round start
-#else
-    (void)r;
-#endif
-  };
   // Roles.  FRONT: the whole transform of the pair whose products this half formed in its previous
   // round -- first pass, the image-bound passes between the round's two barriers, and, after the
   // cross-wave reads, the register-only tail, the accumulation and (closing pair) the statistic and
@@ -852,7 +765,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   };
   auto front_role = [&](int q) {
       const int pi_ = q >> 1;
-      if (q >= 0 && pi_ < nmine && !(DTX_PP_ABLATE & 2)) {     // (timing only: no transform fronts)
+      if (q >= 0 && pi_ < nmine) {
         int oe;                                  // nothing below is hoisted out of the round loop
         asm volatile("v_mov_b32 %0, 0" : "=v"(oe));
         const int te = tid + oe;
@@ -866,18 +779,16 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
         fft8192_back_twiddles<1>(p4, a.tab, te);
         fetch_pair(pr, te, pi, pd, mu, dn);
         __builtin_amdgcn_sched_barrier(0);
-        fft8192<1, true, true>(z, lds, lb, a.tab, tid, st, p1_mode);    // two workgroup barriers inside
-        if constexpr (!(DTX_PP_ABLATE & 4)) {
-          fft8192_back_compute<1>(z, p4);
-          finish_pair(te, pi, pd, mu, dn);
-        }
+        fft8192<1, true, true>(z, lds, lb, a.tab, tid, p1_mode);    // two workgroup barriers inside
+        fft8192_back_compute<1>(z, p4);
+        finish_pair(te, pi, pd, mu, dn);
       } else {
         __syncthreads();
         __syncthreads();
       }
   };
   auto mac_role = [&](int q) {
-      const bool mac = q >= 0 && (q >> 1) < nmine && !(DTX_PP_ABLATE & 8);       // a pair's products to form
+      const bool mac = q >= 0 && (q >> 1) < nmine;       // a pair's products to form
       __syncthreads();       // the image is the other half's from here (our cross-wave reads are done)
       [[maybe_unused]] const int2 pnd = pend;
       [[maybe_unused]] float dnp[kDefer ? VM : 1];
@@ -905,11 +816,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
           constexpr int b = bc, c = b >> 1, h2 = b & 1;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-#if DTX_PP_ABLATE & 1      // timing only: no basis-spectrum loads
-            pw[b % kDepth][j] = make_float4(1.f, 0.f, 1.f, 0.f);
-#else
             pw[b % kDepth][j] = (wq + c * (kN / 2) + 64 * (4 * h2 + j))[0];
-#endif
         };
         dtx::static_for<0, kDepth>([&](auto bc) { issue(bc); });
         if constexpr (kDefer) {
@@ -944,7 +851,6 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
         });
-        DTX_STAMP(st);                             // 5: products done
         if (p1_mode == 1) fft8192_pass1<1>(z);     // register-only first pass of the transform
       }
       else if constexpr (kDefer) {
@@ -956,17 +862,13 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
   if (half == 0) {
 #pragma nounroll
     for (int i = 0; i < rounds2; ++i) {
-      stamp_round(2 * i);
       mac_role(2 * i);
-      stamp_round(2 * i + 1);
       front_role(2 * i + 1);
     }
   } else {
 #pragma nounroll
     for (int i = 0; i < rounds2; ++i) {
-      stamp_round(2 * i);
       front_role(2 * i - 1);
-      stamp_round(2 * i + 1);
       mac_role(2 * i);
     }
   }
@@ -982,7 +884,7 @@ __global__ __launch_bounds__(2 * kT) void ds_fft_pp_kernel(const FftArgs a) {
 
 template <int VM>
 void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
-  const bool xl = DTX_FFT_XLDS && a.nseg == 1;   // block spectra LDS-resident: single-segment templates
+  const bool xl = a.nseg == 1;   // block spectra LDS-resident: single-segment templates
   if (ctx->fft.pingpong) {
     if (two && a.Nc == 3) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 3>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
     else if (two) hipLaunchKernelGGL((ds_fft_pp_kernel<VM, true, 1>), dim3(grid), dim3(2 * kT), 0, ctx->stream, a);
@@ -1008,7 +910,7 @@ void launch_fft(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
 template <int VM>
 void launch_rescan(dtx_ctx* ctx, const FftArgs& a, unsigned grid, bool two) {
   if (two) hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, true, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
-  else if (a.Nc == 3 && DTX_FFT_XLDS) hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
+  else if (a.Nc == 3) hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, false, 3>), dim3(grid), dim3(kT), 0, ctx->stream, a);
   else hipLaunchKernelGGL((ds_fft_rescan_kernel<VM, false, 0>), dim3(grid), dim3(kT), 0, ctx->stream, a);
 }
 
@@ -1102,18 +1004,15 @@ int dtx_fft_basis_build(dtx_ctx* ctx, const int32_t* det_off, int D, int n, int 
   // ping-pong kernel are host arithmetic on det_off alone: dtxplan::plan_fft_basis (dtx_plan.h, the
   // translation unit the CPU sanitizer build covers).
   constexpr int kSeg = kN / 2;
-  dtxplan::FftBasisPlan pl = dtxplan::plan_fft_basis(det_off, D, L, kN, kFftMaxL, DTX_FFT_UNIT);
+  dtxplan::FftBasisPlan pl = dtxplan::plan_fft_basis(det_off, D, L, kN, kFftMaxL, 8);
   f.nseg = pl.nseg;
   f.V = pl.V;
   f.two = pl.two;
   f.nunits = pl.nunits;
   f.npairs = pl.npairs;
-  {
-    const char* e = getenv("DTX_FFT_PP");
-    // the ping-pong kernel keeps the block spectra in LDS (single-segment templates, one or three
-    // channels) and is worth it when the halves are balanced: at least 0.8 pairs per round
-    f.pingpong = DTX_FFT_XLDS && f.nseg == 1 && (Nc == 1 || Nc == 3) && pl.balanced && !(e && e[0] == '0');
-  }
+  // the ping-pong kernel keeps the block spectra in LDS (single-segment templates, one or three
+  // channels) and is worth it when the halves are balanced: at least 0.8 pairs per round
+  f.pingpong = f.nseg == 1 && (Nc == 1 || Nc == 3) && pl.balanced;
   if (f.pingpong) {
     // store the pairs half 0's first: each half-workgroup then walks a contiguous run of pairs
     dtxplan::reorder_pairs_for_halves(pl);
@@ -1199,11 +1098,9 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
   const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
-  if (!(DTX_PP_INLINE_X && pp)) {
-    hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
-                       ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0);
-    DTX_HIP(ctx, hipGetLastError());
-  }
+  hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
+                     ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0);
+  DTX_HIP(ctx, hipGetLastError());
   FftArgs a;
   a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
@@ -1214,14 +1111,6 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   a.nseg = f.nseg; a.nblkx = nblkx;
   a.xp = xp; a.Tpad = Tpad; a.keep = keep;
   a.pb = pp ? pb : nullptr;      // (the one-group kernel of long templates runs every block)
-  a.stamps = nullptr;
-#ifdef DTX_PP_STAMPS
-  const size_t stamp_n = (size_t)kStampWgs * 2 * kStampRounds * 16;
-  if (getenv("DTX_PP_STAMP_FILE") && pp) {
-    DTX_HIP(ctx, hipMalloc(&a.stamps, stamp_n * sizeof(long long)));
-    DTX_HIP(ctx, hipMemsetAsync(a.stamps, 0, stamp_n * sizeof(long long), ctx->stream));
-  }
-#endif
   a.upre = (const int2*)f.upre_dev; a.nfull = nfull; a.nrem = std::max(nrem, 1); a.ngroups = ng;
   std::copy(gb, gb + kMaxGroups + 1, a.gb);
   a.rws = ws; a.runs = (const int2*)f.runs_dev; a.nruns = f.nruns; a.prow = (const int2*)f.prow_dev;
@@ -1297,17 +1186,5 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
     }
     DTX_HIP(ctx, hipGetLastError());
   }
-#ifdef DTX_PP_STAMPS
-  if (a.stamps) {       // dump the last launch's stamps: [workgroup][half][round][16], zeros = not taken
-    std::vector<long long> h(stamp_n);
-    DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    DTX_HIP(ctx, hipMemcpy(h.data(), a.stamps, stamp_n * sizeof(long long), hipMemcpyDeviceToHost));
-    (void)hipFree(a.stamps);
-    if (FILE* fp = fopen(getenv("DTX_PP_STAMP_FILE"), "wb")) {
-      fwrite(h.data(), sizeof(long long), stamp_n, fp);
-      fclose(fp);
-    }
-  }
-#endif
   return DTX_OK;
 }

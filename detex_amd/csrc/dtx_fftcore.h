@@ -19,25 +19,7 @@ constexpr int kXh = kN / 2;
 constexpr int kXlMax = 3;            // channels whose block spectra fit in LDS beside the image
 // L2-sized tiles of the (unit, block) work space: the workgroups an XCD runs together
 // share kTileU units' spectra and kTileB blocks' spectra (see ds_fft_kernel)
-#ifndef DTX_FFT_UNIT
-#define DTX_FFT_UNIT 8                  // pairs per unit (runs of whole detectors)
-#endif
-#ifndef DTX_FFT_TILEU
-#define DTX_FFT_TILEU 1                 // measured (200 basis vectors): 2 x 16 tiles 6.21 ms, 1 x 32 5.85 ms
-#endif
-#ifndef DTX_FFT_TILE
-#define DTX_FFT_TILE 16                  // blocks per L2 tile of the one-group kernel (block-major order: 16 measured best)
-#endif
-#ifndef DTX_FFT_BLOCK_MAJOR
-#define DTX_FFT_BLOCK_MAJOR 1            // consecutive tiles = the same blocks under the next unit (long templates: 15.6 -> 14.3 ms)
-#endif
-constexpr int kTileU = DTX_FFT_TILEU, kTileB = DTX_FFT_TILE / DTX_FFT_TILEU, kTile = kTileU * kTileB;
-#ifndef DTX_FFT_WAVES
-#define DTX_FFT_WAVES 2              // waves per SIMD the scan kernel is compiled for (2: one workgroup per CU,
-#endif                               // 256 registers; 4 -> 128 registers spills and measured 19 % slower)
-#ifndef DTX_FFT_XLDS
-#define DTX_FFT_XLDS 1               // Nc = 1, 3: keep the block's spectra in LDS across the unit's pairs
-#endif
+constexpr int kTileU = 1, kTileB = 16 / 1, kTile = kTileU * kTileB;
 static_assert(kN == 8192, "radix plan 16 x 8 x 8 x 8 is for 8192 points");
 
 typedef float2 c32;
@@ -101,12 +83,6 @@ __device__ __forceinline__ void dft_bitrev(c32 (&u)[R]) {
   dif_stage<SG, R, 4>(u);
   dif_stage<SG, R, 2>(u);
 }
-#ifndef DTX_FFT_FOLD
-#define DTX_FFT_FOLD 1      // inter-pass twiddles folded into the butterflies (dft_tw_bitrev)
-#endif
-#ifndef DTX_FFT_CONST1
-#define DTX_FFT_CONST1 DTX_FFT_FOLD   // the untwiddled pass by constant-root butterflies (dft_const_bitrev)
-#endif
 // (x, y) -> (x + T y, x - T y) in six fused multiply-adds (the difference as 2 x - (x + T y))
 __device__ __forceinline__ void bfly_tw(c32& x, c32& y, c32 T) {
   const float px = __fmaf_rn(T.x, y.x, __fmaf_rn(-T.y, y.y, x.x));
@@ -210,11 +186,7 @@ __device__ __forceinline__ void dft_const_bitrev(c32 (&u)[R]) {
 // the untwiddled 16-point pass
 template <int SG>
 __device__ __forceinline__ void dft16_plain(c32 (&v)[16]) {
-#if DTX_FFT_CONST1
   dft_const_bitrev<SG, 16>(v);
-#else
-  dft_bitrev<SG, 16>(v);
-#endif
 }
 __host__ __device__ constexpr int rev2(int q) { return ((q & 1) << 1) | (q >> 1); }
 __host__ __device__ constexpr int rev3(int q) { return ((q & 1) << 2) | (q & 2) | ((q >> 2) & 1); }
@@ -240,7 +212,7 @@ __host__ __device__ constexpr int rev4(int q) {
 // channels of block spectra sit beside it in the 160 KB).  Every access is conflict-free
 // under it in the bank model of MI355X_MICROARCH.md -- 8-byte stores go in groups of 16 contiguous
 // lanes over 32 banks, ds_read_b64 in half-waves over 64 banks, ds_read2st64_b64 again in groups of
-// 16 over 32 banks (checked exhaustively by scripts/fft_swizzle_check2.py).  Rounds 1-2 used
+// 16 over 32 banks (checked exhaustively by profiles/attic/fft_swizzle_check2.py).  Rounds 1-2 used
 // (a >> 5) & 15, checked every access as half-waves on 64 banks: under the real model their first
 // scatter (slot 16 l + s) put lanes 2 j and 2 j + 1 of a 16-lane group on one bank pair -- the 13 % of
 // conflict cycles rocprofv3 counted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Every address is a
@@ -303,28 +275,12 @@ __device__ __forceinline__ void load_twiddles(Twid& w, const c32* __restrict__ t
 // transform is left bit-reversed in u
 template <int SG, int H>
 __device__ __forceinline__ void bfly8(const c32 (&v)[16], c32 (&u)[8], c32 w1, c32 w2, c32 w4) {
-#if DTX_FFT_FOLD
 #pragma unroll
   for (int sidx = 0; sidx < 8; ++sidx) u[sidx] = v[2 * sidx + H];
   const c32 wp[3] = {w4, w2, w1};
   dft_tw_bitrev<SG, 8>(u, wp);
-#else
-  u[0] = v[H];
-  u[1] = cmul(v[2 + H], w1);
-  u[2] = cmul(v[4 + H], w2);
-  u[4] = cmul(v[8 + H], w4);
-  const c32 w3 = cmul(w1, w2);
-  u[3] = cmul(v[6 + H], w3);
-  u[7] = cmul(v[14 + H], cmul(w3, w4));
-  u[5] = cmul(v[10 + H], cmul(w1, w4));
-  u[6] = cmul(v[12 + H], cmul(w2, w4));
-  dft_bitrev<SG, 8>(u);
-#endif
 }
 
-#ifndef DTX_FFT_PERMLANE
-#define DTX_FFT_PERMLANE 1     // the transform's second in-wave exchange: lane swaps instead of LDS
-#endif
 // a <-> b transposed over (which of the two registers, lane bit 4 / lane bit 5)
 __device__ __forceinline__ void lane_swap16(c32& a, c32& b) {
   auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
@@ -338,27 +294,6 @@ __device__ __forceinline__ void lane_swap32(c32& a, c32& b) {
   a = make_float2(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
   b = make_float2(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
 }
-
-// Diagnostic builds only (-DDTX_PP_STAMPS): a wave appends s_memtime (after draining its memory
-// counters) to its row of a stamp buffer.  Compiled out otherwise.
-#ifdef DTX_PP_STAMPS
-struct Stamp {
-  long long* p;
-  int n;
-  __device__ __forceinline__ void operator()() {
-    if (p) {
-#if DTX_PP_STAMPS == 1      // (2: light stamps -- memory operations in flight are not waited for)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-      p[n++] = (long long)__builtin_amdgcn_s_memtime();
-    }
-  }
-};
-#define DTX_STAMP(st) do { if (st) (*(st))(); } while (0)
-#else
-struct Stamp {};
-#define DTX_STAMP(st) ((void)0)
-#endif
 
 // v[r] = point 8 (l + 64 r) + wave in, natural-order transform point (tid + 512 m) out in v[m]
 // LEAN: for the 128-register kernels -- each pass loads its twiddles just before it uses them
@@ -400,7 +335,7 @@ __device__ __forceinline__ void fft8192_pass1(c32 (&v)[16]) { dft16_plain<SG>(v)
 // p1: where pass 1 runs -- 0 here, before the barrier; 1 the caller has run it (fft8192_pass1)
 template <int SG, bool LEAN = false, bool FRONT_ONLY = false>
 __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& lb0,
-                                        const c32* __restrict__ tab, int tid, Stamp* st = nullptr, int p1 = 0) {
+                                        const c32* __restrict__ tab, int tid, int p1 = 0) {
   // The ~50 swizzled LDS addresses below and the 9 twiddles are loop invariants of the
   // caller's pair loop; hoisted there they cost 70 registers and the kernel spills.  An opaque
   // zero keeps them inside (the twiddle loads are L1 / L2 hits, 9 per transform).
@@ -427,14 +362,11 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
   lb.f = (lb0.f + opaque) << 3;
   // ---- phase A, pass 1: radix 16 over r, no twiddles
   if (p1 == 0) dft16_plain<SG>(v);
-  DTX_STAMP(st);     // pass 1 done
   __syncthreads();   // every wave has finished the phase-B reads of the previous transform
-  DTX_STAMP(st);     // barrier 1 passed
   dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
   wave_sync();
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
   wave_sync();
-  DTX_STAMP(st);     // first exchange done
   // ---- pass 2: radix 16, sub-transforms of 16 -> 256
   {
     if constexpr (LEAN && !FRONT_ONLY) {
@@ -442,54 +374,9 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
 #pragma unroll
       for (int e = 0; e < 4; ++e) w.a[e] = ldtw(l15 << e);
     }
-#if defined(DTX_FFT_MFMA_ABLATE)
-    // TIMING-ONLY ablation (results are wrong; VERDICT r3 next 5, profiles/README.md): what the scan kernel
-    // would cost if the twiddled radix-16 pass -- 208 vector instructions per wave -- ran on the matrix pipe
-    // instead: 64 complex 16-point DFTs per wave = [32 x 32] x [32 x 64] real, i.e. 8 v_mfma_f32_16x16x32_bf16
-    // per bf16 product, 24 for the three products of a split-bf16 float32 product (DTX_FFT_MFMA_ABLATE = the
-    // count).  Operands are whatever bits the registers hold: no twiddle pre-multiplication (64 instructions in
-    // a real build), no f32 -> 2 x bf16 split (~80), no transposition into the operand layout -- the most
-    // favourable case.  -DDTX_DUMMY_VALU=<n> adds those back.
-    {
-      typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 abf16x8;
-      typedef __attribute__((__vector_size__(4 * sizeof(float)))) float af32x4;
-      typedef __attribute__((__vector_size__(4 * sizeof(int)))) int ai32x4;
-      af32x4 acc[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = (af32x4){v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y};
-      const ai32x4 fa = {__float_as_int(w.a[0].x), __float_as_int(w.a[0].y), __float_as_int(w.a[1].x), __float_as_int(w.a[1].y)};
-#pragma unroll
-      for (int m = 0; m < DTX_FFT_MFMA_ABLATE; ++m) {
-        const int q = m & 7, o = (m * 5 + 3) & 7;
-        const ai32x4 xb = {__float_as_int(v[2 * o].x), __float_as_int(v[2 * o].y), __float_as_int(v[2 * o + 1].x),
-                           __float_as_int(v[2 * o + 1].y)};
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, fa), __builtin_bit_cast(abf16x8, xb),
-                                                         acc[q], 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        v[2 * q] = make_float2(acc[q][0], acc[q][1]);
-        v[2 * q + 1] = make_float2(acc[q][2], acc[q][3]);
-      }
-    }
-  }
-#elif DTX_FFT_FOLD
     const c32 wp[4] = {w.a[3], w.a[2], w.a[1], w.a[0]};
     dft_tw_bitrev<SG, 16>(v, wp);
   }
-#else
-    const c32 w1 = w.a[0], w2 = w.a[1], w4 = w.a[2], w8 = w.a[3];
-    const c32 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
-    v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-    v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
-    v[9] = cmul(v[9], cmul(w1, w8)); v[10] = cmul(v[10], cmul(w2, w8));
-    v[11] = cmul(v[11], cmul(w3, w8)); v[12] = cmul(v[12], cmul(w4, w8));
-    v[13] = cmul(v[13], cmul(w5, w8)); v[14] = cmul(v[14], cmul(w6, w8));
-    v[15] = cmul(v[15], cmul(w7, w8));
-  }
-  dft_bitrev<SG, 16>(v);
-#endif
-#if DTX_FFT_PERMLANE
   // Second exchange without LDS.  Output k2 = s of pass 2 sits in v[rev4(s)] of lane
   // l = k1 + 16 x3; pass 3 wants point j = k1 + 16 k2 of sub-sequence x3 in lane j & 63, register
   // (j >> 6) + 4 x3: the low two bits of k2 trade places with lane bits 4 and 5.  gfx950's
@@ -508,27 +395,6 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     // y index: bits 1:0 = x3, bits 3:2 = k2 >> 2 = b
     dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = y[(r >> 2) + 4 * (r & 3)]; });
   }
-  DTX_STAMP(st);     // pass 2 computed
-  DTX_STAMP(st);     // second exchange done
-#else
-  dtx::static_for<0, 16>([&](auto sc) {
-    constexpr int s = sc;
-    lds_at(lds, lb.s2 ^ (8 * ((16 * s) ^ s))) = v[rev4(s)];
-  });
-  DTX_STAMP(st);     // pass 2 computed and written
-  wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
-  wave_sync();
-  DTX_STAMP(st);     // second exchange done
-#endif
-#ifdef DTX_DUMMY_VALU   // diagnostic: what DTX_DUMMY_VALU more vector instructions per transform cost
-  {
-    float d = v[0].x;
-#pragma unroll
-    for (int i = 0; i < DTX_DUMMY_VALU; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
-    if (d == 12345.678f) v[0].x = d;
-  }
-#endif
   // ---- pass 3: radix 4, sub-transforms of 256 -> 1024; butterfly b takes registers b + 4 s
   // and point index l + 64 b: its twiddle angle is b/16 of a turn ahead of butterfly 0's
   if constexpr (LEAN && !FRONT_ONLY) {
@@ -540,29 +406,18 @@ __device__ __forceinline__ void fft8192(c32 (&v)[16], c32* lds, const LdsBases& 
     constexpr int b = bc;
     const c32 w1 = mul_root<SG, 16, b>(w.b[0]), w2 = mul_root<SG, 8, b>(w.b[1]);
     c32 u[4];
-#if DTX_FFT_FOLD
     u[0] = v[b]; u[1] = v[b + 4]; u[2] = v[b + 8]; u[3] = v[b + 12];
     const c32 wp[2] = {w2, w1};
     dft_tw_bitrev<SG, 4>(u, wp);
-#else
-    u[0] = v[b];
-    u[1] = cmul(v[b + 4], w1);
-    u[2] = cmul(v[b + 8], w2);
-    u[3] = cmul(v[b + 12], cmul(w1, w2));
-    dft_bitrev<SG, 4>(u);
-#endif
     dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
   });
   // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 8 across the waves
   dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
-  DTX_STAMP(st);     // pass 3 computed and written
   __syncthreads();
-  DTX_STAMP(st);     // barrier 2 passed
   dtx::static_for<0, 16>([&](auto mc) {
     constexpr int m = mc;
     v[m] = lds_at(lds, lb.f + 8 * (512 * (m & 1) + 1024 * (m >> 1)));
   });
-  DTX_STAMP(st);     // cross-wave reads in
   if constexpr (FRONT_ONLY) return;
   // butterfly h = 1 is point tid + 512: its twiddle angle is pi/8 ahead, so w, w^2, w^4 pick
   // up e^{i pi/8}, e^{i pi/4}, e^{i pi/2}
@@ -704,122 +559,6 @@ __device__ __forceinline__ f2 cmul2_conj(f2 w, f2 p) {
 constexpr int kN16 = 16384;
 constexpr int kT16 = 1024;
 constexpr int kXh16 = kN16 / 2;
-#if defined(DTX_XC16) && DTX_XC16
-// ---------------------------------------------------------------- the 16 384-point transform
-// The same construction one size up, for a workgroup of SIXTEEN waves (1024 threads, 16 points each) on a 128 KB image:
-// n = 16 n2 + w.  Phase A is the 8192-point transform's, wave for wave (a 1024-point Stockham transform of the wave's
-// own subsequence in its own 8 KB region: radices 16 x 16 x 4, one LDS exchange + one by lane swaps, no workgroup
-// barrier); phase B is ONE twiddled radix-16 butterfly per thread across the sixteen waves instead of two radix-8
-// ones across eight: thread tid combines Y_0..15[k2 = tid] -> X[tid + 1024 k1] in register k1.  The image's swizzle
-// is per 1024-slot region, so every address formula of fft8192 carries over (lds_bases: region = wave * 1024; the
-// phase-B read of region w' at slot tid ^ g(tid) is a permutation of 64 consecutive slots per wave: conflict-free).
-// tab: e^{2 pi i m / 16384}, m < 16384.  Used by the all-pairs lag search when one lag block of 16 384 replaces
-// several of 8192 (dtx_xcfft.hip: xc_fft16_kernel).
-template <int SG>
-__device__ __forceinline__ void fft16384(c32 (&v)[16], c32* lds, const LdsBases& lb0,
-                                         const c32* __restrict__ tab, int tid) {
-  int opaque;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
-  auto ldtw = [&](int idx) {
-    c32 t = tab[idx];
-    if (SG < 0) t.y = -t.y;
-    return t;
-  };
-  c32 wa[4], wb[2];
-  {
-    const int l = (tid + opaque) & 63;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wa[e] = ldtw(((l & 15) * (kN16 / 256)) << e);
-    wb[0] = ldtw(l * (kN16 / 1024));
-    wb[1] = ldtw(l * (kN16 / 512));
-  }
-  LdsBases lb;   // in bytes
-  lb.g = (lb0.g + opaque) << 3; lb.s1 = (lb0.s1 + opaque) << 3; lb.s2 = (lb0.s2 + opaque) << 3;
-  lb.f = (lb0.f + opaque) << 3;
-  // ---- phase A, pass 1: radix 16 over r, no twiddles
-  dft16_plain<SG>(v);
-  __syncthreads();   // every wave has finished its reads of the image (the previous transform's phase B, a caller's staging)
-  dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; lds_at(lds, lb.s1 ^ (8 * s)) = v[rev4(s)]; });
-  wave_sync();
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r); });
-  wave_sync();
-  // ---- pass 2: radix 16, sub-transforms of 16 -> 256
-  {
-    const c32 wp[4] = {wa[3], wa[2], wa[1], wa[0]};
-    dft_tw_bitrev<SG, 16>(v, wp);
-  }
-  {
-    c32 y[16];
-    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; y[s] = v[rev4(s)]; });
-    dtx::static_for<0, 16>([&](auto sc) {
-      constexpr int s = sc;
-      if constexpr ((s & 1) == 0) lane_swap16(y[s], y[s + 1]);
-    });
-    dtx::static_for<0, 16>([&](auto sc) {
-      constexpr int s = sc;
-      if constexpr ((s & 2) == 0) lane_swap32(y[s], y[s + 2]);
-    });
-    dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; v[r] = y[(r >> 2) + 4 * (r & 3)]; });
-  }
-  // ---- pass 3: radix 4, sub-transforms of 256 -> 1024
-  dtx::static_for<0, 4>([&](auto bc) {
-    constexpr int b = bc;
-    const c32 w1 = mul_root<SG, 16, b>(wb[0]), w2 = mul_root<SG, 8, b>(wb[1]);
-    c32 u[4];
-    u[0] = v[b]; u[1] = v[b + 4]; u[2] = v[b + 8]; u[3] = v[b + 12];
-    const c32 wp[2] = {w2, w1};
-    dft_tw_bitrev<SG, 4>(u, wp);
-    dtx::static_for<0, 4>([&](auto qc) { constexpr int q = qc; v[b + 4 * q] = u[rev2(q)]; });
-  });
-  // ---- phase B: Y_w[k2 = l + 64 r] to the image, then radix 16 across the waves
-  dtx::static_for<0, 16>([&](auto rc) { constexpr int r = rc; lds_at(lds, (lb.g ^ (8 * swz_gr(r))) + 512 * r) = v[r]; });
-  // the cross-wave twiddles w, w^2, w^4, w^8, w = e^{SG 2 pi i tid / 16384}: issued in front of the barrier (v is dead)
-  c32 p4[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) p4[e] = ldtw((tid + opaque) << e);
-  __syncthreads();
-  dtx::static_for<0, 16>([&](auto mc) { constexpr int m = mc; v[m] = lds_at(lds, lb.f + 8 * 1024 * m); });
-  {
-    const c32 wp[4] = {p4[3], p4[2], p4[1], p4[0]};
-    dft_tw_bitrev<SG, 16>(v, wp);
-    c32 y[16];
-    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; y[s] = v[rev4(s)]; });
-    dtx::static_for<0, 16>([&](auto sc) { constexpr int s = sc; v[s] = y[s]; });
-  }
-}
-
-// pair spectra of the 16 384-point transform in memory: thread (wave w of 16, lane l) holds f = 16 (l + 64 r) + w
-__host__ __device__ constexpr int w_slot16(int f) {
-  const int w = f & 15, n2 = f >> 4, l = n2 & 63, r = n2 >> 6;
-  return w * 1024 + (r >> 1) * 128 + 2 * l + (r & 1);
-}
-
-// Block spectra for the 16 384-point lag search: as xhat_kernel, one transform of 16 384 REAL samples per
-// (stored block, channel, event), half spectrum kept: slot(f) = (f & 15) * 512 + (f >> 4), f < 8192; X[8192] rides
-// in the imaginary part of slot 0.  Stored block j = blk * nsub + s starts at sample blk V + s sub_stride.
-__global__ __launch_bounds__(kT16) void xhat16_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc, int V,
-                                                      int nblk, const c32* __restrict__ tab, c32* __restrict__ xh,
-                                                      int nsub, int sub_stride) {
-  __shared__ c32 lds[kN16];
-  const int tid = threadIdx.x, blk = blockIdx.x, c = blockIdx.y, chunk = blockIdx.z;
-  const LdsBases lb = lds_bases(tid);
-  const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
-  const int tb = 16 * (tid & 63) + (tid >> 6);          // sample within the block
-  const int64_t t0 = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride + tb;
-  c32 v[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t t = t0 + 1024 * r;
-    v[r] = make_float2(t < Tpad ? x[t] : 0.f, 0.f);
-  }
-  fft16384<-1>(v, lds, lb, tab, tid);
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh16 + (tid & 15) * 512 + (tid >> 4);
-  if (tid == 0) v[0].y = v[8].x;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
-}
-
-#endif   // DTX_XC16
 
 // Basis pair spectra in memory: thread (wave w, lane l) of a MAC holds frequencies
 // f = 8 (l + 64 r) + w, r = 0 .. 15.  Registers r = 2 j, 2 j + 1 of one lane are adjacent, so a
@@ -841,9 +580,6 @@ __device__ __forceinline__ void w_load16(const c32* __restrict__ wc, int wl, c32
 }
 
 // ---------------------------------------------------------------- block spectra
-#ifndef DTX_XHAT_ROWSTORE
-#define DTX_XHAT_ROWSTORE 1
-#endif
 // Xh[chunk * nblk + blk][c][slot(f)] = sum_t xp[chunk][c][blk V + t] e^{-2 pi i t f / kN}, f < kN / 2,
 // slot(f) = (f & 7) * 512 + (f >> 3): the wave-decimated order the scan kernel reads (wave w
 // takes the frequencies f = 8 n2 + w); X[kN / 2] rides in the imaginary part of slot 0.
@@ -870,17 +606,7 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     const int64_t t = t0 + 512 * r;
     v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
   }
-#ifndef DTX_XHAT_ABLATE
-#define DTX_XHAT_ABLATE 0      // timing only: 1 no transform, 2 no sample loads
-#endif
-#if DTX_XHAT_ABLATE & 2
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = make_float2((float)(tid + r), 0.f);
-#endif
-#if !(DTX_XHAT_ABLATE & 1)
   fft8192<-1>(v, lds, lb, tab, tid);
-#endif
-#if DTX_XHAT_ROWSTORE
   // Thread tid holds X[tid + 512 m] in v[m]; slot (f & 7) * 512 + (f >> 3) puts a wave's eight
   // values of one m into eight 64-byte pieces 4 KB apart.  Through the (free) image instead: wave w
   // stores row f & 7 = w, 64 consecutive slots (512 bytes) per instruction.  Image layout
@@ -898,12 +624,6 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
     if (tid == 0 && j == 0) o.y = lds[8 * 576].x;
     row[64 * j] = o;
   }
-#else
-  c32* dst = xh + (((int64_t)chunk * nblk + blk) * Nc + c) * kXh + (tid & 7) * 512 + (tid >> 3);   // nblk: blocks STORED per chunk
-  if (tid == 0) v[0].y = v[8].x;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) dst[64 * m] = v[m];
-#endif
 }
 
 }  // namespace

@@ -41,10 +41,7 @@ constexpr int kThreads = 512;  // 8 waves, 2 per SIMD
 constexpr int kRmMax = 13;     // 13 * 16 = 208 rows per K-tile
 constexpr int kKtMax = 16 * kRmMax;
 
-#ifndef DTX_TN_BIG
-#define DTX_TN_BIG 2
-#endif
-__host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? DTX_TN_BIG : (rm >= 5 ? 4 : 8); }
+__host__ __device__ constexpr int tn_for(int rm) { return rm >= 9 ? 2 : (rm >= 5 ? 4 : 8); }
 __host__ __device__ constexpr int pt_for(int rm) { return 128 * tn_for(rm); }
 __host__ __device__ constexpr int kts_for(int rm) { return 16 * rm + ((rm & 1) ? 0 : 16); }
 // floats of LDS one block needs
@@ -277,9 +274,7 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
       if constexpr (GL) DTX_STORE_X((s + 1) & 1);
       else DTX_STORE_TILE((s + 1) & 1);
     }
-#ifndef DTX_DBG_NOBARRIER   /* timing-only ablation, results are wrong without it */
     __syncthreads();
-#endif
   }
 
   if constexpr (TAIL) {
@@ -310,12 +305,6 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
 // a block-wide scan (pandas rolling_mean / rolling_var, detect.py:566-568 and
 // construct.py:446-447).  planes: [batch][Nc][plane_stride].
 // ---------------------------------------------------------------------------
-#ifndef DTX_STATS_ROWSTORE
-#define DTX_STATS_ROWSTORE 1
-#endif
-#ifndef DTX_STATS_BATCHED
-#define DTX_STATS_BATCHED 1
-#endif
 constexpr int kStatsPB = 2048;  // windows per block
 
 // variance below float64 round-off relative to the window power counts as 0
@@ -433,7 +422,7 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   const int64_t pt = p0 + (int64_t)E * tid;
   // (the batched loads read up to sample pt + L + E - 1 of the plane whatever P is: only where that
   // stays inside the plane -- the last threads of a chunk's last block take the guarded loop)
-  if (DTX_STATS_BATCHED && pt + L + E <= tlim) {
+  if (pt + L + E <= tlim) {
   for (int c = 0; c < Nc; ++c) {
     float ha[E + 1], tb[E + 1];                                // ha[j] = o[j], tb[j] = o[L - 1 + j]
     {
@@ -550,7 +539,6 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     S1 = s;
     var = q;
   };
-#if DTX_STATS_ROWSTORE
   // a thread's eight results are eight consecutive windows: stored directly, a wave instruction
   // writes 64 four-byte pieces 32 bytes apart.  Through LDS (slot q + (q >> 5): the strided writes are
   // conflict-free) each instruction stores 256 consecutive bytes.
@@ -582,21 +570,6 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
       so[pw] = sts[q + (q >> 5)];
     }
   }
-#else
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int64_t pw = p0 + (int64_t)E * tid + e + 1;
-    if (pw < P && pw < p0 + kStatsPB) {
-      double S1 = (a1 + off1 + l1[e]) + (ab1 + ofb1 + g1[e]);
-      const double S2 = (a2 + off2 + l2[e]) + (ab2 + ofb2 + g2[e]), S3 = a3 + off3 + l3[e];
-      const bool flat = constant(pw, S3);
-      double var = flat ? 0.0 : clamp_var(S2, S1, dn);
-      if (!flat && S2 - S1 * S1 / dn < recheck) direct(pw, S1, var);
-      mo[pw] = (float)(S1 / dn);
-      so[pw] = stats_out(scale, var);
-    }
-  }
-#endif
 }
 
 }  // namespace dtx

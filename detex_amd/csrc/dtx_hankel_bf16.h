@@ -34,20 +34,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 namespace dtx {
 
 // column tiles per wave in this engine (B fragments are 4 VGPRs each, so fewer than fp32)
-#ifndef DTX_TNS_BIG
-#define DTX_TNS_BIG 3
-#endif
-__host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? DTX_TNS_BIG : 4; }
+__host__ __device__ constexpr int tn_s(int rm) { return rm >= 9 ? 3 : 4; }
 // "wide" variant for the big K-tiles (-DDTX_WIDE=1): 4 waves per block, one per SIMD, with
 // the whole 512-entry register file each -> twice the column tiles per wave (same block
 // tile), i.e. every A fragment read from LDS feeds twice the MFMAs (-41 % LDS reads).
 // Measured (profiles/README.md, "power"): on noise it ties with the 8-wave kernel
 // (58.6 vs 59.1 ms) because both sit on the chip's power limit; on all-zero data, where
 // nothing throttles, one wave per SIMD hides less latency (51.4 vs 46.7 ms).  Off by default.
-#ifndef DTX_WIDE
-#define DTX_WIDE 0
-#endif
-__host__ __device__ constexpr int nw_s(int rm) { return (DTX_WIDE && rm >= 9) ? 4 : 8; }
+__host__ __device__ constexpr int nw_s(int) { return 8; }
 __host__ __device__ constexpr int tnw_s(int rm) { return tn_s(rm) * 8 / nw_s(rm); }
 // slots per shifted copy in LDS (block tile of 128 * tn columns): NS + 4 == 12 (mod 16)
 // makes the B reads conflict-free

@@ -56,7 +56,7 @@ struct DtxFft {
 };
 // templates (samples per channel) the frequency-domain engine takes; others fall back
 constexpr int kFftMinL = 2;
-// measured (scripts/seg_ab.sh, 200 basis vectors): two segments of 4096 take 12.8 ms per
+// measured (profiles/attic/seg_ab.sh, 200 basis vectors): two segments of 4096 take 12.8 ms per
 // station-day; one segment takes 11.3 ms at V = 2560 and 13.6 ms at V = 2048
 #ifndef DTX_FFT_SEG_L
 #define DTX_FFT_SEG_L (DTX_FFT_N - 2560 + 1)
@@ -137,7 +137,7 @@ struct dtx_ctx {
 struct DtxSpike { int t, c; float v; };
 constexpr int kMaxSpk = 48;            // outliers per block; more: the block keeps its transforms and goes to the contraction
 // windows per repair task (column tile of the float32 contraction).  A task is a chain of 3 L / 64 steps whose
-// loads nothing hides on an otherwise idle CU: 128 against 256 windows, scripts/ab_repair_pt.sh: config2_dirty
+// loads nothing hides on an otherwise idle CU: 128 against 256 windows, profiles/r6_dirty_cost.txt (c): config2_dirty
 // 3.53 / 3.57 ms per step, a loud onset (39 / 20 tiles) 3.47 / 3.60, one tile 3.44 / 3.46 (clean: 3.21 - 3.31)
 constexpr int kRepairPT = 128;
 // One workspace (ctx->ws_flag) for a call's guard lists; count[] is cleared by chunk_offset_final_kernel.
@@ -193,7 +193,7 @@ void dtx_kev_commit(dtx_ctx* ctx);   // ... both recorded: the pair counts (dtx_
 int dtx_aux_fork(dtx_ctx* ctx);      // aux waits for what is queued on stream
 int dtx_aux_join(dtx_ctx* ctx);      // stream waits for what is queued on aux
 // a block is handed to the float32 MFMA engine when max / min window energy exceeds this squared.
-// Calibration (tests/test_gpu_engines.py, scripts/sweep_more.py): the error of a quiet window
+// Calibration (tests/test_gpu_engines.py, profiles/attic/sweep_more.py): the error of a quiet window
 // that shares a block with a loud one is ~1.8e-8 * sqrt(DS) * sqrt(energy ratio); 200 keeps it
 // under 4e-6 even for detectors that span half the window's dimensions (DS ~ 0.5 on noise)
 constexpr float kFftGuard = 200.f;

@@ -236,72 +236,11 @@ inline XcSegPlan plan_xc_segments(int L, int Pz, int Nc, int N, int max_single_L
   return p;
 }
 
-// The same choice for the 16 384-point lag search (xc_fft16_kernel: 1024 threads, a thread's lags are 1024 apart, so a
-// lag block advances by a multiple of 1024).  A block needs its lags VALID, not a whole advance of them: the last
-// (or only) block holds Pz - b V < V lags, and segments may be as long as N - (lags of the fullest block) + 1.  One
-// block of 16 384 instead of three of 8192 at L = 13 000: 4 segments of 3250, 13 001 lags in 13 per thread.
-// cost: in MAC steps of the 8192-point kernels (32 768 complex MACs per step there and here; a workgroup of this
-// kernel serves ONE pair spectrum, the 2 x 2 workgroup two: everything counts twice), a block's two transforms
-// + lag search ~ 9.2 steps' worth (14 / 13 of the 8192-point kernel's 8.5).  ok = false: no plan (L too long).
-struct XcSegPlan16 {
-  int nseg = 1, seglen = 0, V = 0, nblk = 0;
-  double cost = 1e300;
-  bool ok = false;
-};
-inline XcSegPlan16 plan_xc_segments16(int L, int Pz, int Nc, int N = 16384) {
-  XcSegPlan16 p;
-  const int S = (Pz - 1) / 2;
-  for (int ns = 1; ns <= 16; ++ns) {
-    const int sl0 = (L + ns - 1) / ns;                      // shortest segments that cover the event
-    const int valid = N - sl0 + 1;                          // lags a block of such segments can hold
-    if (valid < 4 * 1024) continue;
-    int v, nb;
-    if (valid >= Pz) { nb = 1; v = std::min(16, (Pz + 1023) / 1024) * 1024; }
-    else { v = std::min(15 * 1024, valid / 1024 * 1024); nb = (Pz + v - 1) / v; }
-    if (v < 4 * 1024) continue;
-    const int most = std::min(v, Pz);                       // lags of the fullest block
-    // the longest segments those lags allow (fewer (block, segment) products see data), every segment non-empty
-    const int sl = ns == 1 ? L : std::min(N - most + 1, (L + ns - 2) / (ns - 1) - 1);
-    if (sl < sl0) continue;
-    double cost = 0;
-    for (int b = 0; b < nb; ++b) cost += 2.0 * (9.2 + Nc * std::min(ns, std::max(1, (S + L - b * v + sl - 1) / sl)));
-    if (cost < p.cost) { p.cost = cost; p.nseg = ns; p.seglen = sl; p.V = v; p.nblk = nb; p.ok = true; }
-  }
-  return p;
-}
-// the 8192-point plan's cost in the same units (one transform pair + lag search per block ~ 8.5 steps)
-inline double xc_plan_cost(const XcSegPlan& p, int L, int Pz, int Nc) {
-  const int S = (Pz - 1) / 2;
-  double cost = 0;
-  for (int b = 0; b < p.nblk; ++b)
-    cost += 8.5 + Nc * std::min(p.nseg, std::max(1, (S + L - b * p.V + p.seglen - 1) / std::max(1, p.seglen)));
-  return cost;
-}
-
-// Work items {later event c, first pair of a unit}: `group` units are walked together, `ctile` later events
-// at a time -- the workgroups of one later event (one per unit of the group) share its block spectra in L2,
-// those of one unit (one per later event of the tile and lag block) its pair spectra.  Rows b in
-// [b_begin, b_end] hold the pairs of the caller's range; a unit is listed for c when it holds a row < c.
-inline std::vector<I2> plan_xc_items(int N, int64_t b_begin, int64_t b_end, int unit, int group, int ctile) {
-  std::vector<I2> items;
-  const int npr = (N + 1) / 2;
-  for (int g0 = 0; g0 < npr; g0 += unit * group) {
-    const int64_t g_lo = 2 * (int64_t)g0, g_hi = 2 * (int64_t)(g0 + unit * group) - 1;
-    if (g_hi < b_begin || g_lo > b_end) continue;
-    for (int c0 = (int)std::max<int64_t>(g_lo + 1, 1); c0 < N; c0 += ctile)
-      for (int pr0 = g0; pr0 < std::min(npr, g0 + unit * group); pr0 += unit) {
-        const int64_t r_lo = 2 * (int64_t)pr0, r_hi = 2 * (int64_t)(pr0 + unit) - 1;
-        if (r_hi < b_begin || r_lo > b_end) continue;
-        for (int c = c0; c < std::min(N, c0 + ctile); ++c)
-          if (c > r_lo) items.push_back(I2{c, pr0});
-      }
-  }
-  return items;
-}
-
-// Work items of the 2 x 2 workgroup {later event c (and c + 1 when bit 30 of .y is set), first of TWO pair spectra}:
-// the same walk -- groups of `group` units, `ctile` (even) later events at a time --, the later events taken in
-// twos inside a tile.  A unit is listed for the two when it holds a row below the larger of them.
+// Work items {later event c (and c + 1 when bit 30 of .y is set), first of TWO pair spectra}: `group` units (of two
+// pair spectra) are walked together, `ctile` (even) later events at a time, the later events taken in twos inside a
+// tile -- the workgroups of one later event share its block spectra in L2, those of one unit its pair spectra.  Rows b
+// in [b_begin, b_end] hold the pairs of the caller's range; a unit is listed for the two later events when it holds a
+// row below the larger of them.
 inline std::vector<I2> plan_xc_items22(int N, int64_t b_begin, int64_t b_end, int group, int ctile) {
   std::vector<I2> items;
   const int unit = 2, npr = (N + 1) / 2;

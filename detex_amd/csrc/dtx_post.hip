@@ -8,27 +8,15 @@
 namespace {
 
 constexpr int kPostThreads = 256;
-#ifndef DTX_POST_ITEMS
-#define DTX_POST_ITEMS 64
-#endif
-#ifndef DTX_POST_NT
-#define DTX_POST_NT 1
-#endif
-#ifndef DTX_POST_BATCH
-#define DTX_POST_BATCH 4
-#endif
 typedef float fvec4 __attribute__((ext_vector_type(4)));
-constexpr int kPostItems = DTX_POST_ITEMS;   // values per thread -> kPostItems KiB of DS per block
+constexpr int kPostItems = 64;   // values per thread -> kPostItems KiB of DS per block
 
 __device__ inline int hist_bin(float vf) { return dtx_hist_bin_fast(vf); }
 // the float32 images of the float64 edges 1/400 .. 4/400 (dtx_postdev.h: dtx_hist_bin_fast)
 constexpr float kT1 = 0x1.47ae16p-9f, kT2 = 0x1.47ae16p-8f, kT3 = 0x1.eb852p-8f, kT4 = 0x1.47ae16p-7f;
 
-#ifndef DTX_POST_WAVES
-#define DTX_POST_WAVES 8      // waves per SIMD the pass is compiled for (<= 64 registers: 154.7 -> 143.8 us; 7: 148.3)
-#endif
 template <int ITEMS>
-__global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
+__global__ __launch_bounds__(kPostThreads, 8) void ds_post_kernel(
     const float* __restrict__ ds, int64_t P, int64_t ldp, int D, uint32_t* __restrict__ hist,
     float* __restrict__ maxds, const float* __restrict__ thr, uint64_t* __restrict__ cand_key,
     float* __restrict__ cand_val, uint32_t cand_cap, uint32_t* __restrict__ ncand,
@@ -73,7 +61,7 @@ __global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
   unsigned wc[4] = {0u, 0u, 0u, 0u};      // wave-wide cumulative counts of the fast path (uniform)
   // 16-byte loads when the row is 16-byte aligned (ldp % 4 == 0 and an aligned base)
   const bool vec = ((ldp & 3) == 0) && ((reinterpret_cast<uintptr_t>(ds) & 15) == 0);
-  constexpr int kBatch = DTX_POST_BATCH;      // 16-byte loads in flight per thread
+  constexpr int kBatch = 4;      // 16-byte loads in flight per thread
   static_assert(ITEMS / 4 % kBatch == 0, "whole batches");
   const unsigned t4bits = __float_as_uint(kT4);
   const int64_t base = (int64_t)blockIdx.x * (kPostThreads * ITEMS);
@@ -86,8 +74,7 @@ __global__ __launch_bounds__(kPostThreads, DTX_POST_WAVES) void ds_post_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) vb[u][j] = 0.f;
     if (vec && p4 + 3 < P) {
-      const fvec4 q = DTX_POST_NT ? __builtin_nontemporal_load(reinterpret_cast<const fvec4*>(row + p4))
-                                  : *reinterpret_cast<const fvec4*>(row + p4);
+      const fvec4 q = __builtin_nontemporal_load(reinterpret_cast<const fvec4*>(row + p4));
       vb[u][0] = q.x; vb[u][1] = q.y; vb[u][2] = q.z; vb[u][3] = q.w;
     } else {
       whole = false;
@@ -307,6 +294,48 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int n
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
   return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, D, po);
+}
+
+// The small results of a scan handed to the host by a KERNEL on the context's stream: 16-byte stores into
+// page-locked host memory (device-accessible under unified addressing).  A pipelined host copied them back on a
+// side stream behind an event; with several scans in flight those copies and their barrier packets landed in the
+// hardware queue in front of the next scan's first kernel (round 5: ~80 us idle behind every post pass,
+// profiles/p7_e2e_timeline.txt).  words4[0 .. head + min(count, cmax)) and keys[0 .. min(count, cmax)) go out, where
+// count = words4[cnt_word] (the candidate counter inside the packed results).
+namespace {
+__global__ __launch_bounds__(256) void export_results_kernel(const uint32_t* __restrict__ words, uint32_t* __restrict__ hwords,
+                                                             int64_t head, int64_t cmax, int64_t cnt_word,
+                                                             const uint64_t* __restrict__ keys, uint64_t* __restrict__ hkeys) {
+  const int64_t n = min((int64_t)words[cnt_word], cmax);
+  const int64_t nw = head + n;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+  // (16-byte pieces where both sides allow it: torch's allocations are 256-byte aligned, the tail goes word by word)
+  const int64_t nw4 = nw / 4;
+  const uint4* s4 = reinterpret_cast<const uint4*>(words);
+  uint4* d4 = reinterpret_cast<uint4*>(hwords);
+  for (int64_t i = t; i < nw4; i += nt) d4[i] = s4[i];
+  for (int64_t i = 4 * nw4 + t; i < nw; i += nt) hwords[i] = words[i];
+  const int64_t nk2 = n / 2;
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+  uint4* h4 = reinterpret_cast<uint4*>(hkeys);
+  for (int64_t i = t; i < nk2; i += nt) h4[i] = k4[i];
+  for (int64_t i = 2 * nk2 + t; i < n; i += nt) hkeys[i] = keys[i];
+}
+}  // namespace
+
+int dtx_export_results(dtx_ctx* ctx, const uint32_t* words_dev, uint32_t* words_host, int64_t head_words,
+                       int64_t cand_max, int64_t cnt_word, const uint64_t* keys_dev, uint64_t* keys_host) {
+  if (!ctx) return DTX_E_ARG;
+  if (!words_dev || !words_host || !keys_dev || !keys_host || head_words <= 0 || cand_max < 0 || cnt_word < 0 ||
+      cnt_word >= head_words)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_export_results: bad argument");
+  if (((uintptr_t)words_dev | (uintptr_t)words_host | (uintptr_t)keys_dev | (uintptr_t)keys_host) & 15)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_export_results: buffers must be 16-byte aligned");
+  DtxDeviceGuard g(ctx->device);
+  hipLaunchKernelGGL(export_results_kernel, dim3(16), dim3(256), 0, ctx->stream, words_dev, words_host, head_words,
+                     cand_max, cnt_word, keys_dev, keys_host);
+  DTX_HIP(ctx, hipGetLastError());
+  return DTX_OK;
 }
 
 }  // extern "C"

@@ -20,10 +20,7 @@
 namespace {
 
 constexpr int kMaxSec = 8;    // biquad sections (bandpass corners <= 8)
-#ifndef DTX_PP_PB
-#define DTX_PP_PB 256
-#endif
-constexpr int kPB = DTX_PP_PB;   // samples per block (short blocks: more workgroups in flight)
+constexpr int kPB = 256;   // samples per block (short blocks: more workgroups in flight)
 constexpr int kLR = kPB / 64;     // samples per lane of a block in pp_local_kernel
 constexpr int kTrendSlices = 16;
 
@@ -114,18 +111,6 @@ __device__ inline double pp_input(const float* raw, const double* mid, const dou
 //   RUN = true : start from the true entry state, write the output (pass 3);
 //                LAST selects the float32 result: multiplexed x[Nc t + c] (dec <= 1) or
 //                the series' own plane keeping every dec-th sample (dtx_decimate)
-#ifndef DTX_PP_LOADS
-#define DTX_PP_LOADS 16
-#endif
-#ifndef DTX_PP_SCAN
-#define DTX_PP_SCAN 1        // entry states by pp_scan_kernel (0: pp_chain_kernel)
-#endif
-#ifndef DTX_PP_TILED_ABLATE
-#define DTX_PP_TILED_ABLATE 0
-#endif
-#ifndef DTX_PP_LOCAL
-#define DTX_PP_LOCAL 1       // pass 1 as dot products with the impulse table (pp_local_kernel; 0: the tiled filter run)
-#endif
 constexpr int kSub = 32;
 // NSEC (the section count) is a template parameter and the coefficients come from device memory into per-thread
 // registers: as a by-value struct of eight-section arrays behind a switch they lived in scalar registers that did
@@ -178,11 +163,7 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
       const int b = q * (256 / kSub) + tid / kSub, j = tid % kSub;
       const int64_t i = min((int64_t)(g0 + b) * kPB + jj + j, T - 1);
       const int64_t t = rev ? (T - 1 - i) : i;
-#if DTX_PP_TILED_ABLATE & 1      // timing only: no loads
-      pre[q] = (tin_t)i;
-#else
       if constexpr (FIRST) pre[q] = r[t]; else pre[q] = m[t];
-#endif
     }
   };
   fetch(0);
@@ -200,7 +181,7 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
     }
     if (jj + kSub < kPB) fetch(jj + kSub);
     __syncthreads();
-    if (valid && !(DTX_PP_TILED_ABLATE & 2)) {      // (2: timing only, no filter run)
+    if (valid) {
       const int64_t i0 = (int64_t)g * kPB + jj;
 #pragma unroll 4
       for (int j = 0; j < kSub; ++j) {
@@ -225,7 +206,7 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
         const int b = idx / kSub, j = idx - b * kSub;
         const int64_t i = (int64_t)(g0 + b) * kPB + jj + j;
         const double yv = tile[b][j];
-        if (g0 + b < nblk && i < T && !((DTX_PP_TILED_ABLATE & 4) && yv != 1.2345)) {      // (4: timing only, no stores)
+        if (g0 + b < nblk && i < T) {
           const int64_t t = rev ? (T - 1 - i) : i;
           if (LAST) {
             if (dec <= 1) out_mp[(int64_t)chunk * mp_stride + t * Nc + c] = (float)yv;
@@ -708,7 +689,6 @@ int pp_plan(dtx_ctx* ctx, const char* who, const double* sos, int nsec, int nser
 // odd one)
 static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int nser, int nblk, int seg, int ns) {
   const dim3 cgrid((unsigned)nser);
-#if DTX_PP_SCAN
   const double* Mp = Mdev + 2 * ns * ns;
   switch (ns) {
 #define DTX_SCAN_CASE(NS) case NS: hipLaunchKernelGGL(pp_scan_kernel<NS>, cgrid, dim3(kScanT), 0, ctx->stream, fstate, Mp, nblk); return
@@ -717,7 +697,6 @@ static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int n
 #undef DTX_SCAN_CASE
     default: break;
   }
-#endif
   hipLaunchKernelGGL(pp_chain_kernel, cgrid, dim3(64), 0, ctx->stream, fstate, Mdev, Mdev + ns * ns, nblk, seg, ns);
 }
 
@@ -914,7 +893,7 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
 
   if (detrend) {
     DTX_HIP(ctx, hipMemsetAsync(trend, 0, (size_t)nser * 2 * sizeof(double), ctx->stream));
-    if (nsec == 0 || !DTX_PP_LOCAL) {          // (with a filter the trend sums come out of pass 1)
+    if (nsec == 0 || !1) {          // (with a filter the trend sums come out of pass 1)
       hipLaunchKernelGGL(pp_trend_kernel, dim3(kTrendSlices, (unsigned)nser), dim3(256), 0,
                          ctx->stream, raw_dev, T, ser_stride, trend);
       DTX_HIP(ctx, hipGetLastError());
@@ -950,24 +929,14 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   const double* nod = nullptr;
   const float* nof = nullptr;
   // forward pass: raw - trend -> (mid | output)
-  if (DTX_PP_LOCAL) {
-    if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, trend))) return rc;
-  } else {
-    launch_tiled<true, false, false>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false,
-                                     (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
-  }
+  if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, trend))) return rc;
   auto chain = [&]() { launch_chain(ctx, fstate, (const double*)Mdev, nser, nblk, seg, ns); };
   chain();
   if (zerophase) {
     launch_tiled<true, true, false>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false, mid,
                                     (float*)nullptr, Nc, mp_stride, 0);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
-    if (DTX_PP_LOCAL) {
-      if ((rc = launch_local_back(ctx, mid, T, pl))) return rc;
-    } else {
-      launch_tiled<false, false, false>(ctx, grid, pl, nof, ser_stride, (const double*)mid, nod, T, true,
-                                        (double*)nullptr, (float*)nullptr, Nc, mp_stride, 0);
-    }
+    if ((rc = launch_local_back(ctx, mid, T, pl))) return rc;
     chain();
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
     launch_tiled<false, true, true>(ctx, grid, pl, nof, ser_stride, (const double*)mid, nod, T, true,
@@ -995,12 +964,7 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   if ((rc = pp_plan(ctx, "dtx_decimate", sos, nsec, nser, T, false, &pl))) return rc;
   dim3 grid((unsigned)((pl.nblk + 255) / 256), (unsigned)nser);
   const double* nod = nullptr;
-  if (DTX_PP_LOCAL) {
-    if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, nullptr))) return rc;
-  } else {
-    launch_tiled<true, false, false>(ctx, grid, pl, raw_dev, ser_stride, nod, nod, T, false, (double*)nullptr,
-                                     (float*)nullptr, 1, out_stride, 0);
-  }
+  if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, nullptr))) return rc;
   launch_chain(ctx, pl.fstate, (const double*)pl.Mdev, nser, pl.nblk, pl.seg, pl.ns);
   // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
   launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_stride, nod, nod, T, false, (double*)nullptr, out_dev, 1,

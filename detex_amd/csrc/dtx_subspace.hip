@@ -23,12 +23,6 @@
 
 using namespace dtx;
 
-#ifndef DTX_USE_GLDS
-#define DTX_USE_GLDS 1
-#endif
-#ifndef DTX_USE_TAIL
-#define DTX_USE_TAIL 1
-#endif
 
 namespace {
 
@@ -390,7 +384,7 @@ __device__ __forceinline__ void ds_mfma_tile(const DsArgs& a, int chunk, int64_t
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // odd RM: LDS row stride == KT == global row stride -> LDS-DMA staging
-  hankel_mainloop<RM, TN, (RM & 1) != 0 && DTX_USE_GLDS, TAIL>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
+  hankel_mainloop<RM, TN, (RM & 1) != 0, TAIL>(acc, a.ut, KT, a.Lp, a.xp + (int64_t)chunk * a.Nc * a.Tpad + p0, a.Tpad,
                           a.Nc, 0, a.Lp, lds);
 
   ds_epilogue<RM, TN>(acc, a, chunk, p0, lds);
@@ -504,7 +498,7 @@ int launch_tile(dtx_ctx* ctx, const DsArgs& a, int nchunk, bool tail) {
 // rows: real rows of the K-tile; the last row block takes the half-cost 4x4 path
 // when it holds at most 8 of them
 int launch_tile_rm(dtx_ctx* ctx, int rm, int rows, const DsArgs& a_, int nchunk) {
-  const bool tail_ = DTX_USE_TAIL && ((rows - 1) % 16) < 8;
+  const bool tail_ = ((rows - 1) % 16) < 8;
   const DsArgs& a = a_;
   switch (rm) {
     case 1: return launch_tile<1>(ctx, a, nchunk, tail_);
@@ -723,7 +717,6 @@ static int basis_upload_begin(dtx_ctx* ctx, const float* U, const int32_t* det_o
   if ((rc = dtx_reserve(ctx, ctx->U_buf, (size_t)Ktot * n * sizeof(float)))) return rc;
   if ((rc = dtx_reserve(ctx, ctx->srow_all, ((size_t)Ktot + 1) * sizeof(float)))) return rc;   // + cmax
   float* Ud = (float*)ctx->U_buf.p;
-  float* srow_all = (float*)ctx->srow_all.p;
   hipPointerAttribute_t at;
   const bool on_device = hipPointerGetAttributes(&at, U) == hipSuccess &&
                          at.type == hipMemoryTypeDevice;

@@ -179,9 +179,6 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
     s = 0.0;
     for (int q = tid; q < npe; q += kTT) s += (double)pe[q];
     const double shift = block_sum(s, red) / npe;       // std is shift-invariant: kills the cancellation
-#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 1      // timing-only builds: how far the task runs
-    return shift;
-#endif
     // prefix sums of y = pe - shift and y^2: per-thread segment sums, scanned by thread 0 .. 511
     const int seglen = (npe + kTT - 1) / kTT;
     const int q0 = min(tid * seglen, npe), q1 = min(q0 + seglen, npe);
@@ -230,9 +227,6 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
       }
       o1 = b1; o2 = b2;
     };
-#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 2
-    return seg1[tid] + seg2[tid];
-#endif
     const int wper = (count + kTT - 1) / kTT;
     const int i0 = min(tid * wper, count), i1 = min(i0 + wper, count);
     if (wper <= kRegW) {
@@ -270,12 +264,6 @@ __device__ inline double trig_noise(const TrigArgs& a, const float* xc, int64_t 
           }
         }
       }
-#if defined(DTX_TRIG_NOISE_STOP) && DTX_TRIG_NOISE_STOP == 3
-      { unsigned acc = 0u;
-#pragma unroll
-        for (int j = 0; j < kRegW; ++j) acc ^= r[j];
-        return (double)acc; }
-#endif
       if (count & 1) {
         noise = (double)select_rank_regs(r, count / 2, hist, sh);
       } else {                         // the mean of the two middle values
@@ -328,9 +316,6 @@ __global__ __launch_bounds__(kTT) void trig_stats_kernel(const TrigArgs a) {
   // the training events, 2 the pre-event noise -- three workgroups per trigger instead of one (a
   // station-day has tens of triggers: one workgroup each left most of the chip idle for 0.5 ms)
   const int task = blockIdx.y;
-#ifdef DTX_TRIG_ONLY_TASK            // timing-only builds: one of the three tasks alone
-  if (task != DTX_TRIG_ONLY_TASK) return;
-#endif
   for (int t = blockIdx.x; t < a.ntrig; t += gridDim.x) {
     const int32_t* tr = a.trig + 5 * (int64_t)t;
     const int chunk = tr[0], det = tr[1], p = tr[2], sta_lo = tr[3], lta_lo = tr[4];

@@ -24,9 +24,6 @@
 
 using namespace dtx;
 
-#ifndef DTX_USE_GLDS
-#define DTX_USE_GLDS 1
-#endif
 
 namespace {
 
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel(const XcArgs a) {
     for (int t = 0; t < TN; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // RM == 13: the 208-wide event tile is copied whole -> LDS-DMA staging
-  hankel_mainloop<RM, TN, RM == kRmMax && DTX_USE_GLDS>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
+  hankel_mainloop<RM, TN, RM == kRmMax>(acc, a.xt + (int64_t)kt * a.Nc * a.Lp * kKtMax, kKtMax, a.Lp,
                           a.z + (int64_t)c * a.Nc * a.Tz + p0, a.Tz, a.Nc, jlo, jhi, lds);
 
   xc_epilogue<RM, TN>(acc, a, c, kt, p0);
@@ -250,15 +247,6 @@ __global__ __launch_bounds__(kThreads, 2) void xc_mfma_kernel_s(const XcArgs a) 
 }
 
 static constexpr size_t kFin2PrefixBudget = (size_t)4 << 30;   // bytes of float64 prefix sums xc_finish2 may carve
-#ifndef DTX_XCFIN2
-#define DTX_XCFIN2 1        // 1: xc_finish2_kernel for Nc <= 64, 0: xc_finish_kernel always
-#endif
-#ifndef DTX_XCFIN_ABLATE
-#define DTX_XCFIN_ABLATE 0   // timing only: 1 no x_c loads, 2 no LDS reads of x_b (interior iterations)
-#endif
-#ifndef DTX_XCFIN_BATCH
-#define DTX_XCFIN_BATCH 4
-#endif
 // One wave per pair: float64 re-evaluation of the winning lag and its two
 // neighbours, reference scrub, cosine sub-sample fit, outputs.
 __global__ __launch_bounds__(256) void xc_finish_kernel(
@@ -342,29 +330,21 @@ __global__ __launch_bounds__(256) void xc_finish_kernel(
       if (live) {
         const int jend = min(J0 + kCh, n + Nc);
         for (int jb = J0; jb < jend; jb += 64) {        // jb: the iteration's first index (uniform)
-          constexpr int kB = DTX_XCFIN_BATCH;           // interior iterations taken together
+          constexpr int kB = 4;           // interior iterations taken together
           if (kB > 1 && jb + 64 * kB <= jend && jb - Nc >= 0 && jb + 64 * kB - 1 + Nc < n && jb + sh1 >= 0 &&
               jb + 64 * kB - 1 + sh1 < n) {
             // kB interior iterations: their loads of x_c first (all in flight), then the same sums in
             // the same order
             float vb[kB];
 #pragma unroll
-#if DTX_XCFIN_ABLATE & 1
-            for (int k = 0; k < kB; ++k) vb[k] = 0.5f;
-#else
             for (int k = 0; k < kB; ++k) vb[k] = x2[jb + 64 * k + lane + sh1];
-#endif
 #pragma unroll
             for (int k = 0; k < kB; ++k) {
               const int i = jb + 64 * k + lane - J0 + Nc;
               const double v = (double)vb[k];
-#if DTX_XCFIN_ABLATE & 2
-              dot[0] += 0.25 * v; dot[1] += 0.5 * v; dot[2] += 0.75 * v;
-#else
               dot[0] += (double)x1s[i + Nc] * v;
               dot[1] += (double)x1s[i] * v;
               dot[2] += (double)x1s[i - Nc] * v;
-#endif
               swc += v;
               sqc += v * v;
             }
@@ -498,13 +478,7 @@ __global__ __launch_bounds__(256) void xc_prefix_kernel(const float* __restrict_
 //     odd number of 16-byte units, which is what keeps ds_read_b128's lane groups on distinct banks
 //     (MI355X_MICROARCH.md, LDS; 8 doubles apart = 64 bytes would be a 4-way conflict).  What is left is the
 //     stream of the later events from L2: 156 KB per pair, 0.31 TB per launch at configs[2] = 14 TB/s.
-#ifndef DTX_XCFIN_WINDOW
-#define DTX_XCFIN_WINDOW 1
-#endif
-#ifndef DTX_XCFIN_E
-#define DTX_XCFIN_E 6          // configs[2], scripts/ab_xcfin.sh: 6 -> 21.7 ms, 10 -> 25.2, 14 -> 21.9, 18 -> 22.1; every 64th sample: 28.3
-#endif
-constexpr int kFinE = DTX_XCFIN_E;   // samples per lane and step of the window form (2 x an odd number)
+constexpr int kFinE = 6;   // samples per lane and step of the window form (2 x an odd number)
 constexpr int kFinStep = 64 * kFinE; // samples per wave and step
 constexpr int kFinCh = 4 * kFinStep; // x_b samples per staged chunk (2560)
 constexpr int kFinPad = 64;
@@ -831,7 +805,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
   // the second finishing kernel (float64 image of x_b, prefix sums of EVERY event: 16 (n + 1) bytes each --
   // 1.25 GB at configs[2]).  Past kFin2PrefixBudget the first finishing kernel (no prefix workspace) takes
   // over: 20 000 events would otherwise ask for 12 GB per context.
-  const bool fin2 = DTX_XCFIN2 && Nc <= kFinPad &&
+  const bool fin2 = Nc <= kFinPad &&
                     (size_t)2 * N * ((size_t)n + 1) * sizeof(double) <= kFin2PrefixBudget;
   const size_t o_ps = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
   const size_t o_pq = carve(fin2 ? (size_t)N * (n + 1) * sizeof(double) : 0);
@@ -966,7 +940,7 @@ int dtx_xcorr_allpairs(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, 
                          (const double*)essd, (const double*)esq, (const double*)ps, (const double*)pq, N, n,
                          Nc, S, Pz, trunc, pair_begin, pair_end, cc_dev, lag_dev, subsamp_dev, T);
     };
-    switch (DTX_XCFIN_WINDOW ? Nc : 0) {              // (the window form: channel count at compile time)
+    switch (Nc) {              // (the window form: channel count at compile time)
       case 1: fin(std::integral_constant<int, 1>{}); break;
       case 2: fin(std::integral_constant<int, 2>{}); break;
       case 3: fin(std::integral_constant<int, 3>{}); break;

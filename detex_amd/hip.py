@@ -335,6 +335,30 @@ class HipContext(object):
         as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
         whatever was enqueued on the context's stream after the scan (the next station's scan)."""
         main = self._stream
+        if pack is not None:
+            # packed results: written into page-locked host memory by a kernel on the context's own stream
+            # (dtx_export_results) -- no second stream, no copy engine, no event between streams: with several scans in
+            # flight the side stream's copies and their barrier packets sat in the hardware queue in front of the next
+            # scan's first kernel (~80 us idle behind every post pass, profiles/p7_e2e_timeline.txt)
+            nf = min(int(cand_cap), int(fast))
+            nh, nm = hist.numel(), maxds.numel()
+            hp = torch.empty((nh + 1 + nm + nf,), dtype=torch.int32, pin_memory=True)
+            hk = torch.empty((nf,), dtype=torch.int64, pin_memory=True)
+            self._ck(self.lib.dtx_export_results(self.h, _ptr(pack), hp.data_ptr(), nh + 1 + nm, nf, nh,
+                                                 _ptr(key), hk.data_ptr()), 'dtx_export_results')
+            done = torch.cuda.Event()
+            done.record(main)
+            # (the pinned buffers are written by a kernel torch's host allocator knows nothing about: the last few stay
+            # referenced here, so that a fetch() nobody calls cannot hand one back while its kernel is still queued)
+            keep = getattr(self, '_export_keep', None)
+            if keep is None:
+                import collections
+                keep = self._export_keep = collections.deque(maxlen=16)
+            keep.append((hp, hk, pack, key))
+            host = {'key': hk, 'hist': hp[:nh].view(hist.shape), 'cnt': hp[nh:nh + 1],
+                    'maxds': hp[nh + 1:nh + 1 + nm].view(torch.float32).view(maxds.shape),
+                    'val': hp[nh + 1 + nm:].view(torch.float32)}
+            return self._fetcher(done, host, hist, maxds, thr, key, val, cnt, cand_cap)
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(self.device)
         side = self._side
@@ -372,7 +396,9 @@ class HipContext(object):
                     t.record_stream(side)
             done = torch.cuda.Event()
             done.record(side)
+        return self._fetcher(done, host, hist, maxds, thr, key, val, cnt, cand_cap)
 
+    def _fetcher(self, done, host, hist, maxds, thr, key, val, cnt, cand_cap):
         def fetch():
             done.synchronize()
             res = dict(hist=host.get('hist', hist), maxds=host.get('maxds', maxds), cand=None, ncand=0)
@@ -492,10 +518,7 @@ class HipContext(object):
 
     def trigger_stream(self):
         """The stream the trigger-time kernel runs on when asked to run beside the scans
-        (trigger_stats_async): created and registered with the library on first use.
-        DETEX_AMD_TRIG_STREAM=0: none (everything on the context's stream)."""
-        if os.environ.get('DETEX_AMD_TRIG_STREAM', '1') == '0':
-            return None
+        (trigger_stats_async): created and registered with the library on first use."""
         if getattr(self, '_trig', None) is None:
             self._trig = torch.cuda.Stream(self.device)
         return self._trig
@@ -513,7 +536,7 @@ class HipContext(object):
         the stream's tail now); `behind` is the context whose scan is queued NEXT: the kernel then also waits for
         that scan KERNEL to end and runs beside its post pass and the following preparation (small kernels that
         leave room on the CUs) instead of beside a scan kernel, whose workgroups it would keep off every CU it
-        occupies (DETEX_AMD_TRIG_BEHIND=0: beside the scan, as in the first version)."""
+        occupies."""
         side = self.trigger_stream()
         trig = np.ascontiguousarray(trig, dtype=np.int32).reshape(-1, 5)
         if side is None or len(trig) == 0:
@@ -529,7 +552,7 @@ class HipContext(object):
             after = torch.cuda.Event()
             after.record(self._stream)
         side.wait_event(after)
-        if behind is not None and os.environ.get('DETEX_AMD_TRIG_BEHIND', '1') != '0':
+        if behind is not None:
             behind.wait_scan_kernel(side)
         rc0 = self.lib.dtx_ctx_set_trigger_stream(self.h, C.c_void_p(side.cuda_stream))
         self._ck(rc0, 'dtx_ctx_set_trigger_stream')

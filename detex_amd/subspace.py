@@ -272,7 +272,7 @@ class _StationUploader(object):
                     for c in range(Nc):
                         dst[c, off:off + b - a].copy_(pinned[c, a:b], non_blocking=True)
             xdev = None
-            if os.environ.get('DETEX_AMD_MUX_EARLY', '1') != '0' and not getattr(fetcher, 'raw', False):
+            if not getattr(fetcher, 'raw', False):
                 # already filtered planes: the multiplexed stream the scan takes (construct.py:977-978) is made
                 # HERE, behind the upload on the copy stream -- under the previous unit's scan kernel -- instead
                 # of in front of this unit's scan on the station's stream (45 us per station-day)
@@ -1122,26 +1122,9 @@ class SubSpace(object):
             for i in idx:
                 days.setdefault(i // per, []).append(i)
             units += [(sta, days[d]) for d in sorted(days)]
-        # Ramp: nothing hides the FIRST unit's upload (a day is 104 MB: ~3 ms before the first kernel can start) nor
-        # the LAST unit's host half (picks, trigger-time kernel, rows).  A quarter of the first unit goes ahead as a
-        # unit of its own and the last quarter of the last one comes behind as one: both ends of the pipeline are
-        # short units (the tables do not depend on the cut).  ~13 ms of fixed cost per call was a third of an
-        # 8-station-day call.
-        # (OFF by default since the call's first upload goes out ahead of the banks -- SubSpace.detex --: with that in
-        # place the extra units cost the host more than they hide, 4.80 / 4.87 / 4.77 ms per station-day without against
-        # 4.84 / 4.88 / 4.94 with, profiles/p6_ramp_e2e.txt)
-        ramp = os.environ.get('DETEX_AMD_RAMP', '0')            # '1' both ends, 'head' / 'tail' one of them, '0' none
-        if ramp != '0' and units:
-            def chunks_of(u):
-                return list(range(len(bounds[u[0]]))) if u[1] is None else [int(i) for i in u[1]]
-            head = chunks_of(units[0])
-            if ramp in ('1', 'head') and banks[units[0][0]][0] and len(head) >= 8:
-                k = max(2, len(head) // 4)
-                units[0:1] = [(units[0][0], head[:k]), (units[0][0], head[k:])]
-            tail = chunks_of(units[-1])
-            if ramp in ('1', 'tail') and banks[units[-1][0]][0] and len(tail) >= 8:
-                k = max(2, len(tail) // 4)
-                units[-1:] = [(units[-1][0], tail[:-k]), (units[-1][0], tail[-k:])]
+        # (Short units at both ends of the pipeline -- a quarter of the first unit ahead, the last quarter of the last one
+        # behind -- were built in round 4 and measured a loss once the call's first upload went out ahead of the banks:
+        # 4.80 / 4.87 / 4.77 ms per station-day without against 4.84 / 4.88 / 4.94 with, profiles/p6_ramp_e2e.txt; removed.)
         return units
 
     def _adopt_sent_banks(self, stations, banks, sent):

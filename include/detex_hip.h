@@ -159,6 +159,15 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
                 const float* thr_dev, uint64_t* cand_key_dev,
                 float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* The small results of a scan handed to the host by a kernel on the context's stream (no copy engine, no second
+ * stream): words_dev = a caller's packed 4-byte results [head_words | candidate values ...] whose word `cnt_word`
+ * (< head_words) is the candidate counter, keys_dev = the candidate keys; words_host / keys_host = page-locked host
+ * memory (hipHostMalloc: device-accessible).  Copies words[0 .. head_words + min(count, cand_max)) and
+ * keys[0 .. min(count, cand_max)); all four pointers 16-byte aligned.  The host reads them after an event recorded
+ * behind this call.  No reference counterpart (its arrays never leave the host).  Asynchronous. */
+int dtx_export_results(dtx_ctx* ctx, const uint32_t* words_dev, uint32_t* words_host, int64_t head_words,
+                       int64_t cand_max, int64_t cnt_word, const uint64_t* keys_dev, uint64_t* keys_host);
+
 /* dtx_subspace_ds followed by dtx_ds_post in one call (same arguments, same results).  The
  * reference does exactly this per chunk (detect.py:259-281, 178-181, 410): detection statistic,
  * then its histogram, its maximum and the samples at or above the threshold.

@@ -2,7 +2,7 @@
 """Copy the judged summaries of gpurun_out/prof_<tag>/ (scripts/profile_xc.sh) into profiles/:
    python scripts/summarize_xc.py <tag>
 Writes profiles/<tag>_xcorr_kernel_stats.csv and profiles/<tag>_xcorr_pmc.json (mean per launch of
-every counter for the lag-search kernel (xc_fft22_kernel; xc_fft_kernel when DETEX_AMD_XC22=0) and xc_finish_kernel; FETCH_SIZE doubled per the gfx950 note of
+every counter for the lag-search kernel (xc_fft22_kernel / xc_fft12_kernel) and xc_finish_kernel; FETCH_SIZE doubled per the gfx950 note of
 MI355X_MICROARCH.md)."""
 import collections
 import csv

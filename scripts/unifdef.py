@@ -3,7 +3,10 @@
 line (the shipped defaults of closed timing-ablation / variant questions), and drop those macros' `#ifndef X /
 #define X v / #endif` default blocks.  Conditionals that mention any other identifier stay as they are.
 
-usage: unifdef.py file MACRO=VALUE [MACRO=VALUE ...]      (rewrites the file in place)
+usage: unifdef.py file MACRO=VALUE|undef [...]      (rewrites the file in place)
+
+MACRO=undef: the macro is known to be undefined (`#ifdef` false, `#ifndef` true).  Uses of a resolved macro in CODE
+(outside comments) are replaced by its value, so that its `#define` can go.
 
 Round 6: used once to prune detex_amd/csrc (VERDICT r5 "variant debris"); kept so the step can be repeated."""
 import re
@@ -16,19 +19,69 @@ def evaluate(expr, macros):
     """None if the expression mentions anything but the known macros; else its truth value."""
     expr = re.sub(r'//.*$', '', expr)
     expr = re.sub(r'/\*.*?\*/', '', expr).strip()
-    expr = re.sub(r'defined\s*\(\s*([A-Za-z_][A-Za-z0-9_]*)\s*\)|defined\s+([A-Za-z_][A-Za-z0-9_]*)',
-                  lambda m: ('1' if (m.group(1) or m.group(2)) in macros else '@%s@' % (m.group(1) or m.group(2))), expr)
+    def _defined(m):
+        name = m.group(1) or m.group(2)
+        if name not in macros:
+            return '@%s@' % name
+        return '0' if macros[name] is None else '1'
+    expr = re.sub(r'defined\s*\(\s*([A-Za-z_][A-Za-z0-9_]*)\s*\)|defined\s+([A-Za-z_][A-Za-z0-9_]*)', _defined, expr)
     names = set(IDENT.findall(expr.replace('@', ' ')))
     if '@' in expr or not names <= set(macros):
         return None
-    py = IDENT.sub(lambda m: str(macros[m.group(0)]), expr)
+    py = IDENT.sub(lambda m: str(macros[m.group(0)] or 0), expr)      # (an undefined macro is 0 in #if)
     py = py.replace('&&', ' and ').replace('||', ' or ')
     py = re.sub(r'!(?!=)', ' not ', py)
     return bool(eval(py, {'__builtins__': {}}))          # noqa: S307 -- integers and operators only
 
 
+def substitute(line, macros, state):
+    """Replace resolved macros by their values in the code part of a line (comments untouched).
+    state['block']: inside a /* */ comment that began on an earlier line."""
+    res, i, n = [], 0, len(line)
+    code = []
+
+    def flush():
+        if code:
+            txt = ''.join(code)
+            txt = IDENT.sub(lambda m: str(macros[m.group(0)]) if macros.get(m.group(0)) is not None and m.group(0) in macros
+                            else m.group(0), txt)
+            res.append(txt)
+            del code[:]
+    while i < n:
+        if state['block']:
+            j = line.find('*/', i)
+            if j < 0:
+                res.append(line[i:])
+                return ''.join(res)
+            res.append(line[i:j + 2])
+            i = j + 2
+            state['block'] = False
+        elif line.startswith('//', i):
+            flush()
+            res.append(line[i:])
+            return ''.join(res)
+        elif line.startswith('/*', i):
+            flush()
+            state['block'] = True
+            res.append('/*')
+            i += 2
+        elif line[i] == '"':
+            j = i + 1
+            while j < n and line[j] != '"':
+                j += 2 if line[j] == '\\' else 1
+            flush()
+            res.append(line[i:j + 1])
+            i = j + 1
+        else:
+            code.append(line[i])
+            i += 1
+    flush()
+    return ''.join(res)
+
+
 def process(lines, macros):
     out = []
+    cstate = {'block': False}
     # stack entries: [kind, state]; kind 'keep' (unresolved: directives stay), 'res' (resolved: directives go)
     # state for 'res': 'taking' (this branch is emitted), 'done' (a branch was taken), 'waiting' (none yet)
     stack = []
@@ -42,12 +95,16 @@ def process(lines, macros):
         m = re.match(r'\s*#\s*(ifdef|ifndef|if|elif|else|endif)\b(.*)$', ln.rstrip('\n'))
         if not m:
             if emitting():
-                out.append(ln)
+                if re.match(r'\s*#', ln):
+                    out.append(ln)              # (other directives: #define / #include / #pragma lines stay as they are)
+                else:
+                    out.append(substitute(ln, macros, cstate))
             i += 1
             continue
         d, rest = m.group(1), m.group(2)
         if d in ('if', 'ifdef', 'ifndef'):
-            if d == 'ifndef' and rest.strip().split('//')[0].strip() in macros:
+            if d == 'ifndef' and rest.strip().split('//')[0].strip() in macros and \
+                    macros[rest.strip().split('//')[0].strip()] is not None:
                 # `#ifndef X / #define X ... / #endif` default block (possibly with comment lines): drop it whole
                 j = i + 1
                 while j < len(lines) and not re.match(r'\s*#\s*endif', lines[j]):
@@ -63,7 +120,7 @@ def process(lines, macros):
                 name = rest.strip().split()[0] if rest.strip() else ''
                 v = None
                 if name in macros:
-                    v = (d == 'ifdef')
+                    v = (d == 'ifdef') == (macros[name] is not None)
             if v is None:
                 if emitting():
                     out.append(ln)
@@ -105,7 +162,7 @@ def main():
     macros = {}
     for a in sys.argv[2:]:
         k, v = a.split('=')
-        macros[k] = int(v, 0)
+        macros[k] = None if v == 'undef' else int(v, 0)
     lines = open(path).readlines()
     out = process(lines, macros)
     open(path, 'w').writelines(out)

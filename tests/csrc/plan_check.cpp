@@ -152,45 +152,18 @@ static void check_xc(int N, int L, int Nc) {
   CHECK((int64_t)sp.nseg * sp.seglen >= L && (int64_t)(sp.nseg - 1) * sp.seglen < L);
   CHECK(sp.nblk == (Pz + sp.V - 1) / sp.V && sp.nblk >= 1);
   if (L > kMaxSingle) CHECK(sp.V >= 4 * 512 && sp.nseg >= 2 && sp.nseg <= 16);
-  CHECK(xc_plan_cost(sp, L, Pz, Nc) > 0);
-  {
-    // the 16 384-point plan (opt-in build of the lag search): lag blocks a multiple of 1024 apart, at most 16 lags
-    // per thread, every block's lags valid (N - seglen + 1 of them), the segments cover the event
-    const XcSegPlan16 p = plan_xc_segments16(L, Pz, Nc);
-    if (p.ok) {
-      CHECK(p.V % 1024 == 0 && p.V >= 4 * 1024 && p.V <= 16 * 1024);
-      CHECK(p.nblk == (Pz + p.V - 1) / p.V && p.nblk >= 1);
-      CHECK(p.nseg >= 1 && p.nseg <= 16 && (int64_t)p.nseg * p.seglen >= L);
-      CHECK(p.nseg == 1 || (int64_t)(p.nseg - 1) * p.seglen < L);
-      CHECK(std::min(p.V, Pz) <= 16384 - p.seglen + 1);
-      CHECK(p.cost > 0 && p.cost < 1e9);
-    }
-  }
   const int64_t npairs = (int64_t)N * (N - 1) / 2;
   auto row_of = [&](int64_t idx) {                             // row b of condensed index idx
     int64_t b = 0;
     while ((b + 1) * N - (b + 1) * (b + 2) / 2 <= idx) ++b;
     return b;
   };
-  const int unit = 1, group = 8, ctile = 4;                      // the shipped work list (dtx_xcfft.hip)
+  const int group = 8, ctile = 4;                                // the shipped work list (dtx_xcfft.hip)
   std::vector<std::pair<int64_t, int64_t>> ranges = {{0, npairs}};
   if (npairs > 3) { ranges.push_back({1, npairs / 2}); ranges.push_back({npairs / 2, npairs}); ranges.push_back({npairs - 1, npairs}); }
   for (auto [pb, pe] : ranges) {
     const int64_t bb = row_of(pb), be = row_of(pe - 1);
-    for (int un : {unit, 4}) {
-      std::vector<I2> items = plan_xc_items(N, bb, be, un, group, ctile);
-      std::set<std::pair<int, int>> uniq;
-      const int npr = (N + 1) / 2;
-      for (const I2& it : items) {
-        CHECK(it.x >= 1 && it.x < N && it.y >= 0 && it.y < npr && it.y % un == 0);
-        CHECK(it.x > 2 * it.y);                                 // the unit holds a row < c
-        CHECK(uniq.insert({it.x, it.y}).second);
-      }
-      // coverage: every pair (b, c) of the range has the item of its unit
-      for (int64_t b = bb; b <= be; ++b)
-        for (int c = (int)b + 1; c < N; ++c) CHECK(uniq.count({c, (int)(b / 2 / un * un)}) == 1);
-    }
-    // the 2 x 2 workgroup's list: units of two pair spectra against one or two later events; every
+    // units of two pair spectra against one or two later events; every
     // (later event, unit) of the range exactly once, nothing listed that holds no pair
     for (int ct : {ctile, 2, 6}) {
       std::vector<I2> items = plan_xc_items22(N, bb, be, group, ct);

@@ -358,11 +358,6 @@ def test_stations_in_flight_equal_one_at_a_time(monkeypatch):
     for s in stas:
         for k, v in ss.histSubSpaces[s].items():
             assert np.array_equal(v, hist_p[s][k]), (s, k)
-    # the planes interleaved in front of each station's scan instead of behind its upload on the copy stream
-    monkeypatch.setenv('DETEX_AMD_MUX_EARLY', '0')
-    late = ss.detex(subspaceDB=None, triggerLTATime=5, triggerSTATime=0, estimateMags=True)
-    pd.testing.assert_frame_equal(piped['ss_df'], late['ss_df'])
-    pd.testing.assert_frame_equal(piped['sg_df'], late['sg_df'])
 
 
 def test_stream_contract_non_default_current_stream(workflow):
@@ -472,7 +467,7 @@ def test_classifyEvents_and_utcSaves_on_the_device(workflow, tmp_path, monkeypat
 
 def test_trigger_stream_and_day_units_do_not_change_the_tables(workflow, monkeypatch):
     """The trigger-time kernel beside the next scans on a stream of its own (HipContext.trigger_stats_async)
-    against everything on the context's stream (DETEX_AMD_TRIG_STREAM=0), and the record scanned in day units
+    against everything on the context's stream (no trigger stream handed out), and the record scanned in day units
     (DETEX_AMD_DS_BUDGET_MB=0: two chunks here) against one launch: identical tables, magnitudes included."""
     ss = workflow['ss']
     ss.SVD(selectCriteria=3, selectValue=0.75, threshold=None, useSingles=False)
@@ -483,9 +478,10 @@ def test_trigger_stream_and_day_units_do_not_change_the_tables(workflow, monkeyp
         return df.fillna(-999.0).values.tolist()
     ref = table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True))
     assert SOAK or len(ref) >= 6
-    monkeypatch.setenv('DETEX_AMD_TRIG_STREAM', '0')
-    assert table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True)) == ref
-    monkeypatch.delenv('DETEX_AMD_TRIG_STREAM')
+    from detex_amd.hip import HipContext
+    with monkeypatch.context() as mp:
+        mp.setattr(HipContext, 'trigger_stream', lambda self: None)
+        assert table(ss.detex(subspaceDB=None, useSingles=True, estimateMags=True)) == ref
     monkeypatch.setenv('DETEX_AMD_DS_BUDGET_MB', '0')
     cf = workflow['cf']
     old = cf.conDatDuration

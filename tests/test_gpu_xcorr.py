@@ -246,9 +246,10 @@ def test_long_events_frequency_domain(ctx, Nc, L, N):
 @pytest.mark.parametrize('Nc,L,N', [(3, 3000, 23), (1, 2500, 12), (3, 13000, 9), (2, 7777, 5), (6, 6000, 6), (3, 1024, 2),
                                     (5, 2000, 9), (9, 1024, 8)])
 def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
-    """The frequency-domain lag search has three kernels: the 2 x 2 workgroup (two later events x two pair spectra),
-    the round-3 one (DETEX_AMD_XC22=0) and the half-size workgroup of round 5 (one pair spectrum x two later events,
-    two workgroups per CU: DETEX_AMD_XC12=1; the library picks between it and the 2 x 2 workgroup by the lag blocks' step count).  The same products summed in the same order and the same
+    """The frequency-domain lag search has two kernels: the 2 x 2 workgroup (two later events x two pair spectra,
+    DETEX_AMD_XC=22) and the half-size workgroup (one pair spectrum x two later events, two workgroups per CU:
+    DETEX_AMD_XC=12); the library picks between them by the lag blocks' step count.  (Round 3's kernel, a third
+    bit-identical variant until round 5, was removed in round 6.)  The same products summed in the same order and the same
     transform: identical answers, on the whole matrix and on disjoint pair ranges (odd and even event counts: a
     last later event without a partner, a last pair spectrum with one row)."""
     from detex_amd import synth
@@ -263,12 +264,8 @@ def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
         td[6, : Nc * (L // 3)] = 500.0
     npairs = N * (N - 1) // 2
     res = {}
-    for v in ('1', '0', '12'):
-        if v == '12':                  # the half-size workgroup, two per CU (round 5; the default for most shapes)
-            monkeypatch.delenv('DETEX_AMD_XC22')
-            monkeypatch.setenv('DETEX_AMD_XC12', '1')
-        else:
-            monkeypatch.setenv('DETEX_AMD_XC22', v)
+    for v in ('22', '12'):
+        monkeypatch.setenv('DETEX_AMD_XC', v)
         full = _gpu(ctx, td, Nc)
         cuts = sorted({0, 1, npairs // 3, npairs // 3 + 1, (2 * npairs) // 3, npairs})
         acc = [np.zeros(npairs, np.float32), np.zeros(npairs, np.int32), np.zeros(npairs, np.float32)]
@@ -280,12 +277,9 @@ def test_both_lag_search_kernels(ctx, monkeypatch, Nc, L, N):
         for a, f in zip(acc, full):
             assert np.array_equal(a, f, equal_nan=True)       # (a NaN subsample shift is an answer: _subSamp's arccos, construct.py:397-422)
         res[v] = full
-    for a, b in zip(res['1'], res['0']):
+    for a, b in zip(res['22'], res['12']):
         assert np.array_equal(a, b, equal_nan=True)
-    for a, b in zip(res['1'], res['12']):
-        assert np.array_equal(a, b, equal_nan=True)
-    monkeypatch.delenv('DETEX_AMD_XC12')
-
+    monkeypatch.delenv('DETEX_AMD_XC')
 
 
 @pytest.mark.parametrize('seed', range(16))
@@ -306,12 +300,8 @@ def test_lag_search_random_shapes(ctx, monkeypatch, seed):
     npairs = N * (N - 1) // 2
     cut = int(rs.randint(0, npairs + 1))
     res = {}
-    for v in ('1', '0', '12'):
-        if v == '12':
-            monkeypatch.delenv('DETEX_AMD_XC22')
-            monkeypatch.setenv('DETEX_AMD_XC12', '1')
-        else:
-            monkeypatch.setenv('DETEX_AMD_XC22', v)
+    for v in ('22', '12'):
+        monkeypatch.setenv('DETEX_AMD_XC', v)
         full = _gpu(ctx, td, Nc)
         acc = [np.zeros(npairs, np.float32), np.zeros(npairs, np.int32), np.zeros(npairs, np.float32)]
         for lo, hi in ((0, cut), (cut, npairs)):
@@ -323,12 +313,10 @@ def test_lag_search_random_shapes(ctx, monkeypatch, seed):
         for a, f in zip(acc, full):
             assert np.array_equal(a, f, equal_nan=True)       # (a NaN subsample shift is an answer: _subSamp's arccos, construct.py:397-422)
         res[v] = full
-    for a, b in zip(res['1'], res['0']):
+    for a, b in zip(res['22'], res['12']):
         assert np.array_equal(a, b, equal_nan=True)
-    for a, b in zip(res['1'], res['12']):
-        assert np.array_equal(a, b, equal_nan=True)
-    monkeypatch.delenv('DETEX_AMD_XC12')
-    cc, lag, ss = res['1']
+    monkeypatch.delenv('DETEX_AMD_XC')
+    cc, lag, ss = res['22']
     n = Nc * L
     trunc = n // (2 * Nc) - 1
     pairs = [(b, c) for b in range(N) for c in range(b + 1, N)]

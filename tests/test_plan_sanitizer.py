@@ -34,7 +34,7 @@ def test_library_sources_use_the_sanitized_planners():
     xc = open(os.path.join(csrc, 'dtx_xcfft.hip')).read()
     ctx = open(os.path.join(csrc, 'dtx_ctx.hip')).read()
     assert 'dtxplan::plan_fft_basis(' in fft and 'dtxplan::plan_pp_grid(' in fft
-    assert 'dtxplan::plan_xc_segments(' in xc and 'dtxplan::plan_xc_items(' in xc
+    assert 'dtxplan::plan_xc_segments(' in xc and 'dtxplan::plan_xc_items22(' in xc
     assert 'dtxplan::ring_last_slots(' in ctx and 'dtxplan::check_chunk_table(' in ctx
     plan = open(os.path.join(csrc, 'dtx_plan.h')).read()
     assert 'hip' not in plan.replace('.hip', '').replace('HIP', '').lower().replace('libdetexhip', '')
