@@ -259,10 +259,23 @@ def _sync_copy(ctx):
         torch.cuda.current_stream(dev).synchronize()
 
 
-def _makeDFcclags(eventList, row, ctx):
-    """construct.py:369-394 on the GPU: all pairs b < c of ``eventList`` in one
-    dtx_xcorr_allpairs call.  Returns (DFcc, DFlag, DFsubsamp)."""
+def _fill_workers():
+    """Threads for the host-side copies of createCluster (NumPy releases the GIL inside large copies): the cores
+    this process may use (a rank bound to its GPU's NUMA node: parallel.bind_to_device), at most four."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(4, n))
+
+
+def _xcorr_condensed(eventList, row, ctx):
+    """construct.py:369-394 on the GPU: all pairs b < c of ``eventList`` in one dtx_xcorr_allpairs call.
+    Returns (N, cc, lag, subsamp) as condensed NumPy vectors (pair (b, c), b < c, row-major: the order of the
+    reference's double loop)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     if len(set(len(row.Channels[e]) for e in eventList)) != 1:
         _error('Number of Channels not equal, cannot perform correlation')      # 429-431
     lazy = isinstance(row.MPtd, _LazyMPtd)
@@ -272,25 +285,44 @@ def _makeDFcclags(eventList, row, ctx):
     Nc = len(row.Channels[eventList[0]])
     N = len(eventList)
     with _phase('fill'):
-        # the event matrix, assembled in page-locked memory (row by row: a list of 2000 float64 arrays through
-        # ascontiguousarray took 1.2 s); its upload then runs at the link's rate instead of through a pageable
-        # staging copy
+        # The event matrix, assembled in page-locked memory and uploaded slab by slab: a few threads copy (and
+        # convert) the events of a slab while the previous slab is on its way to the device -- the upload then runs
+        # at the link's rate instead of through a pageable staging copy, and under the next slab's copies.  (Round 5:
+        # one thread, event by event, then one upload: 19 + 6 ms at 2000 events; a list of 2000 float64 arrays
+        # through ascontiguousarray took 1.2 s in round 4.)
         n = row.MPtd.length(eventList[0]) if lazy else len(row.MPtd[eventList[0]])
         lazy = lazy and n % Nc == 0
+        on_gpu = True
         try:
             tdt = torch.empty((N, n), dtype=torch.float32, pin_memory=True)
         except RuntimeError:                                                # (no GPU runtime: the CPU stand-in of the tests)
             tdt = torch.empty((N, n), dtype=torch.float32)
+            on_gpu = False
         td = tdt.numpy()
-        if lazy:
-            # channel planes [N][Nc][n / Nc]: one contiguous copy per channel; interleaved on the device below
-            # (construct.py:977-978; dtx_preprocess without filter or detrend)
-            td3 = td.reshape(N, Nc, n // Nc)
-            for i, e in enumerate(eventList):
-                row.MPtd.planes_f32(e, td3[i])
-        else:
-            for i, e in enumerate(eventList):
-                td[i] = row.MPtd[e]
+        td3 = td.reshape(N, Nc, n // Nc) if lazy else None
+
+        def copy_rows(a, b):
+            for i in range(a, b):
+                if lazy:
+                    # channel planes [N][Nc][n / Nc]: one contiguous copy per channel; interleaved on the device
+                    # below (construct.py:977-978; dtx_preprocess without filter or detrend)
+                    row.MPtd.planes_f32(eventList[i], td3[i])
+                else:
+                    td[i] = row.MPtd[eventList[i]]
+        nw = _fill_workers()
+        nslab = 4 if (on_gpu and N >= 64) else 1
+        tdev = torch.empty((N, n), dtype=torch.float32, device=ctx.device) if on_gpu else None
+        with ThreadPoolExecutor(max_workers=nw) as ex:
+            for sl in range(nslab):
+                a, b = sl * N // nslab, (sl + 1) * N // nslab
+                cuts = [a + q * (b - a) // nw for q in range(nw + 1)]
+                list(ex.map(lambda q: copy_rows(cuts[q], cuts[q + 1]), range(nw)))
+                if on_gpu:
+                    tdev[a:b].copy_(tdt[a:b], non_blocking=True)
+    with _phase('h2d'):
+        if not on_gpu:
+            tdev = tdt.to(ctx.device, non_blocking=True)
+        _sync_copy(ctx)
     rank, world = parallel.dist_info()
     if parallel.dist_active():
         # one process per GPU: every rank correlates a contiguous range of the condensed pair
@@ -298,9 +330,6 @@ def _makeDFcclags(eventList, row, ctx):
         npairs = N * (N - 1) // 2
         ranges = [parallel.shard_pairs(npairs, r, world) for r in range(world)]
         b, e = ranges[rank]
-        with _phase('h2d'):
-            tdev = tdt.to(ctx.device, non_blocking=True)
-            _sync_copy(ctx)
         with _phase('kernels'):
             if lazy:
                 tdev = ctx.preprocess(tdev.reshape(N, Nc, n // Nc), filt=None, detrend=False)
@@ -308,9 +337,6 @@ def _makeDFcclags(eventList, row, ctx):
             ctx.sync()
         cc, lag, ss = (parallel.gather_condensed(v, ranges, npairs, ctx.device) for v in (cc, lag, ss))
     else:
-        with _phase('h2d'):
-            tdev = tdt.to(ctx.device, non_blocking=True)
-            _sync_copy(ctx)
         with _phase('kernels'):
             if lazy:
                 tdev = ctx.preprocess(tdev.reshape(N, Nc, n // Nc), filt=None, detrend=False)
@@ -318,6 +344,12 @@ def _makeDFcclags(eventList, row, ctx):
             ctx.sync()
     with _phase('d2h'):
         cc, lag, ss = cc.cpu().numpy(), lag.cpu().numpy(), ss.cpu().numpy()
+    return N, cc, lag, ss
+
+
+def _makeDFcclags(eventList, row, ctx):
+    """construct.py:369-394: (DFcc, DFlag, DFsubsamp) of all pairs b < c of ``eventList``."""
+    N, cc, lag, ss = _xcorr_condensed(eventList, row, ctx)
     with _phase('frames'):
         return _frames_from_condensed(N, cc, lag, ss)
 
@@ -423,13 +455,22 @@ def createCluster(CCreq=0.5, fetch_arg=None, filt=[1, 10, 2, True], stationKey=N
                 eventList = list(row.Events)
             if len(row.Events) < 2:       # construct.py:143-146: skip the station
                 continue
-            DFcc, DFlag, DFsubsamp = _makeDFcclags(eventList, row, ctx)
+            N, cc, lag, ss = _xcorr_condensed(eventList, row, ctx)
+            # the three frames (construct.py:373-378; 3 x 32 MB at 2000 events) are laid out by a second thread while
+            # this one clusters: the condensed vector IS the frame's upper triangle in row-major order, i.e. what
+            # _flatNoNan(1.0000001 - DFcc) (construct.py:153-156) flattens it back to
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                fut = ex.submit(_frames_from_condensed, N, cc, lag, ss)
+                with _phase('linkage'):
+                    cx = 1.0000001 - np.asarray(cc, dtype=np.float64)
+                    cx = cx[~np.isnan(cx)]
+                    TRDF.at[ind, 'Link'] = linkage(cx)         # default: single
+                with _phase('frames'):
+                    DFcc, DFlag, DFsubsamp = fut.result()
             TRDF.at[ind, 'Lags'] = DFlag
             TRDF.at[ind, 'CCs'] = DFcc
             TRDF.at[ind, 'Subsamp'] = DFsubsamp
-            with _phase('linkage'):
-                cx = _flatNoNan(1.0000001 - DFcc)              # construct.py:153-156
-                TRDF.at[ind, 'Link'] = linkage(cx)             # default: single
     finally:
         if own:
             ctx.close()

@@ -332,10 +332,11 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
                                                         int64_t P, int64_t Ppad, double scale,
                                                         float* __restrict__ mean,
                                                         float* __restrict__ ssd,
-                                                        const float* __restrict__ tau = nullptr) {
+                                                        const float* __restrict__ tau = nullptr,
+                                                        int* __restrict__ over = nullptr, int redo = 0) {
   constexpr int E = kStatsPB / 256;  // windows per thread
-  __shared__ double sh1[4], sh2[4], sh3[4], shb1[4], shb2[4];
-  __shared__ double anchor[5];
+  __shared__ double sh1[4], sh2[4], sh3[4];
+  __shared__ double anchor[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
   const float* xb = planes + (int64_t)b * Nc * plane_stride;
@@ -343,19 +344,45 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
   auto at = [&](int c, int64_t t) -> float { return xb[(int64_t)c * plane_stride + t]; };
   const int64_t p0 = (int64_t)blockIdx.x * kStatsPB;
   if (p0 >= P) return;
-  // Samples far beyond the batch element's ordinary scatter (tau[b]: the square from which; +inf without one) are
-  // summed APART, sums b1 / b2 beside s1 / s2: a 10^6-sigma glitch then never enters the sliding sums of the
-  // ordinary samples, and the windows that do not hold it come out as if it were not there -- float64 sliding
-  // sums otherwise keep ~1e-16 of the largest power they passed through, and the re-summation below, meant for a
-  // few windows, met every quiet window of the block (round 5: 10 such glitches took a station-day from 3.3 to
-  // 23 ms).  S = s + b in exact arithmetic whatever tau is.
-  const float big = tau != nullptr ? tau[b] : INFINITY;
+  // Samples far beyond the batch element's ordinary scatter (tau[b]: the square from which; none without a tau) are
+  // kept OUT of the sliding sums -- they enter as zeros -- and listed (LDS: frame, value); a window's sums get the
+  // listed samples it holds added at the end.  A 10^6-sigma glitch then never passes through the float64 sliding
+  // sums, and the windows that do not hold it come out as if it were not there: the sums otherwise keep ~1e-16 of
+  // the largest power they passed through, and the direct re-summation below, meant for a few windows, met every
+  // quiet window of the block (round 5: 10 such glitches took a station-day from 3.3 to 23 ms).  Exact whatever tau
+  // is.  More than kBigCap such samples in a block's span (a sustained loud signal): the block raises its flag in
+  // `over` ([batch][blocks], cleared by the caller) and the SECOND launch (redo = 1: only flagged blocks run) sums
+  // it as one class, round 5's way -- a launch that finds no flag on ordinary data.
+  constexpr int kBigCap = 128;
+  __shared__ int big_t[kBigCap];
+  __shared__ float big_v[kBigCap];
+  __shared__ int nbig_s;
+  int* myflag = over != nullptr ? over + (int64_t)b * gridDim.x + blockIdx.x : nullptr;
+  if (redo && (myflag == nullptr || *myflag == 0)) return;
+  const float big = (tau != nullptr && !redo) ? tau[b] : INFINITY;
+  // (a sample seen as part of the anchor window, frames [p0, p0 + L), or ENTERING a later window, frames >= p0 + L:
+  // every sample of the block's span exactly once)
+  auto keep_or_list = [&](float v, int64_t t) -> float {
+    if (!(v * v > big)) return v;
+    const int k = atomicAdd(&nbig_s, 1);
+    if (k < kBigCap) { big_t[k] = (int)(t - p0); big_v[k] = v; }
+    return 0.f;
+  };
+  auto small = [&](float v) -> float { return (v * v > big) ? 0.f : v; };
+  // (the per-sample tests sit behind ONE vote per batch of loads -- does any lane of the wave hold such a sample? --
+  // so that on ordinary data the loops below are round 5's: with the tests inline the kernel ran 124 us against 92)
+  auto any_big = [&](float m) -> bool { return __any(m * m > big) != 0; };
+
+  double l1[kStatsPB / 256], l2[kStatsPB / 256], l3[kStatsPB / 256];
+  double off1, off2, off3;
+  if (tid == 0) nbig_s = 0;
+  __syncthreads();
 
   // third running quantity: the number of sample-to-sample changes inside the window
   // (per channel).  It is an exact integer, so "the window is constant" -- the
   // zero-variance case the statistic defines as 0 -- is decided exactly, however much
   // round-off the float64 sliding sums have picked up from large values elsewhere.
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0, b1 = 0.0, b2 = 0.0;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   {
   // (twelve loads in flight per pass -- a whole channel of a 30 s template at 100 Hz: taken one at a time
   // this sum was a chain of ~36 exposed memory latencies per block; the previous sample of a lane's
@@ -372,15 +399,21 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
         v[k] = j < L ? w0[j] : 0.f;
         vl[k] = (lane == 0 && j < L && j > 0) ? w0[j - 1] : 0.f;     // (lane 0 only: the wave's left neighbour)
       }
+      float vmax = 0.f;
+#pragma unroll
+      for (int k = 0; k < kAB; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
+      const bool hot = any_big(vmax);
 #pragma unroll
       for (int k = 0; k < kAB; ++k) {
         const int j = j0 + 256 * k + tid;
         const float up = __shfl_up(v[k], 1, 64);
         const float vp = lane == 0 ? vl[k] : up;
         if (j < L) {
-          const double d = (double)v[k];
-          if (v[k] * v[k] > big) { b1 += d; b2 += d * d; }
-          else { s1 += d; s2 += d * d; }
+          float vs = v[k];
+          if (hot) vs = keep_or_list(vs, p0 + j);
+          const double d = (double)vs;
+          s1 += d;
+          s2 += d * d;
           if (j > 0) s3 += (v[k] != vp) ? 1.0 : 0.0;
         }
       }
@@ -392,33 +425,22 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     s1 += __shfl_down(s1, off, 64);
     s2 += __shfl_down(s2, off, 64);
     s3 += __shfl_down(s3, off, 64);
-    b1 += __shfl_down(b1, off, 64);
-    b2 += __shfl_down(b2, off, 64);
   }
-  if (lane == 0) { sh1[wv] = s1; sh2[wv] = s2; sh3[wv] = s3; shb1[wv] = b1; shb2[wv] = b2; }
+  if (lane == 0) { sh1[wv] = s1; sh2[wv] = s2; sh3[wv] = s3; }
   __syncthreads();
   if (tid == 0) {
     anchor[0] = sh1[0] + sh1[1] + sh1[2] + sh1[3];
     anchor[1] = sh2[0] + sh2[1] + sh2[2] + sh2[3];
     anchor[2] = sh3[0] + sh3[1] + sh3[2] + sh3[3];
-    anchor[3] = shb1[0] + shb1[1] + shb1[2] + shb1[3];
-    anchor[4] = shb2[0] + shb2[1] + shb2[2] + shb2[3];
   }
   __syncthreads();
 
   // local element e turns window (p0 + E*tid + e) into the next one: per channel the thread's E
   // steps touch E + 1 consecutive samples at the head and E + 1 at the tail of its windows -- all
   // loaded first (independent loads in flight), each once
-  double l1[E], l2[E], l3[E], g1[E], g2[E];
-  double r1_ = 0.0, r2_ = 0.0, r3_ = 0.0, q1_ = 0.0, q2_ = 0.0;
+  double r1_ = 0.0, r2_ = 0.0, r3_ = 0.0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) l1[e] = l2[e] = l3[e] = g1[e] = g2[e] = 0.0;
-  // one sample entering (sign + 1) or leaving (- 1) the window, into the sums of its class
-  auto slide = [&](float v, double sign, double& o1, double& o2, double& h1, double& h2) {
-    const double d = (double)v;
-    if (v * v > big) { h1 += sign * d; h2 += sign * d * d; }
-    else { o1 += sign * d; o2 += sign * d * d; }
-  };
+  for (int e = 0; e < E; ++e) l1[e] = l2[e] = l3[e] = 0.0;
   const int64_t pt = p0 + (int64_t)E * tid;
   // (the batched loads read up to sample pt + L + E - 1 of the plane whatever P is: only where that
   // stays inside the plane -- the last threads of a chunk's last block take the guarded loop)
@@ -432,35 +454,44 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j <= E; ++j) tb[j] = o[L - 1 + j];
     }
+    float hmax = 0.f;
+#pragma unroll
+    for (int j = 0; j <= E; ++j) hmax = fmaxf(hmax, fmaxf(fabsf(ha[j]), fabsf(tb[j])));
+    const bool hot = any_big(hmax);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      slide(tb[e + 1], 1.0, l1[e], l2[e], g1[e], g2[e]);
-      slide(ha[e], -1.0, l1[e], l2[e], g1[e], g2[e]);
+      float fo = ha[e], fn = tb[e + 1];
+      if (hot) {
+        fo = small(fo);
+        fn = (pt + e + 1 < P) ? keep_or_list(fn, pt + L + e) : 0.f;
+      }
+      const double vo = (double)fo, vn = (double)fn;
+      l1[e] += vn - vo;
+      l2[e] += vn * vn - vo * vo;
       // changes entering (between samples L-1 and L) and leaving (between 0 and 1)
       if (L > 1) l3[e] += ((tb[e + 1] != tb[e]) ? 1.0 : 0.0) - ((ha[e + 1] != ha[e]) ? 1.0 : 0.0);
     }
   }
-  double r1 = 0.0, r2 = 0.0, r3 = 0.0, q1 = 0.0, q2 = 0.0;
+  double r1 = 0.0, r2 = 0.0, r3 = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    if (pt + e + 1 < P) { r1 += l1[e]; r2 += l2[e]; r3 += l3[e]; q1 += g1[e]; q2 += g2[e]; }
+    if (pt + e + 1 < P) { r1 += l1[e]; r2 += l2[e]; r3 += l3[e]; }
     l1[e] = r1;
     l2[e] = r2;
     l3[e] = r3;
-    g1[e] = q1;
-    g2[e] = q2;
   }
-  r1_ = r1; r2_ = r2; r3_ = r3; q1_ = q1; q2_ = q2;
+  r1_ = r1; r2_ = r2; r3_ = r3;
   } else {
-  double r1 = 0.0, r2 = 0.0, r3 = 0.0, q1 = 0.0, q2 = 0.0;
+  double r1 = 0.0, r2 = 0.0, r3 = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int64_t pw = p0 + (int64_t)E * tid + e;
     if (pw + 1 < P) {
       for (int c = 0; c < Nc; ++c) {
         const float o0 = at(c, pw), o1 = at(c, pw + 1), oL1 = at(c, pw + L - 1), oL = at(c, pw + L);
-        slide(oL, 1.0, r1, r2, q1, q2);
-        slide(o0, -1.0, r1, r2, q1, q2);
+        const double vo = (double)small(o0), vn = (double)keep_or_list(oL, pw + L);
+        r1 += vn - vo;
+        r2 += vn * vn - vo * vo;
         // changes entering (between samples L-1 and L) and leaving (between 0 and 1)
         if (L > 1) r3 += ((oL != oL1) ? 1.0 : 0.0) - ((o1 != o0) ? 1.0 : 0.0);
       }
@@ -468,24 +499,35 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     l1[e] = r1;
     l2[e] = r2;
     l3[e] = r3;
-    g1[e] = q1;
-    g2[e] = q2;
   }
-  r1_ = r1; r2_ = r2; r3_ = r3; q1_ = q1; q2_ = q2;
+  r1_ = r1; r2_ = r2; r3_ = r3;
   }
-  const double r1 = r1_, r2 = r2_, r3 = r3_, q1 = q1_, q2 = q2_;
+  const double r1 = r1_, r2 = r2_, r3 = r3_;
   const double i1 = wave_incl_scan(r1, lane), i2 = wave_incl_scan(r2, lane),
                i3 = wave_incl_scan(r3, lane);
-  // (the sums of the samples taken apart: all zero on ordinary data -- one vote per wave instead of two scans)
-  const bool anyb = __any(q1 != 0.0 || q2 != 0.0);
-  const double j1 = anyb ? wave_incl_scan(q1, lane) : 0.0, j2 = anyb ? wave_incl_scan(q2, lane) : 0.0;
   __syncthreads();
-  if (lane == 63) { sh1[wv] = i1; sh2[wv] = i2; sh3[wv] = i3; shb1[wv] = j1; shb2[wv] = j2; }
+  if (lane == 63) { sh1[wv] = i1; sh2[wv] = i2; sh3[wv] = i3; }
   __syncthreads();
-  double off1 = i1 - r1, off2 = i2 - r2, off3 = i3 - r3;  // exclusive within the wave
-  double ofb1 = j1 - q1, ofb2 = j2 - q2;
-  for (int w = 0; w < wv; ++w) { off1 += sh1[w]; off2 += sh2[w]; off3 += sh3[w]; ofb1 += shb1[w]; ofb2 += shb2[w]; }
-  const double a1 = anchor[0], a2 = anchor[1], a3 = anchor[2], ab1 = anchor[3], ab2 = anchor[4];
+  off1 = i1 - r1; off2 = i2 - r2; off3 = i3 - r3;  // exclusive within the wave
+  for (int w = 0; w < wv; ++w) { off1 += sh1[w]; off2 += sh2[w]; off3 += sh3[w]; }
+  // (every append lies in front of the barriers above)
+  if (nbig_s > kBigCap) {                            // too many for the list: the second launch takes the block
+    if (tid == 0 && myflag != nullptr) *myflag = 1;
+    return;
+  }
+  const int nbig = nbig_s;
+  // what window (p0 + q) holds of the listed samples: frames q .. q + L - 1 of the block's span
+  auto listed = [&](int q, double& S1, double& S2) {
+    for (int k = 0; k < nbig; ++k) {
+      const int dt = big_t[k] - q;
+      if (dt >= 0 && dt < L) {
+        const double d = (double)big_v[k];
+        S1 += d;
+        S2 += d * d;
+      }
+    }
+  };
+  const double a1 = anchor[0], a2 = anchor[1], a3 = anchor[2];
   const double dn = (double)Nc * (double)L;
   float* mo = mean + (int64_t)b * Ppad;
   float* so = ssd + (int64_t)b * Ppad;
@@ -499,16 +541,18 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     return true;
   };
   if (tid == 0) {
-    mo[p0] = (float)((a1 + ab1) / dn);
-    so[p0] = constant(p0, a3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(a2 + ab2, a1 + ab1, dn));
+    double S1 = a1, S2 = a2;
+    listed(0, S1, S2);
+    mo[p0] = (float)(S1 / dn);
+    so[p0] = constant(p0, a3) ? stats_out(scale, 0.0) : stats_out(scale, clamp_var(S2, S1, dn));
   }
   // The sliding sums of a block pass through the largest window power of the block, and what float64 rounds
   // off there (~1e-16 of it) stays in every later window's sums: a 10^4-sigma spike leaves 4e-9 behind, 2e-3 of
   // the sum of squares of a window that holds ONE live sample at the edge of a dead stretch (found by a soak run of
   // test_random_scan: DS off by 2.5e-4 there).  A window whose variance is below kStatsRecheck of the block's
   // largest power is therefore summed again directly (mean first, then the squares of the residuals): rare, exact.
-  // (The power is that of the ORDINARY samples' sums -- what is summed apart never enters them -- so with a tau it
-  // is at most n tau = 2^20 n x the ordinary scatter, and an ordinary full window, n x the scatter, never qualifies.)
+  // (The power is that of the sliding sums, which the listed samples never enter: with a tau it is at most n tau =
+  // 2^20 n x the ordinary scatter, and an ordinary full window, n x the scatter, never qualifies.)
   __shared__ double shm[4];
   __shared__ double blockmax;
   {
@@ -548,11 +592,14 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     const int64_t pw = p0 + (int64_t)E * tid + e + 1;
     float m = 0.f, sd = 0.f;
     if (pw < P && pw < p0 + kStatsPB) {
-      double S1 = (a1 + off1 + l1[e]) + (ab1 + ofb1 + g1[e]);
-      const double S2 = (a2 + off2 + l2[e]) + (ab2 + ofb2 + g2[e]), S3 = a3 + off3 + l3[e];
+      double S1 = a1 + off1 + l1[e];
+      double S2 = a2 + off2 + l2[e];
+      const double S3 = a3 + off3 + l3[e];
       const bool flat = constant(pw, S3);
+      const bool quiet = !flat && S2 - S1 * S1 / dn < recheck;      // (judged on the sliding sums alone)
+      listed((int)(pw - p0), S1, S2);
       double var = flat ? 0.0 : clamp_var(S2, S1, dn);
-      if (!flat && S2 - S1 * S1 / dn < recheck) direct(pw, S1, var);
+      if (quiet) direct(pw, S1, var);
       m = (float)(S1 / dn);
       sd = stats_out(scale, var);
     }

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __
                                                                 const int64_t* __restrict__ ctab, int64_t M,
                                                                 int n, int Nc, int* __restrict__ pb,
                                                                 int* __restrict__ zlist, float* __restrict__ zmax,
-                                                                int D) {
+                                                                int D, int* __restrict__ zover, int nover) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  for (int q = lane; q < nover; q += 64) zover[(int64_t)b * nover + q] = 0;      // win_stats_kernel's flags
   if (zlist != nullptr && b == 0 && lane < 4) zlist[lane] = 0;      // DtxRepairWs::count
   if (zmax != nullptr)
     for (int d = lane; d < D; d += 64) zmax[(int64_t)b * D + d] = 0.f;
@@ -905,14 +906,17 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   // (slices of at least 16 samples: a record of a few hundred samples still has enough of them for the median to
   // ignore a spike -- with M / 256 a chunk under 768 samples had one or two slices, and its level followed the spike)
   const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(kMeanSlices, M / 16));
+  const int nsb = (int)((P + kStatsPB - 1) / kStatsPB);     // blocks of the window statistics per chunk (their overflow flags)
   if ((rc = dtx_reserve(ctx, ctx->ws_csum,
-                        (size_t)nchunk * (nsl * kCsum * sizeof(double) + 2 * sizeof(float) + sizeof(int)))))
+                        (size_t)nchunk * (nsl * kCsum * sizeof(double) + 2 * sizeof(float) + sizeof(int) + nsb * sizeof(int)))))
     return rc;
   double* cslice = (double*)ctx->ws_csum.p;
   float* m0f = (float*)(cslice + (size_t)nchunk * nsl * kCsum);
   float* tauf = m0f + nchunk;                 // per chunk: the square from which a sample is summed apart (win_stats_kernel)
   // ragged batch: every chunk's own window count, for the passes that must not look past it
-  int* pb = ctab ? (int*)(tauf + nchunk) : nullptr;
+  int* pbuf = (int*)(tauf + nchunk);
+  int* pb = ctab ? pbuf : nullptr;
+  int* sover = pbuf + nchunk;                  // [nchunk][nsb]: blocks whose big samples overflowed the list (win_stats_kernel)
   const bool use_fft = (ctx->engine == DTX_ENGINE_FFT && dtx_fft_eligible(ctx->L)) ||
                        (ctx->engine == DTX_ENGINE_AUTO && ctx->L >= kFftAutoMinL && ctx->L <= kFftLongMaxL);
   // the guards' lists (DtxRepairWs): the frequency-domain engine lists blocks of its advance V, the split-bf16
@@ -948,7 +952,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
                      (const double*)cslice, nsl, m0f, tauf, ctab, M, n, Nc, pb, list,
-                     post ? post->maxds : (float*)nullptr, ctx->D);
+                     post ? post->maxds : (float*)nullptr, ctx->D, sover, nsb);
   DTX_HIP(ctx, hipGetLastError());
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
   const double scale = (double)n / ((double)n - 1.0);
@@ -964,7 +968,9 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
                  (const int*)nullptr, ctab, n, nchunk);
     if ((rc = dtx_aux_fork(ctx))) return rc;
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
-                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf);
+                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 0);
+    hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
+                       Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 1);
     DTX_HIP(ctx, hipGetLastError());
     // Dynamic-range guard.  The transforms' float32 rounding is relative to the largest
     // amplitude in an 8192-sample block, not to the window: a block whose loudest window
@@ -983,7 +989,9 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp,
                (const int*)nullptr, ctab, n, nchunk);
   hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
-                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf);
+                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 0);
+  hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
+                     Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 1);
   DTX_HIP(ctx, hipGetLastError());
 
   i32x4* g16 = nullptr;
