@@ -220,8 +220,8 @@ __global__ __launch_bounds__(kSplitT) void spike_split_kernel(const float* __res
   }
 }
 
-// The block spectra of the blocks whose outliers were split off, again without them (in place: the scan that
-// read the originals is done).  As xhat_kernel; grid (any, Nc).
+// The block spectra of the blocks whose outliers were split off, again without them, into a buffer of their own
+// (same layout as xhat_kernel's: on the side stream, beside it -- the scan keeps reading the originals).  Grid (any, Nc).
 __global__ __launch_bounds__(kT) void xhat_clean_kernel(const float* __restrict__ xp, int64_t Tpad, int Nc, int V,
                                                         int nblk, int nblkx, int keep,
                                                         const c32* __restrict__ tab, c32* __restrict__ xh,
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(kT) void xhat_clean_kernel(const float* __restrict_
 constexpr int kMaxGroups = 32;
 struct FftArgs {
   const c32* xh;        // [nchunk][nblkx][Nc][kXh] half spectra, nblkx = nblk + nseg - 1
+  const c32* xhc;       // the same layout: spectra WITHOUT the outliers of the blocks that had some split off (xhat_clean_kernel)
   const c32* W;         // [npairs][Nc][kN]
   const c32* tab;       // [kN] e^{+2 pi i m / kN}
   const int4* unit;     // [nunits] {first pair, pairs, -, -}: consecutive pairs of whole detectors
@@ -385,7 +386,7 @@ __device__ __forceinline__ void ds_fft_block(const FftArgs& a, const int cb, con
   const int wlo = 512 * wv + ln;              // basis spectra: see w_slot (float4 units)
   // block spectra of this block; a template longer than one segment also reads the following
   // blocks': segment s of the template meets the data of block blk + s (advance == segment length)
-  const c32* xh = a.xh + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
+  const c32* xh = (SPLIT ? a.xhc : a.xh) + ((int64_t)chunk * a.nblkx + blk) * a.Nc * kXh;
   c32* xs = lds + kLdsC;                      // NCH > 0: the block's spectra, [NCH][kXh]
   if constexpr (NCH > 0) {
     const float4* src = reinterpret_cast<const float4*>(xh);
@@ -1095,14 +1096,18 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   if (grid >= ((int64_t)1 << 31)) return dtx_fail(ctx, DTX_E_ARG, "FFT engine: grid too large");
   int rc;
   const int nblkx = nblk + f.nseg - 1;   // a segmented template also reads the blocks behind its own
-  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2)))) return rc;
+  // (single-segment templates: a second set for the blocks scanned again without their outliers -- 172 MB at
+  // configs[1], written only where the guard lists something)
+  const size_t xh_bytes = (size_t)nchunk * nblkx * Nc * kXh * sizeof(float2);
+  if ((rc = dtx_reserve(ctx, ctx->ws_xhat, (f.nseg == 1 ? 2 : 1) * xh_bytes))) return rc;
   c32* xh = (c32*)ctx->ws_xhat.p;
+  c32* xhc = f.nseg == 1 ? (c32*)((char*)ctx->ws_xhat.p + xh_bytes) : xh;
   const int keep = f.nseg == 1 ? std::min(kN, V + ctx->n / Nc - 1) : kN;
   hipLaunchKernelGGL(xhat_kernel, dim3((unsigned)nblkx, (unsigned)Nc, (unsigned)nchunk), dim3(kT), 0,
                      ctx->stream, xp, Tpad, Nc, V, nblkx, keep, (const c32*)f.tab_dev, xh, 1, 0);
   DTX_HIP(ctx, hipGetLastError());
   FftArgs a;
-  a.xh = xh; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
+  a.xh = xh; a.xhc = xhc; a.W = (const c32*)f.W_dev; a.tab = (const c32*)f.tab_dev;
   a.unit = (const int4*)f.unit_dev; a.pinfo = (const float4*)f.pinfo_dev;
   a.pdet = (const int2*)f.pdet_dev;
   a.mean = mean; a.den = den; a.ds = ds; a.Ppad = Ppad; a.ldp = ldp; a.P = P;
@@ -1123,6 +1128,13 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   hipLaunchKernelGGL(spike_split_kernel, dim3((unsigned)ctx->ncu), dim3(kSplitT), 0, ctx->aux, xp, Tpad, Nc, ctx->L,
                      den, Ppad, P, V, nblk, f.nseg, ws, pb);
   DTX_HIP(ctx, hipGetLastError());
+  if (f.nseg == 1) {
+    // ... and the spectra of the blocks with outliers split off, without them (a launch sized for the chip that finds
+    // an empty list on ordinary data)
+    hipLaunchKernelGGL(xhat_clean_kernel, dim3((unsigned)ctx->ncu, (unsigned)Nc), dim3(kT), 0, ctx->aux, xp, Tpad,
+                       Nc, V, nblk, nblkx, keep, (const c32*)f.tab_dev, xhc, ws);
+    DTX_HIP(ctx, hipGetLastError());
+  }
   {
     const int rcj = dtx_aux_join(ctx);
     if (rcj) return rcj;
@@ -1155,12 +1167,8 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   dtx_kev_commit(ctx);
   if (f.nseg == 1) {
-    // blocks with outliers split off: their spectra again without them, in place (the scan above is done with
-    // the originals), then the blocks again on the one-role kernel; both launches are sized for the chip and find
-    // an empty list on ordinary data
-    hipLaunchKernelGGL(xhat_clean_kernel, dim3((unsigned)ctx->ncu, (unsigned)Nc), dim3(kT), 0, ctx->stream, xp, Tpad,
-                       Nc, V, nblk, nblkx, keep, (const c32*)f.tab_dev, xh, ws);
-    DTX_HIP(ctx, hipGetLastError());
+    // blocks with outliers split off: again on the one-role kernel, on their clean spectra (a launch sized for the
+    // chip that finds an empty list on ordinary data)
     const unsigned rgrid = (unsigned)(4 * ctx->ncu);
     switch (V / 512) {
 #ifndef DTX_FFT_ONLY_VM
