@@ -20,7 +20,8 @@ SYMBOLS = [
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
     'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean', 'dtx_subspace_scan_ragged',
     'dtx_trigger_stats_ragged', 'dtx_chunk_table_check', 'dtx_ctx_set_trigger_stream', 'dtx_stream_wait_scan_kernel',
-    'dtx_kernel_ms_list', 'dtx_stalta_max', 'dtx_repair_counts', 'dtx_device_pci_bus_id', 'dtx_export_results',
+    'dtx_kernel_ms_list', 'dtx_stalta_max', 'dtx_repair_counts', 'dtx_device_pci_bus_id', 'dtx_export_results', 'dtx_ctx_set_post_stream',
+    'dtx_stream_wait_post',
 ]
 
 
@@ -118,6 +119,10 @@ def load():
     lib.dtx_kernel_ms_list.argtypes = [vp, i32, pf]
     lib.dtx_device_pci_bus_id.restype = i32
     lib.dtx_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
+    lib.dtx_ctx_set_post_stream.restype = i32
+    lib.dtx_ctx_set_post_stream.argtypes = [vp, vp]
+    lib.dtx_stream_wait_post.restype = i32
+    lib.dtx_stream_wait_post.argtypes = [vp, vp]
     lib.dtx_export_results.restype = i32
     lib.dtx_export_results.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp]
     lib.dtx_repair_counts.restype = i32

@@ -125,6 +125,13 @@ class _LazyMPtd(Mapping):
     def __len__(self):
         return len(self._planes)
 
+    def __getstate__(self):
+        """Pickled without the multiplexed arrays built so far (ClusterStream.write after createSubSpace had read
+        every event wrote both copies: twice the file) -- they are rebuilt when asked for."""
+        d = dict(self.__dict__)
+        d['_done'] = {}
+        return d
+
     def length(self, ev):
         """len(self[ev]) without building it"""
         p = self._planes[ev]

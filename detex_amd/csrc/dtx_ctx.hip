@@ -103,6 +103,14 @@ int dtx_aux_join(dtx_ctx* ctx) {
   return DTX_OK;
 }
 
+int dtx_wait_post(dtx_ctx* ctx) {
+  if (ctx->post_pending) {
+    DTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_post_done, 0));
+    ctx->post_pending = false;
+  }
+  return DTX_OK;
+}
+
 extern "C" {
 
 int dtx_version(void) { return DTX_ABI_VERSION; }
@@ -157,6 +165,7 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
   if (!ctx) return DTX_OK;
   DtxDeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->post_stream && ctx->ev_post_done && ctx->post_on_side) (void)hipEventSynchronize(ctx->ev_post_done);
   if (ctx->aux && !ctx->aux_is_main) (void)hipStreamSynchronize(ctx->aux);
   if (ctx->ev_trig) {
     if (ctx->trig_pending) (void)hipEventSynchronize(ctx->ev_trig);
@@ -175,7 +184,7 @@ int dtx_ctx_destroy(dtx_ctx* ctx) {
     if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     if (ctx->stage_buf[k]) (void)hipHostFree(ctx->stage_buf[k]);
   }
-  hipEvent_t evs[2] = {ctx->ev_t0, ctx->ev_t1};
+  hipEvent_t evs[4] = {ctx->ev_t0, ctx->ev_t1, ctx->ev_post_ready, ctx->ev_post_done};
   for (auto ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < dtx_ctx::kKev; ++i) {
@@ -197,6 +206,8 @@ int dtx_ctx_sync(dtx_ctx* ctx) {
   if (!ctx) return DTX_E_ARG;
   DtxDeviceGuard g(ctx->device);
   DTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->post_stream && ctx->post_on_side) DTX_HIP(ctx, hipStreamSynchronize(ctx->post_stream));   // (a scan's post pass)
+  ctx->post_pending = false;
   return DTX_OK;
 }
 
@@ -205,6 +216,27 @@ void* dtx_ctx_stream(dtx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int dtx_ctx_set_trigger_stream(dtx_ctx* ctx, void* stream) {
   if (!ctx) return DTX_E_ARG;
   ctx->trig_stream = (hipStream_t)stream;     // (launches on different streams are ordered by event: dtx_trig.hip)
+  return DTX_OK;
+}
+
+int dtx_ctx_set_post_stream(dtx_ctx* ctx, void* stream) {
+  if (!ctx) return DTX_E_ARG;
+  DtxDeviceGuard g(ctx->device);
+  { const int rc = dtx_wait_post(ctx); if (rc) return rc; }
+  ctx->post_stream = (hipStream_t)stream;
+  if (stream && !ctx->ev_post_ready) {
+    DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_post_ready, hipEventDisableTiming));
+    DTX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_post_done, hipEventDisableTiming));
+  }
+  return DTX_OK;
+}
+
+int dtx_stream_wait_post(dtx_ctx* ctx, void* stream) {
+  if (!ctx) return DTX_E_ARG;
+  if (!ctx->post_on_side || !ctx->ev_post_done) return DTX_OK;
+  DtxDeviceGuard g(ctx->device);
+  DTX_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_post_done, 0));
+  if ((hipStream_t)stream == ctx->stream) ctx->post_pending = false;
   return DTX_OK;
 }
 

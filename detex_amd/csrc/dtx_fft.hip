@@ -1139,6 +1139,7 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
     const int rcj = dtx_aux_join(ctx);
     if (rcj) return rcj;
   }
+  { const int rcw = dtx_wait_post(ctx); if (rcw) return rcw; }     // (an earlier scan's post pass may still be reading this DS tensor)
   { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));   // times the dominant kernel only
   switch (V / 512) {

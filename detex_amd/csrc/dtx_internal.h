@@ -87,6 +87,14 @@ struct dtx_ctx {
   // queued hands in a stream of its own (dtx_ctx_set_trigger_stream): the kernel -- a few dozen workgroups of
   // dependent passes, 0.2 .. 0.4 ms -- then runs beside the next scan instead of in front of it
   hipStream_t trig_stream = nullptr;
+  // stream of a scan's post pass (histogram / maxima / candidates): NULL = `stream`.  A caller that keeps several scans
+  // queued hands in a stream of its own (dtx_ctx_set_post_stream): the pass -- a read of the whole DS tensor at the
+  // memory's rate -- then runs beside the NEXT scan's preparation (offsets, channel planes, block spectra, window
+  // statistics: chains of latencies that leave the memory system idle) instead of in front of it
+  hipStream_t post_stream = nullptr;
+  hipEvent_t ev_post_ready = nullptr, ev_post_done = nullptr;
+  bool post_pending = false;           // a post pass on post_stream that nothing on `stream` has waited for yet
+  bool post_on_side = false;           // the last scan's post pass ran on post_stream (dtx_export_results follows it there)
   hipStream_t trig_last = nullptr;     // stream of the last trigger-time launch ...
   hipEvent_t ev_trig = nullptr;        // ... and the event recorded behind it (orders a launch on another stream, basis uploads, destroy)
   bool trig_pending = false;
@@ -206,7 +214,9 @@ constexpr int kSplitGuardV = 1024;
 constexpr float kSplitGuardTau = 0.1f;
 // pb != NULL (ragged batch): chunk b's own window count; the pass covers p < min(P, pb[b])
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
-                    const DtxPost& po, const int* pb = nullptr);
+                    const DtxPost& po, const int* pb = nullptr, hipStream_t st = nullptr);
+// `stream` waits for the post pass still running on post_stream (before anything overwrites the DS tensor it reads)
+int dtx_wait_post(dtx_ctx* ctx);
 // shortest events (samples per channel) the all-pairs cross-correlation sends through the
 // frequency domain under DTX_ENGINE_AUTO / DTX_ENGINE_FFT (dtx_xcfft.hip)
 constexpr int kXcFftMinL = 1024;

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kPostThreads) void ds_moments_kernel(
 }  // namespace
 
 int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, int D,
-                    const DtxPost& po, const int* pb) {
+                    const DtxPost& po, const int* pb, hipStream_t st) {
+  if (st == nullptr) st = ctx->stream;
   // 64 values per thread (64 KB of a row per workgroup) when the launch fills the chip several times over anyway;
   // a small launch (configs[4]: ONE detector x one hour = 110 such workgroups on 256 CUs, 45 us for 7 MB) is cut
   // four times finer
@@ -247,13 +248,13 @@ int dtx_post_launch(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, i
   const int64_t nwg = (P + per_block - 1) / per_block * D * nchunk;
   if (nwg >= 8 * ctx->ncu) {
     dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)D, (unsigned)nchunk);
-    hipLaunchKernelGGL((ds_post_kernel<kPostItems>), grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+    hipLaunchKernelGGL((ds_post_kernel<kPostItems>), grid, dim3(kPostThreads), 0, st, ds_dev, P, ldp, D,
                        po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
   } else {
     constexpr int kSmall = 16;
     const int64_t pbs = (int64_t)kPostThreads * kSmall;
     dim3 grid((unsigned)((P + pbs - 1) / pbs), (unsigned)D, (unsigned)nchunk);
-    hipLaunchKernelGGL((ds_post_kernel<kSmall>), grid, dim3(kPostThreads), 0, ctx->stream, ds_dev, P, ldp, D,
+    hipLaunchKernelGGL((ds_post_kernel<kSmall>), grid, dim3(kPostThreads), 0, st, ds_dev, P, ldp, D,
                        po.hist, po.maxds, po.thr, po.cand_key, po.cand_val, po.cand_cap, po.ncand, pb);
   }
   DTX_HIP(ctx, hipGetLastError());
@@ -293,6 +294,8 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int n
   DtxPost po;
   po.hist = hist_dev; po.maxds = maxds_dev; po.thr = thr_dev; po.cand_key = cand_key_dev;
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
+  { const int rcw = dtx_wait_post(ctx); if (rcw) return rcw; }      // (an earlier scan's pass may still be adding to the same histogram)
+  ctx->post_on_side = false;
   return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, D, po);
 }
 
@@ -332,7 +335,9 @@ int dtx_export_results(dtx_ctx* ctx, const uint32_t* words_dev, uint32_t* words_
   if (((uintptr_t)words_dev | (uintptr_t)words_host | (uintptr_t)keys_dev | (uintptr_t)keys_host) & 15)
     return dtx_fail(ctx, DTX_E_ARG, "dtx_export_results: buffers must be 16-byte aligned");
   DtxDeviceGuard g(ctx->device);
-  hipLaunchKernelGGL(export_results_kernel, dim3(16), dim3(256), 0, ctx->stream, words_dev, words_host, head_words,
+  // (behind the post pass that wrote them: on its stream)
+  hipLaunchKernelGGL(export_results_kernel, dim3(16), dim3(256), 0,
+                     (ctx->post_on_side && ctx->post_stream) ? ctx->post_stream : ctx->stream, words_dev, words_host, head_words,
                      cand_max, cnt_word, keys_dev, keys_host);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;

@@ -870,6 +870,29 @@ static void launch_demux(dtx_ctx* ctx, hipStream_t st, const float* x_dev, int64
                      list, ctab, n);
 }
 
+// The post pass of a scan: on the context's stream, or -- when the caller handed in a stream for it
+// (dtx_ctx_set_post_stream) -- on that stream behind an event, so that the NEXT scan's preparation, which the caller
+// has queued meanwhile, runs beside it: the pass reads the whole DS tensor at the memory's rate (150 us at configs[1])
+// while offsets, channel planes, block spectra and window statistics (270 us) are chains of latencies.  The maxima
+// it accumulates into are then cleared on that stream too (not by the next call's offset pass, which may run early).
+static int launch_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, const DtxPost& po,
+                       const int* pb) {
+  if (!ctx->post_stream) {
+    ctx->post_on_side = false;
+    return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, po, pb);
+  }
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_post_ready, ctx->stream));
+  DTX_HIP(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->ev_post_ready, 0));
+  if (po.maxds)
+    DTX_HIP(ctx, hipMemsetAsync(po.maxds, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->post_stream));
+  const int rc = dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, po, pb, ctx->post_stream);
+  if (rc) return rc;
+  DTX_HIP(ctx, hipEventRecord(ctx->ev_post_done, ctx->post_stream));
+  ctx->post_pending = true;
+  ctx->post_on_side = true;
+  return DTX_OK;
+}
+
 // post != NULL: also the histogram / maximum / candidate pass over DS (dtx_ds_post semantics)
 // ctab != NULL: a ragged batch (dtx_subspace_scan_ragged): chunk b = ctab[2 b + 1] <= M samples at x_dev + ctab[2 b]
 static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t chunk_stride,
@@ -952,7 +975,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
                      (const double*)cslice, nsl, m0f, tauf, ctab, M, n, Nc, pb, list,
-                     post ? post->maxds : (float*)nullptr, ctx->D, sover, nsb);
+                     (post && !ctx->post_stream) ? post->maxds : (float*)nullptr, ctx->D, sover, nsb);
   DTX_HIP(ctx, hipGetLastError());
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
   const double scale = (double)n / ((double)n - 1.0);
@@ -982,7 +1005,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     // scan (dtx_launch_repair): launches that find empty lists on ordinary data.
     if ((rc = dtx_fft_scan(ctx, xp, Tpad, mean, den, Ppad, P, nchunk, ds_dev, ldp, rws, pb))) return rc;
     if ((rc = dtx_launch_repair(ctx, rws, xp, Tpad, mean, den, Ppad, P, ds_dev, ldp))) return rc;
-    if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
+    if (post) return launch_post(ctx, ds_dev, P, ldp, nchunk, *post, pb);
     return DTX_OK;
   }
 
@@ -1013,6 +1036,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_launch_demux16(ctx, xp, Tpad, nchunk * Nc, g16))) return rc;
   }
 
+  if ((rc = dtx_wait_post(ctx))) return rc;      // (an earlier scan's post pass may still be reading this DS tensor)
   if (!split) DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   for (const DtxKTile& t : ctx->tiles) {
     DsArgs a;
@@ -1028,7 +1052,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_launch_repair(ctx, rws, xp, Tpad, mean, den, Ppad, P, ds_dev, ldp))) return rc;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   dtx_kev_commit(ctx);
-  if (post) return dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, *post, pb);
+  if (post) return launch_post(ctx, ds_dev, P, ldp, nchunk, *post, pb);
   return DTX_OK;
 }
 

@@ -119,7 +119,7 @@ struct XcFftArgs {
 
 // ---- the 2 x 2 workgroup ------------------------------------------------------------------------------------
 // Round 3's kernel (one workgroup of 512 threads per later event and unit of two pair spectra: removed in round 6,
-// profiles/LADDERS_r2_r4.md) was bound by the sum of its phases under two waves per SIMD, and by 80 KB through a CU's
+// profiles/LADDERS_r2_r5.md) was bound by the sum of its phases under two waves per SIMD, and by 80 KB through a CU's
 // L1 per product (a pair spectrum to registers + half of a staged block spectrum).  Here a workgroup of 1024 threads takes
 // TWO later events x TWO pair spectra of one lag block: half h (512 threads, the transform's own layout) holds pair
 // spectrum pr0 + h in registers and multiplies it with BOTH later events' block spectra, which the halves stage

@@ -108,28 +108,48 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
             Nc = len(fetcher.channels)
             sr = fetcher.sampling_rate
             n = U.shape[1]
-            if getattr(fetcher, 'counts', {}).get(sta) is not None:
-                # (add_counts keeps fragments, not planes: the per-chunk merge / longest-run trimming of
-                # detect._trim_to_gapfree would have to run for every candidate chunk first)
-                raise DetexHipError('getFAS on a fetcher of raw count fragments (add_counts) is not supported: '
-                                    'attach merged data (ContinuousFetcher.add) for the false-alarm statistics, '
-                                    'or set the thresholds directly (SVD(threshold=...))')
+            counts = getattr(fetcher, 'counts', {}).get(sta)
             data, _t0 = fetcher.data[sta]
             raw = bool(getattr(fetcher, 'raw', False))
             dec = int(getattr(ss.clusters, 'decimate', None) or 1) if raw else 1
             sr_raw, sr = sr, sr / dec                              # detect.py:239
-
-            bounds = [b for b in fetcher.chunk_bounds(sta) if _declen(b[1], dec) * Nc > n]
-            if not bounds:
-                raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
-            # fas.py:92-93: ask for 4x more chunks than needed, in random order
-            order = [int(k) for k in rs.permutation(len(bounds))[:conDatNum * 4]]
+            dropped = set()
+            if counts is not None:
+                # Raw count fragments (ContinuousFetcher.add_counts: the record as it came off the digitiser).  The
+                # reference's FAS filters every sampled chunk like a scanned one -- fas.py:101: _applyFilter(st, filt,
+                # deci, dtype), i.e. fillZeros=False: merged, cut to its longest stretch without a gap, dropped when
+                # still fractured (construct.py:1003-1023) -- and a chunk that comes back empty still counts as drawn
+                # (fas.py:99-103).  The same front half the scan runs (detect.StationScan): one ingest of the
+                # station's fragments, then the per-chunk trimming on the device.
+                from . import detect
+                T = int(data.shape[1])
+                planes = detect._ingest_station(ctx, counts, Nc, T,
+                                                pinned=getattr(fetcher, 'counts_pinned', {}).get(sta))
+                every = fetcher.chunk_bounds(sta)
+                kept = detect._trim_to_gapfree(ctx, planes, counts,
+                                               [(b[0], b[1], b[2], i) for i, b in enumerate(every)], sr_raw, sta)
+                kept = {b[3]: (b[0], b[1], b[2]) for b in kept if _declen(b[1], dec) * Nc > n}
+                if not kept:
+                    raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
+                # (the draw is over ALL chunks, as the reference's getConData(randSamps=...) draws before it filters)
+                drawn = [int(k) for k in rs.permutation(len(every))[:conDatNum * 4]]
+                dropped = set(k for k in drawn if k not in kept)
+                bounds = {k: kept[k] for k in drawn if k in kept}
+                order = [k for k in drawn if k in kept]
+                order_all = drawn
+            else:
+                bounds = [b for b in fetcher.chunk_bounds(sta) if _declen(b[1], dec) * Nc > n]
+                if not bounds:
+                    raise DetexHipError('Could not get any data for %s' % sta)       # fas.py:113-115
+                # fas.py:92-93: ask for 4x more chunks than needed, in random order
+                order = [int(k) for k in rs.permutation(len(bounds))[:conDatNum * 4]]
+                order_all = order
+                pinned = getattr(fetcher, 'pinned', {}).get(sta)
+                planes = (pinned if pinned is not None else
+                          torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))).to(ctx.device, non_blocking=True)
             zs = [i for i, c in enumerate(fetcher.channels) if str(c).upper().endswith('Z')]
             zi = zs[0] if zs else 0                                   # fas.py:175-205: the Z (else first) channel
             nsta, nlta = int(STATime * sr), int(LTATime * sr)
-            pinned = getattr(fetcher, 'pinned', {}).get(sta)
-            planes = (pinned if pinned is not None else
-                      torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))).to(ctx.device, non_blocking=True)
             T = int(planes.shape[1])
             # candidate chunks on the device, multiplexed, grouped by length: rows[M] = (tensor [G, M], [chunk ids])
             groups = {}
@@ -167,9 +187,9 @@ def run_fas(ss, conDatNum, LTATime=5, STATime=0.5, staltalimit=7.5, useSubSpaces
 
             def pick(limit):
                 chosen, count = [], 0
-                for k in order:
+                for k in order_all:
                     count += 1
-                    if limit is not None and not ok(k, limit):
+                    if k in dropped or (limit is not None and not ok(k, limit)):
                         continue
                     if len(chosen) >= conDatNum:
                         break

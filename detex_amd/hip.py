@@ -317,6 +317,10 @@ class HipContext(object):
             raise ValueError('packed results come through fetch(): lazy=True')
         hist, maxds, thr_t, key, val, cnt, pack = self._post_buffers(nchunk, self.D, x.device, thr, hist,
                                                                      want_max, cand_cap, packed)
+        post = self._ensure_post_stream()
+        for t in (thr_t, hist, maxds, key, val, cnt, pack, out):     # (from the context stream's pool, read / written on the post pass's stream)
+            if t is not None:
+                t.record_stream(post)
         if chunk_tab is not None:
             rc = self.lib.dtx_subspace_scan_ragged(self.h, _ptr(x), _ptr(tab_dev), int(M), int(nchunk),
                                                    _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
@@ -328,13 +332,30 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
             return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap, pack=pack)
+        # (the post pass ran on its own stream: the context's waits for it before the results are read)
+        self._ck(self.lib.dtx_stream_wait_post(self.h, C.c_void_p(self._stream.cuda_stream)), 'dtx_stream_wait_post')
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
+
+    def _ensure_post_stream(self):
+        """A stream of its own for the scans' post pass (dtx_ctx_set_post_stream): in a pipelined loop -- several
+        scans enqueued before their results are fetched -- the pass then runs beside the next scan's preparation.
+        Results are complete on THAT stream: _lazy_fetch records its event there, the plain call makes the context's
+        stream wait (above)."""
+        if getattr(self, '_post', None) is None:
+            self._post = torch.cuda.Stream(self.device)
+            self._ck(self.lib.dtx_ctx_set_post_stream(self.h, C.c_void_p(self._post.cuda_stream)),
+                     'dtx_ctx_set_post_stream')
+        return self._post
 
     def _lazy_fetch(self, hist, maxds, thr, key, val, cnt, cand_cap, fast=1 << 14, pack=None):
         """The small results of an enqueued scan copied to pinned host memory on a side stream
         as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
         whatever was enqueued on the context's stream after the scan (the next station's scan)."""
-        main = self._stream
+        main = self._post if getattr(self, '_post', None) is not None else self._stream     # where the post pass ran
+        if main is not self._stream:
+            for t in (hist, maxds, key, val, cnt, pack):     # (allocated from the context stream's pool, used on the post pass's)
+                if t is not None:
+                    t.record_stream(main)
         if pack is not None:
             # packed results: written into page-locked host memory by a kernel on the context's own stream
             # (dtx_export_results) -- no second stream, no copy engine, no event between streams: with several scans in
@@ -354,7 +375,7 @@ class HipContext(object):
             if keep is None:
                 import collections
                 keep = self._export_keep = collections.deque(maxlen=16)
-            keep.append((hp, hk, pack, key))
+            keep.append((hp, hk, pack, key, thr))
             host = {'key': hk, 'hist': hp[:nh].view(hist.shape), 'cnt': hp[nh:nh + 1],
                     'maxds': hp[nh + 1:nh + 1 + nm].view(torch.float32).view(maxds.shape),
                     'val': hp[nh + 1 + nm:].view(torch.float32)}

@@ -359,6 +359,16 @@ class _LinkRow(dict):
         self['II'] = self._cluster.members(self['clust'])
         return self['II']
 
+    # ('II' answers through every way a dict is asked: row['II'], row.get('II'), 'II' in row, keys / items of a
+    # row that was asked once -- ADVICE r5: only __getitem__ went through __missing__)
+    def get(self, key, default=None):
+        if key == 'II':
+            return self['II']
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key == 'II' or dict.__contains__(self, key)
+
 
 class _DbWriter(object):
     """The SQLite file of a SubSpace.detex call, written by a thread of its own: the detection rows of

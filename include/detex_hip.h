@@ -159,6 +159,16 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
                 const float* thr_dev, uint64_t* cand_key_dev,
                 float* cand_val_dev, uint32_t cand_cap, uint32_t* ncand_dev);
 
+/* A stream for the post pass (histogram / maxima / candidates) of dtx_subspace_scan(_ragged); NULL (default): the
+ * context's own.  With one, the pass runs there behind the scan, BESIDE whatever the caller queues next on the
+ * context's stream -- in a pipelined loop the next scan's preparation -- and the library orders the next scan's
+ * kernel (which overwrites DS) behind it.  Its results (hist / maxds / candidates) are then complete on that stream,
+ * not on the context's: wait with dtx_ctx_sync, make a stream wait with dtx_stream_wait_post, or read them through
+ * dtx_export_results (which follows the pass onto its stream).  DS itself is complete on the context's stream as
+ * before.  No reference counterpart (a host loop: detect.py:259-281). */
+int dtx_ctx_set_post_stream(dtx_ctx* ctx, void* stream);
+int dtx_stream_wait_post(dtx_ctx* ctx, void* stream);
+
 /* The small results of a scan handed to the host by a kernel on the context's stream (no copy engine, no second
  * stream): words_dev = a caller's packed 4-byte results [head_words | candidate values ...] whose word `cnt_word`
  * (< head_words) is the candidate counter, keys_dev = the candidate keys; words_host / keys_host = page-locked host

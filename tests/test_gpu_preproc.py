@@ -343,6 +343,22 @@ def test_detex_on_raw_counts_with_gaps(ctx):
     assert len(gz) == len(wz) >= len(want)
     for (_, g), w in zip(gz.iterrows(), sorted(wz)):
         assert g.STMP == w[0] and abs(g.DS - w[1]) <= 1e-5 and g.DS_STALTA == 0.0
+    # false-alarm statistics from the same fragments (fas.py:88-117: every sampled chunk through _applyFilter with
+    # fillZeros=False, i.e. trimmed to its gap-free stretch; the fractured chunk is drawn, counted and skipped): the
+    # histogram of the DS values of the two kept stretches (this raised until round 6)
+    ss.getFAS(conDatNum=3, staltalimit=None, seed=0)
+    fas = ss.subspaces['XX.STA'].FAS.iloc[0]
+    alld = []
+    for (a, rl) in kept:
+        x = multiplex(orc.apply_filter([m.astype(np.float32) for m in merged[:, a:a + rl]], filt, sr))
+        alld.append(orc.mpxds_fft(x, U.astype(np.float32), Nc))
+    allv = np.sort(np.concatenate(alld))
+    edges = np.linspace(-.01, 1, 401)
+    ref = np.histogram(allv, bins=edges)[0]
+    assert fas['hist'].sum() == ref.sum() == sum(len(d) for d in alld)
+    near = np.searchsorted(allv, edges[1:] + 1e-5, 'right') - np.searchsorted(allv, edges[1:] - 1e-5, 'left')
+    flips = np.abs(np.cumsum(fas['hist']) - np.cumsum(ref))
+    assert np.all(flips <= near), (int(flips.max()), int(near[np.argmax(flips)]))
 
 
 def test_detex_on_raw_counts_with_resent_packets(ctx):

@@ -1227,3 +1227,26 @@ def test_loadClusters_loadSubSpace_round_trip(tmp_path, monkeypatch):
         detex_amd.loadClusters('subspace.pkl')
     with pytest.raises(detex_amd.DetexHipError):
         detex_amd.loadSubSpace('clust.pkl')
+
+
+def test_lazy_mptd_pickles_without_its_cache_and_link_rows_answer_II():
+    """a pickled ClusterStream holds the events once (the multiplexed arrays built so far are not written
+    beside the channel planes), and a dflink row answers 'II' through get / in as well as [...]."""
+    import pickle
+    from detex_amd.construct import _LazyMPtd
+    rs = np.random.RandomState(0)
+    planes = {'e%d' % i: rs.standard_normal((3, 500)) for i in range(6)}
+    m = _LazyMPtd(planes, 1500, np.float64)
+    bare = len(pickle.dumps(m))
+    for k in planes:
+        assert m[k].shape == (1500,)                       # builds (and caches) the multiplexed arrays
+    assert len(pickle.dumps(m)) == bare
+    m2 = pickle.loads(pickle.dumps(m))
+    assert all(np.array_equal(m2[k], m[k]) for k in planes)
+    ctx = OracleCtx()
+    ss, _, _, _ = small_workflow(ctx)
+    c = ss.clusters[0]
+    row = c.dflink.iloc[0] if hasattr(c.dflink, 'iloc') else c.dflink[0]
+    row = row if isinstance(row, dict) else row.to_dict()
+    if hasattr(row, '_cluster'):
+        assert 'II' in row and row.get('II') == row['II'] and len(row['II']) >= 2
