@@ -134,7 +134,7 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
-def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
+def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg, kernel_name=None):
     """Roofline object of the dominant kernel of one engine (kms: its average launch
     duration from HIP events on the launch stream)."""
     import glob
@@ -176,7 +176,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
         # single-segment templates on 1 or 3 channels run the ping-pong kernel (two half-workgroups
         # per CU taking turns on the transform image), everything else the one-group kernel
         pp = Nc in (1, 3) and nseg == 1
-        kname = ('ds_fft_pp_kernel<%d>' if pp else 'ds_fft_kernel<%d>') % (V // 512)
+        kname = kernel_name or (('ds_fft_pp_kernel<%d>' if pp else 'ds_fft_kernel<%d>') % (V // 512))   # (the library's own name of what it dispatched)
         return {'bound': 'hbm', 'kernel': kname, 'achieved': gbs, 'peak': 8000.0,
                 'unit': 'GB/s', 'frac': gbs / 8000.0,
                 'traffic': pmc('*_bench_pmc_ds_fft_pp_kernel.json' if pp else '*_bench_pmc_ds_fft_kernel.json',
@@ -206,7 +206,7 @@ def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg):
                         'bound is the dependent instruction chains of the four waves per SIMD, DESIGN.md 4.1' % nfft}
     if eng == 'fp32':
         ach = flops / (kms * 1e-3) / 1e12
-        return {'bound': 'mfma', 'kernel': 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8)),
+        return {'bound': 'mfma', 'kernel': kernel_name or 'ds_mfma_kernel<%d,%d>' % (rm, 2 if rm >= 9 else (4 if rm >= 5 else 8)),
                 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc('*_bench_pmc_ds_mfma_kernel.json'),
                 'kernel_ms': kms, 'flop_per_launch': flops, 'engine': 'fp32',
@@ -375,6 +375,8 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
         cc, lag, ss = ctx.xcorr_allpairs(td, Nc)
         ctx.sync()
         res[eng] = (time.perf_counter() - t1, ctx.last_kernel_ms(), float(cc.mean()))
+        if eng == 'auto':
+            kname_full = ctx.last_kernel_name()
     ctx.set_engine('auto')
     dt, kms, ccm = res['auto']
     dtm, kmsm, _ = res['bf16x3']
@@ -388,6 +390,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
         ctx.xcorr_allpairs(tds, Nc)
         ctx.sync()
         ks = ctx.last_kernel_ms()
+        kname_short = ctx.last_kernel_name()
         Ls = 3000
         Ss = Ls - Ls // 2
         b_s = 4.0 * N * Nc * Ls + 12.0 * npairs
@@ -397,7 +400,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
                  # one segment, one lag block (3001 lags in a block of 8192): one transform and Nc products per event pair;
                  # outside the lag search: the float64 finish (xc_finish2_kernel) + preparation, seconds - kernel_ms
                  'outside_lag_search_ms': 1e3 * (time.perf_counter() - t1) - ks,
-                 'roofline': {'bound': 'hbm', 'kernel': 'xc_fft12_kernel<10>', 'kernel_ms': ks, 'bytes_per_launch': b_s,
+                 'roofline': {'bound': 'hbm', 'kernel': kname_short, 'kernel_ms': ks, 'bytes_per_launch': b_s,
                               'achieved': b_s / (ks * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                               'frac': b_s / (ks * 1e-3) / 1e9 / 8000.0, 'traffic': None,
                               'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
@@ -453,7 +456,7 @@ def xcorr_full(ctx, synth, Nc, cpu=True):
     return {'value': npairs / dt, 'unit': 'pairs/s', 'seconds': dt,
             'workload': 'configs[2]: %d events, Nc=%d, L=%d (n=%d), %d pairs' % (N, Nc, L, n, npairs),
             'cc_mean': ccm, 'cpu_baseline': cpu_leg, 'short_variant': short,
-            'roofline': {'bound': 'hbm', 'kernel': 'xc_fft22_kernel', 'kernel_ms': kms,
+            'roofline': {'bound': 'hbm', 'kernel': kname_full, 'kernel_ms': kms,
                          'achieved': bytes_alg / (kms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': bytes_alg / (kms * 1e-3) / 1e9 / 8000.0,
                          'traffic': ({'bytes': hbm, 'source': pmc_src, 'live': False,
@@ -509,6 +512,8 @@ def config5(ctx, synth):
             ds, r = ctx.subspace_scan(xt, out=ds, thr=thr)
         ctx.sync()
         res[eng] = ((time.perf_counter() - t1) / 5, ctx.last_kernel_ms())
+        if eng == 'auto':
+            kname5 = ctx.last_kernel_name()
         cb, cd, cp, cv = r['cand']
         assert all(((cp - p) == 0).any() for (_, p, _) in plants), 'config5: planted event missed'
     ctx.set_engine('auto')
@@ -540,7 +545,7 @@ def config5(ctx, synth):
     return {'value': P / res['auto'][0], 'unit': 'windows/s', 'ms_per_hour_of_data': 1e3 * res['auto'][0],
             'kernel_ms': res['auto'][1], 'step_over_kernel': 1e3 * res['auto'][0] / res['auto'][1],
             'day_per_call': day,
-            'roofline': {'bound': 'hbm', 'kernel': 'ds_fft_kernel<14,false,6>', 'kernel_ms': ka, 'bytes_per_launch': b_alg,
+            'roofline': {'bound': 'hbm', 'kernel': kname5, 'kernel_ms': ka, 'bytes_per_launch': b_alg,
                          'achieved': b_alg / (ka * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': b_alg / (ka * 1e-3) / 1e9 / 8000.0, 'traffic': None,
                          'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
@@ -594,7 +599,7 @@ def config2_singles(ctx, synth, a, xt, M, Nc, n, cpu_rate=None):
     out = {'value': W / dt, 'unit': 'windows/s', 'ms_per_step': 1e3 * dt, 'kernel_ms': kms, 'post_ms': post_ms,
            'workload': 'configs[1] as singles: %d detectors x 1 vector x %d chunks, n=%d; DS tensor %.2f GB'
                        % (D, a.chunks, n, 4.0 * D * W / 1e9),
-           'roofline': {'bound': 'hbm', 'kernel': 'ds_fft_pp_kernel<10,false,3> + ds_post_kernel',
+           'roofline': {'bound': 'hbm', 'kernel': ctx.last_kernel_name() + ' + ds_post_kernel',
                         'bytes_per_launch': b_scan + b_post, 'kernel_ms': kms + post_ms,
                         'achieved': (b_scan + b_post) / ((kms + post_ms) * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                         'frac': (b_scan + b_post) / ((kms + post_ms) * 1e-3) / 1e9 / 8000.0, 'traffic': None,
@@ -1319,7 +1324,7 @@ def main():
                    'results': 'maxima and candidate lists of every step fetched to the host inside the timed '
                               'region, each while the next step runs (pinned buffers, side stream)',
                    'binding': dict(binding)},
-        'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg),
+        'roofline': roofline(eng, kms, K, n, Nc, L, D, P, a.chunks, flops, default_cfg, kernel_name=ctx.last_kernel_name()),
     }
     tr = out['roofline'].get('traffic') if out['roofline'] else None
     if tr and tr.get('bytes') and out['roofline'].get('bytes_per_launch'):
@@ -1360,7 +1365,8 @@ def main():
             dto = time.perf_counter() - t1
             ko = ctx.last_kernel_ms()
             out[key] = {'value': a.chunks * P / dto, 'unit': 'windows/s',
-                        'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg)}
+                        'roofline': roofline(other, ko, K, n, Nc, L, D, P, a.chunks, flops, default_cfg,
+                                             kernel_name=ctx.last_kernel_name())}
         ctx.set_engine(a.engine)
         try:
             out['dist_overhead'] = dist_overhead(local, timed_loop, min(a.steps, 100), 1e3 * dt / a.steps,

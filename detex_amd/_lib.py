@@ -21,7 +21,7 @@ SYMBOLS = [
     'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean', 'dtx_subspace_scan_ragged',
     'dtx_trigger_stats_ragged', 'dtx_chunk_table_check', 'dtx_ctx_set_trigger_stream', 'dtx_stream_wait_scan_kernel',
     'dtx_kernel_ms_list', 'dtx_stalta_max', 'dtx_repair_counts', 'dtx_device_pci_bus_id', 'dtx_export_results', 'dtx_ctx_set_post_stream',
-    'dtx_stream_wait_post',
+    'dtx_stream_wait_post', 'dtx_last_kernel_name',
 ]
 
 
@@ -123,6 +123,8 @@ def load():
     lib.dtx_ctx_set_post_stream.argtypes = [vp, vp]
     lib.dtx_stream_wait_post.restype = i32
     lib.dtx_stream_wait_post.argtypes = [vp, vp]
+    lib.dtx_last_kernel_name.restype = C.c_char_p
+    lib.dtx_last_kernel_name.argtypes = [vp]
     lib.dtx_export_results.restype = i32
     lib.dtx_export_results.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp]
     lib.dtx_repair_counts.restype = i32

@@ -266,23 +266,11 @@ def _sync_copy(ctx):
         torch.cuda.current_stream(dev).synchronize()
 
 
-def _fill_workers():
-    """Threads for the host-side copies of createCluster (NumPy releases the GIL inside large copies): the cores
-    this process may use (a rank bound to its GPU's NUMA node: parallel.bind_to_device), at most four."""
-    import os
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(4, n))
-
-
 def _xcorr_condensed(eventList, row, ctx):
     """construct.py:369-394 on the GPU: all pairs b < c of ``eventList`` in one dtx_xcorr_allpairs call.
     Returns (N, cc, lag, subsamp) as condensed NumPy vectors (pair (b, c), b < c, row-major: the order of the
     reference's double loop)."""
     import torch
-    from concurrent.futures import ThreadPoolExecutor
     if len(set(len(row.Channels[e]) for e in eventList)) != 1:
         _error('Number of Channels not equal, cannot perform correlation')      # 429-431
     lazy = isinstance(row.MPtd, _LazyMPtd)
@@ -292,11 +280,11 @@ def _xcorr_condensed(eventList, row, ctx):
     Nc = len(row.Channels[eventList[0]])
     N = len(eventList)
     with _phase('fill'):
-        # The event matrix, assembled in page-locked memory and uploaded slab by slab: a few threads copy (and
-        # convert) the events of a slab while the previous slab is on its way to the device -- the upload then runs
-        # at the link's rate instead of through a pageable staging copy, and under the next slab's copies.  (Round 5:
-        # one thread, event by event, then one upload: 19 + 6 ms at 2000 events; a list of 2000 float64 arrays
-        # through ascontiguousarray took 1.2 s in round 4.)
+        # The event matrix, assembled in page-locked memory and uploaded slab by slab: a slab is on its way to the
+        # device -- at the link's rate, not through a pageable staging copy -- while the next one is copied (and
+        # converted) event by event.  (Round 5: all events, then one upload: 19 + 6 ms at 2000 events; a list of 2000
+        # float64 arrays through ascontiguousarray took 1.2 s in round 4.  Four threads copying, round 6: 54 ms -- 2000
+        # short copies hand the interpreter lock back and forth.)
         n = row.MPtd.length(eventList[0]) if lazy else len(row.MPtd[eventList[0]])
         lazy = lazy and n % Nc == 0
         on_gpu = True
@@ -316,16 +304,13 @@ def _xcorr_condensed(eventList, row, ctx):
                     row.MPtd.planes_f32(eventList[i], td3[i])
                 else:
                     td[i] = row.MPtd[eventList[i]]
-        nw = _fill_workers()
-        nslab = 4 if (on_gpu and N >= 64) else 1
+        nslab = 8 if (on_gpu and N >= 64) else 1
         tdev = torch.empty((N, n), dtype=torch.float32, device=ctx.device) if on_gpu else None
-        with ThreadPoolExecutor(max_workers=nw) as ex:
-            for sl in range(nslab):
-                a, b = sl * N // nslab, (sl + 1) * N // nslab
-                cuts = [a + q * (b - a) // nw for q in range(nw + 1)]
-                list(ex.map(lambda q: copy_rows(cuts[q], cuts[q + 1]), range(nw)))
-                if on_gpu:
-                    tdev[a:b].copy_(tdt[a:b], non_blocking=True)
+        for sl in range(nslab):
+            a, b = sl * N // nslab, (sl + 1) * N // nslab
+            copy_rows(a, b)
+            if on_gpu:
+                tdev[a:b].copy_(tdt[a:b], non_blocking=True)
     with _phase('h2d'):
         if not on_gpu:
             tdev = tdt.to(ctx.device, non_blocking=True)

@@ -1123,21 +1123,35 @@ int dtx_fft_scan(dtx_ctx* ctx, const float* xp, int64_t Tpad, const float* mean,
   hipLaunchKernelGGL(guard_kernel, dim3((unsigned)(nchunk * nblk)), dim3(256), 0, ctx->aux, den,
                      Ppad, P, V, nblk, f.nseg == 1 ? V : 2 * V, ws, pb);
   DTX_HIP(ctx, hipGetLastError());
-  // what becomes of the listed blocks (outliers split off, repair tasks): still on the side stream, beside the
-  // block spectra -- the scan does not wait longer for it than for the statistics
-  hipLaunchKernelGGL(spike_split_kernel, dim3((unsigned)ctx->ncu), dim3(kSplitT), 0, ctx->aux, xp, Tpad, Nc, ctx->L,
+  // What becomes of the listed blocks (outliers split off, repair tasks; the spectra of the blocks with outliers split
+  // off, without them): launches sized for the chip that find empty lists on ordinary data.  Still on the side stream,
+  // beside the block spectra -- the chain statistics -> guard -> these is shorter than `xhat` there -- unless the call
+  // is small (fewer blocks than 2 x CUs: configs[4] one hour per call): then `xhat` is the short side and they follow
+  // it on the main stream.
+  const bool small_call = (int64_t)nchunk * nblk < 2 * (int64_t)ctx->ncu;
+  if (small_call) {
+    const int rcj = dtx_aux_join(ctx);
+    if (rcj) return rcj;
+  }
+  const hipStream_t sst = small_call ? ctx->stream : ctx->aux;
+  hipLaunchKernelGGL(spike_split_kernel, dim3((unsigned)ctx->ncu), dim3(kSplitT), 0, sst, xp, Tpad, Nc, ctx->L,
                      den, Ppad, P, V, nblk, f.nseg, ws, pb);
   DTX_HIP(ctx, hipGetLastError());
   if (f.nseg == 1) {
-    // ... and the spectra of the blocks with outliers split off, without them (a launch sized for the chip that finds
-    // an empty list on ordinary data)
-    hipLaunchKernelGGL(xhat_clean_kernel, dim3((unsigned)ctx->ncu, (unsigned)Nc), dim3(kT), 0, ctx->aux, xp, Tpad,
+    hipLaunchKernelGGL(xhat_clean_kernel, dim3((unsigned)ctx->ncu, (unsigned)Nc), dim3(kT), 0, sst, xp, Tpad,
                        Nc, V, nblk, nblkx, keep, (const c32*)f.tab_dev, xhc, ws);
     DTX_HIP(ctx, hipGetLastError());
   }
-  {
+  if (!small_call) {
     const int rcj = dtx_aux_join(ctx);
     if (rcj) return rcj;
+  }
+  {
+    char nm[96];
+    if (pp) snprintf(nm, sizeof nm, "ds_fft_pp_kernel<%d,%s,%d>", V / 512, f.two ? "true" : "false", Nc);
+    else snprintf(nm, sizeof nm, "ds_fft_kernel<%d,%s,%d>", V / 512, f.two ? "true" : "false",
+                  (f.nseg == 1 && !f.two && (Nc == 1 || Nc == 3)) || (f.nseg == 1 && f.two && Nc == 3) ? Nc : 0);
+    ctx->last_kernel = nm;
   }
   { const int rcw = dtx_wait_post(ctx); if (rcw) return rcw; }     // (an earlier scan's post pass may still be reading this DS tensor)
   { const int rck = dtx_kev_next(ctx); if (rck) return rck; }

@@ -118,6 +118,7 @@ struct dtx_ctx {
   std::vector<double> pp_key[kPpCache];
   int pp_next = 0;                     // round-robin replacement
   int engine = DTX_ENGINE_AUTO;
+  std::string last_kernel;             // the dominant kernel the last call dispatched (dtx_last_kernel_name)
   bool guard_ran = false;              // the last scan filled DtxRepairWs::count (dtx_repair_counts)
 
   // small host tables on their way to the device without a stream synchronisation: a ring of page-locked

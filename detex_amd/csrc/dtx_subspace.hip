@@ -992,6 +992,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     if ((rc = dtx_aux_fork(ctx))) return rc;
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
                        Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 0);
+    // (the second launch takes the blocks whose outlier list overflowed: none on ordinary data)
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
                        Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 1);
     DTX_HIP(ctx, hipGetLastError());
@@ -1037,6 +1038,13 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   }
 
   if ((rc = dtx_wait_post(ctx))) return rc;      // (an earlier scan's post pass may still be reading this DS tensor)
+  {
+    char nm[64];
+    const int rm0 = ctx->tiles.front().rm;
+    if (split) snprintf(nm, sizeof nm, "ds_mfma_kernel_s<%d>", rm0);
+    else snprintf(nm, sizeof nm, "ds_mfma_kernel<%d,%d>", rm0, tn_for(rm0));
+    ctx->last_kernel = nm;
+  }
   if (!split) DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   for (const DtxKTile& t : ctx->tiles) {
     DsArgs a;
@@ -1085,6 +1093,8 @@ int dtx_subspace_scan_ragged(dtx_ctx* ctx, const float* x_dev, const int64_t* ch
   po.cand_val = cand_val_dev; po.cand_cap = cand_cap; po.ncand = ncand_dev;
   return subspace_ds_impl(ctx, x_dev, M, 0, nchunk, ds_dev, ldp, &po, chunk_tab_dev);
 }
+
+const char* dtx_last_kernel_name(dtx_ctx* ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
 int dtx_repair_counts(dtx_ctx* ctx, int32_t counts[4]) {
   if (!ctx) return DTX_E_ARG;

@@ -633,6 +633,11 @@ int dtx_xcfft_run(dtx_ctx* ctx, const float* td_dev, int N, int n, int Nc, int L
   a.N = N; a.Nc = Nc; a.nseg = nseg; a.nblk = nblk; a.V = V; a.Pz = Pz;
   a.seglen = seglen; a.zend = S + L;
   a.per_xcd = per_xcd; a.nwork = nwork;
+  {
+    char nm[64];
+    snprintf(nm, sizeof nm, "%s<%d>", t12 ? "xc_fft12_kernel" : "xc_fft22_kernel", V / 512);
+    ctx->last_kernel = nm;
+  }
   { const int rck = dtx_kev_next(ctx); if (rck) return rck; }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   if (t12) switch (V / 512) {

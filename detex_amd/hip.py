@@ -317,10 +317,13 @@ class HipContext(object):
             raise ValueError('packed results come through fetch(): lazy=True')
         hist, maxds, thr_t, key, val, cnt, pack = self._post_buffers(nchunk, self.D, x.device, thr, hist,
                                                                      want_max, cand_cap, packed)
-        post = self._ensure_post_stream()
-        for t in (thr_t, hist, maxds, key, val, cnt, pack, out):     # (from the context stream's pool, read / written on the post pass's stream)
-            if t is not None:
-                t.record_stream(post)
+        # a stream of its own for the post pass when the caller pipelines (lazy: results fetched later, the next scan
+        # enqueued meanwhile); a plain call reads the results at once, the pass stays on the context's stream
+        post = self._ensure_post_stream(lazy)
+        if post is not None:
+            for t in (thr_t, hist, maxds, key, val, cnt, pack, out):     # (from the context stream's pool, used on the post pass's stream)
+                if t is not None:
+                    t.record_stream(post)
         if chunk_tab is not None:
             rc = self.lib.dtx_subspace_scan_ragged(self.h, _ptr(x), _ptr(tab_dev), int(M), int(nchunk),
                                                    _ptr(out), int(out.stride(1)), _ptr(hist), _ptr(maxds),
@@ -332,26 +335,31 @@ class HipContext(object):
         self._ck(rc, 'dtx_subspace_scan')
         if lazy:
             return out, self._lazy_fetch(hist, maxds, thr, key, val, cnt, cand_cap, pack=pack)
-        # (the post pass ran on its own stream: the context's waits for it before the results are read)
-        self._ck(self.lib.dtx_stream_wait_post(self.h, C.c_void_p(self._stream.cuda_stream)), 'dtx_stream_wait_post')
         return out, self._post_result(hist, maxds, thr, key, val, cnt, cand_cap)
 
-    def _ensure_post_stream(self):
+    def _ensure_post_stream(self, on=True):
         """A stream of its own for the scans' post pass (dtx_ctx_set_post_stream): in a pipelined loop -- several
         scans enqueued before their results are fetched -- the pass then runs beside the next scan's preparation.
-        Results are complete on THAT stream: _lazy_fetch records its event there, the plain call makes the context's
-        stream wait (above)."""
-        if getattr(self, '_post', None) is None:
-            self._post = torch.cuda.Stream(self.device)
-            self._ck(self.lib.dtx_ctx_set_post_stream(self.h, C.c_void_p(self._post.cuda_stream)),
-                     'dtx_ctx_set_post_stream')
-        return self._post
+        Results are complete on THAT stream: _lazy_fetch records its event there.  on=False: back on the context's
+        stream (the library first orders that stream behind a pass still running on the other)."""
+        if on:
+            if getattr(self, '_post', None) is None:
+                self._post = torch.cuda.Stream(self.device)
+            if not getattr(self, '_post_on', False):
+                self._ck(self.lib.dtx_ctx_set_post_stream(self.h, C.c_void_p(self._post.cuda_stream)),
+                         'dtx_ctx_set_post_stream')
+                self._post_on = True
+            return self._post
+        if getattr(self, '_post_on', False):
+            self._ck(self.lib.dtx_ctx_set_post_stream(self.h, None), 'dtx_ctx_set_post_stream')
+            self._post_on = False
+        return None
 
     def _lazy_fetch(self, hist, maxds, thr, key, val, cnt, cand_cap, fast=1 << 14, pack=None):
         """The small results of an enqueued scan copied to pinned host memory on a side stream
         as soon as the scan is done: the returned fetch() waits for exactly that copy, not for
         whatever was enqueued on the context's stream after the scan (the next station's scan)."""
-        main = self._post if getattr(self, '_post', None) is not None else self._stream     # where the post pass ran
+        main = self._post if getattr(self, '_post_on', False) else self._stream     # where the post pass ran
         if main is not self._stream:
             for t in (hist, maxds, key, val, cnt, pack):     # (allocated from the context stream's pool, used on the post pass's)
                 if t is not None:
@@ -742,6 +750,10 @@ class HipContext(object):
         ms = (C.c_float * int(n))()
         self._ck(self.lib.dtx_kernel_ms_list(self.h, int(n), ms), 'dtx_kernel_ms_list')
         return [float(v) for v in ms][::-1]
+
+    def last_kernel_name(self):
+        """The dominant kernel the last scan / cross-correlation call dispatched (dtx_last_kernel_name)."""
+        return (self.lib.dtx_last_kernel_name(self.h) or b'').decode()
 
     def repair_counts(self):
         """What the dynamic-range guards of the last scan listed (dtx_repair_counts; waits for the stream):

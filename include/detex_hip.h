@@ -405,6 +405,9 @@ int dtx_kernel_ms_list(dtx_ctx* ctx, int n, float* ms);
  * contraction again, counts[2] = blocks scanned again with outlier samples split off, counts[3] = 0.  All zero on
  * ordinary data; the reference has no counterpart (its float64 transforms need no guard: detect.py:559-578). */
 int dtx_repair_counts(dtx_ctx* ctx, int32_t counts[4]);
+/* Name of the dominant kernel the context's last scan / cross-correlation call dispatched (the instantiation the
+ * library chose: e.g. "ds_fft_pp_kernel<10,false,3>", "xc_fft22_kernel<9>"); bench.py labels its roofline with it. */
+const char* dtx_last_kernel_name(dtx_ctx* ctx);
 
 #ifdef __cplusplus
 }
