@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'analyse':
     units = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']),
                  r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:40]) for r in rows)
-    scans = [e for e in ev if e[2].startswith('ds_fft')]
+    scans = [e for e in ev if e[2].startswith(('ds_fft_pp_kernel', 'ds_fft_kernel'))]      # (not the re-scan of listed blocks)
     t0, t1 = scans[-units - 1][0], scans[-1][0]
     win = [e for e in ev if t0 <= e[0] < t1]
     busy, end, gaps = 0, win[0][0], []
