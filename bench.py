@@ -134,32 +134,36 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
+def pmc_summary(pattern, instance=None):
+    """HBM-side bytes per launch from the newest committed rocprofv3 --pmc summary profiles/<pattern>
+    (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes; scripts/summarize_profile.py)."""
+    import glob
+    pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), key=_tag_order)
+    if not pm:
+        return None
+    with open(pm[-1]) as f:
+        prof = json.load(f)
+    b = prof.get('counters', {}).get('hbm_bytes_per_launch_corrected')
+    # NOT a live counter: read from the committed rocprofv3 --pmc summary of the same command
+    # (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes).  The summary names the kernel
+    # instantiation(s) it counted and the sha1 of the kernel sources it was built from: a summary of an
+    # older kernel, or of another instantiation than the one that just ran, is flagged here
+    inst = prof.get('kernel_instances')
+    sha = prof.get('source_sha1')
+    return {'bytes': b, 'source': 'profiles/' + os.path.basename(pm[-1]), 'live': False,
+            'same_kernel_source': (sha == kernel_source_digest()) if sha else None,
+            'same_instantiation': (any(instance.replace(' ', '') in k.replace(' ', '') for k in inst)
+                                   if inst and instance else None)}
+
+
 def roofline(eng, kms, K, n, Nc, L, D, P, chunks, flops, default_cfg, kernel_name=None):
     """Roofline object of the dominant kernel of one engine (kms: its average launch
     duration from HIP events on the launch stream)."""
-    import glob
     rm = (min(K, 208) + 15) // 16            # row blocks of the (first) K-tile, dtx_hankel.h
+
     def pmc(pattern, instance=None):
-        # HBM-side bytes per launch: PMC counters collected by scripts/profile.sh (separate
-        # --pmc passes, gfx950 FETCH_SIZE x2 correction) for the default configuration only
-        if not default_cfg:
-            return None
-        pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), key=_tag_order)
-        if not pm:
-            return None
-        with open(pm[-1]) as f:
-            prof = json.load(f)
-        b = prof.get('counters', {}).get('hbm_bytes_per_launch_corrected')
-        # NOT a live counter: read from the committed rocprofv3 --pmc summary of the same command
-        # (scripts/profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes).  The summary names the kernel
-        # instantiation(s) it counted and the sha1 of the kernel sources it was built from: a summary of an
-        # older kernel, or of another instantiation than the one that just ran, is flagged here
-        inst = prof.get('kernel_instances')
-        sha = prof.get('source_sha1')
-        return {'bytes': b, 'source': 'profiles/' + os.path.basename(pm[-1]), 'live': False,
-                'same_kernel_source': (sha == kernel_source_digest()) if sha else None,
-                'same_instantiation': (any(instance.replace(' ', '') in k.replace(' ', '') for k in inst)
-                                       if inst and instance else None)}
+        # for the default configuration only
+        return pmc_summary(pattern, instance) if default_cfg else None
     if eng == 'fft':
         N = 8192
         V = (N - L + 1) // 512 * 512 if L <= 5633 else 4096      # segmented templates advance by 4096
@@ -547,7 +551,8 @@ def config5(ctx, synth):
             'day_per_call': day,
             'roofline': {'bound': 'hbm', 'kernel': kname5, 'kernel_ms': ka, 'bytes_per_launch': b_alg,
                          'achieved': b_alg / (ka * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': b_alg / (ka * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                         'frac': b_alg / (ka * 1e-3) / 1e9 / 8000.0,
+                         'traffic': pmc_summary('*c5_bench_pmc_ds_fft_kernel.json', kname5),
                          'compute': {'unit': 'TFLOP/s', 'peak_f32_vector': PEAK_FP32_MFMA_TFLOPS,
                                      'issued': flop_fft / (ka * 1e-3) / 1e12,
                                      'frac': flop_fft / (ka * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
