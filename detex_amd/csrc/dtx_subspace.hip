@@ -873,8 +873,9 @@ static void launch_demux(dtx_ctx* ctx, hipStream_t st, const float* x_dev, int64
 // The post pass of a scan: on the context's stream, or -- when the caller handed in a stream for it
 // (dtx_ctx_set_post_stream) -- on that stream behind an event, so that the NEXT scan's preparation, which the caller
 // has queued meanwhile, runs beside it: the pass reads the whole DS tensor at the memory's rate (150 us at configs[1])
-// while offsets, channel planes, block spectra and window statistics (270 us) are chains of latencies.  The maxima
-// it accumulates into are then cleared on that stream too (not by the next call's offset pass, which may run early).
+// while offsets, channel planes, block spectra and window statistics (270 us) are chains of latencies.  (The maxima it
+// accumulates into are cleared by THIS call's offset pass, in front of it on the context's stream: a caller must not
+// hand the next call the result buffers of a call whose results it has not read -- it would lose them either way.)
 static int launch_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp, int nchunk, const DtxPost& po,
                        const int* pb) {
   if (!ctx->post_stream) {
@@ -883,8 +884,6 @@ static int launch_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp
   }
   DTX_HIP(ctx, hipEventRecord(ctx->ev_post_ready, ctx->stream));
   DTX_HIP(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->ev_post_ready, 0));
-  if (po.maxds)
-    DTX_HIP(ctx, hipMemsetAsync(po.maxds, 0, (size_t)nchunk * ctx->D * sizeof(float), ctx->post_stream));
   const int rc = dtx_post_launch(ctx, ds_dev, P, ldp, nchunk, ctx->D, po, pb, ctx->post_stream);
   if (rc) return rc;
   DTX_HIP(ctx, hipEventRecord(ctx->ev_post_done, ctx->post_stream));
@@ -975,7 +974,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
   // (the final pass also zeroes the guard's list counter and the maxima the post pass accumulates into)
   hipLaunchKernelGGL(chunk_offset_final_kernel, dim3((unsigned)nchunk), dim3(64), 0, ctx->stream,
                      (const double*)cslice, nsl, m0f, tauf, ctab, M, n, Nc, pb, list,
-                     (post && !ctx->post_stream) ? post->maxds : (float*)nullptr, ctx->D, sover, nsb);
+                     post ? post->maxds : (float*)nullptr, ctx->D, sover, nsb);
   DTX_HIP(ctx, hipGetLastError());
   // pandas rolling_var(ddof=1) * n = n/(n-1) * sum (w - mu)^2   (detect.py:567-568)
   const double scale = (double)n / ((double)n - 1.0);

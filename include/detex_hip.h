@@ -165,7 +165,8 @@ int dtx_ds_post(dtx_ctx* ctx, const float* ds_dev, int64_t P, int64_t ldp,
  * kernel (which overwrites DS) behind it.  Its results (hist / maxds / candidates) are then complete on that stream,
  * not on the context's: wait with dtx_ctx_sync, make a stream wait with dtx_stream_wait_post, or read them through
  * dtx_export_results (which follows the pass onto its stream).  DS itself is complete on the context's stream as
- * before.  No reference counterpart (a host loop: detect.py:259-281). */
+ * before.  The result buffers of a call (hist / maxds / candidates) must not be handed to the next call before they
+ * were read.  No reference counterpart (a host loop: detect.py:259-281). */
 int dtx_ctx_set_post_stream(dtx_ctx* ctx, void* stream);
 int dtx_stream_wait_post(dtx_ctx* ctx, void* stream);
 
