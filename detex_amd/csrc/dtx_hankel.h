@@ -79,7 +79,9 @@ __device__ __forceinline__ void lds_wait_all() {
   __builtin_amdgcn_sched_barrier(0);   // keep MFMAs behind the wait (hipcc would hoist them)
 }
 
-template <int RM, int TN, bool GL = false, bool TAIL = false>
+// BQ: contraction indices staged per step (kBQ everywhere but in the repair pass's tasks, whose few MFMAs per step
+// leave every step's load latency exposed: deeper steps, fewer of them)
+template <int RM, int TN, bool GL = false, bool TAIL = false, int BQ = kBQ>
 __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const float* __restrict__ at,
                                                 int ldk, int Lp, const float* __restrict__ xw,
                                                 int64_t plane_stride, int Nc, int jlo, int jhi,
@@ -88,16 +90,16 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   constexpr int KTS = kts_for(RM);
   constexpr int PT = 128 * TN;
   constexpr int KV = KT / 4;                         // float4 per staged row
-  constexpr int UV = kBQ * KV;                       // float4 per A tile
+  constexpr int UV = BQ * KV;                       // float4 per A tile
   constexpr int NUV = (UV + kThreads - 1) / kThreads;
-  constexpr int XV = (PT + kBQ) / 4;                 // float4 per x window
-  constexpr int BUF = kBQ * KTS + PT + kBQ;          // floats per LDS buffer
+  constexpr int XV = (PT + BQ) / 4;                 // float4 per x window
+  constexpr int BUF = BQ * KTS + PT + BQ;          // floats per LDS buffer
   static_assert(XV <= kThreads, "x window staged in one pass");
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, i = lane & 15, kq = lane >> 4;
   const int col0 = wave * 16 * TN;
-  const int spc = (jhi - jlo) / kBQ;                 // steps per channel
+  const int spc = (jhi - jlo) / BQ;                 // steps per channel
   const int nsteps = Nc * spc;
   if (nsteps <= 0) return;
 
@@ -117,7 +119,7 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
 #define DTX_LOAD_TILE(s_)                                                                  \
   do {                                                                                     \
     const int c_ = (s_) / spc;                                                             \
-    const int j0_ = jlo + ((s_) - c_ * spc) * kBQ;                                         \
+    const int j0_ = jlo + ((s_) - c_ * spc) * BQ;                                         \
     const float* ab_ = at + ((int64_t)c_ * Lp + j0_) * ldk;                                \
     _Pragma("unroll") for (int m = 0; m < NUV; ++m) {                                      \
       if ((m + 1) * kThreads <= UV || tid + m * kThreads < UV)                             \
@@ -133,7 +135,7 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
       if ((m + 1) * kThreads <= UV || tid + m * kThreads < UV)                             \
         *reinterpret_cast<float4*>(ud_ + srow[m] * KTS + scol[m]) = ru[m];                 \
     }                                                                                      \
-    if (tid < XV) reinterpret_cast<float4*>(ud_ + kBQ * KTS)[tid] = rx;                    \
+    if (tid < XV) reinterpret_cast<float4*>(ud_ + BQ * KTS)[tid] = rx;                    \
   } while (0)
 
   // LDS-DMA staging of the A tile (GL): the tile is one linear image when the LDS
@@ -141,13 +143,13 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   // 1 KiB units with global_load_lds_dwordx4 -- no staging VGPRs, no ds_write, no
   // address VALU beyond one 64-bit add per unit.
   static_assert(!GL || KTS == KT, "LDS-DMA needs an unpadded LDS image");
-  constexpr int UNITS = kBQ * KT * 4 / 1024;         // 1 KiB wave-instructions per A tile
+  constexpr int UNITS = BQ * KT * 4 / 1024;         // 1 KiB wave-instructions per A tile
   constexpr int NGU = (UNITS + 7) / 8;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #define DTX_GLDS_TILE(s_, buf_)                                                            \
   do {                                                                                     \
     const int c_ = (s_) / spc;                                                             \
-    const int j0_ = jlo + ((s_) - c_ * spc) * kBQ;                                         \
+    const int j0_ = jlo + ((s_) - c_ * spc) * BQ;                                         \
     const float* ab_ = at + ((int64_t)c_ * Lp + j0_) * KT + lane * 4;                      \
     float* ld_ = lds + (buf_) * BUF;                                                       \
     _Pragma("unroll") for (int m = 0; m < NGU; ++m) {                                      \
@@ -162,11 +164,11 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   } while (0)
 #define DTX_STORE_X(buf_)                                                                  \
   do {                                                                                     \
-    if (tid < XV) reinterpret_cast<float4*>(lds + (buf_) * BUF + kBQ * KTS)[tid] = rx;     \
+    if (tid < XV) reinterpret_cast<float4*>(lds + (buf_) * BUF + BQ * KTS)[tid] = rx;     \
   } while (0)
 
   const int aoff = kq * KTS + i;
-  const int boff = kBQ * KTS + col0 + i + kq;
+  const int boff = BQ * KTS + col0 + i + kq;
 
   if constexpr (GL) {
     DTX_GLDS_TILE(0, 0);
@@ -192,13 +194,13 @@ __device__ __forceinline__ void hankel_mainloop(f32x4 (&acc)[RM][TN], const floa
   // 4 g + e of column (l & 31).
   const unsigned lds_base = (unsigned)(unsigned long long)(
       (__attribute__((address_space(3))) float*)lds);
-  constexpr int KS = kBQ / 4;
+  constexpr int KS = BQ / 4;
   constexpr int RF = TAIL ? RM - 1 : RM;          // full 16-row blocks
   constexpr int TH = TN / 2;                      // 32-column groups of the tail
   static_assert(!TAIL || (RM >= 2 && TN % 2 == 0), "tail path needs a full block and even TN");
   const int tg = lane >> 5, ta = (lane >> 2) & 3, tj = lane & 3;
   const int taoff = ta * KTS + 16 * RF + 4 * tg + tj;
-  const int tboff = kBQ * KTS + col0 + (lane & 31);
+  const int tboff = BQ * KTS + col0 + (lane & 31);
   f32x4 tacc[TH > 0 ? TH : 1];
 #pragma unroll
   for (int h = 0; h < (TH > 0 ? TH : 1); ++h) tacc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -414,8 +414,12 @@ struct RepairArgs {
   const int32_t* sdoff;
   int nsub;
 };
+// contraction indices per step of a task: a task's few MFMAs per step (RM x 1 tiles per wave) hide nothing, every
+// step costs a round trip to memory -- a third to a half of the steps with deeper ones (row groups of one or two row
+// blocks, i.e. detectors of up to 32 vectors; wider groups stage kBQ rows like the engine)
+constexpr int repair_bq(int rm) { return rm == 1 ? 256 : (rm == 2 ? 128 : kBQ); }
 constexpr int repair_lds_floats(int rm) {
-  const int loop = 2 * (kBQ * kts_for(rm) + kRepairPT + kBQ);
+  const int loop = 2 * (repair_bq(rm) * kts_for(rm) + kRepairPT + repair_bq(rm));
   const int epi = 2 * 16 * rm + 64;
   return loop > epi ? loop : epi;
 }
@@ -438,8 +442,16 @@ __global__ __launch_bounds__(kThreads, 2) void ds_mfma_task_kernel(const RepairA
     for (int q = 0; q < RM; ++q)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    hankel_mainloop<RM, TN, false, false>(acc, b.ut, b.ldk, b.Lp, b.xp + (int64_t)chunk * b.Nc * b.Tpad + p0, b.Tpad,
-                                          b.Nc, 0, b.Lp, lds);
+    constexpr int BQ = repair_bq(RM);
+    const float* xw = b.xp + (int64_t)chunk * b.Nc * b.Tpad + p0;
+    const int jdeep = b.Lp / BQ * BQ;                  // Lp is a multiple of kBQ: deep steps, then the rest in kBQ steps
+    hankel_mainloop<RM, TN, false, false, BQ>(acc, b.ut, b.ldk, b.Lp, xw, b.Tpad, b.Nc, 0, jdeep, lds);
+    if constexpr (BQ != kBQ) {
+      if (jdeep < b.Lp) {
+        __syncthreads();
+        hankel_mainloop<RM, TN, false, false>(acc, b.ut, b.ldk, b.Lp, xw, b.Tpad, b.Nc, jdeep, b.Lp, lds);
+      }
+    }
     ds_epilogue<RM, TN>(acc, b, chunk, p0, lds);
     __syncthreads();
   }
