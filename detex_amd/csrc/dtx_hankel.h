@@ -569,7 +569,11 @@ static __global__ __launch_bounds__(256) void win_stats_kernel(const float* __re
     if (tid == 0) blockmax = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
     __syncthreads();
   }
-  constexpr double kStatsRecheck = 1e-7;
+  // 1e-9: what the sums round off is a few 1e-16 of the largest power they hold (one rounding of anchor + prefix;
+  // outliers never enter them), i.e. below 1e-6 of such a window's variance.  (Round 5 used 1e-7: a record riding a
+  // level of 5000 x its scatter -- a step no offset removes -- then sent EVERY window through the serial
+  // re-summation: 35 ms per station-day instead of 3.3, profiles/r6_dirty_cost.txt (e))
+  constexpr double kStatsRecheck = 1e-9;
   const double recheck = kStatsRecheck * blockmax;
   auto direct = [&](int64_t pw, double& S1, double& var) {
     double s = 0.0;

@@ -36,4 +36,6 @@ for (amp, K) in ((1e5, 10), (1e5, 1000), (1e6, 10), (1e6, 1000)):
     x = x0.copy(); synth.make_dirty(x, Nc, 3, ngap=0, nspike=K, spike_amp=amp); run(x, '%d glitches of %.0e sigma' % (K, amp))
 x = x0.copy(); synth.make_dirty(x, Nc, 5, ngap=100, nspike=0); run(x, '100 gaps of 60 s')
 x = x0.copy(); x[3, 500000:] *= 3000.0; run(x, 'a loud onset (x 3000 from there on) in one chunk')
+for lvl in (1e3, 5e3, 3e4):
+    x = x0.copy(); x[5, 600000:] += lvl; run(x, 'a level step of %.0e sigma in mid-chunk (ADVICE r5: DC-offset record)' % lvl)
 run(x0, 'clean')
