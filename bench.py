@@ -523,6 +523,27 @@ def config5(ctx, synth):
     ctx.set_engine('auto')
     P = T - L + 1
     flops = 2.0 * K * n * P
+    # the same hour per call from a host that keeps calls in flight (results of call i fetched while call i + 1 runs,
+    # as the headline loop and SubSpace.detex do): the post pass then runs beside the next call's preparation
+    piped = None
+    try:
+        ctx.upload_basis(U, off, Nc)
+        thr_dev = torch.from_numpy(thr).cuda()
+        pend = None
+        for it in range(25):
+            if it == 5:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            f = ctx.subspace_scan(xt, out=ds, thr=thr_dev, lazy=True)[1]
+            if pend is not None:
+                pend()
+            pend = f
+        pend()
+        torch.cuda.synchronize()
+        piped = {'ms_per_hour_of_data': 1e3 * (time.perf_counter() - t1) / 20, 'steps': 20,
+                 'kernel_ms': ctx.kernel_ms_mean(20)}
+    except Exception as e:                              # noqa: BLE001 -- an extra never takes the line down
+        piped = {'error': repr(e)}
     # a DAY per call, the way configs[1] hands its 24 chunks over: 24 hourly chunks (views of one buffer would do; here
     # the hour repeated) in ONE dtx_subspace_scan -- preparation kernels and launch boundaries are paid once per day
     day = None
@@ -548,7 +569,7 @@ def config5(ctx, synth):
     flop_fft = (K / 2) * nblk5 * (5.0 * 8192 * 13 + 8.0 * Nc * 8192)
     return {'value': P / res['auto'][0], 'unit': 'windows/s', 'ms_per_hour_of_data': 1e3 * res['auto'][0],
             'kernel_ms': res['auto'][1], 'step_over_kernel': 1e3 * res['auto'][0] / res['auto'][1],
-            'day_per_call': day,
+            'day_per_call': day, 'pipelined': piped,
             'roofline': {'bound': 'hbm', 'kernel': kname5, 'kernel_ms': ka, 'bytes_per_launch': b_alg,
                          'achieved': b_alg / (ka * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': b_alg / (ka * 1e-3) / 1e9 / 8000.0,
