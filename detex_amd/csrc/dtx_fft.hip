@@ -45,8 +45,8 @@ namespace {
 // ---------------------------------------------------------------- the scan
 // Dynamic-range guard (see dtx_subspace_ds): block cb = chunk * nblk + blk is "loud" when the
 // loudest window over the samples its transforms read holds > kFftGuard^2 times the energy of
-// its quietest live own window.  One workgroup per block appends it to list (list[0] = count)
-// for the repair pass.  wspan: windows whose samples the block's transforms cover -- V for a
+// its quietest live own window.  One workgroup per block; a loud block is appended to DtxRepairWs::list (with the two
+// energies): spike_split_kernel decides what becomes of it.  wspan: windows whose samples the block's transforms cover -- V for a
 // single-segment template (xhat_kernel zeroes the tail no kept output reads), 2 V for a
 // segmented one (segment s meets block blk + s: samples up to (nseg + 1) V are transformed, and
 // windows w0 .. w0 + 2 V - 1 reach sample w0 + 2 V + L - 2 >= w0 + (nseg + 1) V - 1).

@@ -145,14 +145,11 @@ __global__ __launch_bounds__(64) void chunk_offset_final_kernel(const double* __
 }
 
 // xp[b][c][t] = x_b[Nc*t + c] - m0[b] for the samples the windows touch, 0 beyond.
-// list != NULL: only if the list holds anything (list[0] > 0) -- the planes are then built for the repair
-// pass behind the frequency-domain engine, which on ordinary data finds nothing to repair
 __global__ __launch_bounds__(256) void demux_kernel(const float* __restrict__ x, int64_t M,
                                                     int64_t chunk_stride, int Nc, int64_t Tvalid,
                                                     int64_t Tpad, const float* __restrict__ m0f,
-                                                    float* __restrict__ xp, const int* __restrict__ list,
+                                                    float* __restrict__ xp,
                                                     const int64_t* __restrict__ ctab, int n) {
-  if (list != nullptr && list[0] <= 0) return;
   const int b = blockIdx.z, c = blockIdx.y;
   const float* xb = chunk_base(x, chunk_stride, ctab, b, M);
   // ragged batch: the samples the chunk's OWN windows touch, exactly as when it is scanned alone
@@ -189,9 +186,7 @@ template <int NC>
 __global__ __launch_bounds__(256) void demux_vec_kernel(const float* __restrict__ x, int64_t M,
                                                         int64_t chunk_stride, int64_t Tvalid, int64_t Tpad,
                                                         const float* __restrict__ m0f, float* __restrict__ xp,
-                                                        const int* __restrict__ list,
                                                         const int64_t* __restrict__ ctab, int n) {
-  if (list != nullptr && list[0] <= 0) return;
   const int b = blockIdx.z;
   const float* xb = chunk_base(x, chunk_stride, ctab, b, M);
   if (ctab != nullptr) Tvalid = M > n ? (M - n) / NC + n / NC : 0;
@@ -864,13 +859,13 @@ int dtx_basis_bcast(dtx_ctx* const* ctxs, int nctx) {
 
 // channel planes of every chunk: the 16-byte kernel where the planes allow it (Tpad % 4 == 0, aligned workspace)
 static void launch_demux(dtx_ctx* ctx, hipStream_t st, const float* x_dev, int64_t M, int64_t chunk_stride, int Nc,
-                         int64_t Tvalid, int64_t Tpad, const float* m0f, float* xp, const int* list,
+                         int64_t Tvalid, int64_t Tpad, const float* m0f, float* xp,
                          const int64_t* ctab, int n, int nchunk) {
   const bool vec = (Tpad & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0;
   const dim3 vgrid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), 1u, (unsigned)nchunk);
 #define DTX_DEMUX_VEC(NC)                                                                                       \
   hipLaunchKernelGGL(demux_vec_kernel<NC>, vgrid, dim3(256), 0, st, x_dev, M, chunk_stride, Tvalid, Tpad, m0f,  \
-                     xp, list, ctab, n)
+                     xp, ctab, n)
   if (vec && Nc == 1) { DTX_DEMUX_VEC(1); return; }
   if (vec && Nc == 2) { DTX_DEMUX_VEC(2); return; }
   if (vec && Nc == 3) { DTX_DEMUX_VEC(3); return; }
@@ -879,7 +874,7 @@ static void launch_demux(dtx_ctx* ctx, hipStream_t st, const float* x_dev, int64
 #undef DTX_DEMUX_VEC
   const dim3 dgrid((unsigned)std::min<int64_t>((Tpad + 1023) / 1024, 4096), (unsigned)Nc, (unsigned)nchunk);
   hipLaunchKernelGGL(demux_kernel, dgrid, dim3(256), 0, st, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, m0f, xp,
-                     list, ctab, n);
+                     ctab, n);
 }
 
 // The post pass of a scan: on the context's stream, or -- when the caller handed in a stream for it
@@ -998,8 +993,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     // spectra -- both are chains of memory latencies that leave most of the chip idle on their own.
     // channel planes (main stream), then the window statistics on the side stream beside the block
     // spectra: both are chains of memory latencies that leave most of the chip idle on their own
-    launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp,
-                 (const int*)nullptr, ctab, n, nchunk);
+    launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp, ctab, n, nchunk);
     if ((rc = dtx_aux_fork(ctx))) return rc;
     hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->aux, (const float*)xp, Tpad,
                        Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 0);
@@ -1021,8 +1015,7 @@ static int subspace_ds_impl(dtx_ctx* ctx, const float* x_dev, int64_t M, int64_t
     return DTX_OK;
   }
 
-  launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp,
-               (const int*)nullptr, ctab, n, nchunk);
+  launch_demux(ctx, ctx->stream, x_dev, M, chunk_stride, Nc, Tvalid, Tpad, (const float*)m0f, xp, ctab, n, nchunk);
   hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
                      Nc, ctx->L, P, Ppad, scale, mean, den, (const float*)tauf, sover, 0);
   hipLaunchKernelGGL(win_stats_kernel, sgrid, dim3(256), 0, ctx->stream, (const float*)xp, Tpad,
