@@ -136,7 +136,14 @@ int64_t dtx_num_windows(int64_t M, int n, int Nc);
  * Deliberate, documented deviations from the reference's round-off artefacts:
  * a window of exactly zero variance scores 0 (the reference divides round-off
  * by ~0), and +inf is stored as 0 (the reference zeroes infs whenever one is
- * present, detect.py:278-281).  Asynchronous. */
+ * present, detect.py:278-281).
+ * Dirty records (zero-filled gaps, glitches of any size, loud onsets) are held to the same 1e-5: under the
+ * frequency-domain engine a guard lists the blocks whose dynamic range float32 transforms cannot carry, isolated
+ * outlier samples are taken out of the transforms and their products added back directly, and the windows still out
+ * of range are recomputed by the float32 contraction (dtx_repair_counts says what was listed).  The reference's
+ * float64 transforms need none of this.  Data are expected detrended / band-passed as the reference's pipeline
+ * leaves them (construct.py:1005-1028): a record riding a level >~ 1000 x its scatter behind a step inside a block
+ * is held to ~1e-8 x level / scatter only.  Asynchronous. */
 int dtx_subspace_ds(dtx_ctx* ctx, const float* x_dev, int64_t M,
                     int64_t chunk_stride, int nchunk, float* ds_dev,
                     int64_t ldp);
