@@ -216,3 +216,55 @@ def test_config2_dirty_fullsize(ctx):
         row = ds[b, d].cpu().numpy()
         lo = max(0, p - 50)
         assert lo + int(np.argmax(row[lo:p + 50])) == p
+
+
+def test_dirty_ragged_batch_equals_chunk_by_chunk(ctx):
+    """Dirty chunks of different lengths in ONE ragged launch (dtx_subspace_scan_ragged): glitches, a gap's edge beside
+    an event and a clipped burst spread over three chunks -- each chunk comes out bit for bit as when it is scanned
+    alone (the guard's lists, the outliers and the repair tasks of one chunk do not leak into another), and within
+    1e-5 of the oracle's direct form."""
+    Nc, L = 3, 400
+    n = Nc * L
+    rs = np.random.RandomState(911 + SOAK)
+    U, off = bank(rs, Nc, L, [8, 4, 1])
+    frames = [30000, 21000, 26000]
+    chunks = []
+    for i, T in enumerate(frames):
+        x = rs.standard_normal((T, Nc))
+        if i == 0:
+            x[9000, 1] += 1e5
+            x[20000, 2] -= 3e6
+        if i == 1:
+            x[8000:9500] = 0.0
+            rows = U[off[0]:off[1]].astype(np.float64)
+            c = rs.standard_normal(rows.shape[0])
+            x[9520:9520 + L] += (18.0 * np.sqrt(n) * (c / np.linalg.norm(c) @ rows)).reshape(L, Nc)
+        if i == 2:
+            x[5000:5012] = 4e5 * np.sign(rs.standard_normal((12, Nc)))
+        chunks.append(x.reshape(-1).astype(np.float32))
+    starts, pos = [], 0
+    for c in chunks:
+        starts.append(pos)
+        pos += len(c) + 7 * Nc                              # (a few frames of someone else's data between the chunks)
+    flat = rs.standard_normal(pos).astype(np.float32) * 50.0
+    for s0, c in zip(starts, chunks):
+        flat[s0:s0 + len(c)] = c
+    ctx.set_engine('auto')
+    ctx.upload_basis(U, off, Nc)
+    xt = torch.from_numpy(flat).cuda()
+    tab = ctx.chunk_table(starts, [len(c) for c in chunks])
+    thr = np.full(len(off) - 1, 0.3, np.float32)
+    ds, res = ctx.subspace_scan(xt, thr=thr, chunk_tab=tab, cand_cap=1 << 16)
+    cnt = ctx.repair_counts()
+    assert cnt['split'] >= 2 and cnt['tiles'] >= 1, cnt
+    dsr = ds.cpu().numpy()
+    for b, c in enumerate(chunks):
+        Pb = (len(c) - n) // Nc + 1
+        alone = ctx.subspace_ds(torch.from_numpy(c).cuda())[0].cpu().numpy()
+        assert np.array_equal(dsr[b, :, :Pb], alone), (b, float(np.abs(dsr[b, :, :Pb] - alone).max()))
+        xd = c.astype(np.float64)
+        live = np.lib.stride_tricks.sliding_window_view(xd, n)[::Nc].std(axis=1) > 0
+        for d in range(len(off) - 1):
+            ref = orc.mpxds_direct(xd, U[off[d]:off[d + 1]].astype(np.float64), Nc)
+            err = np.abs(alone[d] - ref)
+            assert not ((err > 1e-5 * max(1.0, float(ref[live].max()))) & live).any(), (b, d, float(err[live].max()))
