@@ -1057,7 +1057,7 @@ def run_config4(a, rank, world, local, use_dist, binding=None):
         dt = float(t.item())
     windows = len(units) * a.chunks * P * a.steps
     host_fed = None
-    if (use_dist and world > 1) or os.environ.get('DTX_BENCH_HOST_FED') == '1':
+    if (use_dist and world > 1) or os.environ.get('DTX_BENCH_HOST_FED') == '1':      # (the switch: the leg at world size 1)
         # the same pass with every station-day coming from page-locked host memory, on every rank at once: up to eight
         # distinct pinned station-days per rank, cycled (more than a socket's last-level cache), two device buffers,
         # the next upload on a copy stream under the current scan
@@ -1357,8 +1357,8 @@ def main():
         # flat copies of the nested `traffic` object (a consumer that keeps only scalars keeps these)
         out['roofline']['traffic_bytes'] = tr['bytes']
         out['roofline']['traffic_ratio'] = tr['bytes'] / out['roofline']['bytes_per_launch']
-    if use_dist and world > 1:
-        # N > 1: the same step host-fed, on every rank at once (HBM-resident data scale trivially; the host feed is shared)
+    if use_dist and (world > 1 or os.environ.get('DTX_BENCH_HOST_FED') == '1'):
+        # N > 1 (or asked for at world size 1: the RCCL test of the leg): the same step host-fed, on every rank at once (HBM-resident data scale trivially; the host feed is shared)
         hf_steps = max(20, min(a.steps, 80))
         hf = host_fed_all_ranks(lambda bar: pcie_inclusive(ctx, x, ds, thr, hist, a.chunks * P, hf_steps, barrier=bar),
                                 rank, world, a.chunks * P, binding)

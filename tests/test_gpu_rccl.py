@@ -50,10 +50,15 @@ def test_bench_weak_under_rccl_world1():
     bench = os.path.join(ROOT, 'bench.py')
     args = ['--gpus', '1', '--steps', '3', '--warmup', '1', '--chunks', '6', '--no-extras', '--no-cpu-baseline',
             '--prewarm', '0']
-    d = _torchrun([bench] + args)
+    # (DTX_BENCH_HOST_FED=1: the host-fed leg of N > 1 -- every rank's uploads at once, gathered with
+    # all_gather_object -- at world size 1, so that its collectives have run under RCCL too)
+    d = _torchrun([bench] + args, env={'DTX_BENCH_HOST_FED': '1'})
     p = _plain([bench] + args)
     assert d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['config']['planted_found'] == '50/50'
     assert d['config']['candidates'] == p['config']['candidates']
+    hf = d['host_fed']
+    assert len(hf['per_rank']) == 1 and hf['per_rank'][0]['ms_per_step'] > 0 and 'pci' in hf['per_rank'][0]['binding']
+    assert hf['ms_per_step_min'] == hf['ms_per_step_max'] == hf['per_rank'][0]['ms_per_step']
     P = (int(round(3720.0 * 100.0)) * 3 - 9000) // 3 + 1
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 6 * P) <= 1e-6 * 6 * P
 
@@ -64,10 +69,11 @@ def test_bench_strong_under_rccl_world1():
     bench = os.path.join(ROOT, 'bench.py')
     args = ['--config', '4', '--stations', '2', '--days', '3', '--chunks', '4', '--gpus', '1', '--steps', '2',
             '--warmup', '1']
-    d = _torchrun([bench] + args)
+    d = _torchrun([bench] + args, env={'DTX_BENCH_HOST_FED': '1'})       # (+ the host-fed leg of N > 1, as above)
     p = _plain([bench] + args)
     assert d['n_gpus'] == 1 and d['scaling'] == 'strong' and d['config']['planted_found'] == '30/30'
     assert d['config']['candidates'] == p['config']['candidates']
+    assert d['host_fed']['per_rank'][0]['ms_per_step'] > 0 and d['host_fed']['ms_per_station_day_slowest_rank'] > 0
 
 
 def test_product_api_under_rccl_world1():
