@@ -55,6 +55,42 @@ def pick_triggers_sparse(idx, val, P, threshold, sr, maxds, buff=20, maxcount=40
     return out
 
 
+def pick_triggers_grouped(cp, cv, first, last, Pg, thr_g, maxds_g, sr, buff=20):
+    """pick_triggers_sparse for many (chunk, detector) groups at once: group g's candidates are
+    cp / cv[first[g]:last[g]] (window indices ascending), Pg / thr_g / maxds_g its window count,
+    threshold and DS.max().  Returns one list of (trigIndex, DS) per group.
+
+    A group whose candidates span fewer than buff * sr windows -- one detection's peak, the
+    ordinary case -- has exactly one trigger: the first arg-max, whose zeroed range
+    [index - w, index + w) (clipped at the block's ends, detect.py:551-556) holds every other
+    candidate.  Those groups are answered with a few array operations for all of them; the
+    others (and any whose maximum is below threshold) go through the loop of
+    pick_triggers_sparse."""
+    G = len(first)
+    out = [[] for _ in range(G)]
+    if G == 0:
+        return out
+    cp = np.asarray(cp, dtype=np.int64)
+    cv64 = np.asarray(cv, dtype=np.float64)
+    first = np.asarray(first, dtype=np.int64)
+    last = np.asarray(last, dtype=np.int64)
+    w = buff * sr
+    live = np.asarray(maxds_g, dtype=np.float64) > np.asarray(thr_g, dtype=np.float64)   # detect.py:534
+    gmax = np.maximum.reduceat(cv64, first)
+    single = live & ((cp[last - 1] - cp[first]) < w) & (gmax >= thr_g)
+    # first occurrence of the group's maximum
+    pos = np.arange(len(cp), dtype=np.int64)
+    at = np.minimum.reduceat(np.where(cv64 == np.repeat(gmax, last - first), pos, len(cp)), first)
+    ti = cp[np.minimum(at, len(cp) - 1)]
+    for g in np.nonzero(live)[0]:
+        if single[g]:
+            out[g] = [(int(ti[g]), float(gmax[g]))]
+        else:
+            out[g] = pick_triggers_sparse(cp[first[g]:last[g]], cv64[first[g]:last[g]], int(Pg[g]), float(thr_g[g]),
+                                          sr, float(maxds_g[g]), buff=buff)
+    return out
+
+
 # --------------------------------------------------------------------------
 # STA/LTA of the detection statistic at a trigger       detect.py:501-524
 # --------------------------------------------------------------------------
@@ -80,6 +116,21 @@ def _centered_lo(i, n, P):
     elif i > last:                      # arg[last + 1:] = arg[last]
         i = last
     return i - first
+
+
+def _centered_lo_many(i, n, P):
+    """_centered_lo for arrays of indices i and window counts P: (lo, bad) with bad where the
+    scalar form raises IndexError (lo there is -1)."""
+    i = np.asarray(i, dtype=np.int64)
+    P = np.asarray(P, dtype=np.int64)
+    n = int(n)
+    first = n - 1 - (n - 1) // 2
+    last = first + (P - n)
+    bad = (n < 1) | (n > P)
+    front = i < first
+    bad = bad | (front & (first + 1 > P - 1))
+    lo = np.where(front, np.where(first + 1 > last, -1, 1), np.where(i > last, last - first, i - first))
+    return np.where(bad, -1, lo), bad
 
 
 def _centered_mean_at(fetch, i, n, P):
@@ -250,8 +301,57 @@ class _MagBank(object):
                                     .astype(np.float32)).to(device)
         self.eoff = torch.from_numpy(eoff.astype(np.int32)).to(device)
 
+        # the constants padded to emax events per detector, for estimate_all
+        D = len(self.consts)
+
+        def padded(key, fill):
+            a = np.full((D, max(self.emax, 1)), fill, dtype=np.float64)
+            for d, c in enumerate(self.consts):
+                if c[key] is not None:
+                    a[d, :len(c[key])] = c[key]
+            return a
+        self.issub = np.array([k == 'ss' for k in kinds], dtype=bool)
+        self.mags_p, self.sum_e_p, self.std_e_p = padded('mags', np.nan), padded('sum_e', 0.0), padded('std_e', 1.0)
+        self.var_wfu_p, self.d2_p = padded('var_wfu', 1.0), padded('d2', 1.0)
+        with np.errstate(invalid='ignore'):
+            self.touse_p = self.mags_p > -15                    # (NaN padding compares False)
+
     def estimate(self, d, issub, n, o):
         return mags_from_stats(self.consts[d], issub, n, o)
+
+    def estimate_all(self, dets, n, O):
+        """mags_from_stats for the rows O [k, 6 + emax] of triggers of ANY of the bank's detectors (dets[r] =
+        row r's): the formulas of mags_from_stats_many on the padded constants, the padding masked out of
+        every sum.  One call per batch of chunks instead of one per detector with a trigger in it."""
+        O = np.asarray(O, dtype=np.float64)
+        dets = np.asarray(dets, dtype=np.int64)
+        k = len(O)
+        mean_c, std_c, var_s, noise = O[:, 2], O[:, 3], O[:, 4], O[:, 5]
+        pem, stm = np.full(k, np.nan), np.full(k, np.nan)
+        with np.errstate(all='ignore'):
+            snr = np.divide(std_c, noise)
+            sub = self.issub[dets]
+            r = np.nonzero(sub)[0]
+            if len(r):
+                d = dets[r]
+                tu, mg, se = self.touse_p[d], self.mags_p[d], self.std_e_p[d]
+                dots = O[r, 6:6 + tu.shape[1]]
+                sc = std_c[r, None]
+                ec = (dots - self.sum_e_p[d] * mean_c[r, None]) / (n * se * sc)
+                we = np.where(tu, np.square(ec), 0.0)
+                proEn = var_s[r, None] / self.var_wfu_p[d]
+                wsum = we.sum(axis=1)
+                some = tu.any(axis=1)                                  # detect.py:478-482
+                pem[r] = np.where(some, np.where(tu, (mg + np.log10(np.sqrt(proEn))) * we, 0.0).sum(axis=1) / wsum, np.nan)
+                stm[r] = np.where(some, np.where(tu, (mg + np.log10(sc / se)) * we, 0.0).sum(axis=1) / wsum, np.nan)
+            r = np.nonzero(~sub)[0]
+            if len(r):
+                d = dets[r]
+                m0 = self.mags_p[d, 0]
+                ok = ~(np.isnan(m0) | (m0 < -15))                      # detect.py:490-492
+                pem[r] = np.where(ok, m0 + O[r, 6] / self.d2_p[d, 0], np.nan)
+                stm[r] = np.where(ok, m0 + np.log10(std_c[r] / self.std_e_p[d, 0]), np.nan)
+        return pem, stm, snr
 
     def estimate_many(self, d, issub, n, O):
         return mags_from_stats_many(self.consts[d], issub, n, O)
@@ -769,11 +869,11 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
     ks, first = np.unique(key[order], return_index=True)
     last = np.append(first[1:], len(order))
     trigs = []                                           # (chunk, det, index, coef)
-    for kk, f0, f1 in zip(ks, first, last):
-        b, d = int(kk // D), int(kk % D)
-        sel = order[f0:f1]
-        for (ti, coef) in pick_triggers_sparse(cp[sel], cv[sel], int(Pb[b]), float(thr_arr[d]), sr,
-                                               float(maxds[b, d])):
+    gb, gd = ks // D, ks % D
+    picked = pick_triggers_grouped(cp[order], cv[order], first, last, Pb[gb], np.asarray(thr_arr, dtype=np.float64)[gd],
+                                   np.asarray(maxds, dtype=np.float64)[gb, gd], sr)
+    for b, d, found in zip(gb.tolist(), gd.tolist(), picked):
+        for (ti, coef) in found:
             if coef > 1.05:                              # detect.py:199-204
                 continue
             trigs.append((b, d, ti, coef))
@@ -781,14 +881,17 @@ def _batch_triggers(ctx, sta, st, fillZeros, estimateMags, i0, i1, xb, M, cstrid
     stats = None
     if trigs and bank is not None:
         tab = np.full((len(trigs), 5), -1, dtype=np.int32)
-        for r, (b, d, ti, _) in enumerate(trigs):
-            tab[r, :3] = (b, d, ti)
-            if not fillZeros:
-                try:
-                    tab[r, 3] = ti if STA == 0 else _centered_lo(ti, STA, int(Pb[b]))
-                    tab[r, 4] = _centered_lo(ti, LTA, int(Pb[b]))
-                except IndexError:
-                    bad[r] = True
+        tab[:, :3] = np.array([t[:3] for t in trigs], dtype=np.int64)
+        if not fillZeros:
+            Pt = Pb[tab[:, 0]]
+            lo_l, bad_l = _centered_lo_many(tab[:, 2], LTA, Pt)
+            if STA == 0:
+                lo_s, bad_s = tab[:, 2].astype(np.int64), np.zeros(len(trigs), dtype=bool)
+            else:
+                lo_s, bad_s = _centered_lo_many(tab[:, 2], STA, Pt)
+            bad = bad_s | bad_l                          # (the reference's try covers both windows: neither is kept)
+            tab[:, 3] = np.where(bad, -1, lo_s)
+            tab[:, 4] = np.where(bad, -1, lo_l)
         targs = (xb, M, cstride, ds, tab, 1 if STA == 0 else int(STA), int(LTA),
                  bank.ewf if estimateMags else None, bank.eoff, bank.emax)
         tkw = {} if ctab is None else {'chunk_tab': ctab}
@@ -820,22 +923,21 @@ def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows, k
         stats = stats.cpu().numpy()
     nt = len(trigs)
     pem_a, stm_a, snr_a = np.full(nt, np.nan), np.full(nt, np.nan), np.full(nt, np.nan)
-    if estimateMags:                                     # detect.py:422-429, all triggers of a detector at once
-        dets = np.array([t[1] for t in trigs])
-        for d in np.unique(dets):
-            sel = np.nonzero(dets == d)[0]
-            p_, s_, q_ = bank.estimate_many(int(d), kinds[d] == 'ss', n, stats[sel])
-            pem_a[sel], stm_a[sel], snr_a[sel] = p_, s_, q_
+    if estimateMags:                                     # detect.py:422-429, all the batch's triggers at once
+        pem_a, stm_a, snr_a = bank.estimate_all([t[1] for t in trigs], n, stats)
     if stats is not None:
         with np.errstate(all='ignore'):
             sl_a = np.divide(stats[:, 0], stats[:, 1])
+    ofmm = st.get('offset_minmax')
+    if ofmm is None:
+        ofmm = st['offset_minmax'] = {nm: (np.max(offsets[nm]), np.min(offsets[nm])) for nm in names}
+    stm_l, snr_l, pem_l = stm_a.tolist(), snr_a.tolist(), pem_a.tolist()
     for r, (b, d, ti, coef) in enumerate(trigs):
         name = names[d]
         start = bounds[i0 + b][2]
         sl = 0.0 if (fillZeros or bad[r]) else float(sl_a[r])     # detect.py:414-420, 289-295
         times = float(ti) / sr + start                   # detect.py:413
-        of = offsets[name]
-        rows[kinds[d]].append([coef, sl, times, name, sta, times - np.max(of),
-                               times - np.min(of), float(stm_a[r]), float(snr_a[r]), float(pem_a[r])])
+        omax, omin = ofmm[name]
+        rows[kinds[d]].append([coef, sl, times, name, sta, times - omax, times - omin, stm_l[r], snr_l[r], pem_l[r]])
         if keys is not None:
             keys[kinds[d]].append((bounds[i0 + b][3], d, r))

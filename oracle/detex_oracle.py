@@ -556,19 +556,19 @@ def est_mag(trigIndex, Nc, MPcon, mags, U, ewf, issubspace=True):
 
 
 def trigger_stats_row(trigIndex, Nc, MPcon, U, ewf, ds=None, sta_lo=-1, sta_len=1, lta_lo=-1,
-                      lta_len=1):
+                      lta_len=1, literal_utu=True):
     """What dtx_trigger_stats writes for one trigger, in NumPy float64 (the checker of that
     kernel): means of |DS| over the STA / LTA windows, mean / std of the triggering window,
     var(UtU . ConDat) with the literal n x n UtU of detect.py:367, the median rolling std of
-    the pre-event noise (detect.py:466-472) and the dot products with the training events."""
+    the pre-event noise (detect.py:466-472) and the dot products with the training events.
+    literal_utu=False forms U^T (U ConDat) instead (the same product; for n where n x n does not fit)."""
     MPcon = np.asarray(MPcon, dtype=np.float64)
     U = np.atleast_2d(np.asarray(U, dtype=np.float64))
     ewf = np.atleast_2d(np.asarray(ewf, dtype=np.float64))
     n = U.shape[1]
     a = trigIndex * Nc
     ConDat = MPcon[a:a + n]
-    UtU = np.dot(U.T, U)
-    ssCon = np.dot(UtU, ConDat)
+    ssCon = np.dot(np.dot(U.T, U), ConDat) if literal_utu else np.dot(U.T, np.dot(U, ConDat))
     if a > 5 * n:
         pe = MPcon[a - 5 * n:a]
     else:

@@ -312,6 +312,59 @@ def test_trigger_stats_kernel():
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('Nc,L,tag', [(3, 3000, 'configs[1]: nine tiles of windows, everything in registers'),
+                                      (1, 13000, 'n > 12288: the window and the variances do not fit the registers'),
+                                      (2, 5000, 'n = 10000: in registers before the trigger, 60001 windows after an early one'),
+                                      (1, 37, 'n = 37: one partial tile, n % 4 != 0'),
+                                      (3, 171, 'n = 513: one sample past the threads')])
+def test_trigger_stats_paths_at_size(Nc, L, tag):
+    """dtx_trigger_stats against the oracle's NumPy restatement on the geometries that take its different paths
+    (the triggering window / the first noise window held in registers or walked; the rolling variances in
+    registers or in the scratch buffer; tiles of 4096 windows, whole and partial): triggers with 5 n samples
+    before them, early ones (up to 7 n samples from the trigger, truncated by the chunk's end for the last),
+    odd and even window counts, on data with a level offset, a spike in the noise window and a dead stretch."""
+    from detex_amd import detect
+    from detex_amd.hip import HipContext
+    rs = np.random.RandomState(Nc * 100 + L)
+    n = Nc * L
+    ks, nev = [3, 1], [5, 1]
+    off = np.concatenate([[0], np.cumsum(ks)])
+    Ub = np.concatenate([np.linalg.qr(rs.standard_normal((n, k)))[0].T for k in ks]).astype(np.float32)
+    ewf = rs.standard_normal((sum(nev), n)).astype(np.float32)
+    eoff = np.concatenate([[0], np.cumsum(nev)])
+    ctx = HipContext(0)
+    ctx.upload_basis(Ub, list(off), Nc)
+    for Lc in (13 * L + 5, 6 * L + 7):                     # samples per channel of the one chunk (the short one cuts the early triggers' 7 n)
+        M = Lc * Nc
+        x32 = (rs.standard_normal(M) * 3.0 + 40.0).astype(np.float32)
+        x32[(4 * L) * Nc + 1] = 5e4                        # a spike
+        x32[(2 * L) * Nc:(2 * L + L // 3) * Nc] = 0.0      # a dead stretch
+        x = torch.from_numpy(x32).cuda()[None, :].contiguous()
+        ds = ctx.subspace_ds(x)
+        P = int(ds.shape[2])
+        dsh = ds.cpu().numpy().astype(np.float64)
+        sta, lta = 7, min(60, P)
+        # window indices: early (7 n from the trigger), the first with 5 n before it, one more (even / odd counts),
+        # later ones, the last window
+        trigs = [t for t in (0, 3, 5 * L, 5 * L + 1, 5 * L + 2, 6 * L + 1, 6 * L + 2, 9 * L) if t < P - 1] + [P - 1]
+        tab, want = [], []
+        for d in (0, 1):
+            for ti in trigs:
+                sta_lo, lta_lo = detect._centered_lo(ti, sta, P), detect._centered_lo(ti, lta, P)
+                tab.append([0, d, ti, sta_lo, lta_lo])
+                want.append(orc.trigger_stats_row(ti, Nc, x32.astype(np.float64), Ub[off[d]:off[d + 1]].astype(np.float64),
+                                                  ewf[eoff[d]:eoff[d + 1]].astype(np.float64), ds=dsh[0, d], sta_lo=sta_lo,
+                                                  sta_len=sta, lta_lo=lta_lo, lta_len=lta, literal_utu=n <= 2000))
+        got = ctx.trigger_stats(x, M, M, ds, np.array(tab, np.int32), sta, lta, torch.from_numpy(ewf).cuda(),
+                                torch.from_numpy(eoff.astype(np.int32)).cuda(), max(nev)).cpu().numpy()
+        for g, w, t in zip(got, want, tab):
+            ne = nev[t[1]]
+            assert np.allclose(g[:6], w[:6], rtol=3e-6, atol=1e-9), (tag, Lc, t, g[:6], w[:6])
+            assert np.allclose(g[6:6 + ne], w[6:], rtol=2e-6, atol=1e-4), (tag, Lc, t, g[6:6 + ne], w[6:])
+    ctx.close()
+
+
 def test_stations_in_flight_equal_one_at_a_time(monkeypatch):
     """SubSpace.detex keeps three stations in flight on per-station contexts (scans enqueued ahead,
     trigger picking and the trigger-time kernel of one station under the scan of the next, results

@@ -552,6 +552,91 @@ def test_mags_from_stats_many_equals_row_by_row():
                     assert (np.isnan(g[r]) and np.isnan(w)) or g[r] == w or abs(g[r] - w) <= 1e-12 * abs(w), (issub, mags, r)
 
 
+def test_bank_wide_magnitudes_equal_per_detector_ones():
+    """_MagBank.estimate_all (every trigger of a batch in one call, constants padded to the longest
+    event list) against mags_from_stats_many detector by detector: subspaces and singles mixed,
+    detectors with fewer events than the padding (their unused columns hold NaN, as the device leaves
+    them unwritten), unusable magnitudes."""
+    from detex_amd import detect
+    rs = np.random.RandomState(11)
+    n = 400
+    names = ['SS0', 'SS1', 'SG0', 'SS2', 'SG1']
+    kinds = ['ss', 'ss', 'sg', 'ss', 'sg']
+    nev = [5, 2, 1, 7, 1]
+    mags = {'SS0': [1.0, 2.0, -20.0, 0.5, 3.0], 'SS1': [-99.0, -99.0], 'SG0': [1.5], 'SS2': list(rs.rand(7) * 3),
+            'SG1': [np.nan]}
+    ewf = {nm: rs.standard_normal((k, n)) for nm, k in zip(names, nev)}
+    ks = [3, 2, 1, 4, 1]
+    doff = np.concatenate([[0], np.cumsum(ks)])
+    U = np.concatenate([np.linalg.qr(rs.standard_normal((n, k)))[0].T for k in ks])
+
+    class _SS(object):
+        _bank_aux = {'X': (ewf, mags)}
+    bank = detect._MagBank(_SS(), 'X', names, kinds, U, doff, 'cpu')
+    assert bank.emax == 7
+    k = 40
+    dets = rs.randint(0, len(names), k)
+    O = rs.standard_normal((k, 6 + bank.emax)) * 3
+    O[:, 3:6] = np.abs(O[:, 3:6]) + .1
+    O[3, 5] = 0.0
+    for r in range(k):
+        O[r, 6 + nev[dets[r]]:] = np.nan
+    O[7, 6:] = np.nan
+    got = bank.estimate_all(dets, n, O)
+    for d in range(len(names)):
+        sel = np.nonzero(dets == d)[0]
+        want = bank.estimate_many(d, kinds[d] == 'ss', n, O[sel])
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g[sel], w, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_grouped_trigger_picking_equals_group_by_group():
+    """pick_triggers_grouped (the single-peak groups answered with array operations, the rest by the loop)
+    against pick_triggers_sparse group by group: peaks at the block's ends, groups wider than the zeroed
+    range, two peaks in one group, ties for the maximum, a maximum not above threshold."""
+    from detex_amd import detect
+    rs = np.random.RandomState(5)
+    sr, P = 10.0, 5000
+    for trial in range(30):
+        groups = []
+        for g in range(rs.randint(1, 12)):
+            kind = rs.randint(0, 6)
+            c0 = [0, P - 8, rs.randint(300, P - 300), rs.randint(300, P - 300), rs.randint(300, P - 900), rs.randint(300, P - 300)][kind]
+            width = [6, 8, 5, 150, 700, 199][kind]
+            idx = np.unique(np.clip(c0 + rs.randint(0, width + 1, rs.randint(1, 9)), 0, P - 1))
+            val = (0.5 + 0.5 * rs.rand(len(idx))).astype(np.float32)
+            if rs.rand() < 0.3 and len(idx) > 1:
+                val[-1] = val[0] = val.max()             # a tie: the first occurrence wins
+            groups.append((idx, val))
+        cp = np.concatenate([g[0] for g in groups])
+        cv = np.concatenate([g[1] for g in groups])
+        cnt = np.array([len(g[0]) for g in groups])
+        last = np.cumsum(cnt)
+        first = last - cnt
+        thr = np.where(rs.rand(len(groups)) < 0.2, 0.99, 0.5)
+        maxds = np.array([g[1].max() for g in groups], dtype=np.float64)
+        maxds[rs.rand(len(groups)) < 0.15] = 0.5         # not strictly above threshold: no trigger
+        Pg = np.full(len(groups), P)
+        got = detect.pick_triggers_grouped(cp, cv, first, last, Pg, thr, maxds, sr)
+        for g, (idx, val) in enumerate(groups):
+            want = detect.pick_triggers_sparse(idx, val, P, float(thr[g]), sr, float(maxds[g]))
+            assert got[g] == want, (trial, g)
+
+
+def test_centered_lo_many_equals_scalar():
+    from detex_amd import detect
+    for P in (1, 2, 3, 5, 8, 40, 41):
+        for n in (0, 1, 2, 3, 4, 5, 7, 40, 41, 60):
+            i = np.arange(P)
+            lo, bad = detect._centered_lo_many(i, n, np.full(P, P))
+            for j in range(P):
+                try:
+                    want = detect._centered_lo(j, n, P)
+                    assert not bad[j] and lo[j] == want, (P, n, j)
+                except IndexError:
+                    assert bad[j] and lo[j] == -1, (P, n, j)
+
+
 def test_raw_counts_trimming_is_gated_like_applyFilter():
     """construct.py:1003-1023 on a record that arrives as int32 fragments (ContinuousFetcher.add_counts):
     a chunk with ONE trace per channel is never merged -- genuine zero counts in it are ordinary samples
