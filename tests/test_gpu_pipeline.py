@@ -326,7 +326,7 @@ def test_trigger_stats_paths_at_size(Nc, L, tag):
     odd and even window counts, on data with a level offset, a spike in the noise window and a dead stretch."""
     from detex_amd import detect
     from detex_amd.hip import HipContext
-    rs = np.random.RandomState(Nc * 100 + L)
+    rs = np.random.RandomState(Nc * 100 + L + SOAK)
     n = Nc * L
     ks, nev = [3, 1], [5, 1]
     off = np.concatenate([[0], np.cumsum(ks)])
@@ -338,7 +338,8 @@ def test_trigger_stats_paths_at_size(Nc, L, tag):
     for Lc in (13 * L + 5, 6 * L + 7):                     # samples per channel of the one chunk (the short one cuts the early triggers' 7 n)
         M = Lc * Nc
         x32 = (rs.standard_normal(M) * 3.0 + 40.0).astype(np.float32)
-        x32[(4 * L) * Nc + 1] = 5e4                        # a spike
+        x32[rs.randint(0, M)] = 5e4                        # a spike
+        x32[(4 * L) * Nc + 1] = -2e3                       # and one in the early triggers' noise
         x32[(2 * L) * Nc:(2 * L + L // 3) * Nc] = 0.0      # a dead stretch
         x = torch.from_numpy(x32).cuda()[None, :].contiguous()
         ds = ctx.subspace_ds(x)
@@ -348,6 +349,7 @@ def test_trigger_stats_paths_at_size(Nc, L, tag):
         # window indices: early (7 n from the trigger), the first with 5 n before it, one more (even / odd counts),
         # later ones, the last window
         trigs = [t for t in (0, 3, 5 * L, 5 * L + 1, 5 * L + 2, 6 * L + 1, 6 * L + 2, 9 * L) if t < P - 1] + [P - 1]
+        trigs += [int(t) for t in rs.randint(0, P, 3)]
         tab, want = [], []
         for d in (0, 1):
             for ti in trigs:
