@@ -17,6 +17,27 @@ from scipy.cluster.hierarchy import fcluster  # noqa: F401  (kept for parity che
 from ._lib import DetexHipError
 
 
+def _collector_set_aside(fn):
+    """Run ``fn`` with the objects alive at its start set aside from Python's garbage collector (gc.freeze /
+    gc.unfreeze; the collector stays on for what the call itself allocates).  A full collection walks every
+    tracked object of the process -- 70 ms with torch, pandas and numpy imported -- and the rows a long scan
+    builds start one every few hundred units: one call in three of 240 station-days stopped for it with its
+    scans queued behind (3.9 against 3.5 ms per station-day; scripts/probe/e2e_unit_times.py).  Left alone if the
+    caller runs without the collector or has frozen objects of its own (unfreeze would release those too)."""
+    import gc
+
+    @functools.wraps(fn)
+    def call(*args, **kwargs):
+        if not gc.isenabled() or gc.get_freeze_count() > 0:
+            return fn(*args, **kwargs)
+        gc.freeze()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            gc.unfreeze()
+    return call
+
+
 def _error(msg, exc=DetexHipError):
     raise exc(msg)
 
@@ -802,6 +823,7 @@ class SubSpace(object):
                     recalc=recalc, device=device, seed=seed)
 
     # ------------------------------------------------------------ detex
+    @_collector_set_aside
     def detex(self, utcStart=None, utcEnd=None, subspaceDB='SubSpace.db', trigCon=0,
               triggerLTATime=5, triggerSTATime=0, multiprocess=False, delOldCorrs=True,
               calcHist=True, useSubSpaces=True, useSingles=False, estimateMags=True,

@@ -552,6 +552,40 @@ def test_mags_from_stats_many_equals_row_by_row():
                     assert (np.isnan(g[r]) and np.isnan(w)) or g[r] == w or abs(g[r] - w) <= 1e-12 * abs(w), (issub, mags, r)
 
 
+def test_detex_sets_the_collector_aside_and_puts_it_back():
+    """SubSpace.detex runs with the process's existing objects frozen out of the garbage collector and releases
+    them afterwards, also when the call raises; a caller who runs without the collector, or who has frozen objects
+    of their own, is left alone."""
+    import gc
+    from detex_amd import SubSpace
+    from detex_amd.subspace import _collector_set_aside
+    assert getattr(SubSpace.detex, '__wrapped__', None) is not None      # (the product call is the wrapped one)
+    seen = {}
+
+    @_collector_set_aside
+    def body(fail=False):
+        seen['frozen'], seen['enabled'] = gc.get_freeze_count(), gc.isenabled()
+        if fail:
+            raise ValueError('x')
+        return 7
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    assert body() == 7 and seen['frozen'] > 0 and seen['enabled'] and gc.get_freeze_count() == 0
+    with pytest.raises(ValueError):
+        body(fail=True)
+    assert gc.get_freeze_count() == 0 and gc.isenabled()
+    gc.disable()
+    try:
+        assert body() == 7 and seen['frozen'] == 0 and not gc.isenabled()
+    finally:
+        gc.enable()
+    gc.freeze()
+    try:
+        mine = gc.get_freeze_count()
+        assert body() == 7 and gc.get_freeze_count() == mine > 0
+    finally:
+        gc.unfreeze()
+
+
 def test_bank_wide_magnitudes_equal_per_detector_ones():
     """_MagBank.estimate_all (every trigger of a batch in one call, constants padded to the longest
     event list) against mags_from_stats_many detector by detector: subspaces and singles mixed,
