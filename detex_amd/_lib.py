@@ -16,7 +16,7 @@ SYMBOLS = [
     'dtx_version', 'dtx_ctx_create', 'dtx_ctx_destroy', 'dtx_ctx_sync',
     'dtx_ctx_stream', 'dtx_last_error', 'dtx_set_engine', 'dtx_basis_upload', 'dtx_num_windows',
     'dtx_subspace_ds', 'dtx_subspace_scan', 'dtx_ds_post', 'dtx_ds_moments', 'dtx_subspace_ds_host',
-    'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_decimate', 'dtx_timer_start',
+    'dtx_xcorr_allpairs', 'dtx_xcorr_allpairs_host', 'dtx_preprocess', 'dtx_preprocess_planes', 'dtx_decimate', 'dtx_timer_start',
     'dtx_timer_stop', 'dtx_last_kernel_ms', 'dtx_trigger_stats', 'dtx_normcorr', 'dtx_ingest_counts', 'dtx_gapfree_run',
     'dtx_device_count', 'dtx_basis_bcast', 'dtx_kernel_ms_mean', 'dtx_subspace_scan_ragged',
     'dtx_trigger_stats_ragged', 'dtx_chunk_table_check', 'dtx_ctx_set_trigger_stream', 'dtx_stream_wait_scan_kernel',
@@ -91,6 +91,8 @@ def load():
     lib.dtx_xcorr_allpairs_host.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.dtx_preprocess.restype = i32
     lib.dtx_preprocess.argtypes = [vp, vp, i32, i32, i64, i64, vp, i32, i32, i32, vp, i64]
+    lib.dtx_preprocess_planes.restype = i32
+    lib.dtx_preprocess_planes.argtypes = [vp, vp, i32, i32, i64, i64, i64, vp, i32, i32, i32, vp, i64]
     lib.dtx_decimate.restype = i32
     lib.dtx_decimate.argtypes = [vp, vp, i32, i64, i64, vp, i32, i32, vp, i64]
     lib.dtx_trigger_stats.restype = i32

@@ -54,15 +54,25 @@ __device__ __forceinline__ double sos_step_t(const Sos& f, double x, double* z) 
   return x;
 }
 
+// Where series `ser` -- channel ser % Nc of chunk ser / Nc -- starts in the input: chunks `chunk` samples apart, a
+// chunk's channels `chan` apart.  A packed [nchunk][Nc][T'] array has chan = T', chunk = Nc T'; chunks cut from one
+// [Nc][Tday] record (overlapping or not, dtx_preprocess_planes) have chan = Tday and chunk = their spacing.
+struct SerLayout {
+  int64_t chunk, chan;
+  int Nc;
+  __host__ __device__ int64_t off(int ser) const { return (int64_t)(ser / Nc) * chunk + (int64_t)(ser % Nc) * chan; }
+};
+inline SerLayout ser_uniform(int64_t stride) { return SerLayout{stride, 0, 1}; }   // series s at s * stride
+
 // per series: sums for the least-squares line a + b t (scipy.signal.detrend
 // type='linear'); kTrendSlices workgroups per series add their partial sums of
 // x and x (t - tc) with float64 atomics; trend_of() turns them into (a, b)
 __global__ __launch_bounds__(256) void pp_trend_kernel(const float* __restrict__ raw, int64_t T,
-                                                       int64_t ser_stride,
+                                                       SerLayout sl,
                                                        double* __restrict__ tsum) {
   __shared__ double sh[8];
   const int ser = blockIdx.y, tid = threadIdx.x;
-  const float* x = raw + (int64_t)ser * ser_stride;
+  const float* x = raw + sl.off(ser);
   const double tc = 0.5 * (double)(T - 1);   // centred abscissa: diagonal normal equations
   const int64_t per = (T + kTrendSlices - 1) / kTrendSlices;
   const int64_t t0 = (int64_t)blockIdx.x * per, t1 = min(t0 + per, T);
@@ -118,7 +128,7 @@ constexpr int kSub = 32;
 // v_readlane per sample: the filter run was 99 of the forward pass's 167 us per station-day).
 template <bool FIRST, bool RUN, bool LAST, int NSEC>
 __global__ __launch_bounds__(256) void pp_tiled_kernel(
-    const float* __restrict__ raw, int64_t ser_stride, const double* __restrict__ mid,
+    const float* __restrict__ raw, SerLayout sl, const double* __restrict__ mid,
     const double* __restrict__ trend, int64_t T, int nblk, const double* __restrict__ coef, bool rev,
     double* __restrict__ fstate, double* __restrict__ out_mid, float* __restrict__ out_mp, int Nc,
     int64_t mp_stride, int dec) {
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void pp_tiled_kernel(
   const int g0 = blockIdx.x * 256;
   const int g = g0 + tid;
   const bool valid = g < nblk;
-  const float* r = raw ? raw + (int64_t)ser * ser_stride : nullptr;
+  const float* r = raw ? raw + sl.off(ser) : nullptr;
   const double* m = mid ? mid + (int64_t)ser * T : nullptr;
   double trc[2] = {0.0, 0.0};
   if (FIRST && trend) trend_of(trend + 2 * ser, T, &trc[0], &trc[1]);
@@ -395,12 +405,12 @@ __device__ __forceinline__ void wave_reduce_scatter(double (&acc)[N], int lane, 
 
 // (TIN = double, REV: the same for the backward pass of a zero-phase filter -- the forward output walked from its end)
 template <int NS, bool TREND, typename TIN = float, bool REV = false>
-__global__ __launch_bounds__(256) void pp_local_kernel(const TIN* __restrict__ raw, int64_t ser_stride, int64_t T,
+__global__ __launch_bounds__(256) void pp_local_kernel(const TIN* __restrict__ raw, SerLayout sl, int64_t T,
                                                        int nblk, const double* __restrict__ tab,
                                                        double* __restrict__ fstate, double* __restrict__ tsum) {
   __shared__ double sh[8];
   const int ser = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TIN* x = raw + (int64_t)ser * ser_stride;
+  const TIN* x = raw + sl.off(ser);
   auto at = [&](int64_t i) { return REV ? x[T - 1 - i] : x[i]; };      // sample i in filter order
   double* fs = fstate + (int64_t)ser * nblk * (2 * kMaxSec);
   double tw[kLR][NS];
@@ -496,13 +506,13 @@ __global__ __launch_bounds__(256) void pp_detrend_states_kernel(double* __restri
 
 // no filter: detrend (optional) + multiplex
 __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ raw,
-                                                      int64_t ser_stride,
+                                                      SerLayout sl,
                                                       const double* __restrict__ trend, int64_t T,
                                                       int Nc, int64_t mp_stride,
                                                       float* __restrict__ out_mp) {
   const int ser = blockIdx.y;
   const int chunk = ser / Nc, c = ser - chunk * Nc;
-  const float* r = raw + (int64_t)ser * ser_stride;
+  const float* r = raw + sl.off(ser);
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
     double v = (double)r[t];
     if (trend) {
@@ -518,19 +528,19 @@ __global__ __launch_bounds__(256) void pp_copy_kernel(const float* __restrict__ 
 // one 16-byte load from each plane, NC 16-byte stores of the 4 NC consecutive multiplexed floats.  (The kernel
 // above scatters 4-byte stores NC floats apart: 95 us per station-day against 41 - 50.)
 template <int NC>
-__global__ __launch_bounds__(256) void pp_copy_vec_kernel(const float* __restrict__ raw, int64_t ser_stride,
+__global__ __launch_bounds__(256) void pp_copy_vec_kernel(const float* __restrict__ raw, SerLayout sl,
                                                           int64_t T, int64_t mp_stride,
                                                           float* __restrict__ out_mp) {
   typedef float fv4 __attribute__((ext_vector_type(4)));
   const int chunk = blockIdx.y;
-  const float* r = raw + (int64_t)chunk * NC * ser_stride;
+  const float* r = raw + (int64_t)chunk * sl.chunk;
   float* o = out_mp + (int64_t)chunk * mp_stride;
   for (int64_t t = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); t < T; t += 4 * (int64_t)gridDim.x * 256) {
     float v[4 * NC];
     if (t + 3 < T) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const fv4 w = __builtin_nontemporal_load(reinterpret_cast<const fv4*>(r + (int64_t)c * ser_stride + t));
+        const fv4 w = __builtin_nontemporal_load(reinterpret_cast<const fv4*>(r + (int64_t)c * sl.chan + t));
         v[c] = w.x; v[NC + c] = w.y; v[2 * NC + c] = w.z; v[3 * NC + c] = w.w;
       }
 #pragma unroll
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(256) void pp_copy_vec_kernel(const float* __restric
     } else {
       for (int k = 0; t + k < T; ++k)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) o[(t + k) * NC + c] = r[(int64_t)c * ser_stride + t + k];
+        for (int c = 0; c < NC; ++c) o[(t + k) * NC + c] = r[(int64_t)c * sl.chan + t + k];
     }
   }
 }
@@ -702,12 +712,12 @@ static void launch_chain(dtx_ctx* ctx, double* fstate, const double* Mdev, int n
 
 // pp_tiled_kernel for the plan's section count
 template <bool FIRST, bool RUN, bool LAST>
-static void launch_tiled(dtx_ctx* ctx, dim3 grid, const PpPlan& pl, const float* raw, int64_t ser_stride, const double* mid,
+static void launch_tiled(dtx_ctx* ctx, dim3 grid, const PpPlan& pl, const float* raw, SerLayout sl, const double* mid,
                          const double* trend, int64_t T, bool rev, double* out_mid, float* out_mp, int Nc,
                          int64_t mp_stride, int dec) {
 #define DTX_TILED_CASE(NSEC)                                                                                      \
   case NSEC:                                                                                                      \
-    hipLaunchKernelGGL((pp_tiled_kernel<FIRST, RUN, LAST, NSEC>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, \
+    hipLaunchKernelGGL((pp_tiled_kernel<FIRST, RUN, LAST, NSEC>), grid, dim3(256), 0, ctx->stream, raw, sl,         \
                        mid, trend, T, pl.nblk, pl.coef(), rev, pl.fstate, out_mid, out_mp, Nc, mp_stride, dec);    \
     break
   switch (pl.f.nsec) {
@@ -719,15 +729,15 @@ static void launch_tiled(dtx_ctx* ctx, dim3 grid, const PpPlan& pl, const float*
 }
 
 // pass 1 (+ the trend sums when tsum is given): zero-state exit states of every block of every series
-static int launch_local(dtx_ctx* ctx, const float* raw, int64_t ser_stride, int64_t T, const PpPlan& pl, double* tsum) {
+static int launch_local(dtx_ctx* ctx, const float* raw, SerLayout sl, int64_t T, const PpPlan& pl, double* tsum) {
   // ~2000 workgroups whatever the series count; a wave takes every fourth block of its workgroup's run
   const int slices = std::max(1, std::min((pl.nblk + 7) / 8, (2048 + pl.nser - 1) / pl.nser));
   const dim3 grid((unsigned)slices, (unsigned)pl.nser);
 #define DTX_LOCAL_CASE(NS)                                                                                          \
   case NS:                                                                                                          \
-    if (tsum) hipLaunchKernelGGL((pp_local_kernel<NS, true>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, T,  \
+    if (tsum) hipLaunchKernelGGL((pp_local_kernel<NS, true>), grid, dim3(256), 0, ctx->stream, raw, sl, T,          \
                                  pl.nblk, pl.tab(), pl.fstate, tsum);                                               \
-    else hipLaunchKernelGGL((pp_local_kernel<NS, false>), grid, dim3(256), 0, ctx->stream, raw, ser_stride, T,      \
+    else hipLaunchKernelGGL((pp_local_kernel<NS, false>), grid, dim3(256), 0, ctx->stream, raw, sl, T,              \
                             pl.nblk, pl.tab(), pl.fstate, tsum);                                                    \
     break
   switch (pl.ns) {
@@ -752,7 +762,7 @@ static int launch_local_back(dtx_ctx* ctx, const double* mid, int64_t T, const P
   const dim3 grid((unsigned)slices, (unsigned)pl.nser);
 #define DTX_LOCALB_CASE(NS)                                                                                        \
   case NS:                                                                                                         \
-    hipLaunchKernelGGL((pp_local_kernel<NS, false, double, true>), grid, dim3(256), 0, ctx->stream, mid, T, T,     \
+    hipLaunchKernelGGL((pp_local_kernel<NS, false, double, true>), grid, dim3(256), 0, ctx->stream, mid, ser_uniform(T), T, \
                        pl.nblk, pl.tab(), pl.fstate, (double*)nullptr);                                            \
     break
   switch (pl.ns) {
@@ -873,15 +883,10 @@ int launch_run(dtx_ctx* ctx, const float* planes, int Nc, int64_t T, int64_t str
 
 }  // namespace
 
-extern "C" {
-
-int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
-                   int64_t ser_stride, const double* sos, int nsec, int zerophase, int detrend,
-                   float* mp_dev, int64_t mp_stride) {
-  if (!ctx) return DTX_E_ARG;
-  if (!raw_dev || !mp_dev || nchunk <= 0 || Nc <= 0 || T <= 0 || ser_stride < T ||
-      mp_stride < T * Nc)
-    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: bad argument");
+// dtx_preprocess / dtx_preprocess_planes behind their argument checks
+static int preprocess_impl(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T, const SerLayout sl,
+                           const double* sos, int nsec, int zerophase, int detrend, float* mp_dev,
+                           int64_t mp_stride) {
   DtxDeviceGuard g(ctx->device);
   const int nser = nchunk * Nc;
   PpPlan pl;
@@ -895,17 +900,17 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     DTX_HIP(ctx, hipMemsetAsync(trend, 0, (size_t)nser * 2 * sizeof(double), ctx->stream));
     if (nsec == 0 || !1) {          // (with a filter the trend sums come out of pass 1)
       hipLaunchKernelGGL(pp_trend_kernel, dim3(kTrendSlices, (unsigned)nser), dim3(256), 0,
-                         ctx->stream, raw_dev, T, ser_stride, trend);
+                         ctx->stream, raw_dev, T, sl, trend);
       DTX_HIP(ctx, hipGetLastError());
     }
   }
   if (nsec == 0) {
     // no trend, 16-byte aligned planes and output: the vector kernel
-    const bool vec = trend == nullptr && (ser_stride & 3) == 0 && (mp_stride & 3) == 0 &&
+    const bool vec = trend == nullptr && (sl.chunk & 3) == 0 && (sl.chan & 3) == 0 && (mp_stride & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(mp_dev) & 15) == 0;
     const dim3 vgrid((unsigned)std::min<int64_t>((T + 1023) / 1024, 4096), (unsigned)(nser / std::max(Nc, 1)));
 #define DTX_PP_COPY_VEC(NC)                                                                                  \
-    hipLaunchKernelGGL(pp_copy_vec_kernel<NC>, vgrid, dim3(256), 0, ctx->stream, raw_dev, ser_stride, T,     \
+    hipLaunchKernelGGL(pp_copy_vec_kernel<NC>, vgrid, dim3(256), 0, ctx->stream, raw_dev, sl, T,             \
                        mp_stride, mp_dev)
     if (vec && (Nc == 1 || Nc == 2 || Nc == 3 || Nc == 4 || Nc == 6)) {
       switch (Nc) {
@@ -920,7 +925,7 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
     }
 #undef DTX_PP_COPY_VEC
     dim3 grid((unsigned)std::min<int64_t>((T + 255) / 256, 4096), (unsigned)nser);
-    hipLaunchKernelGGL(pp_copy_kernel, grid, dim3(256), 0, ctx->stream, raw_dev, ser_stride,
+    hipLaunchKernelGGL(pp_copy_kernel, grid, dim3(256), 0, ctx->stream, raw_dev, sl,
                        (const double*)trend, T, Nc, mp_stride, mp_dev);
     DTX_HIP(ctx, hipGetLastError());
     return DTX_OK;
@@ -929,24 +934,48 @@ int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64
   const double* nod = nullptr;
   const float* nof = nullptr;
   // forward pass: raw - trend -> (mid | output)
-  if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, trend))) return rc;
+  if ((rc = launch_local(ctx, raw_dev, sl, T, pl, trend))) return rc;
   auto chain = [&]() { launch_chain(ctx, fstate, (const double*)Mdev, nser, nblk, seg, ns); };
   chain();
   if (zerophase) {
-    launch_tiled<true, true, false>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false, mid,
+    launch_tiled<true, true, false>(ctx, grid, pl, raw_dev, sl, nod, (const double*)trend, T, false, mid,
                                     (float*)nullptr, Nc, mp_stride, 0);
     // backward pass over the forward output (obspy: sosfilt(sos, firstpass[::-1])[::-1])
     if ((rc = launch_local_back(ctx, mid, T, pl))) return rc;
     chain();
     // in place: every thread reads its samples of `mid` into LDS before any store of that tile
-    launch_tiled<false, true, true>(ctx, grid, pl, nof, ser_stride, (const double*)mid, nod, T, true,
+    launch_tiled<false, true, true>(ctx, grid, pl, nof, sl, (const double*)mid, nod, T, true,
                                     (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   } else {
-    launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_stride, nod, (const double*)trend, T, false,
+    launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, sl, nod, (const double*)trend, T, false,
                                    (double*)nullptr, mp_dev, Nc, mp_stride, 0);
   }
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;
+}
+
+extern "C" {
+
+int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
+                   int64_t ser_stride, const double* sos, int nsec, int zerophase, int detrend,
+                   float* mp_dev, int64_t mp_stride) {
+  if (!ctx) return DTX_E_ARG;
+  if (!raw_dev || !mp_dev || nchunk <= 0 || Nc <= 0 || T <= 0 || ser_stride < T ||
+      mp_stride < T * Nc)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess: bad argument");
+  return preprocess_impl(ctx, raw_dev, nchunk, Nc, T, SerLayout{(int64_t)Nc * ser_stride, ser_stride, Nc}, sos, nsec,
+                         zerophase, detrend, mp_dev, mp_stride);
+}
+
+int dtx_preprocess_planes(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
+                          int64_t chunk_stride, int64_t chan_stride, const double* sos, int nsec, int zerophase,
+                          int detrend, float* mp_dev, int64_t mp_stride) {
+  if (!ctx) return DTX_E_ARG;
+  if (!raw_dev || !mp_dev || nchunk <= 0 || Nc <= 0 || T <= 0 || chunk_stride < 0 || (Nc > 1 && chan_stride < T) ||
+      mp_stride < T * Nc)
+    return dtx_fail(ctx, DTX_E_ARG, "dtx_preprocess_planes: bad argument");
+  return preprocess_impl(ctx, raw_dev, nchunk, Nc, T, SerLayout{chunk_stride, chan_stride, Nc}, sos, nsec, zerophase,
+                         detrend, mp_dev, mp_stride);
 }
 
 // Trace.decimate of construct.py:1016-1017: causal low-pass (forward sosfilt of the
@@ -964,10 +993,10 @@ int dtx_decimate(dtx_ctx* ctx, const float* raw_dev, int nser, int64_t T, int64_
   if ((rc = pp_plan(ctx, "dtx_decimate", sos, nsec, nser, T, false, &pl))) return rc;
   dim3 grid((unsigned)((pl.nblk + 255) / 256), (unsigned)nser);
   const double* nod = nullptr;
-  if ((rc = launch_local(ctx, raw_dev, ser_stride, T, pl, nullptr))) return rc;
+  if ((rc = launch_local(ctx, raw_dev, ser_uniform(ser_stride), T, pl, nullptr))) return rc;
   launch_chain(ctx, pl.fstate, (const double*)pl.Mdev, nser, pl.nblk, pl.seg, pl.ns);
   // Nc = 1: "multiplexed" and planar coincide, so factor 1 is plain causal filtering
-  launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_stride, nod, nod, T, false, (double*)nullptr, out_dev, 1,
+  launch_tiled<true, true, true>(ctx, grid, pl, raw_dev, ser_uniform(ser_stride), nod, nod, T, false, (double*)nullptr, out_dev, 1,
                                  out_stride, factor);
   DTX_HIP(ctx, hipGetLastError());
   return DTX_OK;

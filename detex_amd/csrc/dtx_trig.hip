@@ -1,4 +1,4 @@
-// Trigger-time estimates on the device, one workgroup per trigger:
+// Trigger-time estimates on the device, three workgroups per trigger (trig_stats_kernel):
 //   * the STA / LTA of the detection statistic at the trigger (detex/detect.py:501-524
 //     _getStaLtaArray: centred rolling means of |DS|, evaluated only where a trigger fell),
 //   * the ingredients of the magnitude / SNR estimates of detex/detect.py:447-499 (_estMag,
@@ -28,7 +28,7 @@ struct TrigArgs {
   const float* ewf;      // [Etot][n] training-event waveforms (trimmed, as the detector saw them)
   const int32_t* eoff;   // [D + 1] events of each detector
   double* out;           // [ntrig][kTrigHead + emax]
-  float* scratch;        // [gridDim.x][scap] rolling standard deviations of one trigger
+  float* scratch;        // [gridDim.x][scap] rolling variances of one trigger (when they do not fit the registers)
   int64_t scap;
   int D, n, Nc, emax;
   int full;              // 0: STA / LTA only (no magnitude ingredients asked for)
@@ -78,7 +78,7 @@ __device__ inline void block_sum4(double (&v)[4], double* red) {
 // one barrier per pass; a first pass takes the minimum and maximum and the bisection starts below the bits they
 // share (rolling variances of stationary noise share 10 .. 12 of their 31).  (Rounds 4-5 took 4 bits a pass and
 // counted 16 buckets in registers: 37 vector instructions per value and pass, 28 000 per wave for a trigger's
-// 36 001 rolling standard deviations -- 0.1 ms of the kernel's 0.2; rounds 1-3 counted 8 bits a pass with LDS
+// 36 001 values -- 0.1 ms of the kernel's 0.2; rounds 1-3 counted 8 bits a pass with LDS
 // atomics, which a narrow distribution serialises on one bin.  Counting with the wave's ballot and a scalar
 // popcount instead of the add with carry measured 3x slower: each scalar read of the compare's mask waits out
 // the vector pipeline.)  Returns the value(s) to every thread.  hist: >= 64 words of LDS.

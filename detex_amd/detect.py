@@ -576,7 +576,14 @@ class StationScan(object):
         ctx = ctx or self.ctx
         b = self.st['bounds']
         cnt = b[i0][1]
-        planes = torch.stack([rawdev[:, b[k][0]:b[k][0] + cnt] for k in range(i0, i1)])
+        step = b[i0 + 1][0] - b[i0][0] if i1 - i0 > 1 else 0
+        if rawdev.stride(1) == 1 and all(b[k + 1][0] - b[k][0] == step for k in range(i0, i1 - 1)) and step >= 0:
+            # equally spaced chunks of one record: a view of it (the reference's chunks overlap by conBuff, so they
+            # are not a reshape; a packed copy of a station-day cost 0.14 ms ahead of every unit's filter)
+            planes = rawdev.as_strided((i1 - i0, rawdev.shape[0], cnt), (step, rawdev.stride(0), 1),
+                                       rawdev.storage_offset() + b[i0][0])
+        else:
+            planes = torch.stack([rawdev[:, b[k][0]:b[k][0] + cnt] for k in range(i0, i1)])
         if dec > 1:                                      # construct.py:1016-1017
             planes = ctx.decimate(planes, dec, sr_raw)
         return ctx.preprocess(planes, filt=self.ss.clusters.filt, sampling_rate=sr, out=out)

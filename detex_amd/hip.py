@@ -656,23 +656,27 @@ class HipContext(object):
     def preprocess(self, raw, filt=None, sampling_rate=None, detrend=True, out=None):
         """Detrend + band-pass + multiplex on the device (construct.py:990-1030).
 
-        raw : [nchunk, Nc, T] float32 CUDA tensor (channels in st.sort() order);
+        raw : [nchunk, Nc, T] float32 CUDA tensor (channels in st.sort() order), packed or a view with unit
+        sample stride -- chunks where they lie in a longer [Nc, Tday] record, overlapping or not
+        (dtx_preprocess_planes: no packed copy);
         filt : [freqmin, freqmax, corners, zerophase] as in the reference, or None.
         Returns [nchunk, Nc*T] multiplexed float32."""
         if raw.dtype != torch.float32 or not raw.is_cuda or raw.dim() != 3:
             raise ValueError('raw must be a [nchunk, Nc, T] float32 CUDA tensor')
-        raw = raw.contiguous()
         nchunk, Nc, T = (int(s) for s in raw.shape)
+        if raw.stride(2) != 1 or raw.stride(0) < 0 or (Nc > 1 and raw.stride(1) < T):
+            raw = raw.contiguous()
         sos, nsec, zp = None, 0, 0
         if filt is not None:
             sos = np.ascontiguousarray(bandpass_sos(filt[0], filt[1], sampling_rate, filt[2]))
             nsec, zp = len(sos), int(bool(filt[3]))
         if out is None:
             out = torch.empty((nchunk, Nc * T), dtype=torch.float32, device=raw.device)
-        rc = self.lib.dtx_preprocess(self.h, _ptr(raw), nchunk, Nc, T, T,
-                                     sos.ctypes.data_as(C.c_void_p) if sos is not None else None,
-                                     nsec, zp, int(bool(detrend)), _ptr(out), int(out.stride(0)))
-        self._ck(rc, 'dtx_preprocess')
+        rc = self.lib.dtx_preprocess_planes(self.h, _ptr(raw), nchunk, Nc, T, int(raw.stride(0)) if nchunk > 1 else 0,
+                                            int(raw.stride(1)) if Nc > 1 else T,
+                                            sos.ctypes.data_as(C.c_void_p) if sos is not None else None,
+                                            nsec, zp, int(bool(detrend)), _ptr(out), int(out.stride(0)))
+        self._ck(rc, 'dtx_preprocess_planes')
         return out
 
     @_on_ctx_stream

@@ -357,6 +357,15 @@ int dtx_xcorr_allpairs_host(dtx_ctx* ctx, const float* td_host, int N, int n,
 int dtx_preprocess(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc,
                    int64_t T, int64_t ser_stride, const double* sos, int nsec,
                    int zerophase, int detrend, float* mp_dev, int64_t mp_stride);
+/* The same for chunks that are cut from longer channel planes where they lie -- the reference's chunks
+ * overlap (conDatDuration + conBuff, getdata.py:869-886), so a day's [Nc][Tday] record holds them as
+ * views, not as a packed array: channel c of chunk b at raw_dev + b*chunk_stride + c*chan_stride
+ * (chunk_stride >= 0: overlapping chunks are fine, the input is only read; chan_stride >= T).  Saves the
+ * caller a packed copy of every chunk (0.14 ms per station-day of SubSpace.detex with an unfiltered
+ * fetcher).  dtx_preprocess is this with chunk_stride = Nc*ser_stride, chan_stride = ser_stride. */
+int dtx_preprocess_planes(dtx_ctx* ctx, const float* raw_dev, int nchunk, int Nc, int64_t T,
+                          int64_t chunk_stride, int64_t chan_stride, const double* sos, int nsec,
+                          int zerophase, int detrend, float* mp_dev, int64_t mp_stride);
 
 /* The front half of _applyFilter (construct.py:1005-1022) for one chunk that arrives as
  * fragments of raw int32 digitiser counts (one ObsPy trace each):

@@ -46,6 +46,38 @@ def test_preprocess_matches_scipy(ctx, T, Nc, nchunk, filt, sr, detrend):
         assert np.max(np.abs(got[b] - want)) <= 2e-6 * scale + 1e-7 * 400, (b, scale)
 
 
+@pytest.mark.parametrize('Nc,T,step,nchunk,filt,detrend', [
+    (3, 3720, 3600, 5, [1, 10, 2, True], True),       # the reference's chunks: conDatDuration + conBuff, overlapping
+    (3, 3720, 3600, 5, [1, 10, 2, False], True),
+    (3, 4000, 4000, 3, None, False),                  # no filter, no trend: the 16-byte multiplex kernel
+    (3, 3721, 3601, 4, None, True),                   # ... with a trend, strides that are no multiples of four
+    (1, 999, 10, 6, [2, 8, 4, True], True),           # one channel, heavy overlap
+    (2, 2048, 0, 3, [5, 20, 3, True], False),         # the same chunk three times
+])
+def test_preprocess_of_chunks_where_they_lie_equals_packed_copy(ctx, Nc, T, step, nchunk, filt, detrend):
+    """dtx_preprocess_planes: chunks taken as views of one [Nc, Tday] record (channel stride Tday, chunk stride =
+    their spacing, overlapping as the reference's chunks do) against the same chunks copied into a packed
+    [nchunk, Nc, T] array first -- bit-identical; a view the entry point cannot express (sample stride 2) falls
+    back to the packed copy."""
+    rs = np.random.RandomState(Nc * 1000 + T + SOAK)
+    Tday = step * (nchunk - 1) + T + 37
+    t = np.arange(Tday)
+    rec = (rs.standard_normal((Nc, Tday)) * 50 + 300.0 + 0.01 * t[None, :]).astype(np.float32)
+    recd = torch.from_numpy(rec).cuda()
+    first = 5
+    view = recd.as_strided((nchunk, Nc, T), (step, Tday, 1), first)
+    packed = torch.stack([recd[:, first + k * step:first + k * step + T] for k in range(nchunk)])
+    assert view.data_ptr() == recd.data_ptr() + 4 * first and torch.equal(view, packed)
+    a = ctx.preprocess(view, filt=filt, sampling_rate=100.0, detrend=detrend)
+    b = ctx.preprocess(packed, filt=filt, sampling_rate=100.0, detrend=detrend)
+    ctx.sync()
+    assert torch.equal(a, b)
+    odd = torch.from_numpy(np.repeat(rec, 2, axis=1)).cuda()[:, ::2].as_strided((nchunk, Nc, T), (2 * step, 2 * Tday, 2), 2 * first)
+    c = ctx.preprocess(odd, filt=filt, sampling_rate=100.0, detrend=detrend)
+    ctx.sync()
+    assert torch.equal(c, b)
+
+
 @pytest.mark.parametrize('seed', range(26))
 def test_preprocess_random_shapes(ctx, seed):
     """Seeded random lengths around the block structure of the filter kernels (blocks of 256 samples: shorter than
