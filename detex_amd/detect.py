@@ -935,9 +935,14 @@ def _batch_rows(sta, st, fillZeros, estimateMags, i0, trigs, bad, stats, rows, k
     if stats is not None:
         with np.errstate(all='ignore'):
             sl_a = np.divide(stats[:, 0], stats[:, 1])
-    ofmm = st.get('offset_minmax')
+    # the detectors' largest / smallest offsets (MSTAMPmin / MSTAMPmax): kept with the station's bank, like its constants
+    ofmm = getattr(bank, 'offset_minmax', None) if bank is not None else st.get('offset_minmax')
     if ofmm is None:
-        ofmm = st['offset_minmax'] = {nm: (np.max(offsets[nm]), np.min(offsets[nm])) for nm in names}
+        ofmm = {nm: (np.max(offsets[nm]), np.min(offsets[nm])) for nm in names}
+        if bank is not None:
+            bank.offset_minmax = ofmm
+        else:
+            st['offset_minmax'] = ofmm
     stm_l, snr_l, pem_l = stm_a.tolist(), snr_a.tolist(), pem_a.tolist()
     for r, (b, d, ti, coef) in enumerate(trigs):
         name = names[d]
