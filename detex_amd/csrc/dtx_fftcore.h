@@ -599,12 +599,38 @@ __global__ __launch_bounds__(kT) void xhat_kernel(const float* __restrict__ xp, 
   const LdsBases lb = lds_bases(tid);
   const float* x = xp + ((int64_t)chunk * Nc + c) * Tpad;
   const int tb = 8 * (tid & 63) + (tid >> 6);          // sample within the block
-  const int64_t t0 = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride + tb;
+  const int64_t ts = (int64_t)(blk / nsub) * V + (int64_t)(blk % nsub) * sub_stride;   // the block's first sample
   c32 v[16];
+  // The transform wants v[r] = sample tb + 512 r: taken from memory directly that is sixteen 4-byte loads a thread
+  // whose lanes sit 32 bytes apart (rounds 1-5).  Instead the workgroup reads the block with four coalesced 16-byte
+  // loads a thread (dword-aligned: a cross-correlation block starts anywhere) and hands the samples over through
+  // the still unused image; element i at word i + (i >> 3): the reads (lane stride 9 words) are conflict-free.
+  // Step - scan kernel at configs[1] 0.435 -> 0.410 ms (scripts/probe/ab_xhat.sh, alternating builds on one box).
+  {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float* stage = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t t = t0 + 512 * r;
-    v[r] = make_float2((t < Tpad && tb + 512 * r < keep) ? x[t] : 0.f, 0.f);
+    for (int k = 0; k < 4; ++k) {
+      const int i = 4 * tid + 2048 * k;
+      const int64_t t = ts + i;
+      float e[4];
+      if (t + 3 < Tpad) {
+        const f4u q = *reinterpret_cast<const f4u*>(x + t);
+        e[0] = q.x; e[1] = q.y; e[2] = q.z; e[3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = t + j < Tpad ? x[t + j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stage[i + j + ((i + j) >> 3)] = i + j < keep ? e[j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = tb + 512 * r;
+      v[r] = make_float2(stage[i + (i >> 3)], 0.f);
+    }
+    __syncthreads();                                   // (the transform's first pass writes the image)
   }
   fft8192<-1>(v, lds, lb, tab, tid);
   // Thread tid holds X[tid + 512 m] in v[m]; slot (f & 7) * 512 + (f >> 3) puts a wave's eight
