@@ -95,6 +95,26 @@ def test_host_entry_points(raw):
     assert np.array_equal(lag, rlag[iu[0], iu[1] - 1].astype(np.int32))
 
 
+def test_preprocess_planes_arguments(raw):
+    """dtx_preprocess_planes: the channel stride must hold a chunk, the chunk stride may be anything >= 0 (chunks
+    overlap in the record they are cut from), the output rows must hold Nc T samples."""
+    lib, h = raw
+    rec = torch.randn(3 * 5000, device='cuda')
+    out = torch.zeros(4 * 3 * 1000, device='cuda')
+    pp = lambda T, cs, hs, mps, Nc=3, nch=4: lib.dtx_preprocess_planes(  # noqa: E731
+        h, C.c_void_p(rec.data_ptr()), nch, Nc, T, cs, hs, None, 0, 0, 0, C.c_void_p(out.data_ptr()), mps)
+    assert pp(1000, 900, 999, 3000) == -1 and 'dtx_preprocess_planes' in _msg(lib, h)      # channels would overlap
+    assert pp(1000, -1, 5000, 3000) == -1
+    assert pp(1000, 900, 5000, 2999) == -1                                                  # output rows too short
+    assert pp(0, 900, 5000, 3000) == -1
+    assert lib.dtx_preprocess_planes(h, None, 4, 3, 1000, 900, 5000, None, 0, 0, 0, C.c_void_p(out.data_ptr()), 3000) == -1
+    assert pp(1000, 900, 5000, 3000) == 0 and pp(1000, 0, 5000, 3000) == 0
+    assert pp(1000, 1000, 0, 1000, Nc=1) == 0                                               # one channel: no channel stride
+    assert lib.dtx_ctx_sync(h) == 0
+    # (the last good call: one channel, chunks of 1000 samples 1000 apart -> the record's first 4000 samples)
+    assert torch.equal(out[:4000], rec[:4000])
+
+
 def test_wrapper_rejects_misshapen_outputs():
     """A caller-supplied DS / histogram / sums tensor of the wrong shape, dtype or pitch is refused
     before the kernels would write through it."""
