@@ -586,6 +586,39 @@ def test_detex_sets_the_collector_aside_and_puts_it_back():
         gc.unfreeze()
 
 
+def test_unfiltered_chunks_are_handed_over_as_views_when_equally_spaced():
+    """StationScan._filtered: a group of equally spaced chunks goes to the filter as ONE strided view of the
+    record (overlapping chunks, no packed copy); unequal spacing or a record with a sample stride falls back to
+    the packed copy.  Same values either way."""
+    import torch
+    from detex_amd import detect
+
+    class _Ctx(object):
+        def preprocess(self, planes, filt=None, sampling_rate=None, out=None):
+            self.seen = planes
+            return planes
+
+    class _Clusters(object):
+        filt = [1, 10, 2, True]
+
+    class _SS(object):
+        clusters = _Clusters()
+    rec = torch.arange(3 * 5000, dtype=torch.float32).reshape(3, 5000)[:, 7:]          # (a view with a storage offset)
+    job = detect.StationScan.__new__(detect.StationScan)
+    job.ss = _SS()
+    ctx = _Ctx()
+    for starts, shares in (([100, 1000, 1900, 2800], True), ([100, 1000, 1950, 2800], False), ([40], True)):
+        job.st = {'bounds': [(a, 1200, 0.0, k) for k, a in enumerate(starts)]}
+        got = job._filtered(rec, 0, len(starts), 1, 100.0, 100.0, ctx=ctx)
+        want = torch.stack([rec[:, a:a + 1200] for a in starts])
+        assert torch.equal(got, want)
+        assert (ctx.seen.untyped_storage().data_ptr() == rec.untyped_storage().data_ptr()) == shares
+    job.st = {'bounds': [(100, 500, 0.0, 0), (700, 500, 0.0, 1)]}
+    got = job._filtered(rec[:, ::2], 0, 2, 1, 100.0, 100.0, ctx=ctx)
+    assert torch.equal(got, torch.stack([rec[:, ::2][:, a:a + 500] for a in (100, 700)]))
+    assert ctx.seen.untyped_storage().data_ptr() != rec.untyped_storage().data_ptr()
+
+
 def test_bank_wide_magnitudes_equal_per_detector_ones():
     """_MagBank.estimate_all (every trigger of a batch in one call, constants padded to the longest
     event list) against mags_from_stats_many detector by detector: subspaces and singles mixed,
