@@ -126,7 +126,11 @@ def bind_to_device(device, sysfs='/sys/bus/pci/devices', pci_bus_id=None):
             rec['reason'] = 'local CPUs outside the affinity mask'
             return rec
         if len(use) < len(allowed):
-            os.sched_setaffinity(0, use)
+            try:
+                os.sched_setaffinity(0, use)
+            except OSError as e:                         # (a sandbox that forbids it: the run goes on unbound)
+                rec['reason'] = 'sched_setaffinity refused: %s' % e
+                return rec
             rec['applied'] = True
         else:
             rec['reason'] = 'every allowed CPU is local'

@@ -125,6 +125,15 @@ def test_bind_to_device_reads_sysfs(tmp_path, monkeypatch):
             rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
             assert rec['applied'] is True and rec['cpus'] == len(half) and rec['device'] == 3 and rec['pci'] == '0000:c1:00.0'
             assert sorted(os.sched_getaffinity(0)) == half
+            # a sandbox that refuses the call: recorded, the run goes on unbound
+            os.sched_setaffinity(0, allowed)
+
+            def refuse(pid, cpus):
+                raise PermissionError(1, 'Operation not permitted')
+            monkeypatch.setattr(os, 'sched_setaffinity', refuse)
+            rec = parallel.bind_to_device(3, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+            assert rec['applied'] is False and 'refused' in rec['reason'] and parallel.BINDING == rec
+            monkeypatch.undo()
     finally:
         os.sched_setaffinity(0, allowed)
         parallel.BINDING.clear()
